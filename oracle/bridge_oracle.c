@@ -1,0 +1,1066 @@
+/*
+ * bridge_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY; see bridge_oracle.h)
+ *
+ * Plain-C restatement of Bridge.jl's guided-proposal hot path.  Single-threaded scalar code in
+ * the reference's operation order; every function cites the reference file:line it follows
+ * (paths relative to /root/reference).  Nothing here is used by the product library.
+ *
+ * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC).
+ */
+#include "bridge_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* The Box-Muller helpers use explicit fma(); build an FMA3 clone so the cpu_baseline timing is
+ * not dominated by libm's software fma on hosts that have the instruction.  Both clones are
+ * bit-identical (fma is correctly rounded either way; implicit contraction is disabled). */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(BO_NO_CLONES)
+#define BO_CLONES __attribute__((target_clones("fma", "default")))
+#else
+#define BO_CLONES
+#endif
+
+#define D2 (BO_MAXD * BO_MAXD)
+
+/* ------------------------------------------------------------------------------------------
+ * small dense linear algebra, column-major, StaticArrays operation order:
+ *   (A*x)[i] = A[i,1]*x[1] + A[i,2]*x[2] + ...   (left-to-right, first product starts the sum)
+ * ------------------------------------------------------------------------------------------ */
+static void mv(int r, int c, const double *A, const double *x, double *y)
+{
+    for (int i = 0; i < r; i++) {
+        double s = A[i] * x[0];
+        for (int j = 1; j < c; j++) s += A[i + r * j] * x[j];
+        y[i] = s;
+    }
+}
+/* C(r x c) = A(r x k) * B(k x c) */
+static void mm(int r, int k, int c, const double *A, const double *B, double *C)
+{
+    for (int j = 0; j < c; j++)
+        for (int i = 0; i < r; i++) {
+            double s = A[i] * B[k * j];
+            for (int l = 1; l < k; l++) s += A[i + r * l] * B[l + k * j];
+            C[i + r * j] = s;
+        }
+}
+/* C(r x c) = A(r x k) * B'(k x c),  B is c x k */
+static void mmt(int r, int k, int c, const double *A, const double *B, double *C)
+{
+    for (int j = 0; j < c; j++)
+        for (int i = 0; i < r; i++) {
+            double s = A[i] * B[j];
+            for (int l = 1; l < k; l++) s += A[i + r * l] * B[j + c * l];
+            C[i + r * j] = s;
+        }
+}
+/* C(r x c) = A'(r x k) * B(k x c),  A is k x r */
+static void mtm(int r, int k, int c, const double *A, const double *B, double *C)
+{
+    for (int j = 0; j < c; j++)
+        for (int i = 0; i < r; i++) {
+            double s = A[k * i] * B[k * j];
+            for (int l = 1; l < k; l++) s += A[l + k * i] * B[l + k * j];
+            C[i + r * j] = s;
+        }
+}
+static double dotv(int n, const double *a, const double *b)
+{
+    double s = a[0] * b[0];
+    for (int i = 1; i < n; i++) s += a[i] * b[i];
+    return s;
+}
+
+/* LU with partial pivoting (generic n > 3; LinearAlgebra.lu semantics, unpinned op order) */
+static int lu_factor(int n, double *A, int *piv)
+{
+    for (int k = 0; k < n; k++) {
+        int p = k;
+        double best = fabs(A[k + n * k]);
+        for (int i = k + 1; i < n; i++)
+            if (fabs(A[i + n * k]) > best) { best = fabs(A[i + n * k]); p = i; }
+        piv[k] = p;
+        if (best == 0.0) return -1;
+        if (p != k)
+            for (int j = 0; j < n; j++) { double t = A[k + n * j]; A[k + n * j] = A[p + n * j]; A[p + n * j] = t; }
+        double inv = 1.0 / A[k + n * k];
+        for (int i = k + 1; i < n; i++) A[i + n * k] *= inv;
+        for (int j = k + 1; j < n; j++) {
+            double akj = A[k + n * j];
+            for (int i = k + 1; i < n; i++) A[i + n * j] -= A[i + n * k] * akj;
+        }
+    }
+    return 0;
+}
+static void lu_solve(int n, const double *LU, const int *piv, double *b)
+{
+    for (int k = 0; k < n; k++) { int p = piv[k]; if (p != k) { double t = b[k]; b[k] = b[p]; b[p] = t; } }
+    for (int k = 0; k < n; k++) for (int i = k + 1; i < n; i++) b[i] -= LU[i + n * k] * b[k];
+    for (int k = n - 1; k >= 0; k--) { b[k] /= LU[k + n * k]; for (int i = 0; i < k; i++) b[i] -= LU[i + n * k] * b[k]; }
+}
+
+/* StaticArrays det.jl: 1x1, 2x2 (A[1]*A[4] - A[3]*A[2]), 3x3 (dot(x0, cross(x1,x2))); else LU */
+double bo_det(int n, const double *A)
+{
+    if (n == 1) return A[0];
+    if (n == 2) return A[0] * A[3] - A[2] * A[1];
+    if (n == 3) {
+        double c0 = A[4] * A[8] - A[5] * A[7];
+        double c1 = A[5] * A[6] - A[3] * A[8];
+        double c2 = A[3] * A[7] - A[4] * A[6];
+        return A[0] * c0 + A[1] * c1 + A[2] * c2;
+    }
+    double *T = (double *)malloc(sizeof(double) * n * n);
+    int *piv = (int *)malloc(sizeof(int) * n);
+    memcpy(T, A, sizeof(double) * n * n);
+    double d = 1.0;
+    if (lu_factor(n, T, piv) != 0) d = 0.0;
+    else for (int k = 0; k < n; k++) { d *= T[k + n * k]; if (piv[k] != k) d = -d; }
+    free(T); free(piv);
+    return d;
+}
+
+/* StaticArrays inv.jl (v1.x): 1x1 inv(a); 2x2 adjugate/det; 3x3 cross-product form; else LU */
+int bo_inv(int n, const double *A, double *Ai)
+{
+    if (n == 1) { Ai[0] = 1.0 / A[0]; return 0; }
+    if (n == 2) {
+        double d = bo_det(2, A);
+        double a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3];
+        Ai[0] = a3 / d; Ai[1] = -(a1 / d); Ai[2] = -(a2 / d); Ai[3] = a0 / d;
+        return 0;
+    }
+    if (n == 3) {
+        double x0[3] = {A[0], A[1], A[2]}, x1[3] = {A[3], A[4], A[5]}, x2[3] = {A[6], A[7], A[8]};
+        double y0[3] = {x1[1] * x2[2] - x1[2] * x2[1], x1[2] * x2[0] - x1[0] * x2[2], x1[0] * x2[1] - x1[1] * x2[0]};
+        double d = x0[0] * y0[0] + x0[1] * y0[1] + x0[2] * y0[2];
+        for (int k = 0; k < 3; k++) { x0[k] = x0[k] / d; y0[k] = y0[k] / d; }
+        double y1[3] = {x2[1] * x0[2] - x2[2] * x0[1], x2[2] * x0[0] - x2[0] * x0[2], x2[0] * x0[1] - x2[1] * x0[0]};
+        double y2[3] = {x0[1] * x1[2] - x0[2] * x1[1], x0[2] * x1[0] - x0[0] * x1[2], x0[0] * x1[1] - x0[1] * x1[0]};
+        Ai[0] = y0[0]; Ai[1] = y1[0]; Ai[2] = y2[0];
+        Ai[3] = y0[1]; Ai[4] = y1[1]; Ai[5] = y2[1];
+        Ai[6] = y0[2]; Ai[7] = y1[2]; Ai[8] = y2[2];
+        return 0;
+    }
+    double *T = (double *)malloc(sizeof(double) * n * n);
+    int *piv = (int *)malloc(sizeof(int) * n);
+    memcpy(T, A, sizeof(double) * n * n);
+    int rc = lu_factor(n, T, piv);
+    if (rc == 0)
+        for (int j = 0; j < n; j++) {
+            double *col = Ai + n * j;
+            for (int i = 0; i < n; i++) col[i] = (i == j) ? 1.0 : 0.0;
+            lu_solve(n, T, piv, col);
+        }
+    free(T); free(piv);
+    return rc;
+}
+
+/* StaticArrays solve.jl: 1x1 b/a; 2x2, 3x3 Cramer with the published operation order; else LU */
+int bo_solve(int n, const double *a, const double *b, double *x)
+{
+#define AA(i, j) a[(i - 1) + n * (j - 1)]
+    if (n == 1) { x[0] = b[0] / a[0]; return 0; }
+    if (n == 2) {
+        double d = bo_det(2, a);
+        double x0 = (AA(2, 2) * b[0] - AA(1, 2) * b[1]) / d;
+        double x1 = (AA(1, 1) * b[1] - AA(2, 1) * b[0]) / d;
+        x[0] = x0; x[1] = x1;
+        return 0;
+    }
+    if (n == 3) {
+        double d = bo_det(3, a);
+        double x0 = ((AA(2, 2) * AA(3, 3) - AA(2, 3) * AA(3, 2)) * b[0] + (AA(1, 3) * AA(3, 2) - AA(1, 2) * AA(3, 3)) * b[1] +
+                     (AA(1, 2) * AA(2, 3) - AA(1, 3) * AA(2, 2)) * b[2]) / d;
+        double x1 = ((AA(2, 3) * AA(3, 1) - AA(2, 1) * AA(3, 3)) * b[0] + (AA(1, 1) * AA(3, 3) - AA(1, 3) * AA(3, 1)) * b[1] +
+                     (AA(1, 3) * AA(2, 1) - AA(1, 1) * AA(2, 3)) * b[2]) / d;
+        double x2 = ((AA(2, 1) * AA(3, 2) - AA(2, 2) * AA(3, 1)) * b[0] + (AA(1, 2) * AA(3, 1) - AA(1, 1) * AA(3, 2)) * b[1] +
+                     (AA(1, 1) * AA(2, 2) - AA(1, 2) * AA(2, 1)) * b[2]) / d;
+        x[0] = x0; x[1] = x1; x[2] = x2;
+        return 0;
+    }
+#undef AA
+    double *T = (double *)malloc(sizeof(double) * n * n);
+    int *piv = (int *)malloc(sizeof(int) * n);
+    memcpy(T, a, sizeof(double) * n * n);
+    int rc = lu_factor(n, T, piv);
+    if (rc == 0) { for (int i = 0; i < n; i++) x[i] = b[i]; lu_solve(n, T, piv, x); }
+    free(T); free(piv);
+    return rc;
+}
+
+/* src/gaussian.jl:66-75  logpdf of a centred Gaussian:  S = chol(Sigma).L;
+ *   -((norm(S\x))^2 + 2*sumlogdiag(S) + d*log(2pi))/2 ; scalar: -(x^2/S + log(S) + log(2pi))/2 */
+double bo_logpdfnormal(int d, const double *x, const double *Sigma)
+{
+    const double log2pi = log(2 * M_PI);
+    if (d == 1) return -(x[0] * x[0] / Sigma[0] + log(Sigma[0]) + log2pi) / 2;
+    double S[D2], y[BO_MAXD];
+    memset(S, 0, sizeof(double) * d * d);
+    for (int j = 0; j < d; j++) { /* lower Cholesky, column by column */
+        double s = Sigma[j + d * j];
+        for (int k = 0; k < j; k++) s -= S[j + d * k] * S[j + d * k];
+        S[j + d * j] = sqrt(s);
+        for (int i = j + 1; i < d; i++) {
+            double t = Sigma[i + d * j];
+            for (int k = 0; k < j; k++) t -= S[i + d * k] * S[j + d * k];
+            S[i + d * j] = t / S[j + d * j];
+        }
+    }
+    for (int i = 0; i < d; i++) { /* forward substitution S\x */
+        double t = x[i];
+        for (int k = 0; k < i; k++) t -= S[i + d * k] * y[k];
+        y[i] = t / S[i + d * i];
+    }
+    double n2 = 0, sl = 0;
+    for (int i = 0; i < d; i++) { n2 += y[i] * y[i]; sl += log(S[i + d * i]); }
+    double nrm = sqrt(n2);
+    return -(nrm * nrm + 2 * sl + d * log2pi) / 2;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * RNG, specification "bhip-philox-v1" (DESIGN.md).  The reference draws from Julia's global
+ * randn (src/wiener.jl:31,44,55) which cannot be reproduced outside Julia; this is
+ * the counter-based replacement shared, by specification, with the HIP kernels.
+ * ------------------------------------------------------------------------------------------ */
+void bo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* deterministic natural log for x in (0,1] built from +,-,*,/,fma only (bit-identical on CPU and
+ * GPU): x = 2^e * m, m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(s), s = (m-1)/(m+1). */
+BO_CLONES double bo_log(double x)
+{
+    union { double d; uint64_t u; } v; v.d = x;
+    int e = (int)((v.u >> 52) & 0x7ff) - 1023;
+    v.u = (v.u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = v.d;
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    double s = (m - 1.0) / (m + 1.0);
+    double z = s * s;
+    double p = 1.0 / 23.0;
+    p = fma(p, z, 1.0 / 21.0);
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    double t = s * z;                 /* s^3 */
+    double lm = fma(t, p, s);         /* atanh(s) */
+    lm = lm + lm;
+    double de = (double)e;
+    /* ln2 split: hi has 32 significant bits so de*hi is exact */
+    return fma(de, 6.93147180369123816490e-01, fma(de, 1.90821492927058770002e-10, lm));
+}
+
+/* deterministic sin/cos(2*pi*u), u in [0,1): quadrant q = round(4u), f = u - q/4 exact,
+ * theta = 2pi*f in [-pi/4, pi/4], Taylor polynomials evaluated with fma. */
+BO_CLONES void bo_sincos2pi(double u, double *sn, double *cs)
+{
+    double q = floor(fma(u, 4.0, 0.5));
+    double f = fma(q, -0.25, u);
+    double th = f * 6.283185307179586;
+    double z = th * th;
+    double ps = -1.0 / 1307674368000.0;          /* -1/15! */
+    ps = fma(ps, z, 1.0 / 6227020800.0);         /*  1/13! */
+    ps = fma(ps, z, -1.0 / 39916800.0);          /* -1/11! */
+    ps = fma(ps, z, 1.0 / 362880.0);             /*  1/9!  */
+    ps = fma(ps, z, -1.0 / 5040.0);              /* -1/7!  */
+    ps = fma(ps, z, 1.0 / 120.0);                /*  1/5!  */
+    ps = fma(ps, z, -1.0 / 6.0);                 /* -1/3!  */
+    double s0 = fma(th * z, ps, th);
+    double pc = 1.0 / 20922789888000.0;          /*  1/16! */
+    pc = fma(pc, z, -1.0 / 87178291200.0);       /* -1/14! */
+    pc = fma(pc, z, 1.0 / 479001600.0);          /*  1/12! */
+    pc = fma(pc, z, -1.0 / 3628800.0);           /* -1/10! */
+    pc = fma(pc, z, 1.0 / 40320.0);              /*  1/8!  */
+    pc = fma(pc, z, -1.0 / 720.0);               /* -1/6!  */
+    pc = fma(pc, z, 1.0 / 24.0);                 /*  1/4!  */
+    pc = fma(pc, z, -0.5);                       /* -1/2!  */
+    double c0 = fma(z, pc, 1.0);
+    int qi = (int)q & 3;
+    double s, c;
+    if (qi == 0) { s = s0; c = c0; }
+    else if (qi == 1) { s = c0; c = -s0; }
+    else if (qi == 2) { s = -s0; c = -c0; }
+    else { s = -c0; c = s0; }
+    *sn = s; *cs = c;
+}
+
+/* one Philox block -> two standard normals (Box-Muller).  counter = (path, stream, iter, block),
+ * key = (seed_lo, seed_hi); stream 0 = Wiener normals, 1 = accept uniforms. */
+BO_CLONES void bo_normal_pair(uint64_t seed, uint32_t path, uint32_t iter, uint32_t block, double z[2])
+{
+    uint32_t ctr[4] = {path, 0u, iter, block}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, r[4];
+    bo_philox4x32_10(ctr, key, r);
+    uint64_t a = ((uint64_t)r[1] << 32) | r[0], b = ((uint64_t)r[3] << 32) | r[2];
+    double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;   /* (0,1] */
+    double u2 = (double)(b >> 11) * 0x1.0p-53;         /* [0,1) */
+    double rad = sqrt(-2.0 * bo_log(u1));
+    double s, c;
+    bo_sincos2pi(u2, &s, &c);
+    z[0] = rad * c;
+    z[1] = rad * s;
+}
+
+double bo_uniform_accept(uint64_t seed, uint32_t path, uint32_t iter)
+{
+    uint32_t ctr[4] = {path, 1u, iter, 0u}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, r[4];
+    bo_philox4x32_10(ctr, key, r);
+    uint64_t a = ((uint64_t)r[1] << 32) | r[0];
+    return (double)((a >> 11) + 1) * 0x1.0p-53;
+}
+
+void bo_normals(uint64_t seed, uint32_t path, uint32_t iter, int n0, int n, double *z)
+{
+    double pr[2]; long have = -1;
+    for (int j = 0; j < n; j++) {
+        int idx = n0 + j;
+        if ((idx >> 1) != have) { bo_normal_pair(seed, path, iter, (uint32_t)(idx >> 1), pr); have = idx >> 1; }
+        z[j] = pr[idx & 1];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * target models: b(t,x,P), _scale(dw, sigma(t,x,P)), a(t,x,P)
+ * ------------------------------------------------------------------------------------------ */
+int bo_model_dims(int model, int d_hint, int *d, int *mp)
+{
+    switch (model) {
+    case BO_MODEL_WIENER: *d = d_hint; *mp = d_hint; return 0;
+    case BO_MODEL_OU: *d = 1; *mp = 1; return 0;
+    case BO_MODEL_LINPRO: *d = d_hint; *mp = d_hint; return 0;
+    case BO_MODEL_FHN: *d = 2; *mp = 1; return 0;
+    case BO_MODEL_NCLAR: *d = 3; *mp = 1; return 0;
+    case BO_MODEL_INTDIFF: *d = 2; *mp = 1; return 0;
+    case BO_MODEL_LORENZ: *d = 3; *mp = 3; return 0;
+    case BO_MODEL_FHN2: *d = 2; *mp = 2; return 0;
+    case BO_MODEL_PENDULUM: *d = 2; *mp = 1; return 0;
+    }
+    return -1;
+}
+
+void bo_b(int model, int d, const double *p, double t, const double *x, double *o)
+{
+    (void)t;
+    switch (model) {
+    case BO_MODEL_WIENER: /* src/wiener.jl:143 b = 0 */
+        for (int k = 0; k < d; k++) o[k] = 0.0;
+        break;
+    case BO_MODEL_OU: /* test/guip.jl:21, README.md:75  b = -beta*x */
+        o[0] = -p[0] * x[0];
+        break;
+    case BO_MODEL_LINPRO: { /* src/linpro.jl:80  b = P.B*(x .- P.mu) */
+        double xm[BO_MAXD];
+        const double *B = p, *mu = p + d * d;
+        for (int k = 0; k < d; k++) xm[k] = x[k] - mu[k];
+        mv(d, d, B, xm, o);
+        break; }
+    case BO_MODEL_FHN: /* partialbridge_fitzhugh.jl:44  ((x1-x2-x1^3+s)/eps, gamma*x1-x2+beta) */
+        o[0] = (x[0] - x[1] - x[0] * x[0] * x[0] + p[1]) / p[0];
+        o[1] = p[2] * x[0] - x[1] + p[3];
+        break;
+    case BO_MODEL_NCLAR: /* partialbridge_nclar.jl:58  (x2, x3, -alpha*sin(omega*x3)) */
+        o[0] = x[1]; o[1] = x[2]; o[2] = -p[0] * sin(p[1] * x[2]);
+        break;
+    case BO_MODEL_INTDIFF: /* test/partialbridge.jl:11-12  (x2, -(x2+sin(x2)) + 1/2) */
+        o[0] = x[1]; o[1] = -(x[1] + sin(x[1])) + 0.5;
+        break;
+    case BO_MODEL_LORENZ: /* src/Models.jl:47 */
+        o[0] = p[0] * (x[1] - x[0]);
+        o[1] = x[0] * (p[1] - x[2]) - x[1];
+        o[2] = x[0] * x[1] - p[2] * x[2];
+        break;
+    case BO_MODEL_FHN2: /* src/Models.jl:18  (eps\(x1 - x1^3 - x2 + s), gamma*x1 - x2 + beta) */
+        o[0] = (x[0] - x[0] * x[0] * x[0] - x[1] + p[1]) / p[0];
+        o[1] = p[2] * x[0] - x[1] + p[3];
+        break;
+    case BO_MODEL_PENDULUM: /* src/Models.jl:79  (x2, -theta2*sin(x1)) */
+        o[0] = x[1]; o[1] = -p[0] * sin(x[0]);
+        break;
+    }
+}
+
+/* _scale(dw, sigma(t,x,P)) = sigma*dw, src/euler.jl:3-4 */
+void bo_sigma_apply(int model, int d, int mp, const double *p, double t, const double *x,
+                    const double *dw, double *o)
+{
+    (void)t; (void)x; (void)mp;
+    switch (model) {
+    case BO_MODEL_WIENER: for (int k = 0; k < d; k++) o[k] = dw[k]; break;  /* sigma = I */
+    case BO_MODEL_OU: o[0] = p[1] * dw[0]; break;
+    case BO_MODEL_LINPRO: mv(d, d, p + d * d + d, dw, o); break;            /* P.sigma*dw */
+    case BO_MODEL_FHN: o[0] = 0.0 * dw[0]; o[1] = p[4] * dw[0]; break;      /* R2(0, sigma)*dw */
+    case BO_MODEL_NCLAR: o[0] = 0.0 * dw[0]; o[1] = 0.0 * dw[0]; o[2] = p[2] * dw[0]; break;
+    case BO_MODEL_INTDIFF: o[0] = 0.0 * dw[0]; o[1] = p[0] * dw[0]; break;
+    case BO_MODEL_LORENZ: for (int k = 0; k < 3; k++) o[k] = p[3 + k] * dw[k]; break;  /* SDiagonal */
+    case BO_MODEL_FHN2: o[0] = p[4] * dw[0]; o[1] = p[5] * dw[1]; break;
+    case BO_MODEL_PENDULUM: o[0] = 0.0 * dw[0]; o[1] = p[1] * dw[0]; break;
+    }
+}
+
+/* sigma as a d x mp matrix (for a = sigma*sigma') */
+static void model_sigma_mat(int model, int d, int mp, const double *p, double *S)
+{
+    memset(S, 0, sizeof(double) * d * mp);
+    switch (model) {
+    case BO_MODEL_WIENER: for (int k = 0; k < d; k++) S[k + d * k] = 1.0; break;
+    case BO_MODEL_OU: S[0] = p[1]; break;
+    case BO_MODEL_LINPRO: memcpy(S, p + d * d + d, sizeof(double) * d * d); break;
+    case BO_MODEL_FHN: S[1] = p[4]; break;
+    case BO_MODEL_NCLAR: S[2] = p[2]; break;
+    case BO_MODEL_INTDIFF: S[1] = p[0]; break;
+    case BO_MODEL_LORENZ: for (int k = 0; k < 3; k++) S[k + 3 * k] = p[3 + k]; break;
+    case BO_MODEL_FHN2: S[0] = p[4]; S[3] = p[5]; break;
+    case BO_MODEL_PENDULUM: S[1] = p[1]; break;
+    }
+}
+
+/* a(t,x,P): src/types.jl:32 fallback outer(sigma) = sigma*sigma'; OU: sigma^2 (test/guip.jl:23);
+ * LinPro: P.a = sigma*sigma' (src/linpro.jl:72,84) */
+void bo_a(int model, int d, int mp, const double *p, double t, const double *x, double *A)
+{
+    (void)t; (void)x;
+    double S[D2];
+    model_sigma_mat(model, d, mp, p, S);
+    mmt(d, mp, d, S, S, A);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * auxiliary linear processes
+ * ------------------------------------------------------------------------------------------ */
+static double fhn_uv(const double *p, double t)
+{ /* partialbridge_fitzhugh.jl:70-73 */
+    double lam = (t - p[5]) / (p[7] - p[5]);
+    return p[8] * lam + p[6] * (1 - lam);
+}
+void bo_aux_B(int aux, int d, const double *p, double t, double *B)
+{
+    if (aux == BO_AUX_FHN_STARTEND) { /* :103  [1/eps-3*uv^2/eps  -1/eps; gamma -1.0] */
+        double uv = fhn_uv(p, t);
+        B[0] = 1 / p[0] - 3 * (uv * uv) / p[0]; B[2] = -1 / p[0];
+        B[1] = p[2]; B[3] = -1.0;
+        return;
+    }
+    memcpy(B, p, sizeof(double) * d * d);
+}
+void bo_aux_beta(int aux, int d, const double *p, double t, double *beta)
+{
+    if (aux == BO_AUX_FHN_STARTEND) { /* :104  (s/eps + 2*uv^3/eps, beta) */
+        double uv = fhn_uv(p, t);
+        beta[0] = p[1] / p[0] + 2 * (uv * uv * uv) / p[0];
+        beta[1] = p[3];
+        return;
+    }
+    if (aux == BO_AUX_LINPRO) { /* src/linpro.jl:79  beta = -P.B*P.mu */
+        double nB[D2];
+        for (int k = 0; k < d * d; k++) nB[k] = -p[k];
+        mv(d, d, nB, p + d * d, beta);
+        return;
+    }
+    memcpy(beta, p + d * d, sizeof(double) * d);
+}
+void bo_aux_sigma(int aux, int d, int mp, const double *p, double t, double *S)
+{
+    (void)t;
+    if (aux == BO_AUX_FHN_STARTEND) { S[0] = 0.0; S[1] = p[4]; return; }
+    memcpy(S, p + d * d + d, sizeof(double) * d * mp);
+}
+void bo_aux_a(int aux, int d, int mp, const double *p, double t, double *A)
+{ /* a(t,Pt) = sigma(t,Pt)*sigma(t,Pt)'  (partialbridge_fitzhugh.jl:115; linpro.jl:72) */
+    double S[D2];
+    bo_aux_sigma(aux, d, mp, p, t, S);
+    mmt(d, mp, d, S, S, A);
+}
+/* b(t,x,Pt): affine processes B(t)*x + beta(t) (partialbridge_fitzhugh.jl:114); LinPro B*(x-mu) */
+void bo_aux_b(int aux, int d, const double *p, double t, const double *x, double *o)
+{
+    if (aux == BO_AUX_LINPRO) {
+        double xm[BO_MAXD];
+        for (int k = 0; k < d; k++) xm[k] = x[k] - p[d * d + k];
+        mv(d, d, p, xm, o);
+        return;
+    }
+    double B[D2], beta[BO_MAXD];
+    bo_aux_B(aux, d, p, t, B);
+    bo_aux_beta(aux, d, p, t, beta);
+    mv(d, d, B, x, o);
+    for (int k = 0; k < d; k++) o[k] = o[k] + beta[k];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Ralston-3 step  src/ode.jl:44-49
+ *   k1=f(t,y); k2=f(t+1/2*dt, y+1/2*dt*k1); k3=f(t+3/4*dt, y+3/4*dt*k2);
+ *   y + dt*(2/9*k1 + 1/3*k2 + 4/9*k3)
+ * ------------------------------------------------------------------------------------------ */
+typedef void (*rhs_fn)(double t, const double *y, double *k, void *ctx);
+static void kernelr3(rhs_fn f, double t, const double *y, double dt, int n, void *ctx, double *out)
+{
+    double k1[D2], k2[D2], k3[D2], y2[D2];
+    f(t, y, k1, ctx);
+    double h2 = 1.0 / 2 * dt, h34 = 3.0 / 4 * dt;
+    for (int i = 0; i < n; i++) y2[i] = y[i] + h2 * k1[i];
+    f(t + h2, y2, k2, ctx);
+    for (int i = 0; i < n; i++) y2[i] = y[i] + h34 * k2[i];
+    f(t + h34, y2, k3, ctx);
+    for (int i = 0; i < n; i++) out[i] = y[i] + dt * (2.0 / 9 * k1[i] + 1.0 / 3 * k2[i] + 4.0 / 9 * k3[i]);
+}
+
+typedef struct { int aux, d, mp, m; const double *apar; const double *L; } ode_ctx;
+
+/* src/gode.jl:3  _dHinv(t,K,P) = B*K + K*B' - a */
+static void rhs_dHinv(double t, const double *K, double *out, void *vc)
+{
+    ode_ctx *c = (ode_ctx *)vc; int d = c->d;
+    double B[D2], A[D2], BK[D2], KBt[D2];
+    bo_aux_B(c->aux, d, c->apar, t, B);
+    bo_aux_a(c->aux, d, c->mp, c->apar, t, A);
+    mm(d, d, d, B, K, BK);
+    mmt(d, d, d, K, B, KBt);
+    for (int i = 0; i < d * d; i++) out[i] = BK[i] + KBt[i] - A[i];
+}
+/* src/gode.jl:4  _dK(t,K,P) = B*K + K*B' + a */
+static void rhs_dK(double t, const double *K, double *out, void *vc)
+{
+    ode_ctx *c = (ode_ctx *)vc; int d = c->d;
+    double B[D2], A[D2], BK[D2], KBt[D2];
+    bo_aux_B(c->aux, d, c->apar, t, B);
+    bo_aux_a(c->aux, d, c->mp, c->apar, t, A);
+    mm(d, d, d, B, K, BK);
+    mmt(d, d, d, K, B, KBt);
+    for (int i = 0; i < d * d; i++) out[i] = BK[i] + KBt[i] + A[i];
+}
+/* src/gode.jl:2  _F(t,x,P) = B*x + beta */
+static void rhs_F(double t, const double *x, double *out, void *vc)
+{
+    ode_ctx *c = (ode_ctx *)vc; int d = c->d;
+    double B[D2], beta[BO_MAXD];
+    bo_aux_B(c->aux, d, c->apar, t, B);
+    bo_aux_beta(c->aux, d, c->apar, t, beta);
+    mv(d, d, B, x, out);
+    for (int i = 0; i < d; i++) out[i] = out[i] + beta[i];
+}
+/* src/gode.jl:5  _dPhi(t,Phi,P) = B*Phi */
+static void rhs_dPhi(double t, const double *Phi, double *out, void *vc)
+{
+    ode_ctx *c = (ode_ctx *)vc; int d = c->d;
+    double B[D2];
+    bo_aux_B(c->aux, d, c->apar, t, B);
+    mm(d, d, d, B, Phi, out);
+}
+/* src/guip.jl:202  _traceB(t,x,P) = tr(B(t,P)) */
+static void rhs_traceB(double t, const double *y, double *out, void *vc)
+{
+    (void)y;
+    ode_ctx *c = (ode_ctx *)vc; int d = c->d;
+    double B[D2];
+    bo_aux_B(c->aux, d, c->apar, t, B);
+    double s = B[0];
+    for (int i = 1; i < d; i++) s += B[i + d * i];
+    out[0] = s;
+}
+/* the process drift itself, b(t,x,P) of a LinPro, used by test/linprobridge.jl:22 */
+static void rhs_b(double t, const double *x, double *out, void *vc)
+{
+    ode_ctx *c = (ode_ctx *)vc;
+    bo_aux_b(c->aux, c->d, c->apar, t, x, out);
+}
+
+/* GuidedBridge constructor src/guip.jl:172-180: gpHinv!(Hd, Pt, hT); gpV!(V, Pt, v)
+ * via _solvebackward!(R3, ...) src/ode.jl:88-97 */
+void bo_gp_hv(const double *tt, int N, int d, int mp, int aux, const double *apar,
+              const double *v, const double *hT, double *Hd, double *V)
+{
+    ode_ctx c = {aux, d, mp, 0, apar, 0};
+    int dd = d * d;
+    double y[D2];
+    for (int k = 0; k < dd; k++) y[k] = hT ? hT[k] : 0.0;
+    memcpy(Hd + (size_t)(N - 1) * dd, y, sizeof(double) * dd);
+    for (int i = N - 2; i >= 0; i--) {
+        kernelr3(rhs_dHinv, tt[i + 1], y, tt[i] - tt[i + 1], dd, &c, y);
+        memcpy(Hd + (size_t)i * dd, y, sizeof(double) * dd);
+    }
+    double w[BO_MAXD];
+    memcpy(w, v, sizeof(double) * d);
+    memcpy(V + (size_t)(N - 1) * d, w, sizeof(double) * d);
+    for (int i = N - 2; i >= 0; i--) {
+        kernelr3(rhs_F, tt[i + 1], w, tt[i] - tt[i + 1], d, &c, w);
+        memcpy(V + (size_t)i * d, w, sizeof(double) * d);
+    }
+}
+
+/* forward R3 integration, src/ode.jl:178-184 solve(::R3, F, tt, x0, P);
+ * what: 0 _F (gpmu), 1 _dK (gpK), 2 _dPhi (fundamental_matrix), 3 process drift b, 4 _dHinv */
+double bo_r3_forward(const double *tt, int N, int d, int mp, int aux, const double *apar, int what,
+                     const double *y0, int ny, double *yT)
+{
+    ode_ctx c = {aux, d, mp, 0, apar, 0};
+    rhs_fn f = what == 0 ? rhs_F : what == 1 ? rhs_dK : what == 2 ? rhs_dPhi : what == 3 ? rhs_b : rhs_dHinv;
+    double y[D2];
+    memcpy(y, y0, sizeof(double) * ny);
+    for (int i = 1; i < N; i++) kernelr3(f, tt[i - 1], y, tt[i] - tt[i - 1], ny, &c, y);
+    memcpy(yT, y, sizeof(double) * ny);
+    return y[0];
+}
+
+/* traceB(tt,P) = solve(R3(), _traceB, tt, 0.0, P)  src/guip.jl:203 */
+double bo_traceB(const double *tt, int N, int d, int aux, const double *apar)
+{
+    ode_ctx c = {aux, d, 0, 0, apar, 0};
+    double y = 0.0;
+    for (int i = 1; i < N; i++) kernelr3(rhs_traceB, tt[i - 1], &y, tt[i] - tt[i - 1], 1, &c, &y);
+    return y;
+}
+
+/* partialbridgeode!(::R3, t, L, Sigma, Lt, Mt, mut, P)  src/partialbridge.jl:1-22 */
+static void rhs_L(double t, const double *L, double *out, void *vc)
+{ /* (t,y,P) -> -y*B(t,P) */
+    ode_ctx *c = (ode_ctx *)vc; int d = c->d, m = c->m;
+    double B[D2], nL[D2];
+    bo_aux_B(c->aux, d, c->apar, t, B);
+    for (int i = 0; i < m * d; i++) nL[i] = -L[i];
+    mm(m, d, d, nL, B, out);
+}
+static void rhs_Mplus(double t, const double *y, double *out, void *vc)
+{ /* (t,y,(L,P)) -> -outer(L*sigma(t,P)) */
+    (void)y;
+    ode_ctx *c = (ode_ctx *)vc; int d = c->d, m = c->m, mp = c->mp;
+    double S[D2], LS[D2], O[D2];
+    bo_aux_sigma(c->aux, d, mp, c->apar, t, S);
+    mm(m, d, mp, c->L, S, LS);
+    mmt(m, mp, m, LS, LS, O);
+    for (int i = 0; i < m * m; i++) out[i] = -O[i];
+}
+static void rhs_mu(double t, const double *y, double *out, void *vc)
+{ /* (t,y,(L,P)) -> -L*beta(t,P) */
+    (void)y;
+    ode_ctx *c = (ode_ctx *)vc; int d = c->d, m = c->m;
+    double beta[BO_MAXD], nL[D2];
+    bo_aux_beta(c->aux, d, c->apar, t, beta);
+    for (int i = 0; i < m * d; i++) nL[i] = -c->L[i];
+    mv(m, d, nL, beta, out);
+}
+void bo_partialbridge_ode(const double *tt, int N, int d, int mp, int m, int aux, const double *apar,
+                          const double *L0, const double *Sigma, double *Lt, double *Mt, double *mut)
+{
+    double L[D2], Mp[D2], mu[BO_MAXD], Mi[D2];
+    ode_ctx c = {aux, d, mp, m, apar, L};
+    memcpy(L, L0, sizeof(double) * m * d);
+    memcpy(Mp, Sigma, sizeof(double) * m * m);
+    for (int k = 0; k < m; k++) mu[k] = 0 * L0[k];              /* mu = 0*L[:,1] */
+    memcpy(Lt + (size_t)(N - 1) * m * d, L, sizeof(double) * m * d);
+    bo_inv(m, Sigma, Mi);                                       /* Mt[end] = inv(Sigma) (Inf if 0) */
+    memcpy(Mt + (size_t)(N - 1) * m * m, Mi, sizeof(double) * m * m);
+    memcpy(mut + (size_t)(N - 1) * m, mu, sizeof(double) * m);
+    for (int i = N - 2; i >= 0; i--) {
+        double dt = tt[i] - tt[i + 1];
+        kernelr3(rhs_L, tt[i + 1], L, dt, m * d, &c, L);        /* L first ...                   */
+        kernelr3(rhs_Mplus, tt[i + 1], Mp, dt, m * m, &c, Mp);  /* ... M+ and mu use the NEW L   */
+        kernelr3(rhs_mu, tt[i + 1], mu, dt, m, &c, mu);
+        memcpy(Lt + (size_t)i * m * d, L, sizeof(double) * m * d);
+        bo_inv(m, Mp, Mi);
+        memcpy(Mt + (size_t)i * m * m, Mi, sizeof(double) * m * m);
+        memcpy(mut + (size_t)i * m, mu, sizeof(double) * m);
+    }
+}
+
+/* updatenuH+C + partialbridgeodenuH!(::R3,...)  src/partialbridgenuH.jl:1-55; returns C */
+static void rhs_dHplus(double t, const double *y, double *out, void *vc)
+{ /* dH+(t,y,P) = B*y + (B*y)' - a */
+    ode_ctx *c = (ode_ctx *)vc; int d = c->d;
+    double B[D2], A[D2], By[D2];
+    bo_aux_B(c->aux, d, c->apar, t, B);
+    bo_aux_a(c->aux, d, c->mp, c->apar, t, A);
+    mm(d, d, d, B, y, By);
+    for (int j = 0; j < d; j++)
+        for (int i = 0; i < d; i++) out[i + d * j] = By[i + d * j] + By[j + d * i] - A[i + d * j];
+}
+double bo_partialbridge_nuH(const double *tt, int N, int d, int mp, int m, int aux, const double *apar,
+                            const double *L, const double *v, double eps, const double *Sigma,
+                            double *nut, double *Ht)
+{
+    ode_ctx c = {aux, d, mp, m, apar, L};
+    double Si[D2], LtSi[D2], H0[D2], Hp[D2], H[D2], nu[BO_MAXD], T1[D2], T2[D2];
+    /* updatenuH+ :1-9   H = L'*inv(Sigma)*L + eps*I ; H+ = inv(H) ; nu = H+*L'*inv(Sigma)*v */
+    bo_inv(m, Sigma, Si);
+    mtm(d, m, m, L, Si, LtSi);                 /* L' * inv(Sigma)       d x m */
+    mm(d, m, d, LtSi, L, H0);                  /* (L'*inv(Sigma)) * L   d x d */
+    for (int k = 0; k < d; k++) H0[k + d * k] = H0[k + d * k] + eps;
+    bo_inv(d, H0, Hp);
+    mmt(d, d, m, Hp, L, T1);                   /* H+ * L'               d x m */
+    mm(d, m, m, T1, Si, T2);                   /* (H+*L') * inv(Sigma)  d x m */
+    mv(d, m, T2, v, nu);
+    /* updateC :10-14   C = 0.5*dot(v, Sigma\v) + m/2*log(2pi) + 0.5*logdet(Sigma) */
+    double sv[BO_MAXD];
+    bo_solve(m, Sigma, v, sv);
+    double C = 0.0;
+    C += 0.5 * dotv(m, v, sv);
+    C += m / 2.0 * log(2 * M_PI) + 0.5 * log(bo_det(m, Sigma));
+    /* partialbridgeodenuH! :21-55 */
+    bo_inv(d, Hp, H);
+    memcpy(Ht + (size_t)(N - 1) * d * d, H, sizeof(double) * d * d);
+    memcpy(nut + (size_t)(N - 1) * d, nu, sizeof(double) * d);
+    for (int i = N - 2; i >= 0; i--) {
+        double dt = tt[i] - tt[i + 1];
+        kernelr3(rhs_dHplus, tt[i + 1], Hp, dt, d * d, &c, Hp);
+        /* F = H*nu ; C += dC(t[i+1], (F,H), P)*dt,
+         * dC = dot(beta,F) + 0.5*dot(F, a*F) - 0.5*tr(H*a)   (old H, old nu) */
+        double F[BO_MAXD], beta[BO_MAXD], A[D2], aF[BO_MAXD], HA[D2];
+        mv(d, d, H, nu, F);
+        bo_aux_beta(aux, d, apar, tt[i + 1], beta);
+        bo_aux_a(aux, d, mp, apar, tt[i + 1], A);
+        mv(d, d, A, F, aF);
+        mm(d, d, d, H, A, HA);
+        double tr = HA[0];
+        for (int k = 1; k < d; k++) tr += HA[k + d * k];
+        C += (dotv(d, beta, F) + 0.5 * dotv(d, F, aF) - 0.5 * tr) * dt;
+        kernelr3(rhs_F, tt[i + 1], nu, dt, d, &c, nu);
+        memcpy(nut + (size_t)i * d, nu, sizeof(double) * d);
+        bo_inv(d, Hp, H);
+        memcpy(Ht + (size_t)i * d * d, H, sizeof(double) * d * d);
+    }
+    return C;
+}
+
+/* PartialBridge!  src/partialbridgen!.jl:7-56: in-place R3! (src/ode!.jl:21-29) for
+ * nu' = b!(t,nu) (= B*nu+beta of the aux) and Sigma' = dP!(t,p) = B*p + (B*p)' - a, H = inv.(Sigma) */
+void bo_partialbridge_inplace(const double *tt, int N, int d, int mp, int m, int aux, const double *apar,
+                              const double *L, const double *v, double eps, const double *Sn,
+                              double *nut, double *Ht)
+{
+    ode_ctx c = {aux, d, mp, m, apar, L};
+    double G[D2], LtG[D2], H0[D2], S[D2], nu[BO_MAXD], T1[D2], T2[D2];
+    int zero = 1;
+    for (int k = 0; k < m * m; k++) if (Sn[k] != 0.0) zero = 0;
+    if (zero) { /* :17  Gnoise = inv(eps()*one(Sn)) */
+        memset(G, 0, sizeof(double) * m * m);
+        for (int k = 0; k < m; k++) G[k + m * k] = 1.0 / 2.220446049250313e-16;
+    } else bo_inv(m, Sn, G);
+    mtm(d, m, m, L, G, LtG);
+    mm(d, m, d, LtG, L, H0);
+    for (int k = 0; k < d; k++) H0[k + d * k] = H0[k + d * k] + eps;
+    bo_inv(d, H0, S);                           /* Sigma_t[end] = inv(L'*G*L + eps*I) */
+    mmt(d, d, m, S, L, T1);
+    mm(d, m, m, T1, G, T2);
+    mv(d, m, T2, v, nu);                        /* nu_t[end] = Sigma_t[end]*L'*G*v     */
+    double *St = (double *)malloc(sizeof(double) * (size_t)N * d * d);
+    memcpy(St + (size_t)(N - 1) * d * d, S, sizeof(double) * d * d);
+    memcpy(nut + (size_t)(N - 1) * d, nu, sizeof(double) * d);
+    for (int i = N - 2; i >= 0; i--) {
+        double dt = tt[i] - tt[i + 1];
+        kernelr3(rhs_F, tt[i + 1], nu, dt, d, &c, nu);
+        kernelr3(rhs_dHplus, tt[i + 1], S, dt, d * d, &c, S);
+        memcpy(nut + (size_t)i * d, nu, sizeof(double) * d);
+        memcpy(St + (size_t)i * d * d, S, sizeof(double) * d * d);
+    }
+    for (int i = 0; i < N; i++) bo_inv(d, St + (size_t)i * d * d, Ht + (size_t)i * d * d);  /* map!(inv, St, St) */
+    free(St);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * LOOP A  sample!(W, Wiener())  src/wiener.jl:24-35 (SVector), :50-58 (scalar):
+ *   W[1] = 0;  W[i] = W[i-1] + sqrt(tt[i]-tt[i-1])*randn()   (time-major, component-minor)
+ * ------------------------------------------------------------------------------------------ */
+void bo_wiener_sample(const double *tt, int N, int mp, uint64_t seed, uint32_t path, uint32_t iter,
+                      double *W)
+{
+    for (int j = 0; j < mp; j++) W[j] = 0.0;
+    double pr[2]; long have = -1;
+    for (int i = 1; i < N; i++) {
+        double rootdt = sqrt(tt[i] - tt[i - 1]);
+        for (int j = 0; j < mp; j++) {
+            int idx = (i - 1) * mp + j;
+            if ((idx >> 1) != have) { bo_normal_pair(seed, path, iter, (uint32_t)(idx >> 1), pr); have = idx >> 1; }
+            W[mp * i + j] = W[mp * (i - 1) + j] + rootdt * pr[idx & 1];
+        }
+    }
+}
+
+/* LOOP B (unguided)  solve!(::EulerMaruyama, Y, u, W, P)  src/euler.jl:135-152 */
+void bo_solve_em(int model, int d, int mp, const double *par, const double *tt, int N,
+                 const double *u, const double *W, double *X)
+{
+    double y[BO_MAXD], b[BO_MAXD], dw[BO_MAXD], s[BO_MAXD];
+    memcpy(y, u, sizeof(double) * d);
+    for (int i = 0; i < N - 1; i++) {
+        memcpy(X + (size_t)i * d, y, sizeof(double) * d);
+        bo_b(model, d, par, tt[i], y, b);
+        for (int j = 0; j < mp; j++) dw[j] = W[mp * (i + 1) + j] - W[mp * i + j];
+        bo_sigma_apply(model, d, mp, par, tt[i], y, dw, s);
+        double dt = tt[i + 1] - tt[i];
+        for (int k = 0; k < d; k++) y[k] = y[k] + b[k] * dt + s[k];
+    }
+    memcpy(X + (size_t)(N - 1) * d, y, sizeof(double) * d);     /* endpoint(y,P) = y :65 */
+}
+
+/* r((i,t),x,Po): src/guip.jl:193 | src/partialbridge.jl:57 | src/partialbridgenuH.jl:161 |
+ * src/partialbridgen!.jl:67-70   (i is 0-based here) */
+void bo_guided_r(const bo_proposal *P, int i, const double *x, double *r)
+{
+    int d = P->d, m = P->m;
+    if (P->kind == BO_GUIDE_HV) { /* Hd[i] \ (V[i] - x) */
+        double w[BO_MAXD];
+        for (int k = 0; k < d; k++) w[k] = P->V[(size_t)i * d + k] - x[k];
+        bo_solve(d, P->Hd + (size_t)i * d * d, w, r);
+    } else if (P->kind == BO_GUIDE_LMMU) { /* L[i]'*M[i]*(v - mu[i] - L[i]*x) */
+        const double *L = P->L + (size_t)i * m * d, *M = P->M + (size_t)i * m * m, *mu = P->mu + (size_t)i * m;
+        double Lx[BO_MAXD], q[BO_MAXD], LtM[D2];
+        mv(m, d, L, x, Lx);
+        for (int k = 0; k < m; k++) q[k] = P->v[k] - mu[k] - Lx[k];
+        mtm(d, m, m, L, M, LtM);
+        mv(d, m, LtM, q, r);
+    } else { /* H[i]*(nu[i] - x) */
+        double w[BO_MAXD];
+        for (int k = 0; k < d; k++) w[k] = P->nu[(size_t)i * d + k] - x[k];
+        mv(d, d, P->H + (size_t)i * d * d, w, r);
+    }
+}
+
+/* _b((i,t),x,Po): src/guip.jl:192 | src/partialbridge.jl:53-55 | src/partialbridgenuH.jl:157-159 |
+ * src/partialbridgen!.jl:59-63 */
+void bo_guided_drift(const bo_proposal *P, int i, const double *x, double *out)
+{
+    int d = P->d, m = P->m;
+    double b[BO_MAXD], A[D2], g[BO_MAXD];
+    double t = P->tt[i];
+    bo_b(P->model, d, P->par, t, x, b);
+    bo_a(P->model, d, P->mp, P->par, t, x, A);
+    if (P->kind == BO_GUIDE_LMMU) { /* ((a*L')*M)*(v - mu - L*x) */
+        const double *L = P->L + (size_t)i * m * d, *M = P->M + (size_t)i * m * m, *mu = P->mu + (size_t)i * m;
+        double Lx[BO_MAXD], q[BO_MAXD], aLt[D2], aLtM[D2];
+        mv(m, d, L, x, Lx);
+        for (int k = 0; k < m; k++) q[k] = P->v[k] - mu[k] - Lx[k];
+        mmt(d, d, m, A, L, aLt);
+        mm(d, m, m, aLt, M, aLtM);
+        mv(d, m, aLtM, q, g);
+    } else { /* a*(Hd\(V-x))  |  a*(H*(nu-x)) */
+        double r[BO_MAXD];
+        bo_guided_r(P, i, x, r);
+        mv(d, d, A, r, g);
+    }
+    for (int k = 0; k < d; k++) out[k] = b[k] + g[k];
+}
+
+/* LOOP B (guided)  solve!(::Euler, Y, u, W, P::Union{GuidedBridge,PartialBridge,PartialBridgeNuH})
+ * src/euler.jl:247-268 ; endpoint src/euler.jl:241-242 (GuidedBridge) / :65 */
+void bo_solve_guided(const bo_proposal *P, const double *u, const double *W, double *X)
+{
+    int d = P->d, mp = P->mp, N = P->N;
+    double y[BO_MAXD], b[BO_MAXD], dw[BO_MAXD], s[BO_MAXD];
+    memcpy(y, u, sizeof(double) * d);
+    for (int i = 0; i < N - 1; i++) {
+        memcpy(X + (size_t)i * d, y, sizeof(double) * d);
+        bo_guided_drift(P, i, y, b);
+        for (int j = 0; j < mp; j++) dw[j] = W[mp * (i + 1) + j] - W[mp * i + j];
+        bo_sigma_apply(P->model, d, mp, P->par, P->tt[i], y, dw, s);
+        double dt = P->tt[i + 1] - P->tt[i];
+        for (int k = 0; k < d; k++) y[k] = y[k] + b[k] * dt + s[k];
+    }
+    if (P->kind == BO_GUIDE_HV) { /* norm(Hd[end],1) < eps() ? V[end] : y */
+        double n1 = 0;
+        for (int k = 0; k < d * d; k++) n1 += fabs(P->Hd[(size_t)(N - 1) * d * d + k]);
+        if (n1 < 2.220446049250313e-16) memcpy(y, P->V + (size_t)(N - 1) * d, sizeof(double) * d);
+    }
+    memcpy(X + (size_t)(N - 1) * d, y, sizeof(double) * d);
+}
+
+/* LOOP C  llikelihood(::LeftRule, X, Po; skip)  constdiff branch only:
+ * src/guip.jl:429-438 | src/partialbridge.jl:67-77 | src/partialbridgenuH.jl:171-181 :
+ *     som += dot(_b(target) - _b(auxiliary), r) * (tt[i+1]-tt[i])
+ * src/partialbridgen!.jl:81-97 (PartialBridge!):
+ *     som += dot(bout, rout)*dt ; som -= dot(btout, rout)*dt */
+double bo_llikelihood(const bo_proposal *P, const double *X, int skip)
+{
+    int d = P->d, N = P->N;
+    double som = 0.0;
+    double r[BO_MAXD], bt[BO_MAXD], ba[BO_MAXD], df[BO_MAXD];
+    for (int i = 0; i < N - 1 - skip; i++) {
+        const double *x = X + (size_t)i * d;
+        double s = P->tt[i];
+        bo_guided_r(P, i, x, r);
+        bo_b(P->model, d, P->par, s, x, bt);
+        bo_aux_b(P->aux, d, P->apar, s, x, ba);
+        double dt = P->tt[i + 1] - P->tt[i];
+        if (P->kind == BO_GUIDE_NUH_INPLACE) {
+            som += dotv(d, bt, r) * dt;
+            som -= dotv(d, ba, r) * dt;
+        } else {
+            for (int k = 0; k < d; k++) df[k] = bt[k] - ba[k];
+            som += dotv(d, df, r) * dt;
+        }
+    }
+    return som;
+}
+
+static void mk_prop(bo_proposal *P, int kind, int N, int d, int mp, int m, int model, const double *par,
+                    int aux, const double *apar, const double *tt,
+                    const double *A1, const double *A2, const double *A3, const double *A4)
+{
+    memset(P, 0, sizeof(*P));
+    P->kind = kind; P->N = N; P->d = d; P->mp = mp; P->m = m; P->model = model; P->par = par;
+    P->aux = aux; P->apar = apar; P->tt = tt;
+    if (kind == BO_GUIDE_HV) { P->Hd = A1; P->V = A2; }
+    else if (kind == BO_GUIDE_LMMU) { P->L = A1; P->M = A2; P->mu = A3; P->v = A4; }
+    else { P->nu = A1; P->H = A2; }
+}
+
+void bo_solve_guided_flat(int kind, int N, int d, int mp, int m, int model, const double *par,
+                          int aux, const double *apar, const double *tt,
+                          const double *A1, const double *A2, const double *A3, const double *A4,
+                          const double *u, const double *W, double *X)
+{
+    bo_proposal P;
+    mk_prop(&P, kind, N, d, mp, m, model, par, aux, apar, tt, A1, A2, A3, A4);
+    bo_solve_guided(&P, u, W, X);
+}
+double bo_llikelihood_flat(int kind, int N, int d, int mp, int m, int model, const double *par,
+                           int aux, const double *apar, const double *tt,
+                           const double *A1, const double *A2, const double *A3, const double *A4,
+                           const double *X, int skip)
+{
+    bo_proposal P;
+    mk_prop(&P, kind, N, d, mp, m, model, par, aux, apar, tt, A1, A2, A3, A4);
+    return bo_llikelihood(&P, X, skip);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * pCN Metropolis-Hastings chain  project_partialbridge/partialbridge_fitzhugh.jl:125-176
+ *   init : W = sample(tt, Wiener()); solve!(Euler(), X, x0, W, Po); ll = llikelihood(X, Po, skip)
+ *   iter : sample!(W2); Wo = rho*W + sqrt(1-rho^2)*W2; solve!(Xo, Wo); llo = llikelihood(Xo)
+ *          if log(rand()) <= llo - ll: X<-Xo, W<-Wo, ll<-llo, acc+=1
+ * RNG: iteration `it` (1-based; 0 = initial draw) uses Philox stream (seed, path, it).
+ * ------------------------------------------------------------------------------------------ */
+static void mcmc_chain(const bo_proposal *P, const double *x0, double rho, int iters, int skip,
+                       uint64_t seed, uint32_t path, double *W, double *X, double *Wo, double *Xo,
+                       double *W2, double *ll_trace, int *acc_trace, bo_mcmc_result *res)
+{
+    int N = P->N, d = P->d, mp = P->mp;
+    bo_wiener_sample(P->tt, N, mp, seed, path, 0, W);
+    bo_solve_guided(P, x0, W, X);
+    double ll = bo_llikelihood(P, X, skip);
+    long acc = 0;
+    double sr = sqrt(1 - rho * rho);
+    for (int it = 1; it <= iters; it++) {
+        bo_wiener_sample(P->tt, N, mp, seed, path, (uint32_t)it, W2);
+        for (int k = 0; k < N * mp; k++) Wo[k] = rho * W[k] + sr * W2[k];
+        bo_solve_guided(P, x0, Wo, Xo);
+        double llo = bo_llikelihood(P, Xo, skip);
+        int accept = 0;
+        if (bo_log(bo_uniform_accept(seed, path, (uint32_t)it)) <= llo - ll) {
+            memcpy(X, Xo, sizeof(double) * (size_t)N * d);
+            memcpy(W, Wo, sizeof(double) * (size_t)N * mp);
+            ll = llo; accept = 1; acc += 1;
+        }
+        if (ll_trace) ll_trace[it - 1] = llo;
+        if (acc_trace) acc_trace[it - 1] = accept;
+    }
+    res->acc = acc; res->ll = ll;
+}
+
+void bo_mcmc_flat(int kind, int N, int d, int mp, int m, int model, const double *par,
+                  int aux, const double *apar, const double *tt,
+                  const double *A1, const double *A2, const double *A3, const double *A4,
+                  const double *x0, double rho, int iters, int skip, uint64_t seed, uint32_t path,
+                  double *W, double *X, double *ll_trace, int *acc_trace, bo_mcmc_result *res)
+{
+    bo_proposal P;
+    mk_prop(&P, kind, N, d, mp, m, model, par, aux, apar, tt, A1, A2, A3, A4);
+    double *Wo = (double *)malloc(sizeof(double) * (size_t)N * mp), *W2 = (double *)malloc(sizeof(double) * (size_t)N * mp);
+    double *Xo = (double *)malloc(sizeof(double) * (size_t)N * d);
+    mcmc_chain(&P, x0, rho, iters, skip, seed, path, W, X, Wo, Xo, W2, ll_trace, acc_trace, res);
+    free(Wo); free(W2); free(Xo);
+}
+
+double bo_ensemble_proposals(int kind, int N, int d, int mp, int m, int model, const double *par,
+                             int aux, const double *apar, const double *tt,
+                             const double *A1, const double *A2, const double *A3, const double *A4,
+                             const double *x0, int npaths, uint32_t path0, uint64_t seed, uint32_t iter,
+                             int threads, double *ll_out, double *Xlast_out)
+{
+    bo_proposal P;
+    mk_prop(&P, kind, N, d, mp, m, model, par, aux, apar, tt, A1, A2, A3, A4);
+#ifdef _OPENMP
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+        double *W = (double *)malloc(sizeof(double) * (size_t)N * mp), *X = (double *)malloc(sizeof(double) * (size_t)N * d);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int p = 0; p < npaths; p++) {
+            bo_wiener_sample(tt, N, mp, seed, path0 + (uint32_t)p, iter, W);   /* pass 1: sample!      */
+            if (kind == BO_GUIDE_NONE) bo_solve_em(model, d, mp, par, tt, N, x0, W, X);
+            else bo_solve_guided(&P, x0, W, X);                               /* pass 2: solve!       */
+            if (ll_out) ll_out[p] = kind == BO_GUIDE_NONE ? 0.0 : bo_llikelihood(&P, X, 0); /* pass 3 */
+            if (Xlast_out) memcpy(Xlast_out + (size_t)p * d, X + (size_t)(N - 1) * d, sizeof(double) * d);
+        }
+        free(W); free(X);
+    }
+    return (double)npaths * (N - 1);
+}
+
+double bo_ensemble_mcmc(int kind, int N, int d, int mp, int m, int model, const double *par,
+                        int aux, const double *apar, const double *tt,
+                        const double *A1, const double *A2, const double *A3, const double *A4,
+                        const double *x0, double rho, int iters, int nchains, uint32_t path0,
+                        uint64_t seed, int threads, double *ll_out, long *acc_out)
+{
+    bo_proposal P;
+    mk_prop(&P, kind, N, d, mp, m, model, par, aux, apar, tt, A1, A2, A3, A4);
+#ifdef _OPENMP
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+        size_t nw = (size_t)N * mp, nx = (size_t)N * d;
+        double *W = (double *)malloc(sizeof(double) * nw), *Wo = (double *)malloc(sizeof(double) * nw), *W2 = (double *)malloc(sizeof(double) * nw);
+        double *X = (double *)malloc(sizeof(double) * nx), *Xo = (double *)malloc(sizeof(double) * nx);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int p = 0; p < nchains; p++) {
+            bo_mcmc_result r;
+            mcmc_chain(&P, x0, rho, iters, 0, seed, path0 + (uint32_t)p, W, X, Wo, Xo, W2, 0, 0, &r);
+            if (ll_out) ll_out[p] = r.ll;
+            if (acc_out) acc_out[p] = r.acc;
+        }
+        free(W); free(Wo); free(W2); free(X); free(Xo);
+    }
+    return (double)nchains * (iters + 1) * (N - 1);
+}
+
+/* mcnext! src/mclog.jl:48-56 (vector of d-vectors, m2 = outer(delta, x - m)); scalar case :31-38 */
+void bo_mcnext(int n_entries, int d, double *mean, double *m2, long *n, const double *x)
+{
+    long nn = *n;
+    for (int i = 0; i < n_entries; i++) {
+        double delta[BO_MAXD];
+        double *mi = mean + (size_t)i * d, *m2i = m2 + (size_t)i * d * d;
+        const double *xi = x + (size_t)i * d;
+        for (int k = 0; k < d; k++) { delta[k] = xi[k] - mi[k]; mi[k] += delta[k] / (nn + 1); }
+        for (int c = 0; c < d; c++)
+            for (int r = 0; r < d; r++) m2i[r + d * c] += delta[r] * (xi[c] - mi[c]);
+    }
+    *n = nn + 1;
+}

@@ -1,0 +1,170 @@
+/*
+ * bridge_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE ONLY)
+ *
+ * A plain-C, single-threaded, statement-by-statement restatement of the guided-proposal hot
+ * path of mschauer/Bridge.jl v0.11.7 (Julia).  It exists so that the HIP kernels in
+ * bridge.jl_amd/csrc can be checked against the reference's algorithm.
+ *
+ *   ONLY tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *   The product (bridge.jl_amd/, include/bridgehip.h) never links, imports or calls it.
+ *
+ * PARITY STATUS (see DESIGN.md "Oracle"):
+ *   - The reference is Julia; no julia binary exists in the build image, so the reference itself
+ *     was never executed.  The oracle is pinned against the only stored vector the reference
+ *     holds for this path (docs/src/manual.md:59-77, W -> X for OU Euler-Maruyama), against the
+ *     closed-form identities its tests assert for the guide ODEs (test/VHK.jl, test/linpro.jl,
+ *     test/linprobridge.jl, test/partialbridge.jl, test/partialbridgenuH.jl) and against the
+ *     distribution-level importance-weight test (test/guip.jl:245-274).
+ *   - The reference stores NO guided-bridge path / llikelihood fixtures, and its noise comes from
+ *     Julia's global randn() (not reproducible outside Julia): bit-level parity of guided paths
+ *     with Bridge.jl itself is therefore "parity unpinned"; it is pinned only through the
+ *     identities above.  GPU-vs-oracle parity IS bit-level (same inputs, same operation order).
+ *   - StaticArrays/LinearAlgebra arithmetic (inv, \, det, * on SMatrix) is a third-party
+ *     dependency absent from /root/reference (Project.toml:31 compat "0.12, 1.0, 1.1", no
+ *     Manifest): its published small-matrix formulas are restated here (see bo_inv/bo_solve).
+ *
+ * Conventions: matrices are column-major like Julia (A[i + rows*j]); indices in comments are the
+ * reference's 1-based ones; every function cites the reference file:line it follows (paths
+ * relative to /root/reference).  Compile with -O2 -ffp-contract=off (Julia never contracts a*b+c).
+ */
+#ifndef BRIDGE_ORACLE_H
+#define BRIDGE_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BO_MAXD 32
+
+/* target models (parameter layouts are shared, by specification, with include/bridgehip.h) */
+enum {
+    BO_MODEL_WIENER = 0,      /* src/wiener.jl:143-167  b=0, sigma=I                     par: -            */
+    BO_MODEL_OU = 1,          /* test/guip.jl:8-26, README.md:69-77                       par: beta,sigma   */
+    BO_MODEL_LINPRO = 2,      /* src/linpro.jl:65-87                                      par: B,mu,sigma   */
+    BO_MODEL_FHN = 3,         /* project_partialbridge/partialbridge_fitzhugh.jl:36-46    par: eps,s,gamma,beta,sigma */
+    BO_MODEL_NCLAR = 4,       /* project_partialbridge/partialbridge_nclar.jl:52-61       par: alpha,omega,sigma */
+    BO_MODEL_INTDIFF = 5,     /* test/partialbridge.jl:7-15                               par: gamma        */
+    BO_MODEL_LORENZ = 6,      /* src/Models.jl:41-58, test/euler.jl:45-50                 par: th1,th2,th3,s1,s2,s3 */
+    BO_MODEL_FHN2 = 7,        /* src/Models.jl:9-20 (diagonal 2-d noise)                  par: eps,s,gamma,beta,s1,s2 */
+    BO_MODEL_PENDULUM = 8     /* src/Models.jl:69-88                                      par: theta2,gamma */
+};
+
+/* auxiliary (linear) processes  dX = (B(t)X + beta(t))dt + sigma(t)dW */
+enum {
+    BO_AUX_AFFINE = 0,        /* constant B,beta,sigma; drift evaluated as B*x+beta   par: B(d*d),beta(d),sigma(d*mp) */
+    BO_AUX_LINPRO = 1,        /* src/linpro.jl:65-87: drift B*(x-mu), beta=-B*mu      par: B(d*d),mu(d),sigma(d*mp)   */
+    BO_AUX_FHN_STARTEND = 2   /* partialbridge_fitzhugh.jl:58-73,102-105              par: eps,s,gamma,beta,sigma,t0,u,T,v */
+};
+
+/* proposal kinds (guide parametrisations) */
+enum {
+    BO_GUIDE_NONE = 0,
+    BO_GUIDE_HV = 1,          /* GuidedBridge      src/guip.jl:165-194        (Hdiamond, V)        */
+    BO_GUIDE_LMMU = 2,        /* PartialBridge     src/partialbridge.jl:33-58 (L, M, mu, v)        */
+    BO_GUIDE_NUH = 3,         /* PartialBridgeNuH  src/partialbridgenuH.jl:122-162 (nu, H)         */
+    BO_GUIDE_NUH_INPLACE = 4  /* PartialBridge!    src/partialbridgen!.jl:32-97 (nu, H; ll as two dots) */
+};
+
+/* ---- RNG (specification "bhip-philox-v1"; not part of the reference) ---- */
+void bo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+double bo_log(double x);                                  /* deterministic log, x in (0,1]        */
+void bo_sincos2pi(double u, double *s, double *c);        /* deterministic sin/cos(2*pi*u), [0,1) */
+void bo_normal_pair(uint64_t seed, uint32_t path, uint32_t iter, uint32_t block, double z[2]);
+double bo_uniform_accept(uint64_t seed, uint32_t path, uint32_t iter);
+/* fill z[0..n) with the normals n0..n0+n-1 of stream (seed,path,iter) */
+void bo_normals(uint64_t seed, uint32_t path, uint32_t iter, int n0, int n, double *z);
+
+/* ---- model / auxiliary evaluation ---- */
+int bo_model_dims(int model, int d_hint, int *d, int *mp);
+void bo_b(int model, int d, const double *par, double t, const double *x, double *out);
+void bo_sigma_apply(int model, int d, int mp, const double *par, double t, const double *x,
+                    const double *dw, double *out);
+void bo_a(int model, int d, int mp, const double *par, double t, const double *x, double *A);
+void bo_aux_B(int aux, int d, const double *apar, double t, double *B);
+void bo_aux_beta(int aux, int d, const double *apar, double t, double *beta);
+void bo_aux_sigma(int aux, int d, int mp, const double *apar, double t, double *sig);
+void bo_aux_a(int aux, int d, int mp, const double *apar, double t, double *A);
+void bo_aux_b(int aux, int d, const double *apar, double t, const double *x, double *out);
+
+/* ---- small dense linear algebra (StaticArrays formulas restated) ---- */
+double bo_det(int n, const double *A);
+int bo_inv(int n, const double *A, double *Ainv);
+int bo_solve(int n, const double *A, const double *b, double *x);
+double bo_logpdfnormal(int d, const double *x, const double *Sigma);
+
+/* ---- guide pre-computation (backward R3) ---- */
+void bo_gp_hv(const double *tt, int N, int d, int mp, int aux, const double *apar,
+              const double *v, const double *hT, double *Hd, double *V);
+void bo_partialbridge_ode(const double *tt, int N, int d, int mp, int m, int aux, const double *apar,
+                          const double *L, const double *Sigma, double *Lt, double *Mt, double *mut);
+double bo_partialbridge_nuH(const double *tt, int N, int d, int mp, int m, int aux, const double *apar,
+                            const double *L, const double *v, double eps, const double *Sigma,
+                            double *nut, double *Ht);
+void bo_partialbridge_inplace(const double *tt, int N, int d, int mp, int m, int aux, const double *apar,
+                              const double *L, const double *v, double eps, const double *Sigmanoise,
+                              double *nut, double *Ht);
+double bo_traceB(const double *tt, int N, int d, int aux, const double *apar);
+double bo_r3_forward(const double *tt, int N, int d, int mp, int aux, const double *apar, int what,
+                     const double *y0, int ny, double *yT);
+
+/* ---- the hot path, one path at a time (AoS like Vector{SVector}: X[i*d + k]) ---- */
+void bo_wiener_sample(const double *tt, int N, int mp, uint64_t seed, uint32_t path, uint32_t iter,
+                      double *W);
+void bo_solve_em(int model, int d, int mp, const double *par, const double *tt, int N,
+                 const double *u, const double *W, double *X);
+
+typedef struct {
+    int kind, N, d, mp, m;
+    int model; const double *par;
+    int aux; const double *apar;
+    const double *tt;
+    const double *Hd, *V;            /* HV   : N*d*d, N*d             */
+    const double *L, *M, *mu, *v;    /* LMMU : N*m*d, N*m*m, N*m, m   */
+    const double *nu, *H;            /* NUH  : N*d, N*d*d             */
+} bo_proposal;
+
+void bo_solve_guided(const bo_proposal *P, const double *u, const double *W, double *X);
+double bo_llikelihood(const bo_proposal *P, const double *X, int skip);
+void bo_guided_drift(const bo_proposal *P, int i, const double *x, double *out);
+void bo_guided_r(const bo_proposal *P, int i, const double *x, double *out);
+
+/* flat-argument wrappers for ctypes (arrays that do not apply may be NULL) */
+void bo_solve_guided_flat(int kind, int N, int d, int mp, int m, int model, const double *par,
+                          int aux, const double *apar, const double *tt,
+                          const double *A1, const double *A2, const double *A3, const double *A4,
+                          const double *u, const double *W, double *X);
+double bo_llikelihood_flat(int kind, int N, int d, int mp, int m, int model, const double *par,
+                           int aux, const double *apar, const double *tt,
+                           const double *A1, const double *A2, const double *A3, const double *A4,
+                           const double *X, int skip);
+
+/* ---- pCN Metropolis-Hastings chain (partialbridge_fitzhugh.jl:125-176) ---- */
+typedef struct { long acc; double ll; } bo_mcmc_result;
+void bo_mcmc_flat(int kind, int N, int d, int mp, int m, int model, const double *par,
+                  int aux, const double *apar, const double *tt,
+                  const double *A1, const double *A2, const double *A3, const double *A4,
+                  const double *x0, double rho, int iters, int skip, uint64_t seed, uint32_t path,
+                  double *W, double *X, double *ll_trace, int *acc_trace, bo_mcmc_result *res);
+
+/* ensemble drivers used by bench.py's cpu_baseline: `npaths` independent proposals / chains, the
+ * reference's four separate passes per proposal (sample!, pCN mix, solve!, llikelihood).
+ * Returns the number of path-steps performed.  threads<=1: single thread (Bridge.jl is
+ * single-threaded); threads>1: OpenMP over paths. */
+double bo_ensemble_proposals(int kind, int N, int d, int mp, int m, int model, const double *par,
+                             int aux, const double *apar, const double *tt,
+                             const double *A1, const double *A2, const double *A3, const double *A4,
+                             const double *x0, int npaths, uint32_t path0, uint64_t seed, uint32_t iter,
+                             int threads, double *ll_out, double *Xlast_out);
+double bo_ensemble_mcmc(int kind, int N, int d, int mp, int m, int model, const double *par,
+                        int aux, const double *apar, const double *tt,
+                        const double *A1, const double *A2, const double *A3, const double *A4,
+                        const double *x0, double rho, int iters, int nchains, uint32_t path0,
+                        uint64_t seed, int threads, double *ll_out, long *acc_out);
+
+/* ---- online statistics (src/mclog.jl:22-56,89-93) ---- */
+void bo_mcnext(int n_entries, int d, double *mean, double *m2, long *n, const double *x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

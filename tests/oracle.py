@@ -1,0 +1,376 @@
+"""ctypes binding of the CPU oracle (oracle/libbridge_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never from the product package (bridge.jl_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ODIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_SO = os.path.join(_ODIR, "libbridge_oracle.so")
+
+MODEL_WIENER, MODEL_OU, MODEL_LINPRO, MODEL_FHN, MODEL_NCLAR, MODEL_INTDIFF, MODEL_LORENZ, MODEL_FHN2, MODEL_PENDULUM = range(9)
+AUX_AFFINE, AUX_LINPRO, AUX_FHN_STARTEND = range(3)
+GUIDE_NONE, GUIDE_HV, GUIDE_LMMU, GUIDE_NUH, GUIDE_NUH_INPLACE = range(5)
+
+dp = C.POINTER(C.c_double)
+
+
+def _build():
+    src = os.path.join(_ODIR, "bridge_oracle.c")
+    if (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _ODIR, "-s"])
+
+
+def load():
+    _build()
+    lib = C.CDLL(_SO)
+    lib.bo_log.restype = C.c_double
+    lib.bo_log.argtypes = [C.c_double]
+    lib.bo_uniform_accept.restype = C.c_double
+    lib.bo_uniform_accept.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+    lib.bo_det.restype = C.c_double
+    lib.bo_logpdfnormal.restype = C.c_double
+    lib.bo_traceB.restype = C.c_double
+    lib.bo_r3_forward.restype = C.c_double
+    lib.bo_partialbridge_nuH.restype = C.c_double
+    lib.bo_llikelihood_flat.restype = C.c_double
+    lib.bo_ensemble_proposals.restype = C.c_double
+    lib.bo_ensemble_mcmc.restype = C.c_double
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib
+
+
+def _d(a):
+    """contiguous float64 array + pointer (None -> NULL)"""
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(dp)
+
+
+def cm(A):
+    """flatten a matrix (or stack of matrices, leading index = time) column-major per matrix"""
+    A = np.asarray(A, dtype=np.float64)
+    if A.ndim <= 1:
+        return np.ascontiguousarray(A)
+    if A.ndim == 2:
+        return np.ascontiguousarray(A.T).ravel()
+    return np.ascontiguousarray(np.swapaxes(A, -1, -2)).reshape(A.shape[0], -1)
+
+
+def uncm(a, r, c):
+    a = np.asarray(a)
+    if a.ndim == 1:
+        return a.reshape(c, r).T.copy()
+    return np.swapaxes(a.reshape(a.shape[0], c, r), -1, -2).copy()
+
+
+# ---- RNG ----
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().bo_philox4x32_10(c, k, o)
+    return [int(v) for v in o]
+
+
+def bo_log(x):
+    return lib().bo_log(C.c_double(x))
+
+
+def sincos2pi(u):
+    s, c = C.c_double(), C.c_double()
+    lib().bo_sincos2pi(C.c_double(u), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def normals(seed, path, it, n0, n):
+    z = np.empty(n)
+    lib().bo_normals(C.c_uint64(seed), C.c_uint32(path), C.c_uint32(it), C.c_int(n0), C.c_int(n), z.ctypes.data_as(dp))
+    return z
+
+
+def uniform_accept(seed, path, it):
+    return lib().bo_uniform_accept(C.c_uint64(seed), C.c_uint32(path), C.c_uint32(it))
+
+
+# ---- linear algebra ----
+def det(A):
+    A = np.atleast_2d(np.asarray(A, dtype=np.float64))
+    a, p = _d(cm(A))
+    return lib().bo_det(C.c_int(A.shape[0]), p)
+
+
+def inv(A):
+    A = np.atleast_2d(np.asarray(A, dtype=np.float64))
+    n = A.shape[0]
+    a, p = _d(cm(A))
+    o = np.empty(n * n)
+    lib().bo_inv(C.c_int(n), p, o.ctypes.data_as(dp))
+    return uncm(o, n, n)
+
+
+def solve(A, b):
+    A = np.atleast_2d(np.asarray(A, dtype=np.float64))
+    n = A.shape[0]
+    a, p = _d(cm(A))
+    bb, pb = _d(b)
+    o = np.empty(n)
+    lib().bo_solve(C.c_int(n), p, pb, o.ctypes.data_as(dp))
+    return o
+
+
+def logpdfnormal(x, Sigma):
+    x = np.atleast_1d(np.asarray(x, dtype=np.float64))
+    S = np.atleast_2d(np.asarray(Sigma, dtype=np.float64))
+    xx, px = _d(x)
+    ss, ps = _d(cm(S))
+    return lib().bo_logpdfnormal(C.c_int(len(x)), px, ps)
+
+
+# ---- models ----
+def b(model, d, par, t, x):
+    pp, p = _d(par)
+    xx, px = _d(x)
+    o = np.empty(d)
+    lib().bo_b(C.c_int(model), C.c_int(d), p, C.c_double(t), px, o.ctypes.data_as(dp))
+    return o
+
+
+def a(model, d, mp, par, t=0.0, x=None):
+    pp, p = _d(par)
+    xx, px = _d(np.zeros(d) if x is None else x)
+    o = np.empty(d * d)
+    lib().bo_a(C.c_int(model), C.c_int(d), C.c_int(mp), p, C.c_double(t), px, o.ctypes.data_as(dp))
+    return uncm(o, d, d)
+
+
+def aux_b(aux, d, apar, t, x):
+    pp, p = _d(apar)
+    xx, px = _d(x)
+    o = np.empty(d)
+    lib().bo_aux_b(C.c_int(aux), C.c_int(d), p, C.c_double(t), px, o.ctypes.data_as(dp))
+    return o
+
+
+def aux_B(aux, d, apar, t):
+    pp, p = _d(apar)
+    o = np.empty(d * d)
+    lib().bo_aux_B(C.c_int(aux), C.c_int(d), p, C.c_double(t), o.ctypes.data_as(dp))
+    return uncm(o, d, d)
+
+
+def aux_beta(aux, d, apar, t):
+    pp, p = _d(apar)
+    o = np.empty(d)
+    lib().bo_aux_beta(C.c_int(aux), C.c_int(d), p, C.c_double(t), o.ctypes.data_as(dp))
+    return o
+
+
+def aux_a(aux, d, mp, apar, t):
+    pp, p = _d(apar)
+    o = np.empty(d * d)
+    lib().bo_aux_a(C.c_int(aux), C.c_int(d), C.c_int(mp), p, C.c_double(t), o.ctypes.data_as(dp))
+    return uncm(o, d, d)
+
+
+def linpro_par(B, mu, sigma):
+    B = np.atleast_2d(np.asarray(B, dtype=np.float64))
+    d = B.shape[0]
+    return np.concatenate([cm(B), np.atleast_1d(np.asarray(mu, dtype=np.float64)).ravel(),
+                           cm(np.asarray(sigma, dtype=np.float64).reshape(d, -1))])
+
+
+def affine_par(B, beta, sigma):
+    return linpro_par(B, beta, sigma)
+
+
+# ---- guides ----
+def gp_hv(tt, d, mp, aux, apar, v, hT=None):
+    """GuidedBridge(tt, P, Pt, v, hT) -> Hd [N,d,d], V [N,d]"""
+    tt = np.ascontiguousarray(tt, dtype=np.float64)
+    N = len(tt)
+    pp, p = _d(apar)
+    vv, pv = _d(np.atleast_1d(v))
+    hh, ph = _d(None if hT is None else cm(np.atleast_2d(hT)))
+    Hd = np.empty((N, d * d))
+    V = np.empty((N, d))
+    lib().bo_gp_hv(tt.ctypes.data_as(dp), C.c_int(N), C.c_int(d), C.c_int(mp), C.c_int(aux), p, pv, ph,
+                   Hd.ctypes.data_as(dp), V.ctypes.data_as(dp))
+    return uncm(Hd, d, d), V
+
+
+def partialbridge_ode(tt, d, mp, m, aux, apar, L, Sigma):
+    tt = np.ascontiguousarray(tt, dtype=np.float64)
+    N = len(tt)
+    pp, p = _d(apar)
+    ll, pl = _d(cm(np.asarray(L, dtype=np.float64).reshape(m, d)))
+    ss, ps = _d(cm(np.asarray(Sigma, dtype=np.float64).reshape(m, m)))
+    Lt = np.empty((N, m * d))
+    Mt = np.empty((N, m * m))
+    mut = np.empty((N, m))
+    lib().bo_partialbridge_ode(tt.ctypes.data_as(dp), C.c_int(N), C.c_int(d), C.c_int(mp), C.c_int(m),
+                               C.c_int(aux), p, pl, ps, Lt.ctypes.data_as(dp), Mt.ctypes.data_as(dp),
+                               mut.ctypes.data_as(dp))
+    return uncm(Lt, m, d), uncm(Mt, m, m), mut
+
+
+def partialbridge_nuH(tt, d, mp, m, aux, apar, L, v, eps, Sigma, inplace=False):
+    tt = np.ascontiguousarray(tt, dtype=np.float64)
+    N = len(tt)
+    pp, p = _d(apar)
+    ll, pl = _d(cm(np.asarray(L, dtype=np.float64).reshape(m, d)))
+    vv, pv = _d(np.atleast_1d(v))
+    ss, ps = _d(cm(np.asarray(Sigma, dtype=np.float64).reshape(m, m)))
+    nut = np.empty((N, d))
+    Ht = np.empty((N, d * d))
+    if inplace:
+        lib().bo_partialbridge_inplace(tt.ctypes.data_as(dp), C.c_int(N), C.c_int(d), C.c_int(mp), C.c_int(m),
+                                       C.c_int(aux), p, pl, pv, C.c_double(eps), ps,
+                                       nut.ctypes.data_as(dp), Ht.ctypes.data_as(dp))
+        Cc = 0.0
+    else:
+        Cc = lib().bo_partialbridge_nuH(tt.ctypes.data_as(dp), C.c_int(N), C.c_int(d), C.c_int(mp), C.c_int(m),
+                                        C.c_int(aux), p, pl, pv, C.c_double(eps), ps,
+                                        nut.ctypes.data_as(dp), Ht.ctypes.data_as(dp))
+    return nut, uncm(Ht, d, d), Cc
+
+
+def traceB(tt, d, aux, apar):
+    tt = np.ascontiguousarray(tt, dtype=np.float64)
+    pp, p = _d(apar)
+    return lib().bo_traceB(tt.ctypes.data_as(dp), C.c_int(len(tt)), C.c_int(d), C.c_int(aux), p)
+
+
+def r3_forward(tt, d, mp, aux, apar, what, y0):
+    tt = np.ascontiguousarray(tt, dtype=np.float64)
+    pp, p = _d(apar)
+    y0 = np.ascontiguousarray(np.atleast_1d(y0), dtype=np.float64).ravel()
+    out = np.empty_like(y0)
+    lib().bo_r3_forward(tt.ctypes.data_as(dp), C.c_int(len(tt)), C.c_int(d), C.c_int(mp), C.c_int(aux), p,
+                        C.c_int(what), y0.ctypes.data_as(dp), C.c_int(len(y0)), out.ctypes.data_as(dp))
+    return out
+
+
+# ---- hot path ----
+def wiener_sample(tt, mp, seed, path, it):
+    tt = np.ascontiguousarray(tt, dtype=np.float64)
+    W = np.empty((len(tt), mp))
+    lib().bo_wiener_sample(tt.ctypes.data_as(dp), C.c_int(len(tt)), C.c_int(mp), C.c_uint64(seed),
+                           C.c_uint32(path), C.c_uint32(it), W.ctypes.data_as(dp))
+    return W
+
+
+def solve_em(model, d, mp, par, tt, u, W):
+    tt = np.ascontiguousarray(tt, dtype=np.float64)
+    N = len(tt)
+    pp, p = _d(par)
+    uu, pu = _d(np.atleast_1d(u))
+    ww, pw = _d(np.asarray(W).reshape(N, mp))
+    X = np.empty((N, d))
+    lib().bo_solve_em(C.c_int(model), C.c_int(d), C.c_int(mp), p, tt.ctypes.data_as(dp), C.c_int(N), pu, pw,
+                      X.ctypes.data_as(dp))
+    return X
+
+
+class Proposal:
+    """flat description of a guided proposal: kind + arrays in the oracle's layout"""
+
+    def __init__(self, kind, tt, d, mp, m, model, par, aux, apar, A1=None, A2=None, A3=None, A4=None):
+        self.kind, self.d, self.mp, self.m, self.model, self.aux = kind, d, mp, m, model, aux
+        self.tt = np.ascontiguousarray(tt, dtype=np.float64)
+        self.N = len(self.tt)
+        self.par = np.ascontiguousarray(par, dtype=np.float64)
+        self.apar = np.ascontiguousarray(apar, dtype=np.float64)
+        self.A = [None if A is None else np.ascontiguousarray(A, dtype=np.float64) for A in (A1, A2, A3, A4)]
+
+    def _args(self):
+        ptr = [None if A is None else A.ctypes.data_as(dp) for A in self.A]
+        return [C.c_int(self.kind), C.c_int(self.N), C.c_int(self.d), C.c_int(self.mp), C.c_int(self.m),
+                C.c_int(self.model), self.par.ctypes.data_as(dp), C.c_int(self.aux),
+                self.apar.ctypes.data_as(dp), self.tt.ctypes.data_as(dp)] + ptr
+
+
+def proposal_hv(tt, d, mp, model, par, aux, apar, Hd, V):
+    return Proposal(GUIDE_HV, tt, d, mp, d, model, par, aux, apar, cm(Hd), V)
+
+
+def proposal_lmmu(tt, d, mp, m, model, par, aux, apar, Lt, Mt, mut, v):
+    return Proposal(GUIDE_LMMU, tt, d, mp, m, model, par, aux, apar, cm(Lt), cm(Mt), mut, np.atleast_1d(v))
+
+
+def proposal_nuh(tt, d, mp, model, par, aux, apar, nut, Ht, inplace=False):
+    return Proposal(GUIDE_NUH_INPLACE if inplace else GUIDE_NUH, tt, d, mp, d, model, par, aux, apar, nut, cm(Ht))
+
+
+def solve_guided(P, u, W):
+    uu, pu = _d(np.atleast_1d(u))
+    ww, pw = _d(np.asarray(W).reshape(P.N, P.mp))
+    X = np.empty((P.N, P.d))
+    lib().bo_solve_guided_flat(*P._args(), pu, pw, X.ctypes.data_as(dp))
+    return X
+
+
+def llikelihood(P, X, skip=0):
+    xx, px = _d(np.asarray(X).reshape(P.N, P.d))
+    return lib().bo_llikelihood_flat(*P._args(), px, C.c_int(skip))
+
+
+class _Res(C.Structure):
+    _fields_ = [("acc", C.c_long), ("ll", C.c_double)]
+
+
+def mcmc(P, x0, rho, iters, seed, path, skip=0):
+    uu, pu = _d(np.atleast_1d(x0))
+    W = np.empty((P.N, P.mp))
+    X = np.empty((P.N, P.d))
+    llt = np.empty(iters)
+    acct = np.empty(iters, dtype=np.int32)
+    res = _Res()
+    lib().bo_mcmc_flat(*P._args(), pu, C.c_double(rho), C.c_int(iters), C.c_int(skip), C.c_uint64(seed),
+                       C.c_uint32(path), W.ctypes.data_as(dp), X.ctypes.data_as(dp), llt.ctypes.data_as(dp),
+                       acct.ctypes.data_as(C.POINTER(C.c_int)), C.byref(res))
+    return dict(W=W, X=X, ll_trace=llt, acc_trace=acct, acc=res.acc, ll=res.ll)
+
+
+def ensemble_proposals(P, x0, npaths, path0, seed, it, threads=1, want_last=False):
+    uu, pu = _d(np.atleast_1d(x0))
+    ll = np.empty(npaths)
+    last = np.empty((npaths, P.d)) if want_last else None
+    n = lib().bo_ensemble_proposals(*P._args(), pu, C.c_int(npaths), C.c_uint32(path0), C.c_uint64(seed),
+                                    C.c_uint32(it), C.c_int(threads), ll.ctypes.data_as(dp),
+                                    None if last is None else last.ctypes.data_as(dp))
+    return n, ll, last
+
+
+def ensemble_mcmc(P, x0, rho, iters, nchains, path0, seed, threads=1):
+    uu, pu = _d(np.atleast_1d(x0))
+    ll = np.empty(nchains)
+    acc = np.empty(nchains, dtype=np.int64)
+    n = lib().bo_ensemble_mcmc(*P._args(), pu, C.c_double(rho), C.c_int(iters), C.c_int(nchains),
+                               C.c_uint32(path0), C.c_uint64(seed), C.c_int(threads), ll.ctypes.data_as(dp),
+                               acc.ctypes.data_as(C.POINTER(C.c_long)))
+    return n, ll, acc
+
+
+def mcnext(mean, m2, n, x):
+    """in-place Welford update; mean [E,d], m2 [E,d*d] (column-major per entry), returns n+1"""
+    E, d = mean.shape
+    nn = C.c_long(n)
+    xx, px = _d(x)
+    lib().bo_mcnext(C.c_int(E), C.c_int(d), mean.ctypes.data_as(dp), m2.ctypes.data_as(dp), C.byref(nn), px)
+    return nn.value

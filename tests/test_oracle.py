@@ -1,0 +1,360 @@
+"""Pins the CPU oracle (oracle/bridge_oracle.c) against everything the reference's own tests hold
+for the guided-proposal path.  CPU only.
+
+The reference (Julia) cannot run here, so each test restates the identity / known answer that the
+cited reference test asserts and applies it to the oracle's output.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+from scipy.linalg import expm, solve_continuous_lyapunov
+
+import oracle as o
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# --------------------------------------------------------------------------- RNG spec
+def test_philox_known_answers():
+    # Random123 kat_vectors for philox4x32-10 (the generator rocRAND's default PHILOX4_32_10 implements)
+    assert o.philox([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert o.philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert o.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == [
+        0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_deterministic_log_sincos_accuracy():
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.random(5000), 2.0 ** -rng.integers(1, 53, 200), [1.0, 2.0 ** -53, 0.5, 0.70710678, 0.7071068]])
+    for x in xs:
+        ref = math.log(x)
+        assert abs(o.bo_log(x) - ref) <= 4e-16 * max(abs(ref), 1e-300) + 1e-300
+    for u in np.concatenate([rng.random(5000), [0.0, 0.125, 0.25, 0.5, 0.75, 0.875, 1 - 2.0 ** -53]]):
+        s, c = o.sincos2pi(u)
+        assert abs(s - math.sin(2 * math.pi * u)) < 2e-15 and abs(c - math.cos(2 * math.pi * u)) < 2e-15
+        assert abs(s * s + c * c - 1) < 1e-15
+
+
+def test_normal_moments_and_uniform_range():
+    # K13 test/wiener.jl:33-47 analogue for the counter-based generator
+    z = o.normals(12, 3, 0, 0, 400000)
+    assert abs(z.mean()) < 4 / math.sqrt(len(z))
+    assert abs(z.var() - 1) < 4 * math.sqrt(2 / len(z))
+    assert abs((z ** 4).mean() - 3) < 0.06
+    assert abs(np.corrcoef(z[::2], z[1::2])[0, 1]) < 0.01
+    us = [o.uniform_accept(5, p, 1) for p in range(2000)]
+    assert 0 < min(us) and max(us) <= 1 and abs(np.mean(us) - 0.5) < 0.03
+    # stream addressing: normals n0..n0+n of a stream do not depend on where the request starts
+    a = o.normals(7, 9, 2, 0, 64)
+    b = o.normals(7, 9, 2, 13, 20)
+    assert np.array_equal(a[13:33], b)
+
+
+def test_wiener_draw_order_time_major_component_minor():
+    # K3 test/with_srand.jl:1-11 -- vector Wiener consumes normals time-major, component-minor
+    tt = np.linspace(0.0, 1.0, 50)
+    W = o.wiener_sample(tt, 3, 1, 0, 0)
+    z = o.normals(1, 0, 0, 0, 3 * 49).reshape(49, 3)
+    ref = np.zeros((50, 3))
+    for i in range(1, 50):
+        ref[i] = ref[i - 1] + math.sqrt(tt[i] - tt[i - 1]) * z[i - 1]
+    assert np.array_equal(W, ref)
+    # K13 moments of W_T (test/wiener.jl:33-41), n = 1000, T = 2, 5 grid points
+    tt = np.linspace(0.0, 2.0, 5)
+    WT = np.array([o.wiener_sample(tt, 1, 12, p, 0)[-1, 0] for p in range(1000)])
+    assert abs(WT.mean()) < 2.576 * math.sqrt(2 / 1000)
+    assert 888.56 < 1000.0 * WT.var(ddof=1) / 2 < 1118.95
+
+
+# --------------------------------------------------------------------------- K1 / K2: Euler-Maruyama
+def test_K1_manual_doctest_vector():
+    g = json.load(open(os.path.join(GOLD, "manual_ou.json")))
+    X = o.solve_em(o.MODEL_OU, 1, 1, [g["beta"], g["sigma"]], g["tt"], g["x0"], np.array(g["W"]))
+    # inputs are a 6-significant-digit printout; error amplification |1-beta*dt| = 1 per step
+    assert np.abs(X[:, 0] - np.array(g["X"])).max() < 5e-6
+
+
+def test_K2_lorenz_em_layout_independent():
+    # test/euler.jl:63-68: all EM code paths agree < eps(); here: oracle EM == an independent
+    # numpy restatement of src/euler.jl:146-149 on the 5000-step 3-d Lorenz problem
+    n = 5000
+    tt = np.linspace(0.0, 10.0, n + 1)
+    W = o.wiener_sample(tt, 3, 3, 0, 0)
+    par = [10.0, 28.0, 8 / 3, 3.0, 3.0, 3.0]
+    X = o.solve_em(o.MODEL_LORENZ, 3, 3, par, tt, [1.0, 0.0, 0.0], W)
+    y = np.array([1.0, 0.0, 0.0])
+    ref = np.empty_like(X)
+    for i in range(n):
+        ref[i] = y
+        b = np.array([10.0 * (y[1] - y[0]), y[0] * (28.0 - y[2]) - y[1], y[0] * y[1] - (8 / 3) * y[2]])
+        y = y + b * (tt[i + 1] - tt[i]) + 3.0 * (W[i + 1] - W[i])
+    ref[n] = y
+    assert np.array_equal(X, ref)
+
+
+# --------------------------------------------------------------------------- linear algebra restated
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 7])
+def test_small_linear_algebra(n):
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n)) + 3 * np.eye(n)
+    b = rng.standard_normal(n)
+    assert abs(o.det(A) - np.linalg.det(A)) < 1e-12 * abs(np.linalg.det(A))
+    assert np.allclose(o.inv(A), np.linalg.inv(A), rtol=1e-12, atol=1e-13)
+    assert np.allclose(o.solve(A, b), np.linalg.solve(A, b), rtol=1e-12, atol=1e-13)
+    S = A @ A.T
+    x = rng.standard_normal(n)
+    ref = -0.5 * (x @ np.linalg.solve(S, x) + np.linalg.slogdet(S)[1] + n * math.log(2 * math.pi))
+    assert abs(o.logpdfnormal(x, S) - ref) < 1e-11
+
+
+# --------------------------------------------------------------------------- K4/K5: GuidedBridge guide vs closed forms
+def _linpro_closed(B, mu, a, t, T, v):
+    """src/linpro.jl:98-134 closed forms H(t,T,P)^-1 and V(t,T,v,P)"""
+    B = np.atleast_2d(B)
+    lam = solve_continuous_lyapunov(B, -np.atleast_2d(a))          # B*lam + lam*B' + a = 0
+    phim = expm(-(T - t) * B)
+    Hinv = phim @ lam @ phim.T - lam
+    V = phim @ (np.atleast_1d(v) - mu) + mu
+    return Hinv, V
+
+
+def test_K4_VHK_scalar():
+    # test/VHK.jl:1-35: n=200 uniform grid on [0,2]; Pt = LinPro(-0.8, 0.2, sqrt(0.7)), v = 0.1
+    n, T = 200, 2.0
+    tt = np.linspace(0, T, n)
+    beta, mu, a, v, u = 0.8, 0.2, 0.7, 0.1, 0.5
+    apar = o.linpro_par([[-beta]], [mu], [[math.sqrt(a)]])
+    Hd, V = o.gp_hv(tt, 1, 1, o.AUX_LINPRO, apar, [v])
+    for i in range(n):
+        Hc, Vc = _linpro_closed([[-beta]], np.array([mu]), [[math.sqrt(a) ** 2]], tt[i], T, v)
+        assert abs(Hd[i, 0, 0] - Hc[0, 0]) < 1e-5          # :29
+        assert abs(V[i, 0] - Vc[0]) < 1e-5                  # :30
+    # :38  mu(t,u,T,Pt)
+    mu_T = o.r3_forward(tt, 1, 1, o.AUX_LINPRO, apar, 0, [u])[0]
+    assert abs(mu_T - (math.exp(-beta * T) * (u - mu) + mu)) < 1e-5
+    # :39  traceB = log det exp(-beta T)
+    assert abs(o.traceB(tt, 1, o.AUX_LINPRO, apar) - (-beta * T)) < 1e-5
+    # :33  r(t,x,T,v,Pt) == Hd[1] \ (V[1]-x) at x = v
+    Hc, Vc = _linpro_closed([[-beta]], np.array([mu]), [[a]], 0.0, T, v)
+    assert abs((Vc[0] - v) / Hc[0, 0] - (V[0, 0] - v) / Hd[0, 0, 0]) < 1e-5
+    # K5 :56-65  lptilde(GP,u) ~ lp(t,u,T,v,Pt) = logpdfnormal(v - mu(t,u,T), K(t,T))
+    lpt = o.logpdfnormal([V[0, 0] - u], [[Hd[0, 0, 0]]]) - o.traceB(tt, 1, o.AUX_LINPRO, apar)
+    lam = a / (2 * beta)
+    K = lam - math.exp(-beta * T) * lam * math.exp(-beta * T)
+    m_ = math.exp(-beta * T) * (u - mu) + mu
+    lp = -0.5 * ((v - m_) ** 2 / K + math.log(K) + math.log(2 * math.pi))
+    assert abs(lpt - lp) < 1e-5
+    # lptilde2 :59: K and mu by forward R3 (gpK, gpmu)
+    K_r3 = o.r3_forward(tt, 1, 1, o.AUX_LINPRO, apar, 1, [0.0])[0]
+    assert abs(K_r3 - K) < 1e-5
+
+
+def test_K6_linpro_R3_vs_expm_2d():
+    # test/linprobridge.jl:1-25 (n = 10000, tolerance 1e-8) and test/linpro.jl:52-59 (10/n^3)
+    n, T = 10000, 2.0
+    tt = np.linspace(0, T, n + 1)
+    B = np.array([[-1, 0.1], [-0.2, -1]])
+    sigma = 2 * np.array([[-0.212887, 0.0687025], [0.193157, 0.388997]])
+    a = sigma @ sigma.T
+    mu = np.zeros(2)
+    apar = o.linpro_par(B, mu, sigma)
+    u = np.array([1.0, -0.2])
+    lam = solve_continuous_lyapunov(B, -a)
+    phi = expm(T * B)
+    assert np.linalg.norm(o.r3_forward(tt, 2, 2, o.AUX_LINPRO, apar, 3, u) - (phi @ (u - mu) + mu)) < 1e-8
+    K = o.cm(np.zeros((2, 2)))
+    Kr3 = o.uncm(o.r3_forward(tt, 2, 2, o.AUX_LINPRO, apar, 1, K), 2, 2)
+    assert np.linalg.norm(Kr3 - (lam - phi @ lam @ phi.T)) < 1e-8
+    Phi = o.uncm(o.r3_forward(tt, 2, 2, o.AUX_LINPRO, apar, 2, o.cm(np.eye(2))), 2, 2)
+    assert np.linalg.norm(Phi - phi) < 1e-8
+    # backward _dHinv from 0: inv(...) == H(0,T,P)
+    Hd, V = o.gp_hv(tt, 2, 2, o.AUX_LINPRO, apar, [0.5, 0.0])
+    phim = expm(-T * B)
+    Hclosed = np.linalg.inv(phim @ lam @ phim.T - lam)
+    assert np.linalg.norm(np.linalg.inv(Hd[0]) - Hclosed) < 1e-8
+    # test/linpro.jl:21 Lyapunov identity, :52-59 with n2 = 150 on [0.5, 2]
+    assert np.linalg.norm(-lam @ B.T - B @ lam - a) < 1e-14
+    n2 = 150
+    t0 = 0.5
+    tt2 = np.linspace(t0, T, n2)
+    mu2 = 0.1 * np.array([0.2, 0.3])
+    apar2 = o.linpro_par(B, mu2, sigma)
+    v = np.array([0.5, 0.0])
+    Hd2, V2 = o.gp_hv(tt2, 2, 2, o.AUX_LINPRO, apar2, v)
+    Hc, Vc = _linpro_closed(B, mu2, a, t0, T, v)
+    assert np.linalg.norm(Hd2[0] @ np.linalg.inv(Hc) - np.eye(2)) < 10 / n2 ** 3
+    assert np.linalg.norm(V2[0] - Vc) < 10 / n2 ** 3
+
+
+# --------------------------------------------------------------------------- K7/K8: partial bridges
+def _intdiff_setup():
+    # test/partialparam.jl + test/partialbridge.jl:7-36
+    T, dt = 1.5, 1 / 1000
+    tt = np.arange(0, 1501) * dt
+    gamma = 0.7
+    L = np.array([[1.0, 0.0]])
+    Sigma = np.array([[0.1]])
+    v = np.array([2.5])
+    x0 = np.array([2.0, 1.0])
+    apar = o.affine_par([[0.0, 1.0], [0.0, -1.0]], [0.0, 0.5], [[0.0], [gamma]])
+    return tt, dt, gamma, L, Sigma, v, x0, apar
+
+
+def test_K7_partialbridge_ode_finite_differences():
+    tt, dt, gamma, L, Sigma, v, x0, apar = _intdiff_setup()
+    Lt, Mt, mut = o.partialbridge_ode(tt, 2, 1, 1, o.AUX_AFFINE, apar, L, Sigma)
+    j = 10 - 1  # reference j = 10 (1-based)
+    beta = np.array([0.0, 0.5])
+    a = np.array([[0.0, 0.0], [0.0, gamma ** 2]])
+    # test/partialbridge.jl:59-60
+    assert np.linalg.norm((mut[j + 1] - mut[j]) / dt - (-Lt[j + 1] @ beta)) < 0.01
+    assert np.linalg.norm((np.linalg.inv(Mt[j + 1]) - np.linalg.inv(Mt[j])) / dt - (-Lt[j + 1] @ a @ Lt[j + 1].T)) < 0.01
+    assert np.array_equal(Lt[-1], L) and np.allclose(Mt[-1], np.linalg.inv(Sigma)) and np.all(mut[-1] == 0)
+    # closed form: L(t) = L expm((T-t)B)
+    Bm = np.array([[0.0, 1.0], [0.0, -1.0]])
+    for i in (0, 500, 1400):
+        assert np.allclose(Lt[i], L @ expm((tt[-1] - tt[i]) * Bm), atol=1e-9)
+    # Sigma = 0 => M[N] = Inf, never read
+    Lt0, Mt0, _ = o.partialbridge_ode(tt, 2, 1, 1, o.AUX_AFFINE, apar, L, np.zeros((1, 1)))
+    assert np.isinf(Mt0[-1, 0, 0]) and np.all(np.isfinite(Mt0[:-1]))
+
+
+def test_K8_nuH_parametrisation_agrees_with_LMmu():
+    tt, dt, gamma, L, Sigma, v, x0, apar = _intdiff_setup()
+    eps = 0.00001
+    Lt, Mt, mut = o.partialbridge_ode(tt, 2, 1, 1, o.AUX_AFFINE, apar, L, Sigma)
+    nut, Ht, Cc = o.partialbridge_nuH(tt, 2, 1, 1, o.AUX_AFFINE, apar, L, v, eps, Sigma)
+    # test/partialbridge.jl:73  LP = log pdf Normal(mu1 + L1 x0, M1^-1/2)(v)
+    m1 = mut[0, 0] + (Lt[0] @ x0)[0]
+    sd = Mt[0, 0, 0] ** -0.5
+    LP = -0.5 * ((v[0] - m1) / sd) ** 2 - math.log(sd) - 0.5 * math.log(2 * math.pi)
+    # test/partialbridgenuH.jl:124-127
+    LP2 = -0.5 * (x0 @ Ht[0] @ x0 - 2 * x0 @ Ht[0] @ nut[0]) - Cc
+    assert abs(LP - LP2) < 0.01
+    # updatenuH+C / updateFHC consistency :108-112
+    Hend = L.T @ np.linalg.inv(Sigma) @ L + eps * np.eye(2)
+    assert np.allclose(Ht[-1], Hend, rtol=1e-9)
+    assert np.allclose(Ht[-1] @ nut[-1], (L.T @ np.linalg.inv(Sigma) @ v), rtol=1e-6)
+    # the two guiding terms agree along a path (the nuH one has the eps-regularisation)
+    x = np.array([2.2, 0.7])
+    for i in (0, 700, 1450):
+        r1 = Lt[i].T @ Mt[i] @ (v - mut[i] - Lt[i] @ x)
+        r2 = Ht[i] @ (nut[i] - x)
+        assert np.allclose(r1, r2, atol=2e-3 * (1 + np.abs(r1).max()))
+    # PartialBridge! (src/partialbridgen!.jl) gives the same nu,H as PartialBridgeNuH up to inv round-off
+    nut2, Ht2, _ = o.partialbridge_nuH(tt, 2, 1, 1, o.AUX_AFFINE, apar, L, v, eps, Sigma, inplace=True)
+    assert np.max(np.abs(Ht2 - Ht) / np.abs(Ht).max()) < 1e-5
+    assert np.max(np.abs(nut2 - nut)) < 1e-5 * (1 + np.abs(nut).max())
+
+
+def test_partialbridge_solve_ll_consistency_across_parametrisations():
+    tt, dt, gamma, L, Sigma, v, x0, apar = _intdiff_setup()
+    eps = 0.00001
+    Lt, Mt, mut = o.partialbridge_ode(tt, 2, 1, 1, o.AUX_AFFINE, apar, L, Sigma)
+    nut, Ht, _ = o.partialbridge_nuH(tt, 2, 1, 1, o.AUX_AFFINE, apar, L, v, eps, Sigma)
+    P1 = o.proposal_lmmu(tt, 2, 1, 1, o.MODEL_INTDIFF, [gamma], o.AUX_AFFINE, apar, Lt, Mt, mut, v)
+    P2 = o.proposal_nuh(tt, 2, 1, o.MODEL_INTDIFF, [gamma], o.AUX_AFFINE, apar, nut, Ht)
+    P3 = o.proposal_nuh(tt, 2, 1, o.MODEL_INTDIFF, [gamma], o.AUX_AFFINE, apar, nut, Ht, inplace=True)
+    W = o.wiener_sample(tt, 1, 1, 0, 0)
+    X1, X2 = o.solve_guided(P1, x0, W), o.solve_guided(P2, x0, W)
+    assert np.abs(X1 - X2).max() < 1e-3            # test/partialbridgenuH.jl:139-141 (sqrt(eps) there, same inv)
+    ll1, ll2, ll3 = o.llikelihood(P1, X1), o.llikelihood(P2, X2), o.llikelihood(P3, X2)
+    assert abs(ll1 - ll2) < 2e-3                   # :147-149
+    assert abs(ll2 - ll3) < 1e-10 * (1 + abs(ll2))  # one dot of a difference vs difference of two dots
+    # skip semantics: llikelihood(...; skip) drops the last `skip` terms (src/partialbridge.jl:72)
+    assert o.llikelihood(P1, X1, skip=0) != o.llikelihood(P1, X1, skip=3)
+    # X[1] = x0 stored before the first update; guided path approaches the observation
+    assert np.array_equal(X1[0], x0) and abs(X1[-1, 0] - v[0]) < 4 * math.sqrt(Sigma[0, 0]) + 0.3
+
+
+# --------------------------------------------------------------------------- K9: importance weights unbiased
+def test_K9_guided_bridge_importance_weights_unbiased():
+    # test/guip.jl:245-274 with the OU target of :117-120,165-166 (closed-form transition density)
+    n, m, T = 200, 1000, 2.0
+    tt = np.linspace(0, T, n)
+    u, v, a, beta = 0.5, 0.1, 0.7, 0.8
+    par = o.linpro_par([[-beta]], [0.0], [[math.sqrt(a)]])
+    apar = o.linpro_par([[-beta]], [0.2], [[math.sqrt(a)]])
+    Hd, V = o.gp_hv(tt, 1, 1, o.AUX_LINPRO, apar, [v])
+    P = o.proposal_hv(tt, 1, 1, o.MODEL_LINPRO, par, o.AUX_LINPRO, apar, Hd, V)
+    lpt = o.logpdfnormal([V[0, 0] - u], [[Hd[0, 0, 0]]]) - o.traceB(tt, 1, o.AUX_LINPRO, apar)
+    s2 = math.sqrt(a) ** 2
+    K = s2 / (2 * beta) * (1 - math.exp(-2 * beta * T))
+    lp = -0.5 * ((v - u * math.exp(-beta * T)) ** 2 / K + math.log(K) + math.log(2 * math.pi))
+    z = np.empty(m)
+    for p in range(m):
+        W = o.wiener_sample(tt, 1, 5, p, 0)
+        X = o.solve_guided(P, [u], W)
+        assert X[-1, 0] == V[-1, 0] == v       # endpoint rule src/euler.jl:241-242 (Hd[N] = 0)
+        z[p] = o.llikelihood(P, X)
+    w = np.exp(z) * math.exp(lpt) / math.exp(lp)
+    stat = abs(np.mean(w - 1) * math.sqrt(m) / np.std(w, ddof=1))
+    assert stat < 3.0
+
+
+# --------------------------------------------------------------------------- K10: pCN chain
+def test_K10_pcn_chain_accepts_sometimes():
+    # test/partialbridge.jl:79-119 (rho = 0.9; 10^4 iterations there, 300 here for CPU time)
+    tt, dt, gamma, L, Sigma, v, x0, apar = _intdiff_setup()
+    tt = tt[::5].copy()
+    Lt, Mt, mut = o.partialbridge_ode(tt, 2, 1, 1, o.AUX_AFFINE, apar, L, Sigma)
+    P = o.proposal_lmmu(tt, 2, 1, 1, o.MODEL_INTDIFF, [gamma], o.AUX_AFFINE, apar, Lt, Mt, mut, v)
+    iters = 300
+    r = o.mcmc(P, x0, 0.9, iters, seed=1, path=0)
+    assert 1 < r["acc"] < iters
+    assert r["acc"] == r["acc_trace"].sum()
+    # state consistency: X is the solution driven by the stored W, ll its log-likelihood
+    assert np.array_equal(o.solve_guided(P, x0, r["W"]), r["X"])
+    assert o.llikelihood(P, r["X"]) == r["ll"]
+    # rho = 0 makes proposals independent of the state: llo trace equals fresh-proposal lls
+    r0 = o.mcmc(P, x0, 0.0, 5, seed=1, path=0)
+    for it in range(1, 6):
+        W2 = o.wiener_sample(tt, 1, 1, 0, it)
+        assert r0["ll_trace"][it - 1] == o.llikelihood(P, o.solve_guided(P, x0, 0.0 * r0["W"] + 1.0 * W2))
+
+
+# --------------------------------------------------------------------------- K12: online statistics
+def test_K12_welford_matches_mean_cov():
+    # test/onlinestat.jl:1-13
+    rng = np.random.default_rng(3)
+    xs = rng.random((10, 4, 5))                 # 10 iterations, 4 grid entries, d = 5
+    mean = np.zeros((4, 5))
+    m2 = np.zeros((4, 25))
+    n = 0
+    for x in xs:
+        n = o.mcnext(mean, m2, n, x)
+    assert n == 10
+    for e in range(4):
+        assert np.linalg.norm(mean[e] - xs[:, e].mean(0)) < 1e-14
+        cov = o.uncm(m2[e], 5, 5) / (n - 1)
+        assert np.linalg.norm(cov - np.cov(xs[:, e].T, ddof=1)) < 1.5e-14
+
+
+# --------------------------------------------------------------------------- models / time-dependent aux
+def test_models_against_reference_expressions():
+    x = np.array([0.3, -0.7])
+    eps, s, gam, beta, sig = 0.1, 0.0, 1.5, 0.8, 0.3
+    assert np.array_equal(o.b(o.MODEL_FHN, 2, [eps, s, gam, beta, sig], 0.0, x),
+                          [(x[0] - x[1] - x[0] ** 3 + s) / eps, gam * x[0] - x[1] + beta])
+    assert np.array_equal(o.a(o.MODEL_FHN, 2, 1, [eps, s, gam, beta, sig]), [[0, 0], [0, sig * sig]])
+    x3 = np.array([0.1, 0.2, 0.3])
+    assert np.array_equal(o.b(o.MODEL_NCLAR, 3, [6.0, 2 * math.pi, 1.0], 0.0, x3),
+                          [x3[1], x3[2], -6.0 * math.sin(2 * math.pi * x3[2])])
+    # FHN auxiliary "linearised_startend" (partialbridge_fitzhugh.jl:70-73,102-105)
+    t0, u, T, v = 0.0, -0.5, 2.0, 1.1
+    ap = [eps, s, gam, beta, sig, t0, u, T, v]
+    for t in (0.0, 0.7, 2.0):
+        lam = (t - t0) / (T - t0)
+        uv = v * lam + u * (1 - lam)
+        assert np.array_equal(o.aux_B(o.AUX_FHN_STARTEND, 2, ap, t), [[1 / eps - 3 * uv ** 2 / eps, -1 / eps], [gam, -1.0]])
+        assert np.array_equal(o.aux_beta(o.AUX_FHN_STARTEND, 2, ap, t), [s / eps + 2 * uv ** 3 / eps, beta])
+    assert np.array_equal(o.aux_a(o.AUX_FHN_STARTEND, 2, 1, ap, 0.3), [[0, 0], [0, sig * sig]])
+    # LinPro drift form B*(x - mu) vs affine form B*x + beta (beta = -B*mu): equal up to round-off only
+    B = np.array([[-1, 0.1], [-0.2, -1]])
+    mu = np.array([0.02, 0.03])
+    lp = o.linpro_par(B, mu, np.eye(2))
+    assert np.array_equal(o.aux_b(o.AUX_LINPRO, 2, lp, 0.0, x), B @ (x - mu)) or np.allclose(o.aux_b(o.AUX_LINPRO, 2, lp, 0.0, x), B @ (x - mu), rtol=1e-15)
+    assert np.allclose(o.aux_beta(o.AUX_LINPRO, 2, lp, 0.0), -B @ mu, rtol=1e-15)
