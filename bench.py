@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- guided-bridge path-steps/s on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]/[3]): FitzHugh-Nagumo partial bridge
+(project_partialbridge/partialbridge_fitzhugh.jl: eps=0.1, s=0, gamma=1.5, beta=0.8, sigma=0.3,
+x0=(-0.5,-0.6), L=[1 0], Sigma=1e-10, v=1.1 "extreme", auxiliary "linearised_end", rho=0.9),
+1001-point time-changed grid on T=2, fp64, 262 144 chains PER GPU (weak scaling).
+
+A "step" is one pCN Metropolis-Hastings iteration of every chain of the rank = one launch of the
+fused kernel = chains x 1000 path-steps, each path-step being: Philox normal -> Wiener increment ->
+pCN mix -> guided Euler step -> log-likelihood increment (+ the accept at the end of the path).
+All inputs are resident in HBM when the timed region starts.  The timed region ends with the
+device-side reduction of the acceptance / log-weight statistics and (N > 1) ONE RCCL all-gather.
+
+`--mode proposals` times independent fresh proposals instead (sample!+solve!+llikelihood, X stored).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import bridgehip as bh
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+N_GRID = 1001
+FHN = (0.1, 0.0, 1.5, 0.8, 0.3)
+X0 = (-0.5, -0.6)
+V_END = 1.1
+RHO = 0.9
+
+
+def tau_grid(T, N):
+    s = np.linspace(0.0, T, N)
+    return s * (2 - s / T)
+
+
+def build_proposal(ctx):
+    P = bh.FitzhughDiffusion(*FHN)
+    Pt = bh.fitzhugh_aux_linearised_end(P, V_END)
+    return bh.PartialBridge(tau_grid(2.0, N_GRID), P, Pt, [[1.0, 0.0]], [V_END], [[1e-10]], ctx=ctx)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """CPU restatement of Bridge.jl's path (oracle/bridge_oracle.c, the reference's four separate
+    passes per proposal), timed on the host cores of this box on a bounded sample of the SAME workload."""
+    import oracle as o          # checker / baseline leg only
+    import problems
+    tt = tau_grid(2.0, N_GRID)
+    ap = problems.fhn_aux_end(*FHN, V_END)
+    Lt, Mt, mut = o.partialbridge_ode(tt, 2, 1, 1, o.AUX_AFFINE, ap, [[1.0, 0.0]], [[1e-10]])
+    Po = o.proposal_lmmu(tt, 2, 1, 1, o.MODEL_FHN, list(FHN), o.AUX_AFFINE, ap, Lt, Mt, mut, [V_END])
+    cores = os.cpu_count() or 1
+    # calibrate on 1 thread, then size the all-core sample to ~seconds_budget/2 each
+    t0 = time.perf_counter()
+    n1, _, _ = o.ensemble_mcmc(Po, X0, RHO, 3, 16, 0, 1, threads=1)
+    rate1 = n1 / (time.perf_counter() - t0)
+    iters = 9
+    nch1 = max(8, int(rate1 * seconds_budget / 2 / ((iters + 1) * (N_GRID - 1))))
+    t0 = time.perf_counter()
+    n1, _, _ = o.ensemble_mcmc(Po, X0, RHO, iters, nch1, 0, 1, threads=1)
+    rate1 = n1 / (time.perf_counter() - t0)
+    nchc = max(cores, int(rate1 * cores * seconds_budget / 2 / ((iters + 1) * (N_GRID - 1))) // cores * cores)
+    t0 = time.perf_counter()
+    nc, _, _ = o.ensemble_mcmc(Po, X0, RHO, iters, nchc, 0, 1, threads=cores)
+    ratec = nc / (time.perf_counter() - t0)
+    return {"value": ratec, "unit": "path-steps/s", "cores": cores, "kind": "port",
+            "value_1thread": rate1,
+            "sample": f"{nchc} chains x {iters + 1} pCN iterations x {N_GRID - 1} steps of the bench workload "
+                      f"(OpenMP over chains, {cores} threads); 1-thread figure on {nch1} chains; "
+                      "C restatement of Bridge.jl's four-pass loop (no Julia on this box), not Bridge.jl itself"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--chains", type=int, default=262144, help="chains (paths) per GPU")
+    ap.add_argument("--mode", choices=["mcmc", "proposals"], default="mcmc")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    ctx = bh.Context(local)
+    Po = build_proposal(ctx)
+    P = args.chains
+    path0 = rank * P                      # contiguous shard of the global chain ids; RNG keyed by global id
+    steps_per_unit = N_GRID - 1
+    stats = ctx.empty(bh.STATS_LEN)
+    gathered = ctx.empty(world * bh.STATS_LEN) if world > 1 else None
+
+    if args.mode == "mcmc":
+        ch = bh.Chains(Po, X0, P, seed=4, path0=path0, store_X=True)
+
+        def step():
+            ch.step(RHO, 1)
+
+        bytes_per_pathstep = 8 * 2 + 16 * 1      # write Xo (8d) + read W, write Wo (16 m')   SURVEY 8(d) mode M
+        kernel = "k_paths<MFHN, LMMU, 1, PCN>"
+    else:
+        X = bh.EnsemblePath(Po.tt, 2, P, ctx)
+        ll = ctx.empty(P)
+        it = [0]
+        x0 = np.array(X0)
+
+        def step():
+            it[0] += 1
+            ctx.check(ctx.lib.bhip_sample_solve(ctx.h, Po.h, bh.api._dptr(x0), None, None, P, X.ptr(), P,
+                                                bh.api.vp(ll.data_ptr()), 0, P, 4, it[0], path0))
+
+        bytes_per_pathstep = 8 * 2               # write X (8d)                               SURVEY 8(d) mode E
+        kernel = "k_paths<MFHN, LMMU, 1, FRESH>"
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        evs[k].record()
+        step()
+    evs[args.steps].record()
+    if args.mode == "mcmc":
+        ch.stats(stats)
+    else:
+        stats.zero_()
+    if world > 1:
+        dist.all_gather_into_tensor(gathered, stats)     # the ONE collective: acceptance / log-weight statistics
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    kern_ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps)]
+    kern_avg_s = float(np.mean(kern_ms)) * 1e-3
+
+    if rank == 0:
+        total_pathsteps = float(world) * P * steps_per_unit * args.steps
+        value = total_pathsteps / elapsed
+        alg_bytes_per_launch = float(P) * steps_per_unit * bytes_per_pathstep
+        achieved = alg_bytes_per_launch / kern_avg_s / 1e9
+        out = {
+            "metric": "guided-bridge path-steps/sec (whole node)",
+            "value": value,
+            "unit": "path-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": ("FitzHugh-Nagumo PartialBridge (d=2, scalar noise, L=[1 0], Sigma=1e-10, v=1.1), "
+                                    "1001-point tau-grid T=2, "
+                                    + ("pCN-MCMC rho=0.9: one step = one MH iteration of every chain"
+                                       if args.mode == "mcmc" else "independent fused proposals (sample!+solve!+llikelihood)")),
+                       "mode": args.mode, "paths_per_gpu": P, "grid_points": N_GRID, "path_steps_per_step": P * steps_per_unit * world,
+                       "parallelism": f"chains sharded over {world} GPU(s), one RCCL all-gather of the statistics block"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": kernel, "kernel_avg_ms": kern_avg_s * 1e3,
+                         "algorithmic_bytes_per_path_step": bytes_per_pathstep,
+                         "path_steps_per_launch": P * steps_per_unit},
+        }
+        if args.mode == "mcmc":
+            if world > 1:
+                g = gathered.cpu().numpy().reshape(world, bh.STATS_LEN)
+            else:
+                g = stats.cpu().numpy().reshape(1, bh.STATS_LEN)
+            out["config"]["acceptance_rate"] = float(g[:, 2].sum() / (g[:, 0].sum() * max(g[0, 1], 1)))
+            out["config"]["mean_ll"] = float(g[:, 3].sum() / g[:, 0].sum())
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

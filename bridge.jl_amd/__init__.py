@@ -1,0 +1,8 @@
+"""bridgehip -- MI355X-native guided-proposal diffusion-bridge sampler (the hot path of
+mschauer/Bridge.jl behind its own sample/solve/llikelihood interface).
+
+The directory is called `bridge.jl_amd`; import it as `bridgehip` (repo-root shim `bridgehip.py`).
+"""
+from .api import *  # noqa: F401,F403
+from .api import _cm, _uncm  # noqa: F401
+from . import _lib  # noqa: F401

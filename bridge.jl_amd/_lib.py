@@ -1,0 +1,83 @@
+"""ctypes declarations for libbridgehip.so (the C ABI of include/bridgehip.h).
+
+The shared library is the product; this module only loads it.  There is NO CPU fallback: if the
+library is missing the import fails, and creating a context without a GPU raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libbridgehip.so")
+
+dp = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol declared in include/bridgehip.h
+SIGNATURES = {
+    "bhip_version": (C.c_int, []),
+    "bhip_device_count": (C.c_int, []),
+    "bhip_ctx_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
+    "bhip_ctx_destroy": (None, [vp]),
+    "bhip_ctx_sync": (C.c_int, [vp]),
+    "bhip_last_error": (C.c_char_p, [vp]),
+    "bhip_malloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "bhip_free": (C.c_int, [vp, vp]),
+    "bhip_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "bhip_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "bhip_memset": (C.c_int, [vp, vp, C.c_int, C.c_size_t]),
+    "bhip_upload_aos": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, dp]),
+    "bhip_download_aos": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, dp]),
+    "bhip_proposal_create": (C.c_int, [vp, dp, C.c_int, C.c_int, C.c_int, dp, C.c_int, C.POINTER(vp)]),
+    "bhip_proposal_destroy": (None, [vp]),
+    "bhip_proposal_set_aux": (C.c_int, [vp, C.c_int, dp, C.c_int]),
+    "bhip_proposal_set_aux_callback": (C.c_int, [vp, vp, vp, C.c_int, dp]),
+    "bhip_proposal_guide_hv": (C.c_int, [vp, dp, dp]),
+    "bhip_proposal_guide_lmmu": (C.c_int, [vp, C.c_int, dp, dp, dp]),
+    "bhip_proposal_guide_nuh": (C.c_int, [vp, C.c_int, dp, dp, C.c_double, dp, C.c_int]),
+    "bhip_proposal_guide_arrays": (C.c_int, [vp, C.c_int, C.c_int, dp, dp, dp, dp]),
+    "bhip_proposal_guide_get": (C.c_int, [vp, dp, dp, dp, dp]),
+    "bhip_proposal_lptilde": (C.c_int, [vp, dp, dp]),
+    "bhip_proposal_info": (C.c_int, [vp] + [C.POINTER(C.c_int)] * 5),
+    "bhip_wiener_sample": (C.c_int, [vp, dp, C.c_int, C.c_int, vp, C.c_long, C.c_long, C.c_uint64, C.c_uint32, C.c_uint32]),
+    "bhip_solve": (C.c_int, [vp, vp, dp, vp, vp, C.c_long, vp, C.c_long, vp, C.c_int, C.c_long]),
+    "bhip_sample_solve": (C.c_int, [vp, vp, dp, vp, vp, C.c_long, vp, C.c_long, vp, C.c_int, C.c_long,
+                                    C.c_uint64, C.c_uint32, C.c_uint32]),
+    "bhip_llikelihood": (C.c_int, [vp, vp, vp, C.c_long, vp, C.c_int, C.c_long]),
+    "bhip_chains_create": (C.c_int, [vp, vp, C.c_long, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(vp)]),
+    "bhip_chains_destroy": (None, [vp]),
+    "bhip_chains_init": (C.c_int, [vp, dp, C.c_int]),
+    "bhip_chains_step": (C.c_int, [vp, C.c_double, C.c_int, C.c_int]),
+    "bhip_chains_stats": (C.c_int, [vp, vp]),
+    "bhip_chains_get": (C.c_int, [vp, dp, C.POINTER(C.c_int64)]),
+    "bhip_chains_get_paths": (C.c_int, [vp, C.c_long, C.c_long, dp, dp]),
+    "bhip_chains_pathstats": (C.c_int, [vp, dp, dp]),
+    "bhip_welford_merge": (C.c_int, [C.c_long, C.c_int, dp, dp, dp, C.c_double, dp, dp]),
+    "bhip_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "bhip_normals_host": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, dp]),
+}
+
+AUX_FN = C.CFUNCTYPE(None, C.c_double, dp, dp, dp, vp)
+
+_lib = None
+
+
+def load():
+    """dlopen libbridgehip.so and attach prototypes.  torch is imported first so that this process
+    uses ONE HIP runtime (PyTorch-ROCm bundles libamdhip64 under the same soname)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        import torch  # noqa: F401  (device memory / streams / torch.distributed plumbing)
+    except Exception:  # pragma: no cover - torch is part of the image
+        pass
+    if not os.path.exists(SO_PATH):
+        raise ImportError(f"{SO_PATH} is missing: build it with `python __graft_entry__.py` "
+                          f"(or make -C bridge.jl_amd/csrc); there is no CPU fallback")
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,714 @@
+"""Host-side mirror of Bridge.jl's interface for the guided-proposal hot path.
+
+Names, argument order and error behaviour follow the reference (Julia `!` is spelled `_`):
+
+    ContinuousTimeProcess, SamplePath          src/types.jl:23,71-76
+    Wiener, sample, sample_                    src/wiener.jl:1-58
+    Euler / EulerMaruyama, solve, solve_       src/euler.jl:14-16,117-152,246-268
+    bridge_ (deprecated alias of solve_)       src/deprecated.jl:16-17
+    GuidedBridge                               src/guip.jl:165-206
+    PartialBridge                              src/partialbridge.jl:33-58
+    PartialBridgeNuH                           src/partialbridgenuH.jl:122-169
+    PartialBridgeInplace  (`PartialBridge!`)   src/partialbridgen!.jl:32-97
+    LeftRule, llikelihood, lptilde             src/ode.jl:8, src/guip.jl:206,429-438
+    mcmc  (the script loop)                    project_partialbridge/partialbridge_fitzhugh.jl:125-176
+    mcstart / mcnext / mcstats / mcband        src/mclog.jl:22-93
+
+What differs from the reference, by construction: a path object holds an ENSEMBLE of paths
+(`EnsemblePath`, struct-of-arrays on the GPU) instead of one path, user processes are chosen from
+a registry of device functors (arbitrary Julia/Python closures cannot run inside a HIP kernel),
+and the noise comes from a counter-based Philox stream instead of a global RNG.
+
+All numerical work happens in libbridgehip.so; nothing here falls back to the CPU.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import dp, vp
+
+# ----------------------------------------------------------------------------- ids (include/bridgehip.h)
+MODEL_WIENER, MODEL_OU, MODEL_LINPRO, MODEL_FHN, MODEL_NCLAR, MODEL_INTDIFF, MODEL_LORENZ, MODEL_FHN2, MODEL_PENDULUM = range(9)
+AUX_AFFINE, AUX_LINPRO, AUX_FHN_STARTEND, AUX_CALLBACK = range(4)
+GUIDE_NONE, GUIDE_HV, GUIDE_LMMU, GUIDE_NUH, GUIDE_NUH_INPLACE = range(5)
+CHAINS_STORE_X = 1
+STATS_LEN = 8
+
+
+class BridgeError(RuntimeError):
+    """error(...) of the reference / non-zero BHIP_E* code of the library"""
+
+
+def _cm(A):
+    """column-major flattening (Julia memory order) of a matrix or a stack of matrices"""
+    A = np.asarray(A, dtype=np.float64)
+    if A.ndim <= 1:
+        return np.ascontiguousarray(A)
+    if A.ndim == 2:
+        return np.ascontiguousarray(A.T).ravel()
+    return np.ascontiguousarray(np.swapaxes(A, -1, -2)).reshape(A.shape[0], -1)
+
+
+def _uncm(a, r, c):
+    a = np.asarray(a)
+    if a.ndim == 1:
+        return a.reshape(c, r).T.copy()
+    return np.swapaxes(a.reshape(a.shape[0], c, r), -1, -2).copy()
+
+
+def _dptr(a):
+    return a.ctypes.data_as(dp)
+
+
+# ----------------------------------------------------------------------------- context
+class Context:
+    """One device + stream (bhip_ctx).  Launches go to torch's current stream of that device."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = _lib.load()
+        h = vp()
+        if device == -1:   # host-only: guide coefficients can be computed, nothing can be launched
+            self.device, self.stream = None, None
+            rc = self.lib.bhip_ctx_create(-1, None, C.byref(h))
+            if rc != 0:
+                raise BridgeError(f"bhip_ctx_create failed ({rc})")
+            self.h = h
+            return
+        if not torch.cuda.is_available():
+            raise BridgeError("no HIP device visible: bridgehip has no CPU path")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.stream = stream
+        rc = self.lib.bhip_ctx_create(device, vp(stream), C.byref(h))
+        if rc != 0:
+            raise BridgeError(f"bhip_ctx_create failed ({rc})")
+        self.h = h
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self.lib.bhip_last_error(self.h)
+            raise BridgeError((msg.decode() if msg else "") + f" [bhip {rc}]")
+
+    def sync(self):
+        self.check(self.lib.bhip_ctx_sync(self.h))
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float64, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.bhip_ctx_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+# ----------------------------------------------------------------------------- processes
+class ContinuousTimeProcess:
+    """src/types.jl:23.  Subclasses name a device functor (model id) and its parameters."""
+    model_id = None
+    d = None
+    mp = None
+
+    def params(self):
+        raise NotImplementedError
+
+
+class Wiener(ContinuousTimeProcess):
+    """Wiener{SVector{d}}  src/wiener.jl:1-3"""
+    model_id = MODEL_WIENER
+
+    def __init__(self, d=1):
+        self.d = self.mp = d
+
+    def params(self):
+        return np.zeros(0)
+
+
+class OrnsteinUhlenbeck(ContinuousTimeProcess):
+    """b = -beta*x, sigma constant (test/guip.jl:8-26, README.md:69-77)"""
+    model_id, d, mp = MODEL_OU, 1, 1
+
+    def __init__(self, beta, sigma):
+        if not (math.isnan(beta) or beta > 0.0):
+            raise BridgeError("Parameter λ must be positive.")       # test/guip.jl:13
+        if not (math.isnan(sigma) or sigma > 0.0):
+            raise BridgeError("Parameter σ must be positive.")       # test/guip.jl:14
+        self.beta, self.sigma = float(beta), float(sigma)
+
+    def params(self):
+        return np.array([self.beta, self.sigma])
+
+
+class LinPro(ContinuousTimeProcess):
+    """dX = B(X - mu)dt + sigma dW   src/linpro.jl:65-87.  Usable as target and as auxiliary."""
+    model_id = MODEL_LINPRO
+    aux_kind = AUX_LINPRO
+
+    def __init__(self, B, mu, sigma):
+        self.B = np.atleast_2d(np.asarray(B, dtype=np.float64))
+        self.d = self.mp = self.B.shape[0]
+        self.mu = np.atleast_1d(np.asarray(mu, dtype=np.float64)).reshape(self.d)
+        self.sigma = np.atleast_2d(np.asarray(sigma, dtype=np.float64)).reshape(self.d, self.d)
+
+    def params(self):
+        return np.concatenate([_cm(self.B), self.mu, _cm(self.sigma)])
+
+    aux_params = params
+
+
+class FitzhughDiffusion(ContinuousTimeProcess):
+    """project_partialbridge/partialbridge_fitzhugh.jl:36-46"""
+    model_id, d, mp = MODEL_FHN, 2, 1
+
+    def __init__(self, eps, s, gamma, beta, sigma):
+        self.eps, self.s, self.gamma, self.beta, self.sigma = map(float, (eps, s, gamma, beta, sigma))
+
+    def params(self):
+        return np.array([self.eps, self.s, self.gamma, self.beta, self.sigma])
+
+
+class NclarDiffusion(ContinuousTimeProcess):
+    """project_partialbridge/partialbridge_nclar.jl:52-61"""
+    model_id, d, mp = MODEL_NCLAR, 3, 1
+
+    def __init__(self, alpha, omega, sigma):
+        self.alpha, self.omega, self.sigma = map(float, (alpha, omega, sigma))
+
+    def params(self):
+        return np.array([self.alpha, self.omega, self.sigma])
+
+
+class IntegratedDiffusion(ContinuousTimeProcess):
+    """test/partialbridge.jl:7-15"""
+    model_id, d, mp = MODEL_INTDIFF, 2, 1
+
+    def __init__(self, gamma):
+        self.gamma = float(gamma)
+
+    def params(self):
+        return np.array([self.gamma])
+
+
+class Lorenz(ContinuousTimeProcess):
+    """src/Models.jl:41-58"""
+    model_id, d, mp = MODEL_LORENZ, 3, 3
+
+    def __init__(self, theta=(10.0, 28.0, 8 / 3), sigma=(1.0, 1.0, 1.0)):
+        self.theta, self.sigma = tuple(map(float, theta)), tuple(map(float, sigma))
+
+    def params(self):
+        return np.array(self.theta + self.sigma)
+
+
+class FitzHughNagumo(ContinuousTimeProcess):
+    """Bridge.Models.FitzHughNagumo  src/Models.jl:9-20"""
+    model_id, d, mp = MODEL_FHN2, 2, 2
+
+    def __init__(self, eps, s, gamma, beta, sigma1, sigma2):
+        self.p = tuple(map(float, (eps, s, gamma, beta, sigma1, sigma2)))
+
+    def params(self):
+        return np.array(self.p)
+
+
+class Pendulum(ContinuousTimeProcess):
+    """src/Models.jl:69-88"""
+    model_id, d, mp = MODEL_PENDULUM, 2, 1
+
+    def __init__(self, theta2, gamma):
+        self.theta2, self.gamma = float(theta2), float(gamma)
+
+    def params(self):
+        return np.array([self.theta2, self.gamma])
+
+
+# ---- auxiliary processes (Bridge.B / Bridge.beta / Bridge.sigma / Bridge.a 2-arg methods)
+class AffineAux:
+    """constant B, beta, sigma;  b~(t,x) = B*x + beta  (e.g. FitzhughDiffusionAux "linearised_end",
+    partialbridge_fitzhugh.jl:99-101,112-116; NclarDiffusionAux; IntegratedDiffusionAux)"""
+    aux_kind = AUX_AFFINE
+
+    def __init__(self, B, beta, sigma):
+        self.B = np.atleast_2d(np.asarray(B, dtype=np.float64))
+        self.d = self.B.shape[0]
+        self.beta = np.atleast_1d(np.asarray(beta, dtype=np.float64)).reshape(self.d)
+        self.sigma = np.asarray(sigma, dtype=np.float64).reshape(self.d, -1)
+
+    def aux_params(self):
+        return np.concatenate([_cm(self.B), self.beta, _cm(self.sigma)])
+
+
+class FitzhughDiffusionAuxStartEnd:
+    """time-dependent "linearised_startend" auxiliary  partialbridge_fitzhugh.jl:58-73,102-105"""
+    aux_kind = AUX_FHN_STARTEND
+    d = 2
+
+    def __init__(self, eps, s, gamma, beta, sigma, t, u, T, v):
+        self.p = tuple(map(float, (eps, s, gamma, beta, sigma, t, u, T, v)))
+
+    def aux_params(self):
+        return np.array(self.p)
+
+
+def fitzhugh_aux_linearised_end(P, v):
+    """Bridge.B/beta of FitzhughDiffusionAux, aux_choice == "linearised_end" (partialbridge_fitzhugh.jl:99-100)"""
+    B = [[1 / P.eps - 3 * v ** 2 / P.eps, -1 / P.eps], [P.gamma, -1.0]]
+    beta = [P.s / P.eps + 2 * v ** 3 / P.eps, P.beta]
+    return AffineAux(B, beta, [[0.0], [P.sigma]])
+
+
+class CallbackAux:
+    """user-defined auxiliary: fn(t) -> (B, beta, a) evaluated on the host while the guide ODE is
+    integrated (the Python twin of a Julia @cfunction)"""
+    aux_kind = AUX_CALLBACK
+
+    def __init__(self, d, fn, mu=None):
+        self.d, self.fn, self.mu = d, fn, None if mu is None else np.asarray(mu, dtype=np.float64)
+
+        def _cb(t, Bp, bp, ap, _user):
+            B, beta, a = self.fn(t)
+            Bc, ac = _cm(np.atleast_2d(B)), _cm(np.atleast_2d(a))
+            for k in range(d * d):
+                Bp[k] = Bc[k]
+                ap[k] = ac[k]
+            bb = np.atleast_1d(np.asarray(beta, dtype=np.float64))
+            for k in range(d):
+                bp[k] = bb[k]
+
+        self._cfn = _lib.AUX_FN(_cb)
+
+
+# ----------------------------------------------------------------------------- paths
+class SamplePath:
+    """host SamplePath{T}: tt [N], yy [N, dim]   src/types.jl:71-76"""
+
+    def __init__(self, tt, yy):
+        self.tt = np.array(tt, dtype=np.float64)
+        self.yy = np.array(yy, dtype=np.float64).reshape(len(self.tt), -1)
+
+    def __len__(self):
+        return len(self.tt)
+
+    def copy(self):
+        return SamplePath(self.tt.copy(), self.yy.copy())
+
+
+class EnsemblePath:
+    """An ensemble of sample paths on one GPU, struct-of-arrays fp64:
+    data[i, k, p] = component k of path p at grid index i (contiguous in p)."""
+
+    def __init__(self, tt, dim, npaths, ctx=None, data=None):
+        self.ctx = ctx or default_context()
+        self.tt = np.array(tt, dtype=np.float64)
+        self.dim, self.npaths = int(dim), int(npaths)
+        N = len(self.tt)
+        if data is None:
+            data = torch.zeros((N, self.dim, self.npaths), dtype=torch.float64, device=self.ctx.device)
+        if tuple(data.shape) != (N, self.dim, self.npaths) or data.dtype != torch.float64 or not data.is_contiguous():
+            raise BridgeError("EnsemblePath: data must be a contiguous float64 tensor [N, dim, npaths]")
+        self.data = data
+
+    def __len__(self):
+        return len(self.tt)
+
+    @property
+    def ld(self):
+        return self.npaths
+
+    def ptr(self):
+        return vp(self.data.data_ptr())
+
+    def copy(self):
+        return EnsemblePath(self.tt.copy(), self.dim, self.npaths, self.ctx, self.data.clone())
+
+    @classmethod
+    def from_paths(cls, tt, yy, ctx=None):
+        """upload host paths yy [npaths, N, dim] (Vector{SVector} per path) -> SoA ensemble"""
+        yy = np.ascontiguousarray(yy, dtype=np.float64)
+        if yy.ndim == 2:
+            yy = yy[:, :, None]
+        npaths, N, dim = yy.shape
+        E = cls(tt, dim, npaths, ctx)
+        E.ctx.check(E.ctx.lib.bhip_upload_aos(E.ctx.h, E.ptr(), N, dim, E.ld, 0, npaths, _dptr(yy)))
+        return E
+
+    def paths(self, p0=0, n=None):
+        """download paths p0..p0+n as host array [n, N, dim]"""
+        n = self.npaths - p0 if n is None else n
+        out = np.empty((n, len(self.tt), self.dim))
+        self.ctx.check(self.ctx.lib.bhip_download_aos(self.ctx.h, self.ptr(), len(self.tt), self.dim, self.ld, p0, n, _dptr(out)))
+        return out
+
+    def path(self, p):
+        return SamplePath(self.tt, self.paths(p, 1)[0])
+
+
+class SDESolver:
+    pass
+
+
+class EulerMaruyama(SDESolver):
+    pass
+
+
+Euler = EulerMaruyama
+
+
+class LeftRule:
+    pass
+
+
+# ----------------------------------------------------------------------------- proposals
+class _Proposal(ContinuousTimeProcess):
+    """common part of GuidedBridge / PartialBridge*: grid, target, auxiliary, device rows"""
+    kind = GUIDE_NONE
+
+    def __init__(self, tt, P, Pt, ctx=None):
+        self.ctx = ctx or default_context()
+        self.tt = np.array(tt, dtype=np.float64)
+        self.Target, self.Pt = P, Pt
+        self.d, self.mp = P.d, P.mp
+        par = np.ascontiguousarray(P.params(), dtype=np.float64)
+        h = vp()
+        lib = self.ctx.lib
+        self.ctx.check(lib.bhip_proposal_create(self.ctx.h, _dptr(self.tt), len(self.tt), P.model_id, P.d,
+                                                _dptr(par), len(par), C.byref(h)))
+        self.h = h
+        if Pt is not None:
+            if Pt.aux_kind == AUX_CALLBACK:
+                mu = None if Pt.mu is None else _dptr(np.ascontiguousarray(Pt.mu))
+                self.ctx.check(lib.bhip_proposal_set_aux_callback(h, C.cast(Pt._cfn, vp), None, 0 if Pt.mu is None else 1, mu))
+            else:
+                ap = np.ascontiguousarray(Pt.aux_params(), dtype=np.float64)
+                self.ctx.check(lib.bhip_proposal_set_aux(h, Pt.aux_kind, _dptr(ap), len(ap)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.ctx.lib.bhip_proposal_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _get(self, shapes):
+        N = len(self.tt)
+        bufs = [None if s is None else np.empty((N,) + s if s != "v" else (self.m,)) for s in shapes]
+        ptrs = [None if b is None else _dptr(b) for b in bufs]
+        self.ctx.check(self.ctx.lib.bhip_proposal_guide_get(self.h, *ptrs))
+        return bufs
+
+
+class PlainProcess(_Proposal):
+    """wraps an unguided target so that solve(EulerMaruyama(), u, W, P) runs on the device"""
+
+    def __init__(self, tt, P, ctx=None):
+        super().__init__(tt, P, None, ctx)
+
+
+class GuidedBridge(_Proposal):
+    """GuidedBridge(tt, P, Pt, v, h=0)  src/guip.jl:165-180; fields Hd ("H♢") [N,d,d], V [N,d]"""
+    kind = GUIDE_HV
+
+    def __init__(self, tt, P, Pt, v, h=None, ctx=None):
+        super().__init__(tt, P, Pt, ctx)
+        v = np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64)
+        hp = None if h is None else _dptr(_cm(np.atleast_2d(h)))
+        self.ctx.check(self.ctx.lib.bhip_proposal_guide_hv(self.h, _dptr(v), hp))
+        self.m = self.d
+        Hd, V, _, _ = self._get([(self.d * self.d,), (self.d,), None, None])
+        self.Hd, self.V = _uncm(Hd, self.d, self.d), V
+
+
+class PartialBridge(_Proposal):
+    """PartialBridge(tt, P, Pt, L, v, Sigma)  src/partialbridge.jl:33-51; fields L, M, mu, v"""
+    kind = GUIDE_LMMU
+
+    def __init__(self, tt, P, Pt, L, v, Sigma=None, ctx=None):
+        super().__init__(tt, P, Pt, ctx)
+        L = np.atleast_2d(np.asarray(L, dtype=np.float64))
+        self.m = L.shape[0]
+        v = np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64)
+        Sp = None if Sigma is None else _dptr(_cm(np.atleast_2d(Sigma)))
+        self.ctx.check(self.ctx.lib.bhip_proposal_guide_lmmu(self.h, self.m, _dptr(_cm(L)), _dptr(v), Sp))
+        m, d = self.m, self.d
+        Lt, Mt, mut, vv = self._get([(m * d,), (m * m,), (m,), "v"])
+        self.L, self.M, self.mu, self.v = _uncm(Lt, m, d), _uncm(Mt, m, m), mut, vv
+
+
+class PartialBridgeNuH(_Proposal):
+    """PartialBridgeνH(tt, P, Pt, L, v, eps, Sigma)  src/partialbridgenuH.jl:122-146; fields nu, H, C"""
+    kind = GUIDE_NUH
+    _inplace = 0
+
+    def __init__(self, tt, P, Pt, L, v, eps, Sigma=None, ctx=None):
+        super().__init__(tt, P, Pt, ctx)
+        L = np.atleast_2d(np.asarray(L, dtype=np.float64))
+        self.m = L.shape[0]
+        v = np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64)
+        Sp = None if Sigma is None else _dptr(_cm(np.atleast_2d(Sigma)))
+        self.ctx.check(self.ctx.lib.bhip_proposal_guide_nuh(self.h, self.m, _dptr(_cm(L)), _dptr(v), float(eps), Sp, self._inplace))
+        d = self.d
+        nut, Ht, Cc, _ = self._get([(d,), (d * d,), (1,), None])
+        self.nu, self.H, self.C = nut, _uncm(Ht, d, d), float(Cc[0, 0])
+
+
+class PartialBridgeInplace(PartialBridgeNuH):
+    """`PartialBridge!`(tt, P, Pt, L, v, eps, Sigmanoise)  src/partialbridgen!.jl:32-56"""
+    kind = GUIDE_NUH_INPLACE
+    _inplace = 1
+
+
+class ProposalFromArrays(_Proposal):
+    """a proposal whose guide arrays were computed elsewhere (bhip_proposal_guide_arrays)"""
+
+    def __init__(self, tt, P, Pt, kind, m, A1, A2, A3=None, A4=None, ctx=None):
+        super().__init__(tt, P, Pt, ctx)
+        self.kind, self.m = kind, m
+        arrs = [None if A is None else np.ascontiguousarray(A, dtype=np.float64) for A in (A1, A2, A3, A4)]
+        self.ctx.check(self.ctx.lib.bhip_proposal_guide_arrays(self.h, kind, m, *[None if A is None else _dptr(A) for A in arrs]))
+
+
+def lptilde(Po, u):
+    """lptilde(P::GuidedBridge, u)  src/guip.jl:206 ;  NuH: -0.5 (nu1-u)'H1(nu1-u) - C"""
+    out = C.c_double()
+    u = np.ascontiguousarray(np.atleast_1d(u), dtype=np.float64)
+    Po.ctx.check(Po.ctx.lib.bhip_proposal_lptilde(Po.h, _dptr(u), C.byref(out)))
+    return out.value
+
+
+# ----------------------------------------------------------------------------- sample / solve / llikelihood
+def sample(tt, P, npaths=1, seed=0, iter=0, path0=0, ctx=None):
+    """sample(tt, Wiener{...}()) -> W  (src/wiener.jl:11-15), for an ensemble of `npaths` paths.
+    Path p draws from the Philox stream (seed, path0+p, iter)."""
+    if not isinstance(P, Wiener):
+        raise BridgeError("sample: only Wiener processes are sampled exactly on the device")
+    W = EnsemblePath(tt, P.mp, npaths, ctx)
+    return sample_(W, P, seed=seed, iter=iter, path0=path0)
+
+
+def sample_(W, P, seed=0, iter=0, path0=0):
+    """sample!(W, Wiener())  src/wiener.jl:24-58"""
+    if not isinstance(P, Wiener) or P.mp != W.dim:
+        raise BridgeError("sample!: dimension of W and of the Wiener process differ")
+    ctx = W.ctx
+    ctx.check(ctx.lib.bhip_wiener_sample(ctx.h, _dptr(W.tt), len(W.tt), W.dim, W.ptr(), W.ld, W.npaths, seed, iter, path0))
+    return W
+
+
+def _x0(u, d):
+    u = np.ascontiguousarray(np.atleast_1d(u), dtype=np.float64)
+    if u.shape != (d,):
+        raise BridgeError("Starting point has wrong length.")          # src/sde!.jl:31
+    return u
+
+
+def solve_(method, Y, u, W, P, ll=None, skip=0):
+    """solve!(::EulerMaruyama, Y, u, W, P)  src/euler.jl:135-152 and, for guided proposals,
+    solve!(::Euler, Y, u, W, P::Union{GuidedBridge,PartialBridge,PartialBridgeνH})  :247-268.
+    Overwrites Y.tt with the proposal's grid (:256) and returns the endpoints yy[N] (:267) as a
+    tensor [d, npaths].  If `ll` (tensor [npaths]) is given, llikelihood(LeftRule(), Y, P; skip)
+    is accumulated in the same kernel."""
+    if not isinstance(method, EulerMaruyama):
+        raise BridgeError("solve!: only the Euler-Maruyama scheme runs on the device")
+    if not isinstance(P, _Proposal):
+        raise BridgeError("solve!: wrap the target with PlainProcess(tt, P) or use a guided proposal")
+    if len(W) != len(Y):
+        raise BridgeError("Y and W differ in length.")                  # src/euler.jl:137,251
+    if len(P.tt) != len(W):
+        raise BridgeError("Time axis mismatch between bridge P and driving W.")   # :248 (intent)
+    if W.dim != P.mp or Y.dim != P.d or W.npaths != Y.npaths:
+        raise BridgeError("solve!: dimension mismatch between Y, W and P")
+    ctx = Y.ctx
+    Y.tt[:] = P.tt                                                       # :256 / :142
+    per_path = isinstance(u, torch.Tensor)
+    x0 = None if per_path else _dptr(_x0(u, P.d))
+    x0d = vp(u.data_ptr()) if per_path else None
+    if per_path and (tuple(u.shape) != (P.d, Y.npaths) or not u.is_contiguous()):
+        raise BridgeError("per-path starting points must be a contiguous tensor [d, npaths]")
+    llp = None if ll is None else vp(ll.data_ptr())
+    ctx.check(ctx.lib.bhip_solve(ctx.h, P.h, x0, x0d, W.ptr(), W.ld, Y.ptr(), Y.ld, llp, skip, Y.npaths))
+    return Y.data[-1]
+
+
+def solve(method, u, W, P, ll=None, skip=0):
+    """solve(::SDESolver, u, W, P) -> X   src/euler.jl:117-118,246"""
+    X = EnsemblePath(W.tt, P.d, W.npaths, W.ctx)
+    solve_(method, X, u, W, P, ll=ll, skip=skip)
+    return X
+
+
+def bridge_(Y, u, W, P):
+    """bridge!(Y, u, W, P): deprecated alias of solve!(Euler(), Y, u, W, P)  src/deprecated.jl:16-17;
+    the 4-argument form is the one the scripts call (project/partialbridge.jl:63)"""
+    return solve_(Euler(), Y, u, W, P)
+
+
+def llikelihood(rule, X, Po, skip=0):
+    """llikelihood(::LeftRule, X, Po; skip=0) for every path of the ensemble -> tensor [npaths]
+    src/guip.jl:429-438, src/partialbridge.jl:67-77, src/partialbridgenuH.jl:171-181,
+    src/partialbridgen!.jl:81-97  (constant-diffusivity branch)"""
+    if not isinstance(rule, LeftRule):
+        raise BridgeError("llikelihood: only LeftRule is implemented on the device")
+    ctx = X.ctx
+    out = ctx.empty(X.npaths)
+    ctx.check(ctx.lib.bhip_llikelihood(ctx.h, Po.h, X.ptr(), X.ld, vp(out.data_ptr()), skip, X.npaths))
+    return out
+
+
+def sample_solve(u, Po, npaths, seed=0, iter=0, path0=0, store_W=False, store_X=True, skip=0, ctx=None):
+    """fused  W = sample(tt, Wiener()); X = solve(Euler(), u, W, Po); ll = llikelihood(LeftRule(), X, Po)
+    with in-kernel Philox noise.  Returns (X or None, W or None, ll or None)."""
+    ctx = ctx or Po.ctx
+    X = EnsemblePath(Po.tt, Po.d, npaths, ctx) if store_X else None
+    W = EnsemblePath(Po.tt, Po.mp, npaths, ctx) if store_W else None
+    ll = ctx.empty(npaths) if Po.kind != GUIDE_NONE else None
+    per_path = isinstance(u, torch.Tensor)
+    x0 = None if per_path else _dptr(_x0(u, Po.d))
+    x0d = vp(u.data_ptr()) if per_path else None
+    ctx.check(ctx.lib.bhip_sample_solve(ctx.h, Po.h, x0, x0d,
+                                        None if W is None else W.ptr(), npaths,
+                                        None if X is None else X.ptr(), npaths,
+                                        None if ll is None else vp(ll.data_ptr()), skip, npaths, seed, iter, path0))
+    return X, W, ll
+
+
+# ----------------------------------------------------------------------------- MCMC
+class Chains:
+    """An ensemble of independent pCN Metropolis-Hastings chains, one per GPU lane
+    (project_partialbridge/partialbridge_fitzhugh.jl:125-176; test/partialbridgenuH.jl:155-198)."""
+
+    def __init__(self, Po, x0, nchains, seed=0, path0=0, store_X=True, skip=0):
+        self.Po, self.ctx = Po, Po.ctx
+        h = vp()
+        self.ctx.check(self.ctx.lib.bhip_chains_create(self.ctx.h, Po.h, nchains, path0, seed,
+                                                       CHAINS_STORE_X if store_X else 0, C.byref(h)))
+        self.h, self.n, self.skip = h, nchains, skip
+        self.iterations = 0
+        self.ctx.check(self.ctx.lib.bhip_chains_init(h, _dptr(_x0(x0, Po.d)), skip))
+
+    def step(self, rho, iters=1, skip=0):
+        self.ctx.check(self.ctx.lib.bhip_chains_step(self.h, float(rho), int(iters), skip))
+        self.iterations += iters
+
+    def stats(self, out=None):
+        """device tensor [8]: {nchains, iterations, sum acc, sum ll, sum ll^2, min ll, max ll, sum acc^2}"""
+        out = self.ctx.empty(STATS_LEN) if out is None else out
+        self.ctx.check(self.ctx.lib.bhip_chains_stats(self.h, vp(out.data_ptr())))
+        return out
+
+    def ll(self):
+        out = np.empty(self.n)
+        self.ctx.check(self.ctx.lib.bhip_chains_get(self.h, _dptr(out), None))
+        return out
+
+    def acc(self):
+        out = np.empty(self.n, dtype=np.int64)
+        self.ctx.check(self.ctx.lib.bhip_chains_get(self.h, None, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+    def paths(self, p0=0, n=None, want_W=True):
+        n = self.n - p0 if n is None else n
+        N = len(self.Po.tt)
+        X = np.empty((n, N, self.Po.d))
+        W = np.empty((n, N, self.Po.mp)) if want_W else None
+        self.ctx.check(self.ctx.lib.bhip_chains_get_paths(self.h, p0, n, _dptr(X), None if W is None else _dptr(W)))
+        return X, W
+
+    def pathstats(self):
+        """pointwise ensemble (n, mean [N,d], m2 [N,d,d]) of the current X -- mcnext! state"""
+        N, d = len(self.Po.tt), self.Po.d
+        mean, m2 = np.empty((N, d)), np.empty((N, d * d))
+        self.ctx.check(self.ctx.lib.bhip_chains_pathstats(self.h, _dptr(mean), _dptr(m2)))
+        return self.n, mean, _uncm(m2, d, d)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.ctx.lib.bhip_chains_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def mcmc(Po, x0, iterations, rho, nchains=1, seed=0, path0=0, skip=0, subsamples=None, store_X=True):
+    """The MH loop of partialbridge_fitzhugh.jl:125-176 for `nchains` independent chains.
+    Returns dict(chains=Chains, acc=per-chain acceptance counts, ll=final ll,
+                 XX=list of saved X ensembles [n, N, d] at the `subsamples` iterations)."""
+    ch = Chains(Po, x0, nchains, seed=seed, path0=path0, store_X=store_X, skip=skip)
+    XX = []
+    subs = sorted(set(subsamples)) if subsamples is not None else []
+    if 0 in subs and store_X:
+        XX.append(ch.paths(want_W=False)[0])
+    done = 0
+    for s in [s for s in subs if 0 < s <= iterations] + ([iterations] if iterations not in subs else []):
+        ch.step(rho, s - done)
+        done = s
+        if s in subs and store_X:
+            XX.append(ch.paths(want_W=False)[0])
+    return dict(chains=ch, acc=ch.acc(), ll=ch.ll(), XX=XX)
+
+
+# ----------------------------------------------------------------------------- online statistics (src/mclog.jl)
+def mcstart(x):
+    """mcstart(yy) -> (mean, m2, n)   src/mclog.jl:22-23 ; x: [entries, d]"""
+    x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+    E, d = x.shape
+    return np.zeros((E, d)), np.zeros((E, d, d)), 0
+
+
+def mcnext(mc, x):
+    """mcnext!(mc, x)   src/mclog.jl:48-56 (one chain value x [entries, d])"""
+    m, m2, n = mc
+    x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+    delta = x - m
+    m = m + delta / (n + 1)
+    m2 = m2 + delta[:, :, None] * (x - m)[:, None, :]
+    return m, m2, n + 1
+
+
+def mcmerge(mc_a, mc_b):
+    """merge two states (Chan's parallel form of the same recurrence; used across GPUs)"""
+    ma, qa, na = mc_a
+    mb, qb, nb = mc_b
+    lib = _lib.load()
+    E, d = ma.shape
+    ma = np.ascontiguousarray(ma, dtype=np.float64).copy()
+    qa_c = np.ascontiguousarray(_cm(qa).reshape(E, d * d)).copy()
+    n = C.c_double(float(na))
+    lib.bhip_welford_merge(E, d, C.byref(n), _dptr(ma), _dptr(qa_c), float(nb),
+                           _dptr(np.ascontiguousarray(mb, dtype=np.float64)),
+                           _dptr(np.ascontiguousarray(_cm(qb).reshape(E, d * d))))
+    return ma, _uncm(qa_c, d, d), int(n.value)
+
+
+def mcstats(mc):
+    """mean and covariance estimates   src/mclog.jl:89-93"""
+    m, m2, k = mc
+    return m, m2 / (k - 1)
+
+
+def mcband(mc):
+    """marginal 95% band  src/mclog.jl:76-82 ; Q = sqrt(2)*erfinv(0.95)"""
+    from scipy.special import erfinv
+    m, m2, k = mc
+    Q = math.sqrt(2.0) * erfinv(0.95)
+    std = np.sqrt(np.einsum("eii->ei", m2) * (1 / (k - 1)))
+    return m - Q * std, m + Q * std

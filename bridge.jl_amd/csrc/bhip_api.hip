@@ -1,0 +1,726 @@
+// bhip_api.hip -- implementation of the C ABI declared in include/bridgehip.h.
+// Host logic only (context, proposal construction, launch orchestration); the device work is in
+// bhip_path_kernel.h (instantiated per model in bhip_inst.hip) and bhip_util_kernels.h.
+#include "bhip_host.hpp"
+#include "bhip_path_kernel.h"
+#include "bhip_util_kernels.h"
+#include <algorithm>
+#include <cstdio>
+#include <new>
+
+using namespace bhip;
+
+namespace bhip {
+// one translation unit per model (bhip_inst.hip compiled with -DBHIP_INST=<id>)
+launch_fn get_launch_ou(int, int, int);
+launch_fn get_launch_linpro1(int, int, int);
+launch_fn get_launch_linpro2(int, int, int);
+launch_fn get_launch_linpro3(int, int, int);
+launch_fn get_launch_fhn(int, int, int);
+launch_fn get_launch_nclar(int, int, int);
+launch_fn get_launch_intdiff(int, int, int);
+launch_fn get_launch_lorenz(int, int, int);
+launch_fn get_launch_fhn2(int, int, int);
+launch_fn get_launch_pendulum(int, int, int);
+launch_fn get_launch_wiener1(int, int, int);
+launch_fn get_launch_wiener2(int, int, int);
+launch_fn get_launch_wiener3(int, int, int);
+}  // namespace bhip
+
+struct bhip_ctx {
+    int device = 0;
+    bool host_only = false;   // device == -1: guide pre-computation only, every launch is refused
+    hipStream_t stream = nullptr;
+    std::string err;
+    double *scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+struct bhip_proposal {
+    bhip_ctx *ctx = nullptr;
+    std::vector<double> tt;
+    ModelHost mh;
+    Aux aux;
+    bool has_aux = false;
+    Guide g;
+    double *d_rows = nullptr;
+    int rs = 0;
+    bool use_vend = false;
+    double vend[3] = {0, 0, 0};
+};
+
+struct bhip_chains {
+    bhip_ctx *ctx = nullptr;
+    const bhip_proposal *po = nullptr;
+    long n = 0, ld = 0;
+    uint32_t path0 = 0;
+    uint64_t seed = 0;
+    int flags = 0;
+    uint32_t iter = 0;
+    bool inited = false;
+    double x0[3] = {0, 0, 0};
+    double *Wb[2] = {nullptr, nullptr};
+    double *Xb[2] = {nullptr, nullptr};
+    unsigned char *cur = nullptr;
+    double *llcur = nullptr;
+    unsigned int *acc = nullptr;
+};
+
+static int fail(bhip_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) return fail(ctx, BHIP_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define NEED_DEVICE(ctx)                                                                          \
+    do {                                                                                          \
+        if ((ctx)->host_only) return fail(ctx, BHIP_EHIP, "host-only context (device -1): no device work possible"); \
+    } while (0)
+
+static int ensure_scratch(bhip_ctx *ctx, size_t bytes)
+{
+    NEED_DEVICE(ctx);
+    if (ctx->scratch_bytes >= bytes) return BHIP_OK;
+    if (ctx->scratch) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+    HIPCHK(ctx, hipMalloc((void **)&ctx->scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return BHIP_OK;
+}
+
+static launch_fn find_launch(const ModelHost &mh, int gk, int mo, int noise)
+{
+    switch (mh.id) {
+    case BHIP_MODEL_OU: return get_launch_ou(gk, mo, noise);
+    case BHIP_MODEL_LINPRO:
+        if (mh.d == 1) return get_launch_linpro1(gk, mo, noise);
+        if (mh.d == 2) return get_launch_linpro2(gk, mo, noise);
+        if (mh.d == 3) return get_launch_linpro3(gk, mo, noise);
+        return nullptr;
+    case BHIP_MODEL_FHN: return get_launch_fhn(gk, mo, noise);
+    case BHIP_MODEL_NCLAR: return get_launch_nclar(gk, mo, noise);
+    case BHIP_MODEL_INTDIFF: return get_launch_intdiff(gk, mo, noise);
+    case BHIP_MODEL_LORENZ: return get_launch_lorenz(gk, mo, noise);
+    case BHIP_MODEL_FHN2: return get_launch_fhn2(gk, mo, noise);
+    case BHIP_MODEL_PENDULUM: return get_launch_pendulum(gk, mo, noise);
+    case BHIP_MODEL_WIENER:
+        if (mh.d == 1) return get_launch_wiener1(gk, mo, noise);
+        if (mh.d == 2) return get_launch_wiener2(gk, mo, noise);
+        if (mh.d == 3) return get_launch_wiener3(gk, mo, noise);
+        return nullptr;
+    }
+    return nullptr;
+}
+
+extern "C" {
+
+int bhip_version(void) { return BHIP_VERSION; }
+
+int bhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bhip_ctx_create(int device, void *stream, bhip_ctx **out)
+{
+    if (!out) return BHIP_EINVAL;
+    *out = nullptr;
+    if (device == -1) {   // host-only context: proposals / guide coefficients can be built, nothing can run
+        bhip_ctx *c = new (std::nothrow) bhip_ctx();
+        if (!c) return BHIP_EHIP;
+        c->device = -1; c->host_only = true;
+        *out = c;
+        return BHIP_OK;
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return BHIP_EHIP;   // fail loudly: no CPU fallback
+    if (device < 0 || device >= n) return BHIP_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return BHIP_EHIP;
+    bhip_ctx *c = new (std::nothrow) bhip_ctx();
+    if (!c) return BHIP_EHIP;
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    *out = c;
+    return BHIP_OK;
+}
+
+void bhip_ctx_destroy(bhip_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->scratch) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->scratch); }
+    delete ctx;
+}
+
+int bhip_ctx_sync(bhip_ctx *ctx)
+{
+    if (!ctx) return BHIP_EINVAL;
+    if (ctx->host_only) return BHIP_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return BHIP_OK;
+}
+
+const char *bhip_last_error(const bhip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int bhip_malloc(bhip_ctx *ctx, size_t bytes, void **dev)
+{
+    if (!ctx || !dev) return BHIP_EINVAL;
+    NEED_DEVICE(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMalloc(dev, bytes ? bytes : 8));
+    return BHIP_OK;
+}
+int bhip_free(bhip_ctx *ctx, void *dev)
+{
+    if (!ctx) return BHIP_EINVAL;
+    if (!dev) return BHIP_OK;
+    NEED_DEVICE(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(dev));
+    return BHIP_OK;
+}
+int bhip_memcpy_h2d(bhip_ctx *ctx, void *dev, const void *host, size_t bytes)
+{
+    if (!ctx) return BHIP_EINVAL;
+    NEED_DEVICE(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return BHIP_OK;
+}
+int bhip_memcpy_d2h(bhip_ctx *ctx, void *host, const void *dev, size_t bytes)
+{
+    if (!ctx) return BHIP_EINVAL;
+    NEED_DEVICE(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return BHIP_OK;
+}
+int bhip_memset(bhip_ctx *ctx, void *dev, int byte, size_t bytes)
+{
+    if (!ctx) return BHIP_EINVAL;
+    NEED_DEVICE(ctx);
+    HIPCHK(ctx, hipMemsetAsync(dev, byte, bytes, ctx->stream));
+    return BHIP_OK;
+}
+
+int bhip_upload_aos(bhip_ctx *ctx, double *dev, int N, int dim, long ld, long p0, long np, const double *aos)
+{
+    if (!ctx || !dev || !aos || N < 1 || dim < 1 || np < 0 || p0 < 0 || p0 + np > ld) return fail(ctx, BHIP_EINVAL, "bhip_upload_aos: bad argument");
+    if (np == 0) return BHIP_OK;
+    const long E = (long)N * dim;
+    const size_t bytes = sizeof(double) * (size_t)E * np;
+    int rc = ensure_scratch(ctx, bytes);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->scratch, aos, bytes, hipMemcpyHostToDevice, ctx->stream));
+    const long tot = E * np;
+    hipLaunchKernelGGL(k_aos_to_soa, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ctx->scratch, dev, E, ld, p0, np);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return BHIP_OK;
+}
+
+int bhip_download_aos(bhip_ctx *ctx, const double *dev, int N, int dim, long ld, long p0, long np, double *aos)
+{
+    if (!ctx || !dev || !aos || N < 1 || dim < 1 || np < 0 || p0 < 0 || p0 + np > ld) return fail(ctx, BHIP_EINVAL, "bhip_download_aos: bad argument");
+    if (np == 0) return BHIP_OK;
+    const long E = (long)N * dim;
+    const size_t bytes = sizeof(double) * (size_t)E * np;
+    int rc = ensure_scratch(ctx, bytes);
+    if (rc) return rc;
+    const long tot = E * np;
+    hipLaunchKernelGGL(k_soa_to_aos, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, dev, ctx->scratch, E, ld, p0, np);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(aos, ctx->scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return BHIP_OK;
+}
+
+/* ------------------------------------------------------------------ proposal */
+int bhip_proposal_create(bhip_ctx *ctx, const double *tt, int N, int model, int d, const double *par, int npar, bhip_proposal **out)
+{
+    if (!ctx || !out) return BHIP_EINVAL;
+    *out = nullptr;
+    if (!tt || N < 2) return fail(ctx, BHIP_EINVAL, "bhip_proposal_create: need a grid with at least 2 points");
+    for (int i = 0; i + 1 < N; i++)
+        if (!(tt[i + 1] > tt[i])) return fail(ctx, BHIP_EINVAL, "bhip_proposal_create: grid must be strictly increasing");
+    bhip_proposal *po = new (std::nothrow) bhip_proposal();
+    if (!po) return fail(ctx, BHIP_EHIP, "out of host memory");
+    po->ctx = ctx;
+    po->tt.assign(tt, tt + N);
+    std::string err;
+    int rc = model_setup(model, d, par, npar, po->mh, err);
+    if (rc) { delete po; return fail(ctx, rc, "bhip_proposal_create: " + err); }
+    po->g.kind = BHIP_GUIDE_NONE;
+    *out = po;
+    return BHIP_OK;
+}
+
+void bhip_proposal_destroy(bhip_proposal *po)
+{
+    if (!po) return;
+    if (po->d_rows && !po->ctx->host_only) { (void)hipStreamSynchronize(po->ctx->stream); (void)hipFree(po->d_rows); }
+    delete po;
+}
+
+int bhip_proposal_set_aux(bhip_proposal *po, int kind, const double *apar, int napar)
+{
+    if (!po) return BHIP_EINVAL;
+    bhip_ctx *ctx = po->ctx;
+    const int d = po->mh.d, mp = po->mh.mp;
+    int need;
+    if (kind == BHIP_AUX_AFFINE || kind == BHIP_AUX_LINPRO) need = d * d + d + d * mp;
+    else if (kind == BHIP_AUX_FHN_STARTEND) { need = 9; if (d != 2 || mp != 1) return fail(ctx, BHIP_EINVAL, "FHN_STARTEND auxiliary needs d=2, scalar noise"); }
+    else return fail(ctx, BHIP_EINVAL, "bhip_proposal_set_aux: unknown auxiliary kind");
+    if (!apar || napar != need) return fail(ctx, BHIP_EINVAL, "bhip_proposal_set_aux: wrong number of parameters");
+    po->aux = Aux();
+    po->aux.kind = kind; po->aux.d = d; po->aux.mp = mp;
+    po->aux.par.assign(apar, apar + napar);
+    po->has_aux = true;
+    return BHIP_OK;
+}
+
+int bhip_proposal_set_aux_callback(bhip_proposal *po, bhip_aux_fn fn, void *user, int drift_form, const double *mu)
+{
+    if (!po) return BHIP_EINVAL;
+    if (!fn) return fail(po->ctx, BHIP_EINVAL, "bhip_proposal_set_aux_callback: null callback");
+    if (drift_form == 1 && !mu) return fail(po->ctx, BHIP_EINVAL, "LinPro drift form needs mu");
+    po->aux = Aux();
+    po->aux.kind = BHIP_AUX_CALLBACK; po->aux.d = po->mh.d; po->aux.mp = po->mh.mp;
+    po->aux.fn = fn; po->aux.user = user; po->aux.cb_linpro = drift_form == 1;
+    if (drift_form == 1) po->aux.cb_mu.assign(mu, mu + po->mh.d);
+    po->has_aux = true;
+    return BHIP_OK;
+}
+
+static int finish_guide(bhip_proposal *po)
+{
+    bhip_ctx *ctx = po->ctx;
+    const int N = (int)po->tt.size(), d = po->mh.d;
+    po->use_vend = false;
+    if (po->g.kind == BHIP_GUIDE_HV) {   // endpoint(y, P::GuidedBridge)  src/euler.jl:241-242
+        double n1 = 0;
+        for (double x : po->g.Hd[N - 1].a) n1 += std::fabs(x);
+        if (n1 < 2.220446049250313e-16) {
+            po->use_vend = true;
+            for (int k = 0; k < d && k < 3; k++) po->vend[k] = po->g.V[N - 1].a[k];
+        }
+    }
+    if (d > 3) return BHIP_OK;   // large-d rows are built by the tile kernel path
+    if (ctx->host_only) return BHIP_OK;   // coefficients stay on the host (bhip_proposal_guide_get)
+    std::vector<double> rows;
+    int rs = 0;
+    pack_rows(po->tt, po->mh, po->has_aux ? &po->aux : nullptr, po->g, rows, rs);
+    if (po->d_rows) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(po->d_rows)); po->d_rows = nullptr; }
+    HIPCHK(ctx, hipMalloc((void **)&po->d_rows, sizeof(double) * rows.size()));
+    HIPCHK(ctx, hipMemcpy(po->d_rows, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice));
+    po->rs = rs;
+    return BHIP_OK;
+}
+
+int bhip_proposal_guide_hv(bhip_proposal *po, const double *v, const double *hT)
+{
+    if (!po || !v) return BHIP_EINVAL;
+    if (!po->has_aux) return fail(po->ctx, BHIP_ESTATE, "bhip_proposal_guide_hv: set the auxiliary process first");
+    const int d = po->mh.d;
+    Mat vv(d, 1, v), h(d, d);
+    if (hT) h = Mat(d, d, hT);
+    guide_hv(po->tt, po->aux, vv, h, po->g);
+    return finish_guide(po);
+}
+
+int bhip_proposal_guide_lmmu(bhip_proposal *po, int m, const double *L, const double *v, const double *Sigma)
+{
+    if (!po || !L || !v) return BHIP_EINVAL;
+    if (!po->has_aux) return fail(po->ctx, BHIP_ESTATE, "bhip_proposal_guide_lmmu: set the auxiliary process first");
+    const int d = po->mh.d;
+    if (m < 1 || m > d) return fail(po->ctx, BHIP_EINVAL, "observation dimension m must be in 1..d");
+    Mat S(m, m);
+    if (Sigma) S = Mat(m, m, Sigma);   // default Sigma = outer(zero(v)) = 0  (src/partialbridge.jl:42)
+    guide_lmmu(po->tt, po->aux, Mat(m, d, L), Mat(m, 1, v), S, po->g);
+    return finish_guide(po);
+}
+
+int bhip_proposal_guide_nuh(bhip_proposal *po, int m, const double *L, const double *v, double eps, const double *Sigma, int inplace)
+{
+    if (!po || !L || !v) return BHIP_EINVAL;
+    if (!po->has_aux) return fail(po->ctx, BHIP_ESTATE, "bhip_proposal_guide_nuh: set the auxiliary process first");
+    const int d = po->mh.d;
+    if (m < 1 || m > d) return fail(po->ctx, BHIP_EINVAL, "observation dimension m must be in 1..d");
+    Mat S(m, m);
+    if (Sigma) S = Mat(m, m, Sigma);
+    if (inplace) guide_nuh_inplace(po->tt, po->aux, Mat(m, d, L), Mat(m, 1, v), eps, S, po->g);
+    else guide_nuh(po->tt, po->aux, Mat(m, d, L), Mat(m, 1, v), eps, S, po->g);
+    return finish_guide(po);
+}
+
+int bhip_proposal_guide_arrays(bhip_proposal *po, int kind, int m, const double *A1, const double *A2, const double *A3, const double *A4)
+{
+    if (!po) return BHIP_EINVAL;
+    if (!po->has_aux) return fail(po->ctx, BHIP_ESTATE, "bhip_proposal_guide_arrays: set the auxiliary process first");
+    const int N = (int)po->tt.size(), d = po->mh.d;
+    Guide &g = po->g;
+    g = Guide();
+    g.kind = kind;
+    if (kind == BHIP_GUIDE_HV) {
+        if (!A1 || !A2) return fail(po->ctx, BHIP_EINVAL, "HV guide needs Hd and V");
+        g.m = d; g.Hd.resize(N); g.V.resize(N);
+        for (int i = 0; i < N; i++) { g.Hd[i] = Mat(d, d, A1 + (size_t)i * d * d); g.V[i] = Mat(d, 1, A2 + (size_t)i * d); }
+    } else if (kind == BHIP_GUIDE_LMMU) {
+        if (!A1 || !A2 || !A3 || !A4 || m < 1 || m > d) return fail(po->ctx, BHIP_EINVAL, "LMMU guide needs L, M, mu, v and 1 <= m <= d");
+        g.m = m; g.L.resize(N); g.M.resize(N); g.mu.resize(N); g.v = Mat(m, 1, A4);
+        for (int i = 0; i < N; i++) { g.L[i] = Mat(m, d, A1 + (size_t)i * m * d); g.M[i] = Mat(m, m, A2 + (size_t)i * m * m); g.mu[i] = Mat(m, 1, A3 + (size_t)i * m); }
+    } else if (kind == BHIP_GUIDE_NUH || kind == BHIP_GUIDE_NUH_INPLACE) {
+        if (!A1 || !A2) return fail(po->ctx, BHIP_EINVAL, "NUH guide needs nu and H");
+        g.m = d; g.nu.resize(N); g.H.resize(N);
+        for (int i = 0; i < N; i++) { g.nu[i] = Mat(d, 1, A1 + (size_t)i * d); g.H[i] = Mat(d, d, A2 + (size_t)i * d * d); }
+    } else return fail(po->ctx, BHIP_EINVAL, "unknown guide kind");
+    return finish_guide(po);
+}
+
+int bhip_proposal_guide_get(const bhip_proposal *po, double *A1, double *A2, double *A3, double *A4)
+{
+    if (!po) return BHIP_EINVAL;
+    const Guide &g = po->g;
+    const int N = (int)po->tt.size();
+    auto put = [&](double *dst, const std::vector<Mat> &src) {
+        if (!dst) return;
+        size_t off = 0;
+        for (int i = 0; i < N; i++) { std::memcpy(dst + off, src[i].a.data(), sizeof(double) * src[i].a.size()); off += src[i].a.size(); }
+    };
+    if (g.kind == BHIP_GUIDE_HV) { put(A1, g.Hd); put(A2, g.V); }
+    else if (g.kind == BHIP_GUIDE_LMMU) { put(A1, g.L); put(A2, g.M); put(A3, g.mu); if (A4) std::memcpy(A4, g.v.a.data(), sizeof(double) * g.v.a.size()); }
+    else if (g.kind == BHIP_GUIDE_NUH || g.kind == BHIP_GUIDE_NUH_INPLACE) { put(A1, g.nu); put(A2, g.H); if (A3) A3[0] = g.C; }
+    else return BHIP_ESTATE;
+    return BHIP_OK;
+}
+
+int bhip_proposal_lptilde(const bhip_proposal *po, const double *u, double *out)
+{
+    if (!po || !u || !out) return BHIP_EINVAL;
+    const Guide &g = po->g;
+    const int d = po->mh.d;
+    Mat uu(d, 1, u);
+    if (g.kind == BHIP_GUIDE_HV) {   // logpdfnormal(V[1]-u, Hd[1]) - traceB(tt, Pt)   src/guip.jl:206
+        *out = logpdfnormal(g.V[0] - uu, g.Hd[0]) - g.trB;
+        return BHIP_OK;
+    }
+    if (g.kind == BHIP_GUIDE_NUH) {  // -0.5*(nu1-u)'H1(nu1-u) - C
+        const Mat w = g.nu[0] - uu;
+        *out = -0.5 * dot(w, g.H[0] * w) - g.C;
+        return BHIP_OK;
+    }
+    return BHIP_EUNSUPPORTED;
+}
+
+int bhip_proposal_info(const bhip_proposal *po, int *N, int *d, int *mp, int *m, int *kind)
+{
+    if (!po) return BHIP_EINVAL;
+    if (N) *N = (int)po->tt.size();
+    if (d) *d = po->mh.d;
+    if (mp) *mp = po->mh.mp;
+    if (m) *m = po->g.m;
+    if (kind) *kind = po->g.kind;
+    return BHIP_OK;
+}
+
+/* ------------------------------------------------------------------ hot path */
+static int ensure_plain_rows(bhip_proposal *po)
+{   // forward EM without a guide: rows = (t, dt, sqrt(dt))
+    NEED_DEVICE(po->ctx);
+    if (po->d_rows) return BHIP_OK;
+    return finish_guide(po);
+}
+
+static int fill_common(const bhip_proposal *po, KArgs &a, const double *x0, const double *x0_dev, long npaths, int skip)
+{
+    bhip_ctx *ctx = po->ctx;
+    const int d = po->mh.d;
+    std::memset(&a, 0, sizeof(a));
+    NEED_DEVICE(ctx);
+    if (d > 3) return fail(ctx, BHIP_EUNSUPPORTED, "path-per-lane kernel covers d <= 3");
+    if (!po->d_rows) return fail(ctx, BHIP_ESTATE, "proposal has no coefficient rows (compute a guide first)");
+    if (npaths < 1) return fail(ctx, BHIP_EINVAL, "npaths must be positive");
+    if (skip < 0) return fail(ctx, BHIP_EINVAL, "skip must be >= 0");
+    if (!x0 && !x0_dev) return fail(ctx, BHIP_EINVAL, "need a starting point");
+    a.rows = po->d_rows; a.rs = po->rs; a.N = (int)po->tt.size(); a.skip = skip;
+    a.P = npaths;
+    a.aux_linpro = po->has_aux && po->aux.linpro_form();
+    a.ll_two_dots = po->g.kind == BHIP_GUIDE_NUH_INPLACE;
+    a.use_vend = po->use_vend;
+    for (int k = 0; k < d; k++) {
+        a.x0[k] = x0 ? x0[k] : 0.0;
+        a.vend[k] = po->vend[k];
+        a.mu_aux[k] = a.aux_linpro ? po->aux.mu()[k] : 0.0;
+    }
+    if ((int)po->mh.dpar.size() > 32) return fail(ctx, BHIP_EINVAL, "model parameter block too large");
+    for (size_t k = 0; k < po->mh.dpar.size(); k++) a.mpar[k] = po->mh.dpar[k];
+    return BHIP_OK;
+}
+
+static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
+{
+    bhip_ctx *ctx = po->ctx;
+    const int gk = po->g.kind == BHIP_GUIDE_NUH_INPLACE ? BHIP_GUIDE_NUH : po->g.kind;
+    launch_fn f = find_launch(po->mh, gk, gk == BHIP_GUIDE_LMMU ? po->g.m : 1, noise);
+    if (!f) return fail(ctx, BHIP_EUNSUPPORTED, "no device kernel for this (model, guide, noise) combination");
+    if (a.rs != row_stride(gk, po->mh.d, po->g.m)) return fail(ctx, BHIP_ESTATE, "row stride mismatch");
+    HIPCHK(ctx, f(a, ctx->stream));
+    return BHIP_OK;
+}
+
+int bhip_wiener_sample(bhip_ctx *ctx, const double *tt, int N, int mp, double *W_dev, long ld, long npaths, uint64_t seed, uint32_t iter, uint32_t path0)
+{
+    if (!ctx || !tt || !W_dev || N < 2 || mp < 1 || npaths < 1 || ld < npaths) return fail(ctx, BHIP_EINVAL, "bhip_wiener_sample: bad argument");
+    NEED_DEVICE(ctx);
+    std::vector<double> rdt(N - 1);
+    for (int i = 0; i + 1 < N; i++) rdt[i] = std::sqrt(tt[i + 1] - tt[i]);
+    int rc = ensure_scratch(ctx, sizeof(double) * (size_t)(N - 1));
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->scratch, rdt.data(), sizeof(double) * (N - 1), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // rdt is a stack-lifetime host buffer
+    const dim3 grid((unsigned)((npaths + 255) / 256)), block(256);
+    if (mp <= 4)
+        hipLaunchKernelGGL(k_wiener, grid, block, 0, ctx->stream, ctx->scratch, N, mp, W_dev, ld, npaths, (uint32_t)seed, (uint32_t)(seed >> 32), iter, path0);
+    else
+        hipLaunchKernelGGL(k_wiener_big, grid, block, 0, ctx->stream, ctx->scratch, N, mp, W_dev, ld, npaths, (uint32_t)seed, (uint32_t)(seed >> 32), iter, path0);
+    HIPCHK(ctx, hipGetLastError());
+    return BHIP_OK;
+}
+
+int bhip_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, const double *x0_dev, const double *W_dev, long ldW,
+               double *X_dev, long ldX, double *ll_dev, int skip, long npaths)
+{
+    if (!ctx || !po) return BHIP_EINVAL;
+    if (!W_dev) return fail(ctx, BHIP_EINVAL, "bhip_solve: W_dev is required");
+    if (po->g.kind == BHIP_GUIDE_NONE) {
+        if (ll_dev) return fail(ctx, BHIP_EINVAL, "bhip_solve: llikelihood needs a guided proposal");
+        int rc = ensure_plain_rows(const_cast<bhip_proposal *>(po));
+        if (rc) return rc;
+    }
+    KArgs a;
+    int rc = fill_common(po, a, x0, x0_dev, npaths, skip);
+    if (rc) return rc;
+    if (ldW < npaths || (X_dev && ldX < npaths)) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
+    a.x0_dev = x0_dev; a.ldx0 = ldX;
+    a.Win = W_dev; a.ldWin = ldW; a.X = X_dev; a.ldX = ldX; a.ll = ll_dev;
+    return do_launch(po, NOISE_EXT, a);
+}
+
+int bhip_sample_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, const double *x0_dev, double *W_dev, long ldW,
+                      double *X_dev, long ldX, double *ll_dev, int skip, long npaths, uint64_t seed, uint32_t iter, uint32_t path0)
+{
+    if (!ctx || !po) return BHIP_EINVAL;
+    if (po->g.kind == BHIP_GUIDE_NONE) {
+        if (ll_dev) return fail(ctx, BHIP_EINVAL, "bhip_sample_solve: llikelihood needs a guided proposal");
+        int rc = ensure_plain_rows(const_cast<bhip_proposal *>(po));
+        if (rc) return rc;
+    }
+    KArgs a;
+    int rc = fill_common(po, a, x0, x0_dev, npaths, skip);
+    if (rc) return rc;
+    if ((W_dev && ldW < npaths) || (X_dev && ldX < npaths)) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
+    a.x0_dev = x0_dev; a.ldx0 = ldX;
+    a.Wout = W_dev; a.ldWout = ldW; a.X = X_dev; a.ldX = ldX; a.ll = ll_dev;
+    a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.iter = iter; a.path0 = path0;
+    return do_launch(po, NOISE_FRESH, a);
+}
+
+int bhip_llikelihood(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev, long ldX, double *ll_dev, int skip, long npaths)
+{
+    if (!ctx || !po || !X_dev || !ll_dev) return BHIP_EINVAL;
+    if (po->g.kind == BHIP_GUIDE_NONE) return fail(ctx, BHIP_EINVAL, "bhip_llikelihood: needs a guided proposal");
+    KArgs a;
+    const double zero[3] = {0, 0, 0};
+    int rc = fill_common(po, a, zero, nullptr, npaths, skip);
+    if (rc) return rc;
+    if (ldX < npaths) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
+    a.Win = X_dev; a.ldWin = ldX; a.ll = ll_dev;
+    return do_launch(po, NOISE_LLONLY, a);
+}
+
+/* ------------------------------------------------------------------ chains */
+int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uint32_t path0, uint64_t seed, int flags, bhip_chains **out)
+{
+    if (!ctx || !po || !out) return BHIP_EINVAL;
+    *out = nullptr;
+    NEED_DEVICE(ctx);
+    if (nchains < 1) return fail(ctx, BHIP_EINVAL, "nchains must be positive");
+    if (po->g.kind == BHIP_GUIDE_NONE) return fail(ctx, BHIP_EINVAL, "chains need a guided proposal");
+    if (po->mh.d > 3) return fail(ctx, BHIP_EUNSUPPORTED, "chains: d <= 3");
+    bhip_chains *ch = new (std::nothrow) bhip_chains();
+    if (!ch) return fail(ctx, BHIP_EHIP, "out of host memory");
+    ch->ctx = ctx; ch->po = po; ch->n = nchains; ch->ld = (nchains + 63) / 64 * 64;
+    ch->path0 = path0; ch->seed = seed; ch->flags = flags;
+    const size_t N = po->tt.size();
+    const size_t wbytes = sizeof(double) * N * po->mh.mp * ch->ld, xbytes = sizeof(double) * N * po->mh.d * ch->ld;
+    hipError_t e = hipSuccess;
+    for (int b = 0; b < 2 && e == hipSuccess; b++) {
+        e = hipMalloc((void **)&ch->Wb[b], wbytes);
+        if (e == hipSuccess && (flags & BHIP_CHAINS_STORE_X)) e = hipMalloc((void **)&ch->Xb[b], xbytes);
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&ch->cur, ch->ld);
+    if (e == hipSuccess) e = hipMalloc((void **)&ch->llcur, sizeof(double) * ch->ld);
+    if (e == hipSuccess) e = hipMalloc((void **)&ch->acc, sizeof(unsigned int) * ch->ld);
+    if (e != hipSuccess) { bhip_chains_destroy(ch); return fail(ctx, BHIP_EHIP, std::string("chains allocation: ") + hipGetErrorString(e)); }
+    *out = ch;
+    return BHIP_OK;
+}
+
+void bhip_chains_destroy(bhip_chains *ch)
+{
+    if (!ch) return;
+    (void)hipStreamSynchronize(ch->ctx->stream);
+    for (int b = 0; b < 2; b++) { if (ch->Wb[b]) (void)hipFree(ch->Wb[b]); if (ch->Xb[b]) (void)hipFree(ch->Xb[b]); }
+    if (ch->cur) (void)hipFree(ch->cur);
+    if (ch->llcur) (void)hipFree(ch->llcur);
+    if (ch->acc) (void)hipFree(ch->acc);
+    delete ch;
+}
+
+int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
+{
+    if (!ch || !x0) return BHIP_EINVAL;
+    bhip_ctx *ctx = ch->ctx;
+    const bhip_proposal *po = ch->po;
+    KArgs a;
+    int rc = fill_common(po, a, x0, nullptr, ch->n, skip);
+    if (rc) return rc;
+    for (int k = 0; k < po->mh.d; k++) ch->x0[k] = x0[k];
+    HIPCHK(ctx, hipMemsetAsync(ch->cur, 0, ch->ld, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ch->acc, 0, sizeof(unsigned int) * ch->ld, ctx->stream));
+    a.Wout = ch->Wb[0]; a.ldWout = ch->ld; a.X = ch->Xb[0]; a.ldX = ch->ld; a.ll = ch->llcur;
+    a.k0 = (uint32_t)ch->seed; a.k1 = (uint32_t)(ch->seed >> 32); a.iter = 0; a.path0 = ch->path0;
+    rc = do_launch(po, NOISE_FRESH, a);
+    if (rc) return rc;
+    ch->iter = 0; ch->inited = true;
+    return BHIP_OK;
+}
+
+int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip)
+{
+    if (!ch) return BHIP_EINVAL;
+    bhip_ctx *ctx = ch->ctx;
+    if (!ch->inited) return fail(ctx, BHIP_ESTATE, "bhip_chains_step: call bhip_chains_init first");
+    if (iters < 0) return fail(ctx, BHIP_EINVAL, "iters must be >= 0");
+    const bhip_proposal *po = ch->po;
+    KArgs a;
+    int rc = fill_common(po, a, ch->x0, nullptr, ch->n, skip);
+    if (rc) return rc;
+    a.Wb[0] = ch->Wb[0]; a.Wb[1] = ch->Wb[1]; a.Xb[0] = ch->Xb[0]; a.Xb[1] = ch->Xb[1]; a.ldC = ch->ld;
+    a.cur = ch->cur; a.llcur = ch->llcur; a.acc = ch->acc;
+    a.rho = rho; a.srho = std::sqrt(1 - rho * rho);
+    a.k0 = (uint32_t)ch->seed; a.k1 = (uint32_t)(ch->seed >> 32); a.path0 = ch->path0;
+    for (int it = 0; it < iters; it++) {
+        a.iter = ++ch->iter;
+        rc = do_launch(po, NOISE_PCN, a);
+        if (rc) return rc;
+    }
+    return BHIP_OK;
+}
+
+int bhip_chains_stats(bhip_chains *ch, double *stats_dev)
+{
+    if (!ch || !stats_dev) return BHIP_EINVAL;
+    bhip_ctx *ctx = ch->ctx;
+    if (!ch->inited) return fail(ctx, BHIP_ESTATE, "bhip_chains_stats: chains not initialised");
+    hipLaunchKernelGGL(k_chain_stats, dim3(1), dim3(256), 0, ctx->stream, ch->llcur, ch->acc, ch->n, (double)ch->iter, stats_dev);
+    HIPCHK(ctx, hipGetLastError());
+    return BHIP_OK;
+}
+
+int bhip_chains_get(bhip_chains *ch, double *ll, int64_t *acc)
+{
+    if (!ch) return BHIP_EINVAL;
+    bhip_ctx *ctx = ch->ctx;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ll) HIPCHK(ctx, hipMemcpy(ll, ch->llcur, sizeof(double) * ch->n, hipMemcpyDeviceToHost));
+    if (acc) {
+        std::vector<unsigned int> tmp(ch->n);
+        HIPCHK(ctx, hipMemcpy(tmp.data(), ch->acc, sizeof(unsigned int) * ch->n, hipMemcpyDeviceToHost));
+        for (long p = 0; p < ch->n; p++) acc[p] = tmp[p];
+    }
+    return BHIP_OK;
+}
+
+int bhip_chains_get_paths(bhip_chains *ch, long p0, long np, double *X_aos, double *W_aos)
+{
+    if (!ch) return BHIP_EINVAL;
+    bhip_ctx *ctx = ch->ctx;
+    if (p0 < 0 || np < 0 || p0 + np > ch->n) return fail(ctx, BHIP_EINVAL, "chain range out of bounds");
+    if (np == 0) return BHIP_OK;
+    const long N = (long)ch->po->tt.size();
+    for (int which = 0; which < 2; which++) {
+        double *dst = which == 0 ? X_aos : W_aos;
+        if (!dst) continue;
+        if (which == 0 && !ch->Xb[0]) return fail(ctx, BHIP_ESTATE, "chains were created without BHIP_CHAINS_STORE_X");
+        const long E = N * (which == 0 ? ch->po->mh.d : ch->po->mh.mp);
+        const size_t bytes = sizeof(double) * (size_t)E * np;
+        int rc = ensure_scratch(ctx, bytes);
+        if (rc) return rc;
+        const long tot = E * np;
+        double *const *B = which == 0 ? ch->Xb : ch->Wb;
+        hipLaunchKernelGGL(k_soa2_to_aos, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, B[0], B[1], ch->cur, ctx->scratch, E, ch->ld, p0, np);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(dst, ctx->scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return BHIP_OK;
+}
+
+int bhip_chains_pathstats(bhip_chains *ch, double *mean, double *m2)
+{
+    if (!ch || !mean || !m2) return BHIP_EINVAL;
+    bhip_ctx *ctx = ch->ctx;
+    if (!ch->Xb[0]) return fail(ctx, BHIP_ESTATE, "chains were created without BHIP_CHAINS_STORE_X");
+    const int N = (int)ch->po->tt.size(), d = ch->po->mh.d;
+    const size_t nm = (size_t)N * d, n2 = (size_t)N * d * d;
+    int rc = ensure_scratch(ctx, sizeof(double) * (nm + n2));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_path_stats, dim3(N), dim3(256), 0, ctx->stream, ch->Xb[0], ch->Xb[1], ch->cur, d, ch->ld, ch->n, ctx->scratch, ctx->scratch + nm);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(mean, ctx->scratch, sizeof(double) * nm, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(m2, ctx->scratch + nm, sizeof(double) * n2, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return BHIP_OK;
+}
+
+int bhip_welford_merge(long entries, int d, double *na, double *mean_a, double *m2_a, double nb, const double *mean_b, const double *m2_b)
+{
+    if (!na || !mean_a || !m2_a || !mean_b || !m2_b || d < 1 || entries < 0) return BHIP_EINVAL;
+    const double n1 = *na, n2 = nb, n = n1 + n2;
+    if (n2 == 0) return BHIP_OK;
+    for (long e = 0; e < entries; e++) {
+        double *ma = mean_a + e * d, *qa = m2_a + e * d * d;
+        const double *mb = mean_b + e * d, *qb = m2_b + e * d * d;
+        std::vector<double> delta(d);
+        for (int k = 0; k < d; k++) delta[k] = mb[k] - ma[k];
+        for (int c = 0; c < d; c++)
+            for (int r = 0; r < d; r++) qa[r + d * c] = qa[r + d * c] + qb[r + d * c] + delta[r] * delta[c] * (n1 * n2 / n);
+        for (int k = 0; k < d; k++) ma[k] = ma[k] + delta[k] * (n2 / n);
+    }
+    *na = n;
+    return BHIP_OK;
+}
+
+void bhip_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    const u32x4 r = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+void bhip_normals_host(uint64_t seed, uint32_t path, uint32_t iter, int n0, int n, double *z)
+{
+    double z0 = 0, z1 = 0; long have = -1;
+    for (int j = 0; j < n; j++) {
+        const int idx = n0 + j;
+        if ((idx >> 1) != have) { normal_pair((uint32_t)seed, (uint32_t)(seed >> 32), path, iter, (uint32_t)(idx >> 1), z0, z1); have = idx >> 1; }
+        z[j] = (idx & 1) ? z1 : z0;
+    }
+}
+
+}  // extern "C"

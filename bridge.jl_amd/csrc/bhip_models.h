@@ -1,0 +1,180 @@
+// bhip_models.h -- device functors for the target processes (Bridge.b / Bridge.sigma / Bridge.a
+// methods of the reference) and their host-side descriptions.
+//
+// A functor is constructed from the device parameter block `dp` = the user's `par` followed by
+// derived constants the host computes once (a = sigma*sigma' in the reference's operation order).
+// Member functions follow the reference expressions literally (operation order matters: results
+// are compared bit-for-bit with the CPU oracle; device code is built with -ffp-contract=off).
+#pragma once
+#include "../../include/bridgehip.h"
+#include <hip/hip_runtime.h>
+
+namespace bhip {
+
+#define BHIP_DEV __device__ __forceinline__
+
+// ---- b = -beta*x, sigma, a = sigma^2                      test/guip.jl:21-23, README.md:75-77
+struct MOU {
+    static constexpr int D = 1, MP = 1, ID = BHIP_MODEL_OU;
+    double beta, sig, a;
+    BHIP_DEV explicit MOU(const double *p) : beta(p[0]), sig(p[1]), a(p[2]) {}
+    BHIP_DEV void b(double, const double *x, double *o) const { o[0] = -beta * x[0]; }
+    BHIP_DEV void sdw(const double *dw, double *o) const { o[0] = sig * dw[0]; }
+    BHIP_DEV void amul(const double *r, double *o) const { o[0] = a * r[0]; }
+};
+
+// ---- LinPro: b = B*(x - mu), sigma, a = sigma*sigma'       src/linpro.jl:65-87
+// dp = B(D*D) mu(D) sigma(D*D) a(D*D), column-major
+template <int D_>
+struct MLinPro {
+    static constexpr int D = D_, MP = D_, ID = BHIP_MODEL_LINPRO;
+    const double *p;
+    BHIP_DEV explicit MLinPro(const double *p_) : p(p_) {}
+    BHIP_DEV void b(double, const double *x, double *o) const
+    {
+        double xm[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) xm[k] = x[k] - p[D * D + k];
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            double s = p[i] * xm[0];
+#pragma unroll
+            for (int j = 1; j < D; j++) s += p[i + D * j] * xm[j];
+            o[i] = s;
+        }
+    }
+    BHIP_DEV void sdw(const double *dw, double *o) const
+    {
+        const double *S = p + D * D + D;
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            double s = S[i] * dw[0];
+#pragma unroll
+            for (int j = 1; j < D; j++) s += S[i + D * j] * dw[j];
+            o[i] = s;
+        }
+    }
+    BHIP_DEV void amul(const double *r, double *o) const
+    {
+        const double *A = p + 2 * D * D + D;
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            double s = A[i] * r[0];
+#pragma unroll
+            for (int j = 1; j < D; j++) s += A[i + D * j] * r[j];
+            o[i] = s;
+        }
+    }
+};
+
+// ---- FitzhughDiffusion                project_partialbridge/partialbridge_fitzhugh.jl:36-46
+// b = ((x1-x2-x1^3+s)/eps, gamma*x1-x2+beta), sigma = (0, sigma)  (scalar noise, hypo-elliptic)
+// dp = eps,s,gamma,beta,sigma, a22 = sigma*sigma
+struct MFHN {
+    static constexpr int D = 2, MP = 1, ID = BHIP_MODEL_FHN;
+    double eps, s, gam, beta, sig, a22;
+    BHIP_DEV explicit MFHN(const double *p) : eps(p[0]), s(p[1]), gam(p[2]), beta(p[3]), sig(p[4]), a22(p[5]) {}
+    BHIP_DEV void b(double, const double *x, double *o) const
+    {
+        o[0] = (x[0] - x[1] - x[0] * x[0] * x[0] + s) / eps;
+        o[1] = gam * x[0] - x[1] + beta;
+    }
+    BHIP_DEV void sdw(const double *dw, double *o) const { o[0] = 0.0; o[1] = sig * dw[0]; }
+    BHIP_DEV void amul(const double *r, double *o) const { o[0] = 0.0; o[1] = a22 * r[1]; }
+};
+
+// ---- NclarDiffusion                   project_partialbridge/partialbridge_nclar.jl:52-61
+// b = (x2, x3, -alpha*sin(omega*x3)), sigma = (0,0,sigma);  dp = alpha,omega,sigma,a33
+struct MNCLAR {
+    static constexpr int D = 3, MP = 1, ID = BHIP_MODEL_NCLAR;
+    double al, om, sig, a33;
+    BHIP_DEV explicit MNCLAR(const double *p) : al(p[0]), om(p[1]), sig(p[2]), a33(p[3]) {}
+    BHIP_DEV void b(double, const double *x, double *o) const
+    {
+        o[0] = x[1]; o[1] = x[2]; o[2] = -al * sin(om * x[2]);
+    }
+    BHIP_DEV void sdw(const double *dw, double *o) const { o[0] = 0.0; o[1] = 0.0; o[2] = sig * dw[0]; }
+    BHIP_DEV void amul(const double *r, double *o) const { o[0] = 0.0; o[1] = 0.0; o[2] = a33 * r[2]; }
+};
+
+// ---- IntegratedDiffusion              test/partialbridge.jl:7-15
+// b = (x2, -(x2+sin(x2)) + 1/2), sigma = (0,gamma);  dp = gamma, a22
+struct MIntDiff {
+    static constexpr int D = 2, MP = 1, ID = BHIP_MODEL_INTDIFF;
+    double gam, a22;
+    BHIP_DEV explicit MIntDiff(const double *p) : gam(p[0]), a22(p[1]) {}
+    BHIP_DEV void b(double, const double *x, double *o) const
+    {
+        o[0] = x[1]; o[1] = -(x[1] + sin(x[1])) + 0.5;
+    }
+    BHIP_DEV void sdw(const double *dw, double *o) const { o[0] = 0.0; o[1] = gam * dw[0]; }
+    BHIP_DEV void amul(const double *r, double *o) const { o[0] = 0.0; o[1] = a22 * r[1]; }
+};
+
+// ---- Lorenz                           src/Models.jl:41-58 (test/euler.jl:45-50 with s = 3,3,3)
+// dp = th1,th2,th3,s1,s2,s3, a11,a22,a33
+struct MLorenz {
+    static constexpr int D = 3, MP = 3, ID = BHIP_MODEL_LORENZ;
+    double t1, t2, t3, s1, s2, s3, a1, a2, a3;
+    BHIP_DEV explicit MLorenz(const double *p)
+        : t1(p[0]), t2(p[1]), t3(p[2]), s1(p[3]), s2(p[4]), s3(p[5]), a1(p[6]), a2(p[7]), a3(p[8]) {}
+    BHIP_DEV void b(double, const double *x, double *o) const
+    {
+        o[0] = t1 * (x[1] - x[0]);
+        o[1] = x[0] * (t2 - x[2]) - x[1];
+        o[2] = x[0] * x[1] - t3 * x[2];
+    }
+    BHIP_DEV void sdw(const double *dw, double *o) const { o[0] = s1 * dw[0]; o[1] = s2 * dw[1]; o[2] = s3 * dw[2]; }
+    BHIP_DEV void amul(const double *r, double *o) const { o[0] = a1 * r[0]; o[1] = a2 * r[1]; o[2] = a3 * r[2]; }
+};
+
+// ---- Models.FitzHughNagumo            src/Models.jl:9-20  (diagonal 2-d noise)
+// dp = eps,s,gamma,beta,s1,s2, a11,a22
+struct MFHN2 {
+    static constexpr int D = 2, MP = 2, ID = BHIP_MODEL_FHN2;
+    double eps, s, gam, beta, s1, s2, a1, a2;
+    BHIP_DEV explicit MFHN2(const double *p)
+        : eps(p[0]), s(p[1]), gam(p[2]), beta(p[3]), s1(p[4]), s2(p[5]), a1(p[6]), a2(p[7]) {}
+    BHIP_DEV void b(double, const double *x, double *o) const
+    {
+        o[0] = (x[0] - x[0] * x[0] * x[0] - x[1] + s) / eps;
+        o[1] = gam * x[0] - x[1] + beta;
+    }
+    BHIP_DEV void sdw(const double *dw, double *o) const { o[0] = s1 * dw[0]; o[1] = s2 * dw[1]; }
+    BHIP_DEV void amul(const double *r, double *o) const { o[0] = a1 * r[0]; o[1] = a2 * r[1]; }
+};
+
+// ---- Pendulum                         src/Models.jl:69-88
+// b = (x2, -theta2*sin(x1)), sigma = (0,gamma);  dp = theta2, gamma, a22
+struct MPendulum {
+    static constexpr int D = 2, MP = 1, ID = BHIP_MODEL_PENDULUM;
+    double th2, gam, a22;
+    BHIP_DEV explicit MPendulum(const double *p) : th2(p[0]), gam(p[1]), a22(p[2]) {}
+    BHIP_DEV void b(double, const double *x, double *o) const { o[0] = x[1]; o[1] = -th2 * sin(x[0]); }
+    BHIP_DEV void sdw(const double *dw, double *o) const { o[0] = 0.0; o[1] = gam * dw[0]; }
+    BHIP_DEV void amul(const double *r, double *o) const { o[0] = 0.0; o[1] = a22 * r[1]; }
+};
+
+// ---- Wiener{SVector{D}}: b = 0, sigma = a = I            src/wiener.jl:143-167
+template <int D_>
+struct MWiener {
+    static constexpr int D = D_, MP = D_, ID = BHIP_MODEL_WIENER;
+    BHIP_DEV explicit MWiener(const double *) {}
+    BHIP_DEV void b(double, const double *, double *o) const
+    {
+#pragma unroll
+        for (int k = 0; k < D; k++) o[k] = 0.0;
+    }
+    BHIP_DEV void sdw(const double *dw, double *o) const
+    {
+#pragma unroll
+        for (int k = 0; k < D; k++) o[k] = dw[k];
+    }
+    BHIP_DEV void amul(const double *r, double *o) const
+    {
+#pragma unroll
+        for (int k = 0; k < D; k++) o[k] = r[k];
+    }
+};
+
+}  // namespace bhip

@@ -1,0 +1,195 @@
+/*
+ * bridgehip.h -- C ABI of the MI355X-native guided-proposal diffusion-bridge sampler.
+ *
+ * This is the drop-in boundary for ONE hot path of mschauer/Bridge.jl v0.11.7 (paths below are
+ * relative to the reference checkout):
+ *
+ *     sample!(W, Wiener())                       src/wiener.jl:24-58
+ *     Wo = rho*W + sqrt(1-rho^2)*W2  (pCN)       project_partialbridge/partialbridge_fitzhugh.jl:147
+ *     solve!(Euler(), Xo, x0, Wo, Po)            src/euler.jl:135-152, 247-268
+ *     llikelihood(LeftRule(), Xo, Po; skip)      src/guip.jl:429-438, src/partialbridge.jl:67-77,
+ *                                                src/partialbridgenuH.jl:171-181, src/partialbridgen!.jl:81-97
+ *     MH accept                                  project_partialbridge/partialbridge_fitzhugh.jl:160-167
+ *
+ * The reference has no FFI of its own (it is pure Julia); the entry points below are what a
+ * `ccall` shim for that path binds -- see INTEGRATION.md and bridge.jl_amd/julia/BridgeHIP.jl.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative BHIP_E* code; bhip_last_error() gives text.
+ *     No exceptions cross the ABI.
+ *   - host buffers are caller-owned and only touched during the call. `*_dev` pointers are DEVICE
+ *     pointers (hipMalloc'ed by anyone in the process: bhip_malloc, PyTorch-ROCm, AMDGPU.jl ...).
+ *   - ensembles are fp64 struct-of-arrays:  element (grid index i, component k, path p) lives at
+ *     dev[(i*dim + k)*ld + p]   (ld >= npaths).  One lane owns one path; a wave stores 512
+ *     contiguous bytes per component per step.
+ *   - host-side matrices are column-major like Julia; host AoS paths are [p][i][k]
+ *     (Vector{SVector{dim}} per path, src/types.jl:71-76).
+ *   - all launches go to the stream the context was created with; calls on one context are
+ *     serialised by the caller, different contexts are independent.
+ *   - grid indices in comments are 0-based; step i goes from tt[i] to tt[i+1].
+ */
+#ifndef BRIDGEHIP_H
+#define BRIDGEHIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BHIP_VERSION 100
+
+/* error codes */
+#define BHIP_OK 0
+#define BHIP_EINVAL (-1)       /* bad argument (message names it)                                   */
+#define BHIP_EHIP (-2)         /* a HIP runtime call failed                                         */
+#define BHIP_EUNSUPPORTED (-3) /* no device kernel for this (model, guide, dimension) combination   */
+#define BHIP_ESTATE (-4)       /* call order violated (e.g. guide not computed yet)                 */
+#define BHIP_ELENGTH (-5)      /* "Y and W differ in length."  src/euler.jl:137,251                 */
+
+/* target processes: device functors for Bridge.b / Bridge.sigma / Bridge.a methods.
+ * par layouts (doubles):                                                   reference definition  */
+#define BHIP_MODEL_WIENER 0   /* -                         b=0, sigma=I      src/wiener.jl:143-167  */
+#define BHIP_MODEL_OU 1       /* beta, sigma               b=-beta*x         test/guip.jl:8-26      */
+#define BHIP_MODEL_LINPRO 2   /* B(d*d), mu(d), sigma(d*d) b=B*(x-mu)        src/linpro.jl:65-87    */
+#define BHIP_MODEL_FHN 3      /* eps,s,gamma,beta,sigma    partialbridge_fitzhugh.jl:36-46          */
+#define BHIP_MODEL_NCLAR 4    /* alpha,omega,sigma         partialbridge_nclar.jl:52-61             */
+#define BHIP_MODEL_INTDIFF 5  /* gamma                     test/partialbridge.jl:7-15               */
+#define BHIP_MODEL_LORENZ 6   /* th1,th2,th3,s1,s2,s3      src/Models.jl:41-58                      */
+#define BHIP_MODEL_FHN2 7     /* eps,s,gamma,beta,s1,s2    src/Models.jl:9-20                       */
+#define BHIP_MODEL_PENDULUM 8 /* theta2, gamma             src/Models.jl:69-88                      */
+
+/* auxiliary linear processes dX = (B(t)X + beta(t))dt + sigma(t)dW  (Bridge.B/beta/sigma/a 2-arg
+ * methods, src/partialbridge.jl:13-15, src/gode.jl:2-3) */
+#define BHIP_AUX_AFFINE 0        /* B(d*d), beta(d), sigma(d*mp); drift evaluated as B*x + beta      */
+#define BHIP_AUX_LINPRO 1        /* B(d*d), mu(d), sigma(d*mp);  drift B*(x-mu), beta = -B*mu        */
+#define BHIP_AUX_FHN_STARTEND 2  /* eps,s,gamma,beta,sigma,t0,u,T,v  partialbridge_fitzhugh.jl:58-73,102-105 */
+#define BHIP_AUX_CALLBACK 3      /* user C callback (Julia @cfunction), see bhip_proposal_set_aux_callback */
+
+/* guide parametrisations */
+#define BHIP_GUIDE_NONE 0         /* plain Euler-Maruyama of the target            src/euler.jl:135-152 */
+#define BHIP_GUIDE_HV 1           /* GuidedBridge  (Hdiamond, V)                   src/guip.jl:165-194  */
+#define BHIP_GUIDE_LMMU 2         /* PartialBridge (L, M, mu, v)                   src/partialbridge.jl:33-58 */
+#define BHIP_GUIDE_NUH 3          /* PartialBridgeNuH (nu, H)                      src/partialbridgenuH.jl:122-162 */
+#define BHIP_GUIDE_NUH_INPLACE 4  /* PartialBridge! (nu, H), ll as two dots        src/partialbridgen!.jl:32-97 */
+
+typedef struct bhip_ctx bhip_ctx;
+typedef struct bhip_proposal bhip_proposal;
+typedef struct bhip_chains bhip_chains;
+
+/* user-defined auxiliary process: fill B (d*d col-major), beta (d), a (d*d col-major) at time t.
+ * Called on the host only, O(N) times while the guide is computed. */
+typedef void (*bhip_aux_fn)(double t, double *B, double *beta, double *a, void *user);
+
+/* ------------------------------------------------------------------ context */
+int bhip_version(void);
+int bhip_device_count(void);
+/* device: HIP ordinal; stream: a hipStream_t (NULL = the null stream).
+ * device = -1 creates a HOST-ONLY context: proposals and their guide coefficients can be computed
+ * and read back (bhip_proposal_guide_get), every call that needs the GPU returns BHIP_EHIP. */
+int bhip_ctx_create(int device, void *stream, bhip_ctx **out);
+void bhip_ctx_destroy(bhip_ctx *ctx);
+int bhip_ctx_sync(bhip_ctx *ctx);
+const char *bhip_last_error(const bhip_ctx *ctx);
+/* device memory helpers for callers without their own allocator */
+int bhip_malloc(bhip_ctx *ctx, size_t bytes, void **dev);
+int bhip_free(bhip_ctx *ctx, void *dev);
+int bhip_memcpy_h2d(bhip_ctx *ctx, void *dev, const void *host, size_t bytes);
+int bhip_memcpy_d2h(bhip_ctx *ctx, void *host, const void *dev, size_t bytes);
+int bhip_memset(bhip_ctx *ctx, void *dev, int byte, size_t bytes);
+/* AoS host [np][N][dim] <-> SoA device (i,k,p) -> (i*dim+k)*ld + p0+p   (src/misc.jl:80 `mat`) */
+int bhip_upload_aos(bhip_ctx *ctx, double *dev, int N, int dim, long ld, long p0, long np, const double *aos);
+int bhip_download_aos(bhip_ctx *ctx, const double *dev, int N, int dim, long ld, long p0, long np, double *aos);
+
+/* ------------------------------------------------------------------ proposal  ("Po")
+ * A proposal holds the grid tt (Po.tt), the target P, the auxiliary Pt and the guide coefficient
+ * rows; the latter are computed on the host by backward Ralston-3 (src/ode.jl:44-49,88-97) exactly
+ * as the reference constructors do, then packed per step and uploaded once. */
+int bhip_proposal_create(bhip_ctx *ctx, const double *tt, int N, int model, int d, const double *par,
+                         int npar, bhip_proposal **out);
+void bhip_proposal_destroy(bhip_proposal *po);
+int bhip_proposal_set_aux(bhip_proposal *po, int aux_kind, const double *apar, int napar);
+/* drift_form: 0 -> b~ = B(t)x + beta(t);  1 -> LinPro form B(x - mu) with mu given (d doubles) */
+int bhip_proposal_set_aux_callback(bhip_proposal *po, bhip_aux_fn fn, void *user, int drift_form, const double *mu);
+/* GuidedBridge(tt, P, Pt, v, hT = 0)                                       src/guip.jl:172-180 */
+int bhip_proposal_guide_hv(bhip_proposal *po, const double *v, const double *hT);
+/* PartialBridge(tt, P, Pt, L, v, Sigma)                                    src/partialbridge.jl:42-50 */
+int bhip_proposal_guide_lmmu(bhip_proposal *po, int m, const double *L, const double *v, const double *Sigma);
+/* PartialBridgeNuH(tt, P, Pt, L, v, eps, Sigma)  (inplace=0)               src/partialbridgenuH.jl:134-145
+ * PartialBridge!(tt, P, Pt, L, v, eps, Sigmanoise) (inplace=1)             src/partialbridgen!.jl:40-55 */
+int bhip_proposal_guide_nuh(bhip_proposal *po, int m, const double *L, const double *v, double eps,
+                            const double *Sigma, int inplace);
+/* take guide arrays computed elsewhere (e.g. by Bridge.jl's own constructors):
+ *   HV: A1=Hd[N][d*d] A2=V[N][d]; LMMU: A1=L[N][m*d] A2=M[N][m*m] A3=mu[N][m] A4=v[m];
+ *   NUH: A1=nu[N][d] A2=H[N][d*d]   (matrices column-major) */
+int bhip_proposal_guide_arrays(bhip_proposal *po, int kind, int m, const double *A1, const double *A2,
+                               const double *A3, const double *A4);
+/* read the guide arrays back (same layouts; NULL pointers are skipped) */
+int bhip_proposal_guide_get(const bhip_proposal *po, double *A1, double *A2, double *A3, double *A4);
+/* lptilde(Po, u): GuidedBridge src/guip.jl:206; NuH: -0.5*(nu1-u)'H1(nu1-u) - C (src/partialbridgenuH.jl:169,
+ * with the reference's P.nu typo corrected, cf. test/partialbridgenuH.jl:124) */
+int bhip_proposal_lptilde(const bhip_proposal *po, const double *u, double *out);
+int bhip_proposal_info(const bhip_proposal *po, int *N, int *d, int *mp, int *m, int *kind);
+
+/* ------------------------------------------------------------------ the hot path
+ * x0: host pointer to d doubles (shared start) -- or, if x0_dev != NULL, a device array [d][ldX] of
+ * per-path starting points (segment chaining, src/euler.jl:267 returns the endpoint).
+ * Any output pointer may be NULL (that output is then not stored). */
+
+/* sample!(W, Wiener{SVector{mp}}): W[0]=0, W[i+1] = W[i] + sqrt(tt[i+1]-tt[i])*xi, Philox stream
+ * (seed, path0+p, iter), normals time-major/component-minor.                src/wiener.jl:24-58 */
+int bhip_wiener_sample(bhip_ctx *ctx, const double *tt, int N, int mp, double *W_dev, long ld, long npaths,
+                       uint64_t seed, uint32_t iter, uint32_t path0);
+
+/* solve!(Euler(), X, x0, W, Po) on an ensemble, driven by the given W, with llikelihood fused:
+ *   X_dev [N][d][ld] out, ll_dev [npaths] out = llikelihood(LeftRule(), X, Po; skip)
+ * Forward EM (guide NONE): ll_dev must be NULL.                             src/euler.jl:135-152,247-268 */
+int bhip_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, const double *x0_dev,
+               const double *W_dev, long ldW, double *X_dev, long ldX, double *ll_dev, int skip, long npaths);
+
+/* fused sample! + solve! + llikelihood with in-kernel Philox noise; W_dev (optional) receives the
+ * cumulated Wiener paths so the ensemble can continue as an MCMC state. */
+int bhip_sample_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, const double *x0_dev,
+                      double *W_dev, long ldW, double *X_dev, long ldX, double *ll_dev, int skip,
+                      long npaths, uint64_t seed, uint32_t iter, uint32_t path0);
+
+/* stand-alone llikelihood(LeftRule(), X, Po; skip) of stored paths          src/guip.jl:429-438 ... */
+int bhip_llikelihood(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev, long ldX, double *ll_dev,
+                     int skip, long npaths);
+
+/* ------------------------------------------------------------------ pCN Metropolis-Hastings ensemble
+ * One chain per lane; state (W, X, ll) double-buffered with a per-chain parity bit instead of the
+ * reference's copies on accept.  partialbridge_fitzhugh.jl:125-176, test/partialbridgenuH.jl:155-198 */
+#define BHIP_CHAINS_STORE_X 1   /* keep Xo/X on the device (the SamplePath contract)            */
+int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uint32_t path0, uint64_t seed,
+                       int flags, bhip_chains **out);
+void bhip_chains_destroy(bhip_chains *ch);
+/* iteration 0: W = sample(tt, Wiener()); solve!(X, x0, W, Po); ll = llikelihood(X, Po; skip) */
+int bhip_chains_init(bhip_chains *ch, const double *x0, int skip);
+/* `iters` pCN iterations: sample!(W2); Wo = rho*W + sqrt(1-rho^2)*W2; solve!; llo; accept iff
+ * log(U) <= llo - ll  (skip applies to llo like partialbridge_nclar.jl:121) */
+int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip);
+/* device-side reduction of the ensemble statistics into stats_dev[8] =
+ *   {nchains, iterations done, sum acc, sum ll, sum ll^2, min ll, max ll, sum acc^2}
+ * (the block that is all-gathered over RCCL in the multi-GPU run) */
+#define BHIP_STATS_LEN 8
+int bhip_chains_stats(bhip_chains *ch, double *stats_dev);
+/* per-chain outputs (host pointers, any may be NULL): current ll, acceptance counts */
+int bhip_chains_get(bhip_chains *ch, double *ll, int64_t *acc);
+/* current state of chains p0..p0+np as AoS host arrays: X [np][N][d], W [np][N][mp] */
+int bhip_chains_get_paths(bhip_chains *ch, long p0, long np, double *X_aos, double *W_aos);
+/* pointwise online mean/covariance of the current X over the chain ensemble (mcstart/mcnext!
+ * semantics, src/mclog.jl:22-56): mean [N][d], m2 [N][d*d] (column-major), host pointers */
+int bhip_chains_pathstats(bhip_chains *ch, double *mean, double *m2);
+/* merge two (n, mean, m2) Welford states in place into a: parallel form of src/mclog.jl:31-38 */
+int bhip_welford_merge(long entries, int d, double *na, double *mean_a, double *m2_a, double nb,
+                       const double *mean_b, const double *m2_b);
+
+/* ------------------------------------------------------------------ RNG specification helpers (host)
+ * bhip-philox-v1: Philox4x32-10, key=(seed lo,hi), counter=(path, stream, iter, block); block j of
+ * stream 0 yields the normals 2j, 2j+1 (Box-Muller with the library's deterministic log/sincos). */
+void bhip_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void bhip_normals_host(uint64_t seed, uint32_t path, uint32_t iter, int n0, int n, double *z);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
