@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libbridgehip.so")
+# BRIDGEHIP_SO lets kernel experiments (A/B builds of the same library) be benchmarked side by side
+SO_PATH = os.environ.get("BRIDGEHIP_SO") or os.path.join(_HERE, "libbridgehip.so")
 
 dp = C.POINTER(C.c_double)
 vp = C.c_void_p
@@ -50,6 +51,8 @@ SIGNATURES = {
     "bhip_chains_stats": (C.c_int, [vp, vp]),
     "bhip_chains_get": (C.c_int, [vp, dp, C.POINTER(C.c_int64)]),
     "bhip_chains_get_paths": (C.c_int, [vp, C.c_long, C.c_long, dp, dp]),
+    "bhip_chains_current_X": (C.c_int, [vp, vp, C.c_long]),
+    "bhip_chains_proposal_X": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_long)]),
     "bhip_chains_pathstats": (C.c_int, [vp, dp, dp]),
     "bhip_welford_merge": (C.c_int, [C.c_long, C.c_int, dp, dp, dp, C.c_double, dp, dp]),
     "bhip_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -632,6 +632,26 @@ class Chains:
         self.ctx.check(self.ctx.lib.bhip_chains_get_paths(self.h, p0, n, _dptr(X), None if W is None else _dptr(W)))
         return X, W
 
+    def current_X(self):
+        """EnsemblePath of the chains' CURRENT paths X (re-materialised from the current W)"""
+        X = EnsemblePath(self.Po.tt, self.Po.d, self.n, self.ctx)
+        self.ctx.check(self.ctx.lib.bhip_chains_current_X(self.h, X.ptr(), X.ld))
+        return X
+
+    def proposal_X(self):
+        """view [N, d, ld] of the proposal paths Xo written by the last iteration (store_X=True)"""
+        ptr, ld = vp(), C.c_long()
+        self.ctx.check(self.ctx.lib.bhip_chains_proposal_X(self.h, C.byref(ptr), C.byref(ld)))
+        N, d = len(self.Po.tt), self.Po.d
+        nbytes = N * d * ld.value * 8
+
+        class _Raw:
+            __cuda_array_interface__ = {"shape": (N, d, ld.value), "typestr": "<f8", "data": (ptr.value, False),
+                                        "version": 2, "strides": None}
+        t = torch.as_tensor(_Raw(), device=self.ctx.device)
+        assert t.numel() * 8 == nbytes
+        return t[:, :, :self.n]
+
     def pathstats(self):
         """pointwise ensemble (n, mean [N,d], m2 [N,d,d]) of the current X -- mcnext! state"""
         N, d = len(self.Po.tt), self.Po.d

@@ -12,19 +12,19 @@ using namespace bhip;
 
 namespace bhip {
 // one translation unit per model (bhip_inst.hip compiled with -DBHIP_INST=<id>)
-launch_fn get_launch_ou(int, int, int);
-launch_fn get_launch_linpro1(int, int, int);
-launch_fn get_launch_linpro2(int, int, int);
-launch_fn get_launch_linpro3(int, int, int);
-launch_fn get_launch_fhn(int, int, int);
-launch_fn get_launch_nclar(int, int, int);
-launch_fn get_launch_intdiff(int, int, int);
-launch_fn get_launch_lorenz(int, int, int);
-launch_fn get_launch_fhn2(int, int, int);
-launch_fn get_launch_pendulum(int, int, int);
-launch_fn get_launch_wiener1(int, int, int);
-launch_fn get_launch_wiener2(int, int, int);
-launch_fn get_launch_wiener3(int, int, int);
+launch_fn get_launch_ou(int, int, int, int);
+launch_fn get_launch_linpro1(int, int, int, int);
+launch_fn get_launch_linpro2(int, int, int, int);
+launch_fn get_launch_linpro3(int, int, int, int);
+launch_fn get_launch_fhn(int, int, int, int);
+launch_fn get_launch_nclar(int, int, int, int);
+launch_fn get_launch_intdiff(int, int, int, int);
+launch_fn get_launch_lorenz(int, int, int, int);
+launch_fn get_launch_fhn2(int, int, int, int);
+launch_fn get_launch_pendulum(int, int, int, int);
+launch_fn get_launch_wiener1(int, int, int, int);
+launch_fn get_launch_wiener2(int, int, int, int);
+launch_fn get_launch_wiener3(int, int, int, int);
 }  // namespace bhip
 
 struct bhip_ctx {
@@ -59,11 +59,13 @@ struct bhip_chains {
     uint32_t iter = 0;
     bool inited = false;
     double x0[3] = {0, 0, 0};
-    double *Wb[2] = {nullptr, nullptr};
-    double *Xb[2] = {nullptr, nullptr};
+    double *Wc = nullptr;   // W slots [N][mp][ld][2]
+    double *Xo = nullptr;   // proposal paths [N][d][ld] (BHIP_CHAINS_STORE_X)
+    int skip0 = 0;
     unsigned char *cur = nullptr;
     double *llcur = nullptr;
     unsigned int *acc = nullptr;
+    double *statpart = nullptr;   // [256][6] per-block partial statistics
 };
 
 static int fail(bhip_ctx *ctx, int code, const std::string &msg)
@@ -92,25 +94,25 @@ static int ensure_scratch(bhip_ctx *ctx, size_t bytes)
     return BHIP_OK;
 }
 
-static launch_fn find_launch(const ModelHost &mh, int gk, int mo, int noise)
+static launch_fn find_launch(const ModelHost &mh, int gk, int mo, int noise, int fl)
 {
     switch (mh.id) {
-    case BHIP_MODEL_OU: return get_launch_ou(gk, mo, noise);
+    case BHIP_MODEL_OU: return get_launch_ou(gk, mo, noise, fl);
     case BHIP_MODEL_LINPRO:
-        if (mh.d == 1) return get_launch_linpro1(gk, mo, noise);
-        if (mh.d == 2) return get_launch_linpro2(gk, mo, noise);
-        if (mh.d == 3) return get_launch_linpro3(gk, mo, noise);
+        if (mh.d == 1) return get_launch_linpro1(gk, mo, noise, fl);
+        if (mh.d == 2) return get_launch_linpro2(gk, mo, noise, fl);
+        if (mh.d == 3) return get_launch_linpro3(gk, mo, noise, fl);
         return nullptr;
-    case BHIP_MODEL_FHN: return get_launch_fhn(gk, mo, noise);
-    case BHIP_MODEL_NCLAR: return get_launch_nclar(gk, mo, noise);
-    case BHIP_MODEL_INTDIFF: return get_launch_intdiff(gk, mo, noise);
-    case BHIP_MODEL_LORENZ: return get_launch_lorenz(gk, mo, noise);
-    case BHIP_MODEL_FHN2: return get_launch_fhn2(gk, mo, noise);
-    case BHIP_MODEL_PENDULUM: return get_launch_pendulum(gk, mo, noise);
+    case BHIP_MODEL_FHN: return get_launch_fhn(gk, mo, noise, fl);
+    case BHIP_MODEL_NCLAR: return get_launch_nclar(gk, mo, noise, fl);
+    case BHIP_MODEL_INTDIFF: return get_launch_intdiff(gk, mo, noise, fl);
+    case BHIP_MODEL_LORENZ: return get_launch_lorenz(gk, mo, noise, fl);
+    case BHIP_MODEL_FHN2: return get_launch_fhn2(gk, mo, noise, fl);
+    case BHIP_MODEL_PENDULUM: return get_launch_pendulum(gk, mo, noise, fl);
     case BHIP_MODEL_WIENER:
-        if (mh.d == 1) return get_launch_wiener1(gk, mo, noise);
-        if (mh.d == 2) return get_launch_wiener2(gk, mo, noise);
-        if (mh.d == 3) return get_launch_wiener3(gk, mo, noise);
+        if (mh.d == 1) return get_launch_wiener1(gk, mo, noise, fl);
+        if (mh.d == 2) return get_launch_wiener2(gk, mo, noise, fl);
+        if (mh.d == 3) return get_launch_wiener3(gk, mo, noise, fl);
         return nullptr;
     }
     return nullptr;
@@ -449,6 +451,7 @@ static int fill_common(const bhip_proposal *po, KArgs &a, const double *x0, cons
     if (!x0 && !x0_dev) return fail(ctx, BHIP_EINVAL, "need a starting point");
     a.rows = po->d_rows; a.rs = po->rs; a.N = (int)po->tt.size(); a.skip = skip;
     a.P = npaths;
+    a.wstride = 1;
     a.aux_linpro = po->has_aux && po->aux.linpro_form();
     a.ll_two_dots = po->g.kind == BHIP_GUIDE_NUH_INPLACE;
     a.use_vend = po->use_vend;
@@ -466,7 +469,10 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
 {
     bhip_ctx *ctx = po->ctx;
     const int gk = po->g.kind == BHIP_GUIDE_NUH_INPLACE ? BHIP_GUIDE_NUH : po->g.kind;
-    launch_fn f = find_launch(po->mh, gk, gk == BHIP_GUIDE_LMMU ? po->g.m : 1, noise);
+    int fl = 0;
+    if (noise == NOISE_PCN) fl = a.Xo ? 1 : 0;
+    else fl = (a.X ? 1 : 0) | (a.Wout ? 2 : 0);
+    launch_fn f = find_launch(po->mh, gk, gk == BHIP_GUIDE_LMMU ? po->g.m : 1, noise, fl);
     if (!f) return fail(ctx, BHIP_EUNSUPPORTED, "no device kernel for this (model, guide, noise) combination");
     if (a.rs != row_stride(gk, po->mh.d, po->g.m)) return fail(ctx, BHIP_ESTATE, "row stride mismatch");
     HIPCHK(ctx, f(a, ctx->stream));
@@ -557,15 +563,13 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     ch->ctx = ctx; ch->po = po; ch->n = nchains; ch->ld = (nchains + 63) / 64 * 64;
     ch->path0 = path0; ch->seed = seed; ch->flags = flags;
     const size_t N = po->tt.size();
-    const size_t wbytes = sizeof(double) * N * po->mh.mp * ch->ld, xbytes = sizeof(double) * N * po->mh.d * ch->ld;
-    hipError_t e = hipSuccess;
-    for (int b = 0; b < 2 && e == hipSuccess; b++) {
-        e = hipMalloc((void **)&ch->Wb[b], wbytes);
-        if (e == hipSuccess && (flags & BHIP_CHAINS_STORE_X)) e = hipMalloc((void **)&ch->Xb[b], xbytes);
-    }
+    const size_t wbytes = sizeof(double) * 2 * N * po->mh.mp * ch->ld, xbytes = sizeof(double) * N * po->mh.d * ch->ld;
+    hipError_t e = hipMalloc((void **)&ch->Wc, wbytes);
+    if (e == hipSuccess && (flags & BHIP_CHAINS_STORE_X)) e = hipMalloc((void **)&ch->Xo, xbytes);
     if (e == hipSuccess) e = hipMalloc((void **)&ch->cur, ch->ld);
     if (e == hipSuccess) e = hipMalloc((void **)&ch->llcur, sizeof(double) * ch->ld);
     if (e == hipSuccess) e = hipMalloc((void **)&ch->acc, sizeof(unsigned int) * ch->ld);
+    if (e == hipSuccess) e = hipMalloc((void **)&ch->statpart, sizeof(double) * 256 * 6);
     if (e != hipSuccess) { bhip_chains_destroy(ch); return fail(ctx, BHIP_EHIP, std::string("chains allocation: ") + hipGetErrorString(e)); }
     *out = ch;
     return BHIP_OK;
@@ -575,10 +579,12 @@ void bhip_chains_destroy(bhip_chains *ch)
 {
     if (!ch) return;
     (void)hipStreamSynchronize(ch->ctx->stream);
-    for (int b = 0; b < 2; b++) { if (ch->Wb[b]) (void)hipFree(ch->Wb[b]); if (ch->Xb[b]) (void)hipFree(ch->Xb[b]); }
+    if (ch->Wc) (void)hipFree(ch->Wc);
+    if (ch->Xo) (void)hipFree(ch->Xo);
     if (ch->cur) (void)hipFree(ch->cur);
     if (ch->llcur) (void)hipFree(ch->llcur);
     if (ch->acc) (void)hipFree(ch->acc);
+    if (ch->statpart) (void)hipFree(ch->statpart);
     delete ch;
 }
 
@@ -593,7 +599,9 @@ int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
     for (int k = 0; k < po->mh.d; k++) ch->x0[k] = x0[k];
     HIPCHK(ctx, hipMemsetAsync(ch->cur, 0, ch->ld, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ch->acc, 0, sizeof(unsigned int) * ch->ld, ctx->stream));
-    a.Wout = ch->Wb[0]; a.ldWout = ch->ld; a.X = ch->Xb[0]; a.ldX = ch->ld; a.ll = ch->llcur;
+    a.Wout = ch->Wc; a.ldWout = ch->ld; a.wstride = 2;   // half 0 of every slot, cur = 0
+    a.X = ch->Xo; a.ldX = ch->ld; a.ll = ch->llcur;
+    ch->skip0 = skip;
     a.k0 = (uint32_t)ch->seed; a.k1 = (uint32_t)(ch->seed >> 32); a.iter = 0; a.path0 = ch->path0;
     rc = do_launch(po, NOISE_FRESH, a);
     if (rc) return rc;
@@ -611,7 +619,7 @@ int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip)
     KArgs a;
     int rc = fill_common(po, a, ch->x0, nullptr, ch->n, skip);
     if (rc) return rc;
-    a.Wb[0] = ch->Wb[0]; a.Wb[1] = ch->Wb[1]; a.Xb[0] = ch->Xb[0]; a.Xb[1] = ch->Xb[1]; a.ldC = ch->ld;
+    a.Wc = ch->Wc; a.Xo = ch->Xo; a.ldC = ch->ld;
     a.cur = ch->cur; a.llcur = ch->llcur; a.acc = ch->acc;
     a.rho = rho; a.srho = std::sqrt(1 - rho * rho);
     a.k0 = (uint32_t)ch->seed; a.k1 = (uint32_t)(ch->seed >> 32); a.path0 = ch->path0;
@@ -628,7 +636,10 @@ int bhip_chains_stats(bhip_chains *ch, double *stats_dev)
     if (!ch || !stats_dev) return BHIP_EINVAL;
     bhip_ctx *ctx = ch->ctx;
     if (!ch->inited) return fail(ctx, BHIP_ESTATE, "bhip_chains_stats: chains not initialised");
-    hipLaunchKernelGGL(k_chain_stats, dim3(1), dim3(256), 0, ctx->stream, ch->llcur, ch->acc, ch->n, (double)ch->iter, stats_dev);
+    const int nparts = (int)std::min<long>(256, (ch->n + 1023) / 1024);
+    hipLaunchKernelGGL(k_chain_stats_partial, dim3(nparts), dim3(256), 0, ctx->stream, ch->llcur, ch->acc, ch->n, ch->statpart);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_chain_stats_final, dim3(1), dim3(256), 0, ctx->stream, ch->statpart, nparts, ch->n, (double)ch->iter, stats_dev);
     HIPCHK(ctx, hipGetLastError());
     return BHIP_OK;
 }
@@ -647,28 +658,75 @@ int bhip_chains_get(bhip_chains *ch, double *ll, int64_t *acc)
     return BHIP_OK;
 }
 
+// current W of chains p0..p0+np gathered from the slots into a plain SoA array [N][mp][np]
+static int gather_current_W(bhip_chains *ch, long p0, long np, double *W_soa)
+{
+    bhip_ctx *ctx = ch->ctx;
+    const long E = (long)ch->po->tt.size() * ch->po->mh.mp;
+    const long tot = E * np;
+    hipLaunchKernelGGL(k_slots_to_soa, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ch->Wc, ch->cur, W_soa, E, ch->ld, p0, np);
+    HIPCHK(ctx, hipGetLastError());
+    return BHIP_OK;
+}
+
+// The chain state is (W, ll, parity); the current X is a deterministic function of the current W
+// (X = solve!(Euler(), x0, W, Po)), so it is re-materialised on demand -- bit-identical to the Xo
+// the chain stored when that W was accepted -- instead of being double-buffered every iteration.
+static int current_X(bhip_chains *ch, long p0, long np, double *W_soa, double *X_soa)
+{
+    int rc = gather_current_W(ch, p0, np, W_soa);
+    if (rc) return rc;
+    KArgs a;
+    rc = fill_common(ch->po, a, ch->x0, nullptr, np, 0);
+    if (rc) return rc;
+    a.Win = W_soa; a.ldWin = np; a.X = X_soa; a.ldX = np;
+    return do_launch(ch->po, NOISE_EXT, a);
+}
+
 int bhip_chains_get_paths(bhip_chains *ch, long p0, long np, double *X_aos, double *W_aos)
 {
     if (!ch) return BHIP_EINVAL;
     bhip_ctx *ctx = ch->ctx;
+    if (!ch->inited) return fail(ctx, BHIP_ESTATE, "chains not initialised");
     if (p0 < 0 || np < 0 || p0 + np > ch->n) return fail(ctx, BHIP_EINVAL, "chain range out of bounds");
-    if (np == 0) return BHIP_OK;
-    const long N = (long)ch->po->tt.size();
-    for (int which = 0; which < 2; which++) {
-        double *dst = which == 0 ? X_aos : W_aos;
-        if (!dst) continue;
-        if (which == 0 && !ch->Xb[0]) return fail(ctx, BHIP_ESTATE, "chains were created without BHIP_CHAINS_STORE_X");
-        const long E = N * (which == 0 ? ch->po->mh.d : ch->po->mh.mp);
-        const size_t bytes = sizeof(double) * (size_t)E * np;
-        int rc = ensure_scratch(ctx, bytes);
-        if (rc) return rc;
-        const long tot = E * np;
-        double *const *B = which == 0 ? ch->Xb : ch->Wb;
-        hipLaunchKernelGGL(k_soa2_to_aos, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, B[0], B[1], ch->cur, ctx->scratch, E, ch->ld, p0, np);
-        HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(dst, ctx->scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (np == 0 || (!X_aos && !W_aos)) return BHIP_OK;
+    const long N = (long)ch->po->tt.size(), d = ch->po->mh.d, mp = ch->po->mh.mp;
+    double *tmp = nullptr;
+    const size_t nW = (size_t)N * mp * np, nX = (size_t)N * d * np;
+    HIPCHK(ctx, hipMalloc((void **)&tmp, sizeof(double) * (nW + nX)));
+    int rc = X_aos ? current_X(ch, p0, np, tmp, tmp + nW) : gather_current_W(ch, p0, np, tmp);
+    if (!rc && W_aos) rc = bhip_download_aos(ctx, tmp, (int)N, (int)mp, np, 0, np, W_aos);
+    if (!rc && X_aos) rc = bhip_download_aos(ctx, tmp + nW, (int)N, (int)d, np, 0, np, X_aos);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    return rc;
+}
+
+int bhip_chains_current_X(bhip_chains *ch, double *X_dev, long ldX)
+{
+    if (!ch || !X_dev) return BHIP_EINVAL;
+    bhip_ctx *ctx = ch->ctx;
+    if (!ch->inited) return fail(ctx, BHIP_ESTATE, "chains not initialised");
+    if (ldX < ch->n) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than the number of chains");
+    const long N = (long)ch->po->tt.size(), mp = ch->po->mh.mp;
+    double *tmp = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&tmp, sizeof(double) * (size_t)N * mp * ch->n));
+    int rc = gather_current_W(ch, 0, ch->n, tmp);
+    if (!rc) {
+        KArgs a;
+        rc = fill_common(ch->po, a, ch->x0, nullptr, ch->n, 0);
+        if (!rc) { a.Win = tmp; a.ldWin = ch->n; a.X = X_dev; a.ldX = ldX; rc = do_launch(ch->po, NOISE_EXT, a); }
     }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    return rc;
+}
+
+int bhip_chains_proposal_X(bhip_chains *ch, double **Xo_dev, long *ld)
+{
+    if (!ch || !Xo_dev || !ld) return BHIP_EINVAL;
+    if (!ch->Xo) return fail(ch->ctx, BHIP_ESTATE, "chains were created without BHIP_CHAINS_STORE_X");
+    *Xo_dev = ch->Xo; *ld = ch->ld;
     return BHIP_OK;
 }
 
@@ -676,17 +734,23 @@ int bhip_chains_pathstats(bhip_chains *ch, double *mean, double *m2)
 {
     if (!ch || !mean || !m2) return BHIP_EINVAL;
     bhip_ctx *ctx = ch->ctx;
-    if (!ch->Xb[0]) return fail(ctx, BHIP_ESTATE, "chains were created without BHIP_CHAINS_STORE_X");
+    if (!ch->inited) return fail(ctx, BHIP_ESTATE, "chains not initialised");
     const int N = (int)ch->po->tt.size(), d = ch->po->mh.d;
-    const size_t nm = (size_t)N * d, n2 = (size_t)N * d * d;
-    int rc = ensure_scratch(ctx, sizeof(double) * (nm + n2));
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_path_stats, dim3(N), dim3(256), 0, ctx->stream, ch->Xb[0], ch->Xb[1], ch->cur, d, ch->ld, ch->n, ctx->scratch, ctx->scratch + nm);
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(mean, ctx->scratch, sizeof(double) * nm, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(m2, ctx->scratch + nm, sizeof(double) * n2, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return BHIP_OK;
+    const size_t nm = (size_t)N * d, n2 = (size_t)N * d * d, nX = (size_t)N * d * ch->n;
+    double *tmp = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&tmp, sizeof(double) * (nX + nm + n2)));
+    int rc = bhip_chains_current_X(ch, tmp, ch->n);
+    if (!rc) {
+        hipLaunchKernelGGL(k_path_stats, dim3(N), dim3(256), 0, ctx->stream, tmp, d, ch->n, ch->n, tmp + nX, tmp + nX + nm);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(mean, tmp + nX, sizeof(double) * nm, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(m2, tmp + nX + nm, sizeof(double) * n2, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, BHIP_EHIP, hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    return rc;
 }
 
 int bhip_welford_merge(long entries, int d, double *na, double *mean_a, double *m2_a, double nb, const double *mean_b, const double *m2_b)

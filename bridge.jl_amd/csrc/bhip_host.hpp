@@ -448,7 +448,9 @@ inline void pack_rows(const std::vector<double> &tt, const ModelHost &mh, const 
         r[1] = tt[i + 1] - tt[i];
         r[2] = std::sqrt(tt[i + 1] - tt[i]);   // rootdt of src/wiener.jl:27,53
         if (gk == BHIP_GUIDE_NONE) continue;
-        const Mat B = Pt->B(tt[i]), be = Pt->beta(tt[i]);
+        // kernel evaluates b~ = B(x - mu~) + beta~: affine form has mu~ = 0, LinPro form B(x - mu) has beta~ = 0
+        const Mat B = Pt->B(tt[i]);
+        const Mat be = Pt->linpro_form() ? Mat(d, 1) : Pt->beta(tt[i]);
         std::memcpy(r + 3, B.a.data(), sizeof(double) * d * d);
         std::memcpy(r + 3 + d * d, be.a.data(), sizeof(double) * d);
         double *q = r + 3 + d * d + d;

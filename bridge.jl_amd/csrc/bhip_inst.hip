@@ -4,29 +4,29 @@
 
 namespace bhip {
 #if BHIP_INST == 0
-launch_fn get_launch_ou(int gk, int mo, int noise) { return get_launch<MOU>(gk, mo, noise); }
+launch_fn get_launch_ou(int gk, int mo, int noise, int fl) { return get_launch<MOU>(gk, mo, noise, fl); }
 #elif BHIP_INST == 1
-launch_fn get_launch_linpro1(int gk, int mo, int noise) { return get_launch<MLinPro<1>>(gk, mo, noise); }
+launch_fn get_launch_linpro1(int gk, int mo, int noise, int fl) { return get_launch<MLinPro<1>>(gk, mo, noise, fl); }
 #elif BHIP_INST == 2
-launch_fn get_launch_linpro2(int gk, int mo, int noise) { return get_launch<MLinPro<2>>(gk, mo, noise); }
+launch_fn get_launch_linpro2(int gk, int mo, int noise, int fl) { return get_launch<MLinPro<2>>(gk, mo, noise, fl); }
 #elif BHIP_INST == 3
-launch_fn get_launch_linpro3(int gk, int mo, int noise) { return get_launch<MLinPro<3>>(gk, mo, noise); }
+launch_fn get_launch_linpro3(int gk, int mo, int noise, int fl) { return get_launch<MLinPro<3>>(gk, mo, noise, fl); }
 #elif BHIP_INST == 4
-launch_fn get_launch_fhn(int gk, int mo, int noise) { return get_launch<MFHN>(gk, mo, noise); }
+launch_fn get_launch_fhn(int gk, int mo, int noise, int fl) { return get_launch<MFHN>(gk, mo, noise, fl); }
 #elif BHIP_INST == 5
-launch_fn get_launch_nclar(int gk, int mo, int noise) { return get_launch<MNCLAR>(gk, mo, noise); }
+launch_fn get_launch_nclar(int gk, int mo, int noise, int fl) { return get_launch<MNCLAR>(gk, mo, noise, fl); }
 #elif BHIP_INST == 6
-launch_fn get_launch_intdiff(int gk, int mo, int noise) { return get_launch<MIntDiff>(gk, mo, noise); }
+launch_fn get_launch_intdiff(int gk, int mo, int noise, int fl) { return get_launch<MIntDiff>(gk, mo, noise, fl); }
 #elif BHIP_INST == 7
-launch_fn get_launch_lorenz(int gk, int mo, int noise) { return get_launch<MLorenz>(gk, mo, noise); }
+launch_fn get_launch_lorenz(int gk, int mo, int noise, int fl) { return get_launch<MLorenz>(gk, mo, noise, fl); }
 #elif BHIP_INST == 8
-launch_fn get_launch_fhn2(int gk, int mo, int noise) { return get_launch<MFHN2>(gk, mo, noise); }
+launch_fn get_launch_fhn2(int gk, int mo, int noise, int fl) { return get_launch<MFHN2>(gk, mo, noise, fl); }
 #elif BHIP_INST == 9
-launch_fn get_launch_pendulum(int gk, int mo, int noise) { return get_launch<MPendulum>(gk, mo, noise); }
+launch_fn get_launch_pendulum(int gk, int mo, int noise, int fl) { return get_launch<MPendulum>(gk, mo, noise, fl); }
 #elif BHIP_INST == 10
-launch_fn get_launch_wiener1(int gk, int mo, int noise) { return get_launch<MWiener<1>>(gk, mo, noise); }
-launch_fn get_launch_wiener2(int gk, int mo, int noise) { return get_launch<MWiener<2>>(gk, mo, noise); }
-launch_fn get_launch_wiener3(int gk, int mo, int noise) { return get_launch<MWiener<3>>(gk, mo, noise); }
+launch_fn get_launch_wiener1(int gk, int mo, int noise, int fl) { return get_launch<MWiener<1>>(gk, mo, noise, fl); }
+launch_fn get_launch_wiener2(int gk, int mo, int noise, int fl) { return get_launch<MWiener<2>>(gk, mo, noise, fl); }
+launch_fn get_launch_wiener3(int gk, int mo, int noise, int fl) { return get_launch<MWiener<3>>(gk, mo, noise, fl); }
 #else
 #error "BHIP_INST must be 0..10"
 #endif

@@ -41,10 +41,16 @@ struct KArgs {
     double *X;            // optional X store [N][D][ldX]
     long ldX;
     double *ll;           // optional per-path log-likelihood
-    // pCN chain state (NOISE_PCN): double buffers + per-chain parity
-    double *Wb[2];
-    double *Xb[2];
+    // pCN chain state (NOISE_PCN).  W lives in 16-byte SLOTS: Wc[((i*MP + k)*ldC + p)*2 + h], h = 0/1;
+    // half cur[p] holds the chain's current W, the other half receives the proposal Wo, and an accept
+    // flips cur[p] (the reference's W <-> Wo swap, test/partialbridgenuH.jl:186-187, without copies).
+    // A lane always loads and stores its whole slot: 16 B per lane, 1 KiB contiguous per wave, no
+    // partially written lines although neighbouring chains have different parities.
+    // Xo is the proposal path buffer (plain SoA, every chain writes it every iteration).
+    double *Wc;
+    double *Xo;
     long ldC;
+    int wstride;          // FRESH W store: 1 = plain SoA, 2 = half 0 of the chain slots (chain initialisation)
     unsigned char *cur;
     double *llcur;
     unsigned int *acc;
@@ -73,7 +79,7 @@ struct RowLayout {
 
 // r((i,t),x,Po) and g = a*L'*M*q | a*r, from the packed row
 template <class M, int GK, int MO>
-BHIP_DEV void guide_terms(const M &model, cptr_t g, const double *x, const double *vmu_unused, double *r, double *gd)
+BHIP_DEV void guide_terms(const M &model, const double *g, const double *x, double *r, double *gd)
 {
     constexpr int D = M::D;
     if constexpr (GK == BHIP_GUIDE_HV) {
@@ -101,7 +107,7 @@ BHIP_DEV void guide_terms(const M &model, cptr_t g, const double *x, const doubl
             for (int k = 1; k < D; k++) s += g[j + MO * k] * x[k];
             q[j] = g[MO * D + j] - s;
         }
-        cptr_t R = g + MO * D + MO, G = g + MO * D + MO + D * MO;
+        const double *R = g + MO * D + MO, *G = g + MO * D + MO + D * MO;
 #pragma unroll
         for (int i = 0; i < D; i++) {
             double sr = R[i] * q[0], sg = G[i] * q[0];
@@ -125,8 +131,120 @@ BHIP_DEV void guide_terms(const M &model, cptr_t g, const double *x, const doubl
     }
 }
 
-template <class M, int GK, int MO, int NOISE>
-__global__ __launch_bounds__(256) void k_paths(const KArgs a)
+#ifndef BHIP_KCH
+#define BHIP_KCH 4
+#endif
+
+// per-lane state carried through the time loop
+template <int D, int MP>
+struct LaneState {
+    double y[D];
+    double ll;
+    double wprev[MP], w2prev[MP];
+    double zc;   // second normal of the current Philox block
+};
+
+// One Euler step of one path, branch-free (a single basic block so that the scheduler can interleave
+// the state-independent work -- Philox, Box-Muller, address arithmetic -- with the dependent chain).
+//   win_k : EXT: W[i+1] ; PCN: current chain W[i+1] ; LLONLY: X[i]       (already in registers)
+//   FL    : bit0 store X, bit1 store W
+template <class M, int GK, int MO, int NOISE, int FL>
+BHIP_DEV void path_step(const M &model, const KArgs &a, cptr_t row, int i, int nll, uint32_t path, const double *win_k,
+                        double *wout, long ldwo, double *xout, long ldx, LaneState<M::D, M::MP> &st)
+{
+    constexpr int D = M::D, MP = M::MP;
+    using RL = RowLayout<GK, D, MO>;
+    // the whole coefficient row through the scalar unit, one wait
+    double rw[RL::RS];
+#pragma unroll
+    for (int q = 0; q < RL::LEN; q++) rw[q] = row[q];
+    const double t = rw[RL::T], dt = rw[RL::DT];
+
+    if constexpr (NOISE == NOISE_LLONLY) {
+#pragma unroll
+        for (int k = 0; k < D; k++) st.y[k] = win_k[k];
+    }
+
+    // ---- LOOP A / P: the Wiener increment of this step
+    double dw[MP];
+    if constexpr (NOISE == NOISE_EXT) {
+#pragma unroll
+        for (int k = 0; k < MP; k++) {
+            const double wn = win_k[k];
+            dw[k] = wn - st.wprev[k];
+            st.wprev[k] = wn;
+        }
+    } else if constexpr (NOISE == NOISE_FRESH || NOISE == NOISE_PCN) {
+        const double rdt = rw[RL::RDT];
+#pragma unroll
+        for (int k = 0; k < MP; k++) {
+            const int n = i * MP + k;
+            double z;
+            if ((n & 1) == 0) normal_pair(a.k0, a.k1, path, a.iter, (uint32_t)(n >> 1), z, st.zc);
+            else z = st.zc;
+            if constexpr (NOISE == NOISE_FRESH) {
+                const double wn = st.wprev[k] + rdt * z;          // yy[i] = yy[i-1] + rootdt*randn
+                dw[k] = wn - st.wprev[k];                          // ww[i+1] - ww[i]
+                st.wprev[k] = wn;
+                if constexpr ((FL & 2) != 0) wout[((size_t)(i + 1) * MP + k) * ldwo] = wn;
+            } else {
+                const double wc = win_k[k];
+                const double w2 = st.w2prev[k] + rdt * z;
+                const double wo = a.rho * wc + a.srho * w2;        // Wo = rho*W + sqrt(1-rho^2)*W2
+                dw[k] = wo - st.wprev[k];
+                st.w2prev[k] = w2;
+                st.wprev[k] = wo;                                  // the caller stores it into the chain slot
+            }
+        }
+    }
+
+    // ---- LOOP B: yy[i] = y (stored BEFORE the update, src/euler.jl:263)
+    if constexpr (NOISE != NOISE_LLONLY && (FL & 1) != 0) {
+#pragma unroll
+        for (int k = 0; k < D; k++) xout[((size_t)i * D + k) * ldx] = st.y[k];
+    }
+
+    double bT[D];
+    model.b(t, st.y, bT);
+    if constexpr (GK != BHIP_GUIDE_NONE) {
+        double r[D], g[D];
+        guide_terms<M, GK, MO>(model, rw + RL::G, st.y, r, g);
+        // ---- LOOP C: som += dot(b - b~, r)*dt ;  b~ = B~(x - mu~) + beta~  (mu~ = 0 for the affine form
+        // B~x + beta~, beta~ = 0 for the LinPro form B~(x - mu~): adding/subtracting 0.0 is exact)
+        double xm[D], bA[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) xm[k] = st.y[k] - a.mu_aux[k];
+#pragma unroll
+        for (int q = 0; q < D; q++) {
+            double s = rw[RL::B + q] * xm[0];
+#pragma unroll
+            for (int j = 1; j < D; j++) s += rw[RL::B + q + D * j] * xm[j];
+            bA[q] = s + rw[RL::BETA + q];
+        }
+        double s0 = (bT[0] - bA[0]) * r[0], s1 = bT[0] * r[0], s2 = bA[0] * r[0];
+#pragma unroll
+        for (int k = 1; k < D; k++) { s0 += (bT[k] - bA[k]) * r[k]; s1 += bT[k] * r[k]; s2 += bA[k] * r[k]; }
+        const double ll_one = st.ll + s0 * dt;                  // src/partialbridge.jl:77
+        const double ll_two = (st.ll + s1 * dt) - s2 * dt;      // src/partialbridgen!.jl:96-97
+        const double lln = a.ll_two_dots ? ll_two : ll_one;
+        st.ll = (i < nll) ? lln : st.ll;                        // skip: only i < N-1-skip contribute
+#pragma unroll
+        for (int k = 0; k < D; k++) bT[k] = bT[k] + g[k];       // _b = b + a*(...)
+    }
+    if constexpr (NOISE != NOISE_LLONLY) {
+        double s[D];
+        model.sdw(dw, s);
+#pragma unroll
+        for (int k = 0; k < D; k++) st.y[k] = st.y[k] + bT[k] * dt + s[k];   // src/euler.jl:264
+    }
+}
+
+#ifndef BHIP_WPE
+#define BHIP_WPE 1
+#endif
+
+template <class M, int GK, int MO, int NOISE, int FL>
+__global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
 {
     constexpr int D = M::D, MP = M::MP;
     using RL = RowLayout<GK, D, MO>;
@@ -134,156 +252,131 @@ __global__ __launch_bounds__(256) void k_paths(const KArgs a)
     if (p >= a.P) return;
     const M model(a.mpar);
     const int N = a.N;
+    const int nll = N - 1 - a.skip;
     const cptr_t rows = (cptr_t)(uintptr_t)a.rows;
 
-    double y[D];
+    LaneState<D, MP> st;
 #pragma unroll
-    for (int k = 0; k < D; k++) y[k] = a.x0_dev ? a.x0_dev[k * a.ldx0 + p] : a.x0[k];
+    for (int k = 0; k < D; k++) st.y[k] = a.x0_dev ? a.x0_dev[k * a.ldx0 + p] : a.x0[k];
+    st.ll = 0.0;
+    st.zc = 0.0;
+#pragma unroll
+    for (int k = 0; k < MP; k++) { st.wprev[k] = 0.0; st.w2prev[k] = 0.0; }
 
     // per-lane stream pointers
-    const double *win = nullptr;  // W read (EXT: driving path, PCN: current state, LLONLY: X)
-    double *wout = nullptr;       // W write (FRESH: optional store, PCN: proposal)
+    const double *win = nullptr;  // EXT: driving W, LLONLY: X
+    double *wout = nullptr;       // FRESH: W store
     double *xout = nullptr;
+    double2 *wslot = nullptr;     // PCN: this chain's W slots
     long ldwi = 0, ldwo = 0, ldx = 0;
     int c = 0;
     if constexpr (NOISE == NOISE_PCN) {
         c = a.cur[p];
-        win = a.Wb[c] + p; wout = a.Wb[c ^ 1] + p; ldwi = ldwo = a.ldC;
-        if (a.Xb[0]) { xout = a.Xb[c ^ 1] + p; ldx = a.ldC; }
+        wslot = reinterpret_cast<double2 *>(a.Wc) + p;
+        if constexpr ((FL & 1) != 0) { xout = a.Xo + p; ldx = a.ldC; }
     } else {
-        if (a.Win) { win = a.Win + p; ldwi = a.ldWin; }
-        if (a.Wout) { wout = a.Wout + p; ldwo = a.ldWout; }
-        if (a.X) { xout = a.X + p; ldx = a.ldX; }
+        if constexpr (NOISE != NOISE_FRESH) { win = a.Win + p; ldwi = a.ldWin; }
+        if constexpr ((FL & 2) != 0) { wout = a.Wout + (size_t)p * a.wstride; ldwo = a.ldWout * a.wstride; }
+        if constexpr ((FL & 1) != 0) { xout = a.X + p; ldx = a.ldX; }
     }
-
-    double ll = 0.0;
-    double wprev[MP], w2prev[MP];
-#pragma unroll
-    for (int k = 0; k < MP; k++) { wprev[k] = 0.0; w2prev[k] = 0.0; }
     if constexpr (NOISE == NOISE_EXT) {
 #pragma unroll
-        for (int k = 0; k < MP; k++) wprev[k] = win[k * ldwi];
+        for (int k = 0; k < MP; k++) st.wprev[k] = win[k * ldwi];
     }
-    if constexpr (NOISE == NOISE_FRESH || NOISE == NOISE_PCN) {
-        if (wout) {
+    if constexpr (NOISE == NOISE_FRESH && (FL & 2) != 0) {
 #pragma unroll
-            for (int k = 0; k < MP; k++) wout[k * ldwo] = 0.0;  // W[1] = 0 ; rho*0 + srho*0 = 0
-        }
+        for (int k = 0; k < MP; k++) wout[k * ldwo] = 0.0;   // W[1] = 0
+    }
+    if constexpr (NOISE == NOISE_PCN) {
+#pragma unroll
+        for (int k = 0; k < MP; k++) wslot[(size_t)k * a.ldC] = make_double2(0.0, 0.0);   // W[1] = Wo[1] = 0
     }
     const uint32_t path = a.path0 + (uint32_t)p;
-    double zc = 0.0;  // second normal of the current Philox block
 
-    for (int i = 0; i < N - 1; i++) {
-        const cptr_t row = rows + (size_t)i * RL::RS;
-        const double t = row[RL::T], dt = row[RL::DT];
-
-        if constexpr (NOISE == NOISE_LLONLY) {
+    // Rolling prefetch window: the per-lane HBM read of step i+PF (driving Wiener value / chain slot, or X
+    // for the stand-alone llikelihood) is issued while step i is computed, so PF loads per lane are in
+    // flight and their latency overlaps arithmetic instead of being exposed once per step.  Stores are
+    // fire-and-forget.  The loop is unrolled by two so that the Philox block parity is static.
+    constexpr int PF = BHIP_KCH;
+    constexpr int NIN = NOISE == NOISE_LLONLY ? D : MP;
+    constexpr bool READS = NOISE == NOISE_EXT || NOISE == NOISE_LLONLY;
+    constexpr int OFF = NOISE == NOISE_LLONLY ? 0 : 1;
+    const int nsteps = N - 1;
+    double pf[PF][NIN];
+    double2 pfs[PF][MP];
+    if constexpr (READS) {
 #pragma unroll
-            for (int k = 0; k < D; k++) y[k] = win[((size_t)i * D + k) * ldwi];
+        for (int j = 0; j < PF; j++) {
+            const int ii = min(j, nsteps - 1) + OFF;   // clamped: short grids re-read a valid row
+#pragma unroll
+            for (int k = 0; k < NIN; k++) pf[j][k] = win[((size_t)ii * NIN + k) * ldwi];
         }
-
-        // ---- LOOP A / P: the Wiener increment of this step
-        double dw[MP];
-        if constexpr (NOISE == NOISE_EXT) {
+    }
+    if constexpr (NOISE == NOISE_PCN) {
 #pragma unroll
-            for (int k = 0; k < MP; k++) {
-                const double wn = win[((size_t)(i + 1) * MP + k) * ldwi];
-                dw[k] = wn - wprev[k];
-                wprev[k] = wn;
-            }
-        } else if constexpr (NOISE == NOISE_FRESH || NOISE == NOISE_PCN) {
-            const double rdt = row[RL::RDT];
+        for (int j = 0; j < PF; j++) {
+            const int ii = min(j, nsteps - 1) + 1;
 #pragma unroll
-            for (int k = 0; k < MP; k++) {
-                const int n = i * MP + k;
-                double z;
-                if ((n & 1) == 0) normal_pair(a.k0, a.k1, path, a.iter, (uint32_t)(n >> 1), z, zc);
-                else z = zc;
-                if constexpr (NOISE == NOISE_FRESH) {
-                    const double wn = wprev[k] + rdt * z;          // yy[i] = yy[i-1] + rootdt*randn
-                    dw[k] = wn - wprev[k];                          // ww[i+1] - ww[i]
-                    wprev[k] = wn;
-                    if (wout) wout[((size_t)(i + 1) * MP + k) * ldwo] = wn;
-                } else {
-                    const double wc = win[((size_t)(i + 1) * MP + k) * ldwi];
-                    const double w2 = w2prev[k] + rdt * z;
-                    const double wo = a.rho * wc + a.srho * w2;     // Wo = rho*W + sqrt(1-rho^2)*W2
-                    dw[k] = wo - wprev[k];
-                    w2prev[k] = w2;
-                    wprev[k] = wo;
-                    wout[((size_t)(i + 1) * MP + k) * ldwo] = wo;
-                }
-            }
+            for (int k = 0; k < MP; k++) pfs[j][k] = wslot[((size_t)ii * MP + k) * a.ldC];
         }
-
-        // ---- LOOP B: yy[i] = y (stored BEFORE the update, src/euler.jl:263)
-        if constexpr (NOISE != NOISE_LLONLY) {
-            if (xout) {
+    }
+    double2 slot[MP];
+    auto advance = [&](int i, double (&cur)[NIN]) {
+        if constexpr (READS) {
 #pragma unroll
-                for (int k = 0; k < D; k++) xout[((size_t)i * D + k) * ldx] = y[k];
-            }
+            for (int k = 0; k < NIN; k++) cur[k] = pf[0][k];
+#pragma unroll
+            for (int j = 0; j + 1 < PF; j++)
+#pragma unroll
+                for (int k = 0; k < NIN; k++) pf[j][k] = pf[j + 1][k];
+            const int ii = min(i + PF, nsteps - 1) + OFF;
+#pragma unroll
+            for (int k = 0; k < NIN; k++) pf[PF - 1][k] = win[((size_t)ii * NIN + k) * ldwi];
         }
-
-        double bT[D];
-        model.b(t, y, bT);
-        if constexpr (GK != BHIP_GUIDE_NONE) {
-            double r[D], g[D];
-            guide_terms<M, GK, MO>(model, row + RL::G, y, nullptr, r, g);
-            // ---- LOOP C: som += dot(b - b~, r)*dt
-            if (i < N - 1 - a.skip) {
-                double bA[D];
-                if (a.aux_linpro) {
-                    double xm[D];
+        if constexpr (NOISE == NOISE_PCN) {
 #pragma unroll
-                    for (int k = 0; k < D; k++) xm[k] = y[k] - a.mu_aux[k];
+            for (int k = 0; k < MP; k++) { slot[k] = pfs[0][k]; cur[k] = c ? slot[k].y : slot[k].x; }
 #pragma unroll
-                    for (int q = 0; q < D; q++) {
-                        double s = row[RL::B + q] * xm[0];
+            for (int j = 0; j + 1 < PF; j++)
 #pragma unroll
-                        for (int j = 1; j < D; j++) s += row[RL::B + q + D * j] * xm[j];
-                        bA[q] = s;
-                    }
-                } else {
+                for (int k = 0; k < MP; k++) pfs[j][k] = pfs[j + 1][k];
+            const int ii = min(i + PF, nsteps - 1) + 1;
 #pragma unroll
-                    for (int q = 0; q < D; q++) {
-                        double s = row[RL::B + q] * y[0];
-#pragma unroll
-                        for (int j = 1; j < D; j++) s += row[RL::B + q + D * j] * y[j];
-                        bA[q] = s + row[RL::BETA + q];
-                    }
-                }
-                if (a.ll_two_dots) {
-                    double s1 = bT[0] * r[0], s2 = bA[0] * r[0];
-#pragma unroll
-                    for (int k = 1; k < D; k++) { s1 += bT[k] * r[k]; s2 += bA[k] * r[k]; }
-                    ll += s1 * dt;
-                    ll -= s2 * dt;
-                } else {
-                    double s = (bT[0] - bA[0]) * r[0];
-#pragma unroll
-                    for (int k = 1; k < D; k++) s += (bT[k] - bA[k]) * r[k];
-                    ll += s * dt;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < D; k++) bT[k] = bT[k] + g[k];   // _b = b + a*(...)
+            for (int k = 0; k < MP; k++) pfs[PF - 1][k] = wslot[((size_t)ii * MP + k) * a.ldC];
         }
-        if constexpr (NOISE != NOISE_LLONLY) {
-            double s[D];
-            model.sdw(dw, s);
+    };
+    auto commit = [&](int i) {   // PCN: the proposal Wo[i+1] goes into the other half of the slot
+        if constexpr (NOISE == NOISE_PCN) {
 #pragma unroll
-            for (int k = 0; k < D; k++) y[k] = y[k] + bT[k] * dt + s[k];   // src/euler.jl:264
+            for (int k = 0; k < MP; k++)
+                wslot[((size_t)(i + 1) * MP + k) * a.ldC] = c ? make_double2(st.wprev[k], slot[k].y) : make_double2(slot[k].x, st.wprev[k]);
         }
+    };
+    int i = 0;
+    for (; i + 1 < nsteps; i += 2) {
+        double cur[NIN];
+        advance(i, cur);
+        path_step<M, GK, MO, NOISE, FL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, cur, wout, ldwo, xout, ldx, st);
+        commit(i);
+        advance(i + 1, cur);
+        path_step<M, GK, MO, NOISE, FL>(model, a, rows + (size_t)(i + 1) * RL::RS, i + 1, nll, path, cur, wout, ldwo, xout, ldx, st);
+        commit(i + 1);
+    }
+    if (i < nsteps) {
+        double cur[NIN];
+        advance(i, cur);
+        path_step<M, GK, MO, NOISE, FL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, cur, wout, ldwo, xout, ldx, st);
+        commit(i);
     }
 
     if constexpr (NOISE != NOISE_LLONLY) {
         if (a.use_vend) {   // endpoint(y, P::GuidedBridge) src/euler.jl:241-242
 #pragma unroll
-            for (int k = 0; k < D; k++) y[k] = a.vend[k];
+            for (int k = 0; k < D; k++) st.y[k] = a.vend[k];
         }
-        if (xout) {
+        if constexpr ((FL & 1) != 0) {
 #pragma unroll
-            for (int k = 0; k < D; k++) xout[((size_t)(N - 1) * D + k) * ldx] = y[k];
+            for (int k = 0; k < D; k++) xout[((size_t)(N - 1) * D + k) * ldx] = st.y[k];
         }
     }
 
@@ -291,56 +384,66 @@ __global__ __launch_bounds__(256) void k_paths(const KArgs a)
         // if log(rand()) <= llo - ll: X<-Xo, W<-Wo (parity flip), ll<-llo, acc+=1
         const double u = accept_uniform(a.k0, a.k1, path, a.iter);
         const double llc = a.llcur[p];
-        if (det_log(u) <= ll - llc) {
+        if (det_log(u) <= st.ll - llc) {
             a.cur[p] = (unsigned char)(c ^ 1);
-            a.llcur[p] = ll;
+            a.llcur[p] = st.ll;
             a.acc[p] += 1u;
         }
-        if (a.ll) a.ll[p] = ll;   // llo trace
+        if (a.ll) a.ll[p] = st.ll;   // llo trace
     } else {
-        if (a.ll) a.ll[p] = ll;
+        if (a.ll) a.ll[p] = st.ll;
     }
 }
 
 typedef hipError_t (*launch_fn)(const KArgs &, hipStream_t);
 
-template <class M, int GK, int MO, int NOISE>
+template <class M, int GK, int MO, int NOISE, int FL>
 hipError_t launch_paths(const KArgs &a, hipStream_t st)
 {
     const int block = 256;
     const long grid = (a.P + block - 1) / block;
-    hipLaunchKernelGGL((k_paths<M, GK, MO, NOISE>), dim3((unsigned)grid), dim3(block), 0, st, a);
+    hipLaunchKernelGGL((k_paths<M, GK, MO, NOISE, FL>), dim3((unsigned)grid), dim3(block), 0, st, a);
     return hipGetLastError();
 }
 
-// all (guide, obs-dim, noise) instantiations of one model
-template <class M>
-launch_fn get_launch(int gk, int mo, int noise)
+// all (guide, obs-dim, noise, store-flags) instantiations of one model.  fl: bit0 store X, bit1 store W.
+template <class M, int GK, int MO>
+launch_fn get_launch_gk(int noise, int fl)
 {
-    constexpr int D = M::D;
-#define BHIP_N4(GK_, MO_)                                                              \
-    switch (noise) {                                                                   \
-    case NOISE_EXT: return launch_paths<M, GK_, MO_, NOISE_EXT>;                       \
-    case NOISE_FRESH: return launch_paths<M, GK_, MO_, NOISE_FRESH>;                   \
-    case NOISE_PCN: return launch_paths<M, GK_, MO_, NOISE_PCN>;                       \
-    case NOISE_LLONLY: return launch_paths<M, GK_, MO_, NOISE_LLONLY>;                 \
-    }                                                                                  \
-    return nullptr;
-    switch (gk) {
-    case BHIP_GUIDE_NONE:
-        if (noise == NOISE_EXT) return launch_paths<M, BHIP_GUIDE_NONE, 1, NOISE_EXT>;
-        if (noise == NOISE_FRESH) return launch_paths<M, BHIP_GUIDE_NONE, 1, NOISE_FRESH>;
+    switch (noise) {
+    case NOISE_EXT: return (fl & 1) ? launch_paths<M, GK, MO, NOISE_EXT, 1> : launch_paths<M, GK, MO, NOISE_EXT, 0>;
+    case NOISE_FRESH:
+        switch (fl & 3) {
+        case 0: return launch_paths<M, GK, MO, NOISE_FRESH, 0>;
+        case 1: return launch_paths<M, GK, MO, NOISE_FRESH, 1>;
+        case 2: return launch_paths<M, GK, MO, NOISE_FRESH, 2>;
+        default: return launch_paths<M, GK, MO, NOISE_FRESH, 3>;
+        }
+    case NOISE_PCN:
+        if constexpr (GK != BHIP_GUIDE_NONE) return (fl & 1) ? launch_paths<M, GK, MO, NOISE_PCN, 1> : launch_paths<M, GK, MO, NOISE_PCN, 0>;
         return nullptr;
-    case BHIP_GUIDE_HV: BHIP_N4(BHIP_GUIDE_HV, 1)
-    case BHIP_GUIDE_NUH:
-    case BHIP_GUIDE_NUH_INPLACE: BHIP_N4(BHIP_GUIDE_NUH, 1)
-    case BHIP_GUIDE_LMMU:
-        if (mo == 1) { BHIP_N4(BHIP_GUIDE_LMMU, 1) }
-        if constexpr (D >= 2) { if (mo == 2) { BHIP_N4(BHIP_GUIDE_LMMU, 2) } }
-        if constexpr (D >= 3) { if (mo == 3) { BHIP_N4(BHIP_GUIDE_LMMU, 3) } }
+    case NOISE_LLONLY:
+        if constexpr (GK != BHIP_GUIDE_NONE) return launch_paths<M, GK, MO, NOISE_LLONLY, 0>;
         return nullptr;
     }
-#undef BHIP_N4
+    return nullptr;
+}
+
+template <class M>
+launch_fn get_launch(int gk, int mo, int noise, int fl)
+{
+    constexpr int D = M::D;
+    switch (gk) {
+    case BHIP_GUIDE_NONE: return get_launch_gk<M, BHIP_GUIDE_NONE, 1>(noise, fl);
+    case BHIP_GUIDE_HV: return get_launch_gk<M, BHIP_GUIDE_HV, 1>(noise, fl);
+    case BHIP_GUIDE_NUH:
+    case BHIP_GUIDE_NUH_INPLACE: return get_launch_gk<M, BHIP_GUIDE_NUH, 1>(noise, fl);
+    case BHIP_GUIDE_LMMU:
+        if (mo == 1) return get_launch_gk<M, BHIP_GUIDE_LMMU, 1>(noise, fl);
+        if constexpr (D >= 2) { if (mo == 2) return get_launch_gk<M, BHIP_GUIDE_LMMU, 2>(noise, fl); }
+        if constexpr (D >= 3) { if (mo == 3) return get_launch_gk<M, BHIP_GUIDE_LMMU, 3>(noise, fl); }
+        return nullptr;
+    }
     return nullptr;
 }
 

@@ -23,15 +23,14 @@ __global__ void k_soa_to_aos(const double *__restrict__ soa, double *__restrict_
     const long p = idx % np, e = idx / np;
     aos[p * E + e] = soa[e * ld + p0 + p];
 }
-// same, but each chain reads from the buffer its parity bit selects
-__global__ void k_soa2_to_aos(const double *__restrict__ b0, const double *__restrict__ b1, const unsigned char *__restrict__ cur,
-                              double *__restrict__ aos, long E, long ld, long p0, long np)
+// current W of the chains p0..p0+np out of the 16-byte slots (half cur[p]) into plain SoA [E][np]
+__global__ void k_slots_to_soa(const double *__restrict__ slots, const unsigned char *__restrict__ cur, double *__restrict__ soa,
+                               long E, long ld, long p0, long np)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= E * np) return;
     const long p = idx % np, e = idx / np;
-    const double *src = cur[p0 + p] ? b1 : b0;
-    aos[p * E + e] = src[e * ld + p0 + p];
+    soa[e * np + p] = slots[(e * ld + p0 + p) * 2 + cur[p0 + p]];
 }
 
 // sample!(W, Wiener{SVector{mp}}()):  W[0] = 0; W[i+1] = W[i] + rootdt[i]*xi   (time-major,
@@ -98,31 +97,52 @@ __device__ __forceinline__ double wave_max(double v)
     return v;
 }
 
-// stats[8] = {n, iters, sum acc, sum ll, sum ll^2, min ll, max ll, sum acc^2}; one 256-thread block
-__global__ __launch_bounds__(256) void k_chain_stats(const double *__restrict__ ll, const unsigned int *__restrict__ acc, long P, double iters,
-                                                     double *__restrict__ stats)
+// Ensemble statistics {n, iters, sum acc, sum ll, sum ll^2, min ll, max ll, sum acc^2}: per-path values are
+// reduced with wavefront shuffles, then across the block's waves through LDS; stage 1 leaves one
+// partial per block, stage 2 (one block) folds the partials in a fixed order (deterministic sums).
+struct StatAcc { double sa, sl, sl2, mn, mx, sa2; };
+__device__ __forceinline__ void block_fold(StatAcc &v)
 {
-    __shared__ double sh[4][5];
-    double sa = 0, sl = 0, sl2 = 0, mn = INFINITY, mx = -INFINITY, sa2 = 0;
-    for (long p = threadIdx.x; p < P; p += blockDim.x) {
-        const double l = ll[p], a = (double)acc[p];
-        sa += a; sa2 += a * a; sl += l; sl2 += l * l; mn = fmin(mn, l); mx = fmax(mx, l);
-    }
-    sa = wave_sum(sa); sl = wave_sum(sl); sl2 = wave_sum(sl2); sa2 = wave_sum(sa2); mn = wave_min(mn); mx = wave_max(mx);
+    __shared__ double sh[4][6];
+    v.sa = wave_sum(v.sa); v.sl = wave_sum(v.sl); v.sl2 = wave_sum(v.sl2); v.sa2 = wave_sum(v.sa2); v.mn = wave_min(v.mn); v.mx = wave_max(v.mx);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __shared__ double sh2[4];
-    if (lane == 0) { sh[w][0] = sa; sh[w][1] = sl; sh[w][2] = sl2; sh[w][3] = mn; sh[w][4] = mx; sh2[w] = sa2; }
+    if (lane == 0) { sh[w][0] = v.sa; sh[w][1] = v.sl; sh[w][2] = v.sl2; sh[w][3] = v.mn; sh[w][4] = v.mx; sh[w][5] = v.sa2; }
     __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 1; k < 4; k++) {
+            v.sa += sh[k][0]; v.sl += sh[k][1]; v.sl2 += sh[k][2]; v.mn = fmin(v.mn, sh[k][3]); v.mx = fmax(v.mx, sh[k][4]); v.sa2 += sh[k][5];
+        }
+}
+__global__ __launch_bounds__(256) void k_chain_stats_partial(const double *__restrict__ ll, const unsigned int *__restrict__ acc, long P,
+                                                             double *__restrict__ part)
+{
+    StatAcc v = {0, 0, 0, INFINITY, -INFINITY, 0};
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+        const double l = ll[p], a = (double)acc[p];
+        v.sa += a; v.sa2 += a * a; v.sl += l; v.sl2 += l * l; v.mn = fmin(v.mn, l); v.mx = fmax(v.mx, l);
+    }
+    block_fold(v);
     if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; k++) { sa += sh[k][0]; sl += sh[k][1]; sl2 += sh[k][2]; mn = fmin(mn, sh[k][3]); mx = fmax(mx, sh[k][4]); sa2 += sh2[k]; }
-        stats[0] = (double)P; stats[1] = iters; stats[2] = sa; stats[3] = sl; stats[4] = sl2; stats[5] = mn; stats[6] = mx; stats[7] = sa2;
+        double *o = part + (size_t)blockIdx.x * 6;
+        o[0] = v.sa; o[1] = v.sl; o[2] = v.sl2; o[3] = v.mn; o[4] = v.mx; o[5] = v.sa2;
+    }
+}
+__global__ __launch_bounds__(256) void k_chain_stats_final(const double *__restrict__ part, int nparts, long P, double iters, double *__restrict__ stats)
+{
+    StatAcc v = {0, 0, 0, INFINITY, -INFINITY, 0};
+    for (int b = threadIdx.x; b < nparts; b += blockDim.x) {
+        const double *o = part + (size_t)b * 6;
+        v.sa += o[0]; v.sl += o[1]; v.sl2 += o[2]; v.mn = fmin(v.mn, o[3]); v.mx = fmax(v.mx, o[4]); v.sa2 += o[5];
+    }
+    block_fold(v);
+    if (threadIdx.x == 0) {
+        stats[0] = (double)P; stats[1] = iters; stats[2] = v.sa; stats[3] = v.sl; stats[4] = v.sl2; stats[5] = v.mn; stats[6] = v.mx; stats[7] = v.sa2;
     }
 }
 
 // pointwise ensemble mean and M2 = sum outer(x - mean) of the current X at every grid point
 // (what mcnext! accumulates, src/mclog.jl:48-56).  One block per grid index i; two passes.
-__global__ __launch_bounds__(256) void k_path_stats(const double *__restrict__ b0, const double *__restrict__ b1, const unsigned char *__restrict__ cur,
-                                                    int d, long ld, long P, double *__restrict__ mean, double *__restrict__ m2)
+__global__ __launch_bounds__(256) void k_path_stats(const double *__restrict__ X, int d, long ld, long P, double *__restrict__ mean, double *__restrict__ m2)
 {
     const int i = blockIdx.x;
     __shared__ double sh[4];
@@ -130,10 +150,7 @@ __global__ __launch_bounds__(256) void k_path_stats(const double *__restrict__ b
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int k = 0; k < d; k++) {
         double s = 0;
-        for (long p = threadIdx.x; p < P; p += blockDim.x) {
-            const double *src = (cur && cur[p]) ? b1 : b0;
-            s += src[((size_t)i * d + k) * ld + p];
-        }
+        for (long p = threadIdx.x; p < P; p += blockDim.x) s += X[((size_t)i * d + k) * ld + p];
         s = wave_sum(s);
         if (lane == 0) sh[w] = s;
         __syncthreads();
@@ -143,10 +160,8 @@ __global__ __launch_bounds__(256) void k_path_stats(const double *__restrict__ b
     for (int c = 0; c < d; c++)
         for (int r = 0; r < d; r++) {
             double s = 0;
-            for (long p = threadIdx.x; p < P; p += blockDim.x) {
-                const double *src = (cur && cur[p]) ? b1 : b0;
-                s += (src[((size_t)i * d + r) * ld + p] - mu[r]) * (src[((size_t)i * d + c) * ld + p] - mu[c]);
-            }
+            for (long p = threadIdx.x; p < P; p += blockDim.x)
+                s += (X[((size_t)i * d + r) * ld + p] - mu[r]) * (X[((size_t)i * d + c) * ld + p] - mu[c]);
             s = wave_sum(s);
             if (lane == 0) sh[w] = s;
             __syncthreads();

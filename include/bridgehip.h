@@ -156,9 +156,14 @@ int bhip_llikelihood(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev
                      int skip, long npaths);
 
 /* ------------------------------------------------------------------ pCN Metropolis-Hastings ensemble
- * One chain per lane; state (W, X, ll) double-buffered with a per-chain parity bit instead of the
- * reference's copies on accept.  partialbridge_fitzhugh.jl:125-176, test/partialbridgenuH.jl:155-198 */
-#define BHIP_CHAINS_STORE_X 1   /* keep Xo/X on the device (the SamplePath contract)            */
+ * One chain per lane.  partialbridge_fitzhugh.jl:125-176, test/partialbridgenuH.jl:155-198
+ * Chain state = (W, ll, parity): W and the proposal Wo share a 16-byte slot per (grid index, chain)
+ * and an accept flips the chain's parity bit -- the reference's `W, Wo = Wo, W` swap
+ * (test/partialbridgenuH.jl:186-187) without its copies.  Every iteration writes the proposal path
+ * Xo (solve!(Euler(), Xo, x0, Wo, Po)) when BHIP_CHAINS_STORE_X is set; the CURRENT path X is a
+ * deterministic function of the current W and is re-materialised on demand, bit-identical to the Xo
+ * stored when that W was accepted (bhip_chains_current_X / bhip_chains_get_paths). */
+#define BHIP_CHAINS_STORE_X 1   /* write the proposal paths Xo every iteration (the SamplePath contract) */
 int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uint32_t path0, uint64_t seed,
                        int flags, bhip_chains **out);
 void bhip_chains_destroy(bhip_chains *ch);
@@ -176,6 +181,10 @@ int bhip_chains_stats(bhip_chains *ch, double *stats_dev);
 int bhip_chains_get(bhip_chains *ch, double *ll, int64_t *acc);
 /* current state of chains p0..p0+np as AoS host arrays: X [np][N][d], W [np][N][mp] */
 int bhip_chains_get_paths(bhip_chains *ch, long p0, long np, double *X_aos, double *W_aos);
+/* current paths X of all chains into a device SoA array [N][d][ldX] */
+int bhip_chains_current_X(bhip_chains *ch, double *X_dev, long ldX);
+/* the proposal-path buffer Xo [N][d][*ld] written by the last iteration (needs BHIP_CHAINS_STORE_X) */
+int bhip_chains_proposal_X(bhip_chains *ch, double **Xo_dev, long *ld);
 /* pointwise online mean/covariance of the current X over the chain ensemble (mcstart/mcnext!
  * semantics, src/mclog.jl:22-56): mean [N][d], m2 [N][d*d] (column-major), host pointers */
 int bhip_chains_pathstats(bhip_chains *ch, double *mean, double *m2);

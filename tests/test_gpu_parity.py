@@ -234,8 +234,21 @@ def test_mcmc_driver_and_subsamples(ctx):
     ch = bh.Chains(c.bh_proposal(bh, ctx), c.x0, 128, seed=4, store_X=False)
     ch.step(0.9, 30)
     assert np.array_equal(ch.ll(), out["ll"]) and np.array_equal(ch.acc(), out["acc"])
+    # the current X is a function of the current W: available even when no Xo was ever stored
+    assert np.array_equal(ch.paths(want_W=False)[0], out["XX"][-1])
     with pytest.raises(bh.BridgeError):
-        ch.paths()
+        ch.proposal_X()
+    # with store_X the proposal buffer holds Xo of the last iteration; it equals the current X
+    # exactly for the chains that accepted it
+    ch2 = out["chains"]
+    acc_before = ch2.acc()
+    ch2.step(0.9, 1)
+    accepted = (ch2.acc() - acc_before).astype(bool)
+    Xo = ch2.proposal_X().cpu().numpy()          # [N, d, n]
+    Xc = ch2.current_X().data.cpu().numpy()
+    assert accepted.any() and (~accepted).any()
+    assert np.array_equal(Xo[:, :, accepted], Xc[:, :, accepted])
+    assert not np.array_equal(Xo[:, :, ~accepted], Xc[:, :, ~accepted])
 
 
 # --------------------------------------------------------------------------- reference-style error behaviour
