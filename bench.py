@@ -194,6 +194,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": kernel, "kernel_avg_ms": kern_avg_s * 1e3,
+                         "kernel_min_ms": float(np.min(kern_ms)), "kernel_max_ms": float(np.max(kern_ms)),
                          "algorithmic_bytes_per_path_step": bytes_per_pathstep,
                          "path_steps_per_launch": P * steps_per_unit},
         }

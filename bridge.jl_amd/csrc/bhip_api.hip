@@ -452,13 +452,12 @@ static int fill_common(const bhip_proposal *po, KArgs &a, const double *x0, cons
     a.rows = po->d_rows; a.rs = po->rs; a.N = (int)po->tt.size(); a.skip = skip;
     a.P = npaths;
     a.wstride = 1;
-    a.aux_linpro = po->has_aux && po->aux.linpro_form();
-    a.ll_two_dots = po->g.kind == BHIP_GUIDE_NUH_INPLACE;
+    const bool aux_linpro = po->has_aux && po->aux.linpro_form();   // b~ = B(x - mu~); else b~ = B x + beta~ (mu~ = 0)
     a.use_vend = po->use_vend;
     for (int k = 0; k < d; k++) {
         a.x0[k] = x0 ? x0[k] : 0.0;
         a.vend[k] = po->vend[k];
-        a.mu_aux[k] = a.aux_linpro ? po->aux.mu()[k] : 0.0;
+        a.mu_aux[k] = aux_linpro ? po->aux.mu()[k] : 0.0;
     }
     if ((int)po->mh.dpar.size() > 32) return fail(ctx, BHIP_EINVAL, "model parameter block too large");
     for (size_t k = 0; k < po->mh.dpar.size(); k++) a.mpar[k] = po->mh.dpar[k];
@@ -469,10 +468,11 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
 {
     bhip_ctx *ctx = po->ctx;
     const int gk = po->g.kind == BHIP_GUIDE_NUH_INPLACE ? BHIP_GUIDE_NUH : po->g.kind;
+    const int gk_dispatch = po->g.kind;   // NUH_INPLACE selects the two-dot log-likelihood instantiation
     int fl = 0;
     if (noise == NOISE_PCN) fl = a.Xo ? 1 : 0;
     else fl = (a.X ? 1 : 0) | (a.Wout ? 2 : 0);
-    launch_fn f = find_launch(po->mh, gk, gk == BHIP_GUIDE_LMMU ? po->g.m : 1, noise, fl);
+    launch_fn f = find_launch(po->mh, gk_dispatch, gk == BHIP_GUIDE_LMMU ? po->g.m : 1, noise, fl);
     if (!f) return fail(ctx, BHIP_EUNSUPPORTED, "no device kernel for this (model, guide, noise) combination");
     if (a.rs != row_stride(gk, po->mh.d, po->g.m)) return fail(ctx, BHIP_ESTATE, "row stride mismatch");
     HIPCHK(ctx, f(a, ctx->stream));

@@ -16,6 +16,7 @@ namespace bhip {
 // ---- b = -beta*x, sigma, a = sigma^2                      test/guip.jl:21-23, README.md:75-77
 struct MOU {
     static constexpr int D = 1, MP = 1, ID = BHIP_MODEL_OU;
+    static constexpr bool noisy(int) { return true; }
     double beta, sig, a;
     BHIP_DEV explicit MOU(const double *p) : beta(p[0]), sig(p[1]), a(p[2]) {}
     BHIP_DEV void b(double, const double *x, double *o) const { o[0] = -beta * x[0]; }
@@ -28,6 +29,7 @@ struct MOU {
 template <int D_>
 struct MLinPro {
     static constexpr int D = D_, MP = D_, ID = BHIP_MODEL_LINPRO;
+    static constexpr bool noisy(int) { return true; }
     const double *p;
     BHIP_DEV explicit MLinPro(const double *p_) : p(p_) {}
     BHIP_DEV void b(double, const double *x, double *o) const
@@ -72,6 +74,7 @@ struct MLinPro {
 // dp = eps,s,gamma,beta,sigma, a22 = sigma*sigma
 struct MFHN {
     static constexpr int D = 2, MP = 1, ID = BHIP_MODEL_FHN;
+    static constexpr bool noisy(int k) { return k == 1; }   // sigma = (0, sigma): row 0 of sigma*dw is an exact zero
     double eps, s, gam, beta, sig, a22;
     BHIP_DEV explicit MFHN(const double *p) : eps(p[0]), s(p[1]), gam(p[2]), beta(p[3]), sig(p[4]), a22(p[5]) {}
     BHIP_DEV void b(double, const double *x, double *o) const
@@ -87,6 +90,7 @@ struct MFHN {
 // b = (x2, x3, -alpha*sin(omega*x3)), sigma = (0,0,sigma);  dp = alpha,omega,sigma,a33
 struct MNCLAR {
     static constexpr int D = 3, MP = 1, ID = BHIP_MODEL_NCLAR;
+    static constexpr bool noisy(int k) { return k == 2; }
     double al, om, sig, a33;
     BHIP_DEV explicit MNCLAR(const double *p) : al(p[0]), om(p[1]), sig(p[2]), a33(p[3]) {}
     BHIP_DEV void b(double, const double *x, double *o) const
@@ -101,6 +105,7 @@ struct MNCLAR {
 // b = (x2, -(x2+sin(x2)) + 1/2), sigma = (0,gamma);  dp = gamma, a22
 struct MIntDiff {
     static constexpr int D = 2, MP = 1, ID = BHIP_MODEL_INTDIFF;
+    static constexpr bool noisy(int k) { return k == 1; }
     double gam, a22;
     BHIP_DEV explicit MIntDiff(const double *p) : gam(p[0]), a22(p[1]) {}
     BHIP_DEV void b(double, const double *x, double *o) const
@@ -115,6 +120,7 @@ struct MIntDiff {
 // dp = th1,th2,th3,s1,s2,s3, a11,a22,a33
 struct MLorenz {
     static constexpr int D = 3, MP = 3, ID = BHIP_MODEL_LORENZ;
+    static constexpr bool noisy(int) { return true; }
     double t1, t2, t3, s1, s2, s3, a1, a2, a3;
     BHIP_DEV explicit MLorenz(const double *p)
         : t1(p[0]), t2(p[1]), t3(p[2]), s1(p[3]), s2(p[4]), s3(p[5]), a1(p[6]), a2(p[7]), a3(p[8]) {}
@@ -132,6 +138,7 @@ struct MLorenz {
 // dp = eps,s,gamma,beta,s1,s2, a11,a22
 struct MFHN2 {
     static constexpr int D = 2, MP = 2, ID = BHIP_MODEL_FHN2;
+    static constexpr bool noisy(int) { return true; }
     double eps, s, gam, beta, s1, s2, a1, a2;
     BHIP_DEV explicit MFHN2(const double *p)
         : eps(p[0]), s(p[1]), gam(p[2]), beta(p[3]), s1(p[4]), s2(p[5]), a1(p[6]), a2(p[7]) {}
@@ -148,6 +155,7 @@ struct MFHN2 {
 // b = (x2, -theta2*sin(x1)), sigma = (0,gamma);  dp = theta2, gamma, a22
 struct MPendulum {
     static constexpr int D = 2, MP = 1, ID = BHIP_MODEL_PENDULUM;
+    static constexpr bool noisy(int k) { return k == 1; }
     double th2, gam, a22;
     BHIP_DEV explicit MPendulum(const double *p) : th2(p[0]), gam(p[1]), a22(p[2]) {}
     BHIP_DEV void b(double, const double *x, double *o) const { o[0] = x[1]; o[1] = -th2 * sin(x[0]); }
@@ -159,6 +167,7 @@ struct MPendulum {
 template <int D_>
 struct MWiener {
     static constexpr int D = D_, MP = D_, ID = BHIP_MODEL_WIENER;
+    static constexpr bool noisy(int) { return true; }
     BHIP_DEV explicit MWiener(const double *) {}
     BHIP_DEV void b(double, const double *, double *o) const
     {

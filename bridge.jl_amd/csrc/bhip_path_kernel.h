@@ -28,8 +28,6 @@ enum { NOISE_EXT = 0, NOISE_FRESH = 1, NOISE_PCN = 2, NOISE_LLONLY = 3 };
 struct KArgs {
     const double *rows;   // [N-1][rs] packed per-step coefficients (device)
     int rs, N, skip;
-    int aux_linpro;       // 1: b~ = B(x - mu~), 0: b~ = B x + beta~
-    int ll_two_dots;      // PartialBridge! accumulates dot(b,r)dt - dot(b~,r)dt
     int use_vend;         // GuidedBridge endpoint rule: X[N-1] = V[N-1]
     long P;               // paths
     const double *x0_dev; // optional per-path starts [D][ldx0]
@@ -147,7 +145,7 @@ struct LaneState {
 // One Euler step of one path, branch-free (a single basic block so that the scheduler can interleave
 // the state-independent work -- Philox, Box-Muller, address arithmetic -- with the dependent chain).
 //   win_k : EXT: W[i+1] ; PCN: current chain W[i+1] ; LLONLY: X[i]       (already in registers)
-//   FL    : bit0 store X, bit1 store W
+//   FL    : bit0 store X, bit1 store W, bit2 PartialBridge!-style log-likelihood (two dots)
 template <class M, int GK, int MO, int NOISE, int FL>
 BHIP_DEV void path_step(const M &model, const KArgs &a, cptr_t row, int i, int nll, uint32_t path, const double *win_k,
                         double *wout, long ldwo, double *xout, long ldx, LaneState<M::D, M::MP> &st)
@@ -221,13 +219,20 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, cptr_t row, int i, int n
             for (int j = 1; j < D; j++) s += rw[RL::B + q + D * j] * xm[j];
             bA[q] = s + rw[RL::BETA + q];
         }
-        double s0 = (bT[0] - bA[0]) * r[0], s1 = bT[0] * r[0], s2 = bA[0] * r[0];
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        if constexpr ((FL & 4) != 0) {
+            s1 = bT[0] * r[0]; s2 = bA[0] * r[0];
 #pragma unroll
-        for (int k = 1; k < D; k++) { s0 += (bT[k] - bA[k]) * r[k]; s1 += bT[k] * r[k]; s2 += bA[k] * r[k]; }
-        const double ll_one = st.ll + s0 * dt;                  // src/partialbridge.jl:77
-        const double ll_two = (st.ll + s1 * dt) - s2 * dt;      // src/partialbridgen!.jl:96-97
-        const double lln = a.ll_two_dots ? ll_two : ll_one;
-        st.ll = (i < nll) ? lln : st.ll;                        // skip: only i < N-1-skip contribute
+            for (int k = 1; k < D; k++) { s1 += bT[k] * r[k]; s2 += bA[k] * r[k]; }
+        } else {
+            s0 = (bT[0] - bA[0]) * r[0];
+#pragma unroll
+            for (int k = 1; k < D; k++) s0 += (bT[k] - bA[k]) * r[k];
+        }
+        double lln;
+        if constexpr ((FL & 4) != 0) lln = (st.ll + s1 * dt) - s2 * dt;   // PartialBridge!: src/partialbridgen!.jl:96-97
+        else lln = st.ll + s0 * dt;                                        // src/partialbridge.jl:77
+        st.ll = (i < nll) ? lln : st.ll;                                   // skip: only i < N-1-skip contribute
 #pragma unroll
         for (int k = 0; k < D; k++) bT[k] = bT[k] + g[k];       // _b = b + a*(...)
     }
@@ -235,12 +240,16 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, cptr_t row, int i, int n
         double s[D];
         model.sdw(dw, s);
 #pragma unroll
-        for (int k = 0; k < D; k++) st.y[k] = st.y[k] + bT[k] * dt + s[k];   // src/euler.jl:264
+        for (int k = 0; k < D; k++)   // src/euler.jl:264; a structurally zero sigma row contributes an exact "+ 0.0"
+            st.y[k] = M::noisy(k) ? st.y[k] + bT[k] * dt + s[k] : st.y[k] + bT[k] * dt;
     }
 }
 
+// Minimum waves per SIMD the register allocator must allow.  The BASELINE workloads launch
+// 262 144 lanes = 4096 waves = exactly 4 waves per SIMD on 256 CUs: above 128 VGPRs only 3 waves fit,
+// the last quarter of the grid runs as a second round and the kernel takes 4/3 as long (measured).
 #ifndef BHIP_WPE
-#define BHIP_WPE 1
+#define BHIP_WPE 4
 #endif
 
 template <class M, int GK, int MO, int NOISE, int FL>
@@ -406,24 +415,26 @@ hipError_t launch_paths(const KArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-// all (guide, obs-dim, noise, store-flags) instantiations of one model.  fl: bit0 store X, bit1 store W.
-template <class M, int GK, int MO>
+// all (guide, obs-dim, noise, flags) instantiations of one model.
+// fl: bit0 store X, bit1 store W (FRESH only), bit2 two-dot log-likelihood (PartialBridge!, NUH guide only).
+template <class M, int GK, int MO, int TWO>
 launch_fn get_launch_gk(int noise, int fl)
 {
+    constexpr int T = TWO ? 4 : 0;
     switch (noise) {
-    case NOISE_EXT: return (fl & 1) ? launch_paths<M, GK, MO, NOISE_EXT, 1> : launch_paths<M, GK, MO, NOISE_EXT, 0>;
+    case NOISE_EXT: return (fl & 1) ? launch_paths<M, GK, MO, NOISE_EXT, 1 | T> : launch_paths<M, GK, MO, NOISE_EXT, 0 | T>;
     case NOISE_FRESH:
         switch (fl & 3) {
-        case 0: return launch_paths<M, GK, MO, NOISE_FRESH, 0>;
-        case 1: return launch_paths<M, GK, MO, NOISE_FRESH, 1>;
-        case 2: return launch_paths<M, GK, MO, NOISE_FRESH, 2>;
-        default: return launch_paths<M, GK, MO, NOISE_FRESH, 3>;
+        case 0: return launch_paths<M, GK, MO, NOISE_FRESH, 0 | T>;
+        case 1: return launch_paths<M, GK, MO, NOISE_FRESH, 1 | T>;
+        case 2: return launch_paths<M, GK, MO, NOISE_FRESH, 2 | T>;
+        default: return launch_paths<M, GK, MO, NOISE_FRESH, 3 | T>;
         }
     case NOISE_PCN:
-        if constexpr (GK != BHIP_GUIDE_NONE) return (fl & 1) ? launch_paths<M, GK, MO, NOISE_PCN, 1> : launch_paths<M, GK, MO, NOISE_PCN, 0>;
+        if constexpr (GK != BHIP_GUIDE_NONE) return (fl & 1) ? launch_paths<M, GK, MO, NOISE_PCN, 1 | T> : launch_paths<M, GK, MO, NOISE_PCN, 0 | T>;
         return nullptr;
     case NOISE_LLONLY:
-        if constexpr (GK != BHIP_GUIDE_NONE) return launch_paths<M, GK, MO, NOISE_LLONLY, 0>;
+        if constexpr (GK != BHIP_GUIDE_NONE) return launch_paths<M, GK, MO, NOISE_LLONLY, 0 | T>;
         return nullptr;
     }
     return nullptr;
@@ -434,14 +445,14 @@ launch_fn get_launch(int gk, int mo, int noise, int fl)
 {
     constexpr int D = M::D;
     switch (gk) {
-    case BHIP_GUIDE_NONE: return get_launch_gk<M, BHIP_GUIDE_NONE, 1>(noise, fl);
-    case BHIP_GUIDE_HV: return get_launch_gk<M, BHIP_GUIDE_HV, 1>(noise, fl);
-    case BHIP_GUIDE_NUH:
-    case BHIP_GUIDE_NUH_INPLACE: return get_launch_gk<M, BHIP_GUIDE_NUH, 1>(noise, fl);
+    case BHIP_GUIDE_NONE: return get_launch_gk<M, BHIP_GUIDE_NONE, 1, 0>(noise, fl);
+    case BHIP_GUIDE_HV: return get_launch_gk<M, BHIP_GUIDE_HV, 1, 0>(noise, fl);
+    case BHIP_GUIDE_NUH: return get_launch_gk<M, BHIP_GUIDE_NUH, 1, 0>(noise, fl);
+    case BHIP_GUIDE_NUH_INPLACE: return get_launch_gk<M, BHIP_GUIDE_NUH, 1, 1>(noise, fl);
     case BHIP_GUIDE_LMMU:
-        if (mo == 1) return get_launch_gk<M, BHIP_GUIDE_LMMU, 1>(noise, fl);
-        if constexpr (D >= 2) { if (mo == 2) return get_launch_gk<M, BHIP_GUIDE_LMMU, 2>(noise, fl); }
-        if constexpr (D >= 3) { if (mo == 3) return get_launch_gk<M, BHIP_GUIDE_LMMU, 3>(noise, fl); }
+        if (mo == 1) return get_launch_gk<M, BHIP_GUIDE_LMMU, 1, 0>(noise, fl);
+        if constexpr (D >= 2) { if (mo == 2) return get_launch_gk<M, BHIP_GUIDE_LMMU, 2, 0>(noise, fl); }
+        if constexpr (D >= 3) { if (mo == 3) return get_launch_gk<M, BHIP_GUIDE_LMMU, 3, 0>(noise, fl); }
         return nullptr;
     }
     return nullptr;

@@ -25,23 +25,16 @@
 
 namespace bhip {
 
-BHIP_HD uint32_t mulhi32(uint32_t a, uint32_t b)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umulhi(a, b);
-#else
-    return (uint32_t)(((uint64_t)a * b) >> 32);
-#endif
-}
-
 struct u32x4 { uint32_t x, y, z, w; };
 
 BHIP_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32x32->64 product per multiplier (v_mad_u64_u32 on gfx950) instead of mul_hi + mul_lo
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -117,9 +110,12 @@ BHIP_HD void det_sincos2pi(double u, double &sn, double &cs)
     pc = fma_(pc, z, 1.0 / 24.0);
     pc = fma_(pc, z, -0.5);
     const double c0 = fma_(z, pc, 1.0);
+    // quadrant rotation without branches: q odd swaps sin/cos; sin is negated for q in {2,3}, cos for q in {1,2}
     const int qi = (int)q & 3;
-    sn = (qi == 0) ? s0 : (qi == 1) ? c0 : (qi == 2) ? -s0 : -c0;
-    cs = (qi == 0) ? c0 : (qi == 1) ? -s0 : (qi == 2) ? -c0 : s0;
+    const bool swp = (qi & 1) != 0;
+    const double sb = swp ? c0 : s0, cb = swp ? s0 : c0;
+    sn = (qi & 2) ? -sb : sb;
+    cs = ((qi + 1) & 2) ? -cb : cb;
 }
 
 // block `blk` of stream 0 -> normals 2*blk (z0) and 2*blk+1 (z1)
