@@ -34,6 +34,7 @@ import torch
 import torch.distributed as dist
 
 import bridgehip as bh
+from bridgehip import dist as bdist
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 N_GRID = 1001
@@ -111,7 +112,6 @@ def main():
     path0 = rank * P                      # contiguous shard of the global chain ids; RNG keyed by global id
     steps_per_unit = N_GRID - 1
     stats = ctx.empty(bh.STATS_LEN)
-    gathered = ctx.empty(world * bh.STATS_LEN) if world > 1 else None
 
     if args.mode == "mcmc":
         ch = bh.Chains(Po, X0, P, seed=4, path0=path0, store_X=True)
@@ -152,8 +152,7 @@ def main():
         ch.stats(stats)
     else:
         stats.zero_()
-    if world > 1:
-        dist.all_gather_into_tensor(gathered, stats)     # the ONE collective: acceptance / log-weight statistics
+    gathered = bdist.allgather_stats(stats, world)       # the ONE collective: acceptance / log-weight statistics
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -199,12 +198,10 @@ def main():
                          "path_steps_per_launch": P * steps_per_unit},
         }
         if args.mode == "mcmc":
-            if world > 1:
-                g = gathered.cpu().numpy().reshape(world, bh.STATS_LEN)
-            else:
-                g = stats.cpu().numpy().reshape(1, bh.STATS_LEN)
-            out["config"]["acceptance_rate"] = float(g[:, 2].sum() / (g[:, 0].sum() * max(g[0, 1], 1)))
-            out["config"]["mean_ll"] = float(g[:, 3].sum() / g[:, 0].sum())
+            summary = bdist.combine_stats(gathered)
+            out["config"]["acceptance_rate"] = summary["acceptance_rate"]
+            out["config"]["mean_ll"] = summary["mean_ll"]
+            out["config"]["chains_total"] = summary["chains"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

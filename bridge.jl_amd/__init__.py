@@ -6,3 +6,4 @@ The directory is called `bridge.jl_amd`; import it as `bridgehip` (repo-root shi
 from .api import *  # noqa: F401,F403
 from .api import _cm, _uncm  # noqa: F401
 from . import _lib  # noqa: F401
+from . import dist  # noqa: F401

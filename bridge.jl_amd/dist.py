@@ -1,0 +1,94 @@
+"""Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm,
+"gloo" in the CPU tests).
+
+The path shards trivially: chains / proposals are independent units (test/guip.jl:255-262; one chain
+= partialbridge_fitzhugh.jl:143-176).  Rank r owns the contiguous global ids
+[r*P/world, (r+1)*P/world); the Philox stream is keyed by the GLOBAL id, so results do not depend on
+the number of GPUs.  Grid, model and guide coefficients are replicated (each rank computes the same
+guide on its host, <= a few hundred KB).  There is NO data-path collective; the only communication
+is ONE all-gather of the fixed-size statistics block (acceptance counts, log-weight moments) --
+latency-bound (64 B per rank), independent of the xGMI per-link bandwidth.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+STATS_LEN = 8   # {n, iterations, sum acc, sum ll, sum ll^2, min ll, max ll, sum acc^2}
+
+
+def env_rank():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None, device=None):
+    """rendezvous from the torchrun environment; 127.0.0.1 unless MASTER_ADDR says otherwise"""
+    rank, local, world = env_rank()
+    if world == 1:
+        return rank, local, world
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if backend == "nccl":
+        kw["device_id"] = device if device is not None else torch.device("cuda", local)
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, local, world
+
+
+def shard(total, rank, world):
+    """contiguous shard [lo, hi) of `total` independent units for `rank`"""
+    base, rem = divmod(int(total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allgather_stats(stats, world=None):
+    """ONE all-gather of the per-rank statistics block -> tensor [world, STATS_LEN] on every rank"""
+    world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+    if world == 1:
+        return stats.reshape(1, -1)
+    out = torch.empty(world * stats.numel(), dtype=stats.dtype, device=stats.device)
+    dist.all_gather_into_tensor(out, stats.contiguous())
+    return out.reshape(world, -1)
+
+
+def combine_stats(gathered):
+    """fold the gathered blocks into ensemble-level numbers (host)"""
+    g = np.asarray(gathered.detach().cpu() if isinstance(gathered, torch.Tensor) else gathered, dtype=np.float64).reshape(-1, STATS_LEN)
+    n = g[:, 0].sum()
+    iters = g[:, 1].max()
+    mean_ll = g[:, 3].sum() / n
+    var_ll = max(g[:, 4].sum() / n - mean_ll ** 2, 0.0) * (n / max(n - 1, 1))
+    acc_mean = g[:, 2].sum() / n
+    return dict(chains=int(n), iterations=int(iters), acceptance_rate=float(acc_mean / max(iters, 1)),
+                mean_ll=float(mean_ll), var_ll=float(var_ll), min_ll=float(g[:, 5].min()), max_ll=float(g[:, 6].max()),
+                acc_per_chain_mean=float(acc_mean),
+                acc_per_chain_var=float(max(g[:, 7].sum() / n - acc_mean ** 2, 0.0)))
+
+
+def allgather_pathstats(n, mean, m2, world=None):
+    """all-gather the per-rank pointwise Welford states (n, mean [N,d], m2 [N,d,d]) and merge them with
+    the parallel form of mcnext (src/mclog.jl:31-38)."""
+    from .api import mcmerge
+    world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+    if world == 1:
+        return n, mean, m2
+    payload = torch.from_numpy(np.concatenate([[float(n)], np.ravel(mean), np.ravel(m2)]))
+    out = torch.empty(world * payload.numel(), dtype=payload.dtype)
+    if dist.get_backend() == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+        o = out.to(dev)
+        dist.all_gather_into_tensor(o, payload.to(dev))
+        out = o.cpu()
+    else:
+        dist.all_gather_into_tensor(out, payload)
+    out = out.numpy().reshape(world, -1)
+    N, d = mean.shape
+    state = None
+    for r in range(world):
+        nr, mr, qr = int(out[r, 0]), out[r, 1:1 + N * d].reshape(N, d), out[r, 1 + N * d:].reshape(N, d, d)
+        state = (mr, qr, nr) if state is None else mcmerge(state, (mr, qr, nr))
+    return state[2], state[0], state[1]

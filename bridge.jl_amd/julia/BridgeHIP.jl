@@ -1,0 +1,232 @@
+# BridgeHIP.jl -- thin Julia shim over libbridgehip.so (C ABI: include/bridgehip.h).
+#
+# Drop-in for ONE hot path of Bridge.jl v0.11.7: sample!(W, Wiener()) -> pCN mix -> solve!(Euler(), ...)
+# -> llikelihood(LeftRule(), ...) -> MH accept, for ensembles of independent paths / chains on an
+# MI355X.  It adds methods to Bridge's own generic functions, so call sites keep reading
+#
+#     W  = sample(tt, Wiener(), HIPEnsemble(npaths))     # instead of a single path
+#     X  = solve(HIPEuler(), x0, W, Po)
+#     ll = llikelihood(LeftRule(), X, Po)
+#
+# NOTE: there is no `julia` binary in the build image, so this file has never been executed; it is
+# the declarative ccall layer a maintainer would add (see INTEGRATION.md).  The same ABI is exercised
+# by the Python ctypes mirror (bridge.jl_amd/api.py) in the test-suite.
+module BridgeHIP
+
+using Bridge, StaticArrays, LinearAlgebra
+import Bridge: sample, sample!, solve, solve!, llikelihood, lptilde, LeftRule, Wiener, ContinuousTimeProcess
+
+const lib = get(ENV, "BRIDGEHIP_SO", joinpath(@__DIR__, "..", "libbridgehip.so"))
+
+# ---------------------------------------------------------------- errors (include/bridgehip.h codes)
+struct BHIPError <: Exception
+    code::Cint
+    msg::String
+end
+Base.showerror(io::IO, e::BHIPError) = print(io, "bridgehip error ", e.code, ": ", e.msg)
+
+mutable struct Context
+    h::Ptr{Cvoid}
+    function Context(device::Integer = 0, stream::Ptr{Cvoid} = C_NULL)
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:bhip_ctx_create, lib), Cint, (Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, stream, r)
+        rc == 0 || throw(BHIPError(rc, "bhip_ctx_create failed (no HIP device? there is no CPU fallback)"))
+        c = new(r[])
+        finalizer(c -> ccall((:bhip_ctx_destroy, lib), Cvoid, (Ptr{Cvoid},), c.h), c)
+    end
+end
+check(ctx::Context, rc) = rc == 0 ? nothing :
+    throw(BHIPError(rc, unsafe_string(ccall((:bhip_last_error, lib), Cstring, (Ptr{Cvoid},), ctx.h))))
+
+const default_ctx = Ref{Union{Nothing,Context}}(nothing)
+ctx() = something(default_ctx[], (default_ctx[] = Context(); default_ctx[]))
+
+# ---------------------------------------------------------------- process type -> device functor
+# trait: hipmodel(P) -> (model id, d, parameter vector).  Users with their own process types add a
+# method for one of the registry ids, e.g. for the script's FitzhughDiffusion
+#     BridgeHIP.hipmodel(P::FitzhughDiffusion) = (3, 2, [P.ϵ, P.s, P.γ, P.β, P.σ])
+hipmodel(P) = error("no device functor registered for $(typeof(P)); define BridgeHIP.hipmodel")
+hipmodel(P::Bridge.LinPro) = (2, length(P.μ), vcat(vec(collect(P.B)), collect(P.μ), vec(collect(P.σ))))
+hipmodel(P::Bridge.Models.FitzHughNagumo) = (7, 2, [P.ϵ, P.s, P.γ, P.β, P.σ1, P.σ2])
+hipmodel(P::Bridge.Models.Lorenz) = (6, 3, vcat(collect(P.θ), diag(P.σ)))
+hipmodel(P::Bridge.Models.Pendulum) = (8, 2, [P.θ², P.γ])
+hipmodel(::Wiener{SVector{d,Float64}}) where {d} = (0, d, Float64[])
+hipmodel(::Wiener{Float64}) = (0, 1, Float64[])
+
+# auxiliary process: constant coefficients by default, any Bridge.B/β/a methods through a C callback
+function aux_callback(t::Cdouble, B::Ptr{Cdouble}, beta::Ptr{Cdouble}, a::Ptr{Cdouble}, user::Ptr{Cvoid})::Cvoid
+    Pt = unsafe_pointer_to_objref(user)[]
+    Bt = Bridge.B(t, Pt); bt = Bridge.β(t, Pt); at = Bridge.a(t, Pt)
+    d = length(bt)
+    for k in 1:d*d
+        unsafe_store!(B, Bt[k], k); unsafe_store!(a, at[k], k)       # column-major, like SMatrix
+    end
+    for k in 1:d
+        unsafe_store!(beta, bt[k], k)
+    end
+    nothing
+end
+
+# ---------------------------------------------------------------- ensembles (SoA on the device)
+"`HIPEnsemble(npaths)`: request marker for ensemble versions of sample/solve"
+struct HIPEnsemble
+    npaths::Int
+    seed::UInt64
+    iter::UInt32
+    path0::UInt32
+end
+HIPEnsemble(n; seed = 0, iter = 0, path0 = 0) = HIPEnsemble(n, seed, iter, path0)
+
+"An ensemble of sample paths in HBM: element (i, k, p) at `(i*dim + k)*ld + p` (0-based), Float64."
+mutable struct EnsemblePath{T} <: Bridge.AbstractPath{T}
+    tt::Vector{Float64}
+    dev::Ptr{Cdouble}
+    dim::Int
+    npaths::Int
+    ctx::Context
+end
+Base.length(X::EnsemblePath) = length(X.tt)
+function EnsemblePath{T}(tt, dim, npaths, c::Context = ctx()) where {T}
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(c, ccall((:bhip_malloc, lib), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), c.h, 8 * length(tt) * dim * npaths, r))
+    X = EnsemblePath{T}(collect(Float64, tt), Ptr{Cdouble}(r[]), dim, npaths, c)
+    finalizer(x -> ccall((:bhip_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), x.ctx.h, x.dev), X)
+end
+"download path p (1-based) as an ordinary Bridge.SamplePath"
+function Bridge.SamplePath(X::EnsemblePath{T}, p::Integer) where {T}
+    yy = Vector{T}(undef, length(X))
+    check(X.ctx, ccall((:bhip_download_aos, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Clong, Clong, Clong, Ptr{Cdouble}),
+        X.ctx.h, X.dev, length(X), X.dim, X.npaths, p - 1, 1, pointer(reinterpret(Float64, yy))))
+    Bridge.SamplePath(copy(X.tt), yy)
+end
+
+# ---------------------------------------------------------------- proposals
+"device twin of GuidedBridge / PartialBridge / PartialBridgeνH (holds the bhip_proposal handle)"
+mutable struct HIPProposal{T} <: ContinuousTimeProcess{T}
+    h::Ptr{Cvoid}
+    tt::Vector{Float64}
+    d::Int
+    mp::Int
+    ctx::Context
+    keep::Any            # roots the callback closure
+end
+
+function _proposal(tt, P, Pt, c::Context)
+    id, d, par = hipmodel(P)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    ttv = collect(Float64, tt)
+    check(c, ccall((:bhip_proposal_create, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint, Ptr{Cdouble}, Cint, Ref{Ptr{Cvoid}}),
+        c.h, ttv, length(ttv), id, d, par, length(par), r))
+    keep = Ref{Any}(Pt)
+    cb = @cfunction(aux_callback, Cvoid, (Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cvoid}))
+    check(c, ccall((:bhip_proposal_set_aux_callback, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cdouble}),
+        r[], cb, pointer_from_objref(keep), Pt isa Bridge.LinPro ? 1 : 0, Pt isa Bridge.LinPro ? collect(Pt.μ) : C_NULL))
+    mp = P isa Bridge.LinPro ? d : size(Bridge.σ(ttv[1], zero(Bridge.valtype(P)), P), 2)
+    Po = HIPProposal{Bridge.valtype(P)}(r[], ttv, d, mp, c, keep)
+    finalizer(p -> ccall((:bhip_proposal_destroy, lib), Cvoid, (Ptr{Cvoid},), p.h), Po)
+end
+
+"GuidedBridge(tt, P, Pt, v, h♢)  src/guip.jl:172-180"
+function HIPGuidedBridge(tt, P, Pt, v, h = nothing; ctx = ctx())
+    Po = _proposal(tt, P, Pt, ctx)
+    check(ctx, ccall((:bhip_proposal_guide_hv, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}),
+        Po.h, collect(Float64, v), h === nothing ? C_NULL : vec(collect(Float64, h))))
+    Po
+end
+"PartialBridge(tt, P, Pt, L, v, Σ)  src/partialbridge.jl:42-50"
+function HIPPartialBridge(tt, P, Pt, L, v, Σ = nothing; ctx = ctx())
+    Po = _proposal(tt, P, Pt, ctx)
+    check(ctx, ccall((:bhip_proposal_guide_lmmu, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+        Po.h, size(L, 1), vec(collect(Float64, L)), collect(Float64, v), Σ === nothing ? C_NULL : vec(collect(Float64, Σ))))
+    Po
+end
+"PartialBridgeνH(tt, P, Pt, L, v, ϵ, Σ)  src/partialbridgenuH.jl:134-145  (inplace=true: PartialBridge!)"
+function HIPPartialBridgeνH(tt, P, Pt, L, v, ϵ, Σ = nothing; inplace = false, ctx = ctx())
+    Po = _proposal(tt, P, Pt, ctx)
+    check(ctx, ccall((:bhip_proposal_guide_nuh, lib), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Cint),
+        Po.h, size(L, 1), vec(collect(Float64, L)), collect(Float64, v), ϵ, Σ === nothing ? C_NULL : vec(collect(Float64, Σ)), inplace))
+    Po
+end
+"wrap guide arrays computed by Bridge.jl's own constructors (bhip_proposal_guide_arrays)"
+function HIPProposal(Po::Bridge.PartialBridge; ctx = ctx())
+    Q = _proposal(Po.tt, Po.Target, Po.Pt, ctx)
+    m = length(Po.v)
+    check(ctx, ccall((:bhip_proposal_guide_arrays, lib), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+        Q.h, 2, m, reinterpret(Float64, Po.L), reinterpret(Float64, Po.M), reinterpret(Float64, Po.μ), collect(Float64, Po.v)))
+    Q
+end
+
+function lptilde(Po::HIPProposal, u)
+    r = Ref{Cdouble}(0)
+    check(Po.ctx, ccall((:bhip_proposal_lptilde, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ref{Cdouble}), Po.h, collect(Float64, u), r))
+    r[]
+end
+
+# ---------------------------------------------------------------- sample / solve / llikelihood
+struct HIPEuler <: Bridge.SDESolver end
+
+"sample(tt, Wiener{T}(), HIPEnsemble(n)): n Wiener paths in HBM  (src/wiener.jl:11-15)"
+function sample(tt, P::Wiener{T}, E::HIPEnsemble; ctx = ctx()) where {T}
+    W = EnsemblePath{T}(tt, length(zero(T)), E.npaths, ctx)
+    sample!(W, P; seed = E.seed, iter = E.iter, path0 = E.path0)
+end
+"sample!(W, Wiener())  src/wiener.jl:24-58"
+function sample!(W::EnsemblePath{T}, ::Wiener{T}; seed = 0, iter = 0, path0 = 0) where {T}
+    check(W.ctx, ccall((:bhip_wiener_sample, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Clong, Clong, UInt64, UInt32, UInt32),
+        W.ctx.h, W.tt, length(W.tt), W.dim, W.dev, W.npaths, W.npaths, seed, iter, path0))
+    W
+end
+
+"solve!(HIPEuler(), Y, u, W, Po): src/euler.jl:247-268 for every path; returns Y (endpoints are Y[end])"
+function solve!(::HIPEuler, Y::EnsemblePath, u, W::EnsemblePath, Po::HIPProposal; ll::Ptr{Cdouble} = Ptr{Cdouble}(C_NULL), skip = 0)
+    length(W) != length(Y) && error("Y and W differ in length.")        # src/euler.jl:251
+    Y.tt[:] = Po.tt                                                       # src/euler.jl:256
+    check(Y.ctx, ccall((:bhip_solve, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Cint, Clong),
+        Y.ctx.h, Po.h, collect(Float64, u), C_NULL, W.dev, W.npaths, Y.dev, Y.npaths, ll, skip, Y.npaths))
+    Y
+end
+solve(m::HIPEuler, u, W::EnsemblePath, Po::HIPProposal{T}; kw...) where {T} =
+    solve!(m, EnsemblePath{T}(W.tt, Po.d, W.npaths, W.ctx), u, W, Po; kw...)
+"deprecated alias  src/deprecated.jl:16-17"
+bridge!(Y::EnsemblePath, u, W::EnsemblePath, Po::HIPProposal) = solve!(HIPEuler(), Y, u, W, Po)
+
+"llikelihood(LeftRule(), X, Po; skip): one value per path  src/partialbridge.jl:67-77 etc."
+function llikelihood(::LeftRule, X::EnsemblePath, Po::HIPProposal; skip = 0)
+    out = Vector{Float64}(undef, X.npaths)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(X.ctx, ccall((:bhip_malloc, lib), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), X.ctx.h, 8 * X.npaths, r))
+    check(X.ctx, ccall((:bhip_llikelihood, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Cint, Clong),
+        X.ctx.h, Po.h, X.dev, X.npaths, r[], skip, X.npaths))
+    check(X.ctx, ccall((:bhip_memcpy_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), X.ctx.h, out, r[], 8 * X.npaths))
+    ccall((:bhip_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), X.ctx.h, r[])
+    out
+end
+
+# ---------------------------------------------------------------- the MCMC loop of the scripts
+"""
+    mcmc(Po, x0, iterations; ρ, nchains, seed) -> (acc, ll, chains)
+
+`nchains` independent copies of the loop in project_partialbridge/partialbridge_fitzhugh.jl:125-176
+(one chain per GPU lane; sample!, pCN mix, solve!, llikelihood and the accept fused in one kernel).
+"""
+function mcmc(Po::HIPProposal, x0, iterations; ρ = 0.9, nchains = 1, seed = 0, path0 = 0, skip = 0, store_X = true)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    c = Po.ctx
+    check(c, ccall((:bhip_chains_create, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Clong, UInt32, UInt64, Cint, Ref{Ptr{Cvoid}}),
+        c.h, Po.h, nchains, path0, seed, store_X ? 1 : 0, r))
+    ch = r[]
+    check(c, ccall((:bhip_chains_init, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), ch, collect(Float64, x0), skip))
+    check(c, ccall((:bhip_chains_step, lib), Cint, (Ptr{Cvoid}, Cdouble, Cint, Cint), ch, ρ, iterations, skip))
+    ll = Vector{Float64}(undef, nchains); acc = Vector{Int64}(undef, nchains)
+    check(c, ccall((:bhip_chains_get, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Int64}), ch, ll, acc))
+    acc, ll, ch
+end
+
+end # module
