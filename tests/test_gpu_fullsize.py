@@ -1,0 +1,109 @@
+"""GPU tests at BASELINE.json's full sizes (N = 1001; 65 536 / 262 144 paths), where the oracle can only
+spot-check: a sample of path ids is compared bit-for-bit with the oracle, the rest is covered by
+size-independent properties (checksums, endpoint rules, importance-weight unbiasedness with a much
+sharper sample than the reference's m = 1000, sharding invariance, stationarity of the chains).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import bridgehip as bh
+import oracle as o
+import problems
+
+pytestmark = pytest.mark.gpu
+N = 1001
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return bh.default_context(0)
+
+
+def _case(name):
+    return [c for c in problems.cases(N) if c.name == name][0]
+
+
+def test_C2_ou_guided_bridge_65536_paths(ctx):
+    """config C2 + K9 (test/guip.jl:245-274) with m = 65 536 instead of 1000"""
+    c = _case("ou_guidedbridge")
+    P = 65536
+    Po = c.bh_proposal(bh, ctx)
+    X, W, ll = bh.sample_solve(c.x0, Po, P, seed=2, store_W=True)
+    assert torch.all(X.data[-1, 0] == c.v[0]) and torch.all(X.data[0, 0] == c.x0[0])     # pinned end, x0 stored first
+    llh = ll.cpu().numpy()
+    assert np.all(np.isfinite(llh))
+    # importance weights: E[exp(ll)] * ptilde / p = 1 with p the OU transition density (closed form)
+    beta, a, T, u, v = 0.8, math.sqrt(0.7) ** 2, 2.0, c.x0[0], c.v[0]
+    K = a / (2 * beta) * (1 - math.exp(-2 * beta * T))
+    lp = -0.5 * ((v - u * math.exp(-beta * T)) ** 2 / K + math.log(K) + math.log(2 * math.pi))
+    w = np.exp(llh + bh.lptilde(Po, c.x0) - lp)
+    stat = abs(np.mean(w - 1)) * math.sqrt(P) / np.std(w, ddof=1)
+    assert stat < 4.0, stat
+    assert abs(np.mean(w) - 1) < 0.02
+    # spot check against the oracle, bit for bit
+    ref = c.oracle_proposal()
+    Xh, Wh = X.paths(0, 2), W.paths(0, 2)
+    for p in (0, 1):
+        Wr = o.wiener_sample(c.tt, 1, 2, p, 0)
+        assert np.array_equal(Wh[p], Wr) and np.array_equal(Xh[p], o.solve_guided(ref, c.x0, Wr))
+    for p in (31337, P - 1):
+        Wr = o.wiener_sample(c.tt, 1, 2, p, 0)
+        Xr = o.solve_guided(ref, c.x0, Wr)
+        assert np.array_equal(X.paths(p, 1)[0], Xr) and llh[p] == o.llikelihood(ref, Xr)
+    # checksum of checksums: llikelihood re-evaluated on the stored ensemble reproduces the fused values
+    assert torch.equal(bh.llikelihood(bh.LeftRule(), X, Po), ll)
+
+
+def test_C3_fhn_partial_bridge_262144_paths(ctx):
+    """config C3: FitzHugh-Nagumo PartialBridge, 1001 steps, 262 144 paths"""
+    c = _case("fhn_partialbridge_extreme")
+    P = 262144
+    Po = c.bh_proposal(bh, ctx)
+    X, _, ll = bh.sample_solve(c.x0, Po, P, seed=3)
+    llh = ll.cpu().numpy()
+    assert np.all(np.isfinite(llh)) and bool(torch.isfinite(X.data).all())
+    # the guided proposal hits the observation L x_T = v up to the observation noise scale
+    end = X.data[-1, 0]
+    assert float((end - c.v[0]).abs().max()) < 5e-3
+    assert torch.all(X.data[0, 0] == c.x0[0]) and torch.all(X.data[0, 1] == c.x0[1])
+    ref = c.oracle_proposal()
+    for p in (0, 99999, P - 1):
+        Xr = o.solve_guided(ref, c.x0, o.wiener_sample(c.tt, 1, 3, p, 0))
+        assert np.array_equal(X.paths(p, 1)[0], Xr) and llh[p] == o.llikelihood(ref, Xr)
+    # sharding invariance at full size: the second half computed as its own launch (another "GPU")
+    Xb, _, llb = bh.sample_solve(c.x0, Po, P // 2, seed=3, path0=P // 2)
+    assert torch.equal(Xb.data, X.data[:, :, P // 2:]) and torch.equal(llb, ll[P // 2:])
+    del Xb
+    # 3-d NCLAR at the same size (the "3-d" of BASELINE.json): finite, hits the observation
+    c3 = _case("nclar_firstcomponent")
+    Po3 = c3.bh_proposal(bh, ctx)
+    X3, _, ll3 = bh.sample_solve(c3.x0, Po3, P, seed=3)
+    assert bool(torch.isfinite(ll3).all()) and float((X3.data[-1, 0] - c3.v[0]).abs().max()) < 5e-3
+    ref3 = c3.oracle_proposal()
+    Xr = o.solve_guided(ref3, c3.x0, o.wiener_sample(c3.tt, 1, 3, 4242, 0))
+    assert np.abs(X3.paths(4242, 1)[0] - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max())
+
+
+def test_C4_pcn_mcmc_262144_chains(ctx):
+    """config C4's per-GPU shard: 262 144 pCN chains, a few iterations"""
+    c = _case("fhn_partialbridge_extreme")
+    P, iters = 262144, 6
+    ch = bh.Chains(c.bh_proposal(bh, ctx), c.x0, P, seed=4, path0=7 * P)       # the shard rank 7 would own
+    ll0 = ch.ll()
+    ch.step(0.9, iters)
+    ll, acc = ch.ll(), ch.acc()
+    st = ch.stats().cpu().numpy()
+    assert st[0] == P and st[1] == iters and st[2] == acc.sum()
+    assert abs(st[3] - ll.sum()) <= 1e-9 * np.abs(ll).sum() and st[5] == ll.min() and st[6] == ll.max()
+    rate = acc.sum() / (P * iters)
+    assert 0.1 < rate < 0.9, rate
+    # MH targets exp(ll) * prior: accepted moves raise ll on average relative to the initial draw
+    assert ll.mean() > ll0.mean()
+    ref = c.oracle_proposal()
+    X, W = ch.paths(1234, 2)
+    for k, p in enumerate((1234, 1235)):
+        r = o.mcmc(ref, c.x0, 0.9, iters, 4, 7 * P + p)
+        assert acc[p] == r["acc"] and ll[p] == r["ll"] and np.array_equal(W[k], r["W"]) and np.array_equal(X[k], r["X"])
