@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chains", type=int, default=262144, help="chains (paths) per GPU")
-    ap.add_argument("--mode", choices=["mcmc", "proposals"], default="mcmc")
+    ap.add_argument("--mode", choices=["mcmc", "proposals", "linpro32"], default="mcmc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -107,13 +107,41 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     ctx = bh.Context(local)
-    Po = build_proposal(ctx)
     P = args.chains
     path0 = rank * P                      # contiguous shard of the global chain ids; RNG keyed by global id
     steps_per_unit = N_GRID - 1
     stats = ctx.empty(bh.STATS_LEN)
+    roof = None
+    workload = None
 
-    if args.mode == "mcmc":
+    if args.mode == "linpro32":
+        # config C5: LinPro d=32 GuidedBridge on the fp64 MFMA tile kernel; 65 536 paths by default
+        d = 32
+        if args.chains == 262144:
+            P = 65536
+            path0 = rank * P
+        rng = np.random.default_rng(5)
+        G, G2 = rng.standard_normal((d, d)) / np.sqrt(d), rng.standard_normal((d, d)) / np.sqrt(d)
+        sig = 0.5 * np.eye(d) + 0.05 * G2
+        Po = bh.GuidedBridge(np.linspace(0.0, 1.0, N_GRID), bh.LinPro(-np.eye(d) + 0.1 * G, np.zeros(d), sig),
+                             bh.LinPro(-np.eye(d), np.zeros(d), sig), 0.5 * np.ones(d), ctx=ctx)
+        X = bh.EnsemblePath(Po.tt, d, P, ctx)
+        ll = ctx.empty(P)
+        it = [0]
+        x0 = np.zeros(d)
+
+        def step():
+            it[0] += 1
+            ctx.check(ctx.lib.bhip_sample_solve(ctx.h, Po.h, bh.api._dptr(x0), None, None, P, X.ptr(), P,
+                                                bh.api.vp(ll.data_ptr()), 0, P, 5, it[0], path0))
+
+        bytes_per_pathstep = 8 * d               # write X (8d)
+        flops_per_pathstep = 5 * 2 * d * d       # five d x d mat-vecs
+        kernel = "k_tile<32>"
+        roof = ("mfma", flops_per_pathstep, 78.6, "TFLOP/s")
+        workload = "LinPro d=32 GuidedBridge (dense sigma, pre-inverted Hdiamond), 1001-point grid T=1, independent fused proposals"
+    elif args.mode == "mcmc":
+        Po = build_proposal(ctx)
         ch = bh.Chains(Po, X0, P, seed=4, path0=path0, store_X=True)
 
         def step():
@@ -122,6 +150,7 @@ def main():
         bytes_per_pathstep = 8 * 2 + 16 * 1      # write Xo (8d) + read W, write Wo (16 m')   SURVEY 8(d) mode M
         kernel = "k_paths<MFHN, LMMU, 1, PCN>"
     else:
+        Po = build_proposal(ctx)
         X = bh.EnsemblePath(Po.tt, 2, P, ctx)
         ll = ctx.empty(P)
         it = [0]
@@ -197,6 +226,12 @@ def main():
                          "algorithmic_bytes_per_path_step": bytes_per_pathstep,
                          "path_steps_per_launch": P * steps_per_unit},
         }
+        if workload:
+            out["config"]["workload"] = workload
+        if roof:   # compute-bound kernel: report against the fp64 matrix-core peak
+            tf = float(P) * steps_per_unit * roof[1] / kern_avg_s / 1e12
+            out["roofline"].update({"bound": roof[0], "achieved": tf, "peak": roof[2], "unit": roof[3], "frac": tf / roof[2],
+                                    "algorithmic_flops_per_path_step": roof[1], "hbm_algorithmic_GBs": achieved})
         if args.mode == "mcmc":
             summary = bdist.combine_stats(gathered)
             out["config"]["acceptance_rate"] = summary["acceptance_rate"]

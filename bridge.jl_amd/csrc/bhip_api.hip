@@ -3,6 +3,7 @@
 // bhip_path_kernel.h (instantiated per model in bhip_inst.hip) and bhip_util_kernels.h.
 #include "bhip_host.hpp"
 #include "bhip_path_kernel.h"
+#include "bhip_tile_kernel.h"
 #include "bhip_util_kernels.h"
 #include <algorithm>
 #include <cstdio>
@@ -47,6 +48,9 @@ struct bhip_proposal {
     int rs = 0;
     bool use_vend = false;
     double vend[3] = {0, 0, 0};
+    // large-d (tile kernel) data: per-step fragment matrices, step header, constants
+    double *d_steps = nullptr, *d_hdr = nullptr, *d_cst = nullptr;
+    std::vector<double> cst_host;   // kept so that x0 can be patched per call
 };
 
 struct bhip_chains {
@@ -265,7 +269,13 @@ int bhip_proposal_create(bhip_ctx *ctx, const double *tt, int N, int model, int 
 void bhip_proposal_destroy(bhip_proposal *po)
 {
     if (!po) return;
-    if (po->d_rows && !po->ctx->host_only) { (void)hipStreamSynchronize(po->ctx->stream); (void)hipFree(po->d_rows); }
+    if (!po->ctx->host_only) {
+        (void)hipStreamSynchronize(po->ctx->stream);
+        if (po->d_rows) (void)hipFree(po->d_rows);
+        if (po->d_steps) (void)hipFree(po->d_steps);
+        if (po->d_hdr) (void)hipFree(po->d_hdr);
+        if (po->d_cst) (void)hipFree(po->d_cst);
+    }
     delete po;
 }
 
@@ -299,6 +309,87 @@ int bhip_proposal_set_aux_callback(bhip_proposal *po, bhip_aux_fn fn, void *user
     return BHIP_OK;
 }
 
+
+// ---- large state dimension: data for the MFMA tile kernel (bhip_tile_kernel.h)
+// fragment order of a D x D matrix: Mf[(t*4T + ks)*64 + l] = M[16t + (l&15)][4ks + (l>>4)]
+static void to_fragments(const Mat &M, double *out)
+{
+    const int D = M.r, T = D / 16;
+    for (int t = 0; t < T; t++)
+        for (int ks = 0; ks < 4 * T; ks++)
+            for (int l = 0; l < 64; l++) out[((size_t)t * 4 * T + ks) * 64 + l] = M(16 * t + (l & 15), 4 * ks + (l >> 4));
+}
+
+static int build_tile_data(bhip_proposal *po)
+{
+    bhip_ctx *ctx = po->ctx;
+    const int N = (int)po->tt.size(), d = po->mh.d;
+    if (po->g.kind == BHIP_GUIDE_NONE) return BHIP_OK;
+    if (po->mh.id != BHIP_MODEL_LINPRO || (d != 16 && d != 32))
+        return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: LinPro target with d = 16 or 32");
+    if (po->g.kind != BHIP_GUIDE_HV && po->g.kind != BHIP_GUIDE_NUH)
+        return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: GuidedBridge (Hdiamond,V) or (nu,H) guides");
+    if (!po->has_aux || (po->aux.kind != BHIP_AUX_AFFINE && po->aux.kind != BHIP_AUX_LINPRO))
+        return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: time-constant auxiliary process");
+    const size_t DD = (size_t)d * d, STEP = DD + d;
+    std::vector<double> steps((size_t)(N - 1) * STEP), hdr((size_t)(N - 1) * 2);
+    for (int i = 0; i < N - 1; i++) {
+        // GuidedBridge: r = Hdiamond_i \ (V_i - x) evaluated as inv(Hdiamond_i)*(V_i - x) (path-independent
+        // inverse, LU with partial pivoting); nuH: r = H_i*(nu_i - x) as in the reference.
+        const Mat Hm = po->g.kind == BHIP_GUIDE_HV ? inv(po->g.Hd[i]) : po->g.H[i];
+        const Mat &nu = po->g.kind == BHIP_GUIDE_HV ? po->g.V[i] : po->g.nu[i];
+        to_fragments(Hm, &steps[(size_t)i * STEP]);
+        std::memcpy(&steps[(size_t)i * STEP + DD], nu.a.data(), sizeof(double) * d);
+        hdr[2 * i] = po->tt[i + 1] - po->tt[i];
+        hdr[2 * i + 1] = std::sqrt(po->tt[i + 1] - po->tt[i]);
+    }
+    std::vector<double> &cst = po->cst_host;
+    cst.assign(4 * DD + 5 * d, 0.0);
+    const double *par = po->mh.par.data();
+    to_fragments(Mat(d, d, par), &cst[0]);                               // B
+    to_fragments(po->aux.B(po->tt[0]), &cst[DD]);                        // B~
+    to_fragments(po->mh.a, &cst[2 * DD]);                                // a = sigma*sigma'
+    to_fragments(Mat(d, d, par + DD + d), &cst[3 * DD]);                 // sigma
+    std::memcpy(&cst[4 * DD], par + DD, sizeof(double) * d);             // mu
+    const bool lin = po->aux.linpro_form();
+    if (lin) std::memcpy(&cst[4 * DD + d], po->aux.mu(), sizeof(double) * d);                        // mu~ (else 0)
+    else { const Mat be = po->aux.beta(po->tt[0]); std::memcpy(&cst[4 * DD + 2 * d], be.a.data(), sizeof(double) * d); }   // beta~ (else 0)
+    if (po->g.kind == BHIP_GUIDE_HV) std::memcpy(&cst[4 * DD + 3 * d], po->g.V[N - 1].a.data(), sizeof(double) * d);       // vend
+    for (double **q : {&po->d_steps, &po->d_hdr, &po->d_cst})
+        if (*q) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(*q)); *q = nullptr; }
+    HIPCHK(ctx, hipMalloc((void **)&po->d_steps, sizeof(double) * steps.size()));
+    HIPCHK(ctx, hipMalloc((void **)&po->d_hdr, sizeof(double) * hdr.size()));
+    HIPCHK(ctx, hipMalloc((void **)&po->d_cst, sizeof(double) * cst.size()));
+    HIPCHK(ctx, hipMemcpy(po->d_steps, steps.data(), sizeof(double) * steps.size(), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(po->d_hdr, hdr.data(), sizeof(double) * hdr.size(), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(po->d_cst, cst.data(), sizeof(double) * cst.size(), hipMemcpyHostToDevice));
+    return BHIP_OK;
+}
+
+static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const double *W_in, long ldWin, double *W_out, long ldWout,
+                            double *X, long ldX, double *ll, int skip, long npaths, int noise, uint64_t seed, uint32_t iter, uint32_t path0)
+{
+    bhip_proposal *po = const_cast<bhip_proposal *>(po_c);
+    bhip_ctx *ctx = po->ctx;
+    NEED_DEVICE(ctx);
+    const int d = po->mh.d;
+    if (!po->d_steps) return fail(ctx, BHIP_ESTATE, "proposal has no large-d guide data (compute a guide first)");
+    if (!x0) return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: shared starting point only");
+    if (npaths < 1 || skip < 0) return fail(ctx, BHIP_EINVAL, "bad npaths/skip");
+    const size_t DD = (size_t)d * d;
+    // x0 lives in the constant block (read by every lane by row index)
+    std::memcpy(&po->cst_host[4 * DD + 4 * d], x0, sizeof(double) * d);
+    HIPCHK(ctx, hipMemcpyAsync(po->d_cst + 4 * DD + 4 * d, &po->cst_host[4 * DD + 4 * d], sizeof(double) * d, hipMemcpyHostToDevice, ctx->stream));
+    TArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.steps = po->d_steps; a.hdr = po->d_hdr; a.cst = po->d_cst;
+    a.N = (int)po->tt.size(); a.skip = skip; a.use_vend = po->use_vend; a.noise = noise; a.P = npaths;
+    a.Win = W_in; a.ldWin = ldWin; a.Wout = W_out; a.ldWout = ldWout; a.X = X; a.ldX = ldX; a.ll = ll;
+    a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.iter = iter; a.path0 = path0;
+    HIPCHK(ctx, d == 32 ? launch_tile<32>(a, ctx->stream) : launch_tile<16>(a, ctx->stream));
+    return BHIP_OK;
+}
+
 static int finish_guide(bhip_proposal *po)
 {
     bhip_ctx *ctx = po->ctx;
@@ -312,8 +403,8 @@ static int finish_guide(bhip_proposal *po)
             for (int k = 0; k < d && k < 3; k++) po->vend[k] = po->g.V[N - 1].a[k];
         }
     }
-    if (d > 3) return BHIP_OK;   // large-d rows are built by the tile kernel path
     if (ctx->host_only) return BHIP_OK;   // coefficients stay on the host (bhip_proposal_guide_get)
+    if (d > 3) return build_tile_data(po);
     std::vector<double> rows;
     int rs = 0;
     pack_rows(po->tt, po->mh, po->has_aux ? &po->aux : nullptr, po->g, rows, rs);
@@ -508,10 +599,14 @@ int bhip_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, const d
         int rc = ensure_plain_rows(const_cast<bhip_proposal *>(po));
         if (rc) return rc;
     }
+    if (ldW < npaths || (X_dev && ldX < npaths)) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
+    if (po->mh.d > 3) {
+        if (x0_dev) return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: shared starting point only");
+        return launch_tile_path(po, x0, W_dev, ldW, nullptr, 0, X_dev, ldX, ll_dev, skip, npaths, 0, 0, 0, 0);
+    }
     KArgs a;
     int rc = fill_common(po, a, x0, x0_dev, npaths, skip);
     if (rc) return rc;
-    if (ldW < npaths || (X_dev && ldX < npaths)) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
     a.x0_dev = x0_dev; a.ldx0 = ldX;
     a.Win = W_dev; a.ldWin = ldW; a.X = X_dev; a.ldX = ldX; a.ll = ll_dev;
     return do_launch(po, NOISE_EXT, a);
@@ -526,10 +621,14 @@ int bhip_sample_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, 
         int rc = ensure_plain_rows(const_cast<bhip_proposal *>(po));
         if (rc) return rc;
     }
+    if ((W_dev && ldW < npaths) || (X_dev && ldX < npaths)) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
+    if (po->mh.d > 3) {
+        if (x0_dev) return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: shared starting point only");
+        return launch_tile_path(po, x0, nullptr, 0, W_dev, ldW, X_dev, ldX, ll_dev, skip, npaths, 1, seed, iter, path0);
+    }
     KArgs a;
     int rc = fill_common(po, a, x0, x0_dev, npaths, skip);
     if (rc) return rc;
-    if ((W_dev && ldW < npaths) || (X_dev && ldX < npaths)) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
     a.x0_dev = x0_dev; a.ldx0 = ldX;
     a.Wout = W_dev; a.ldWout = ldW; a.X = X_dev; a.ldX = ldX; a.ll = ll_dev;
     a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.iter = iter; a.path0 = path0;

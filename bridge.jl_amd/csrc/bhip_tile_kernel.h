@@ -1,0 +1,236 @@
+// bhip_tile_kernel.h -- guided Euler-Maruyama + log-likelihood for LARGE state dimension
+// (config C5: LinPro d = 32, SVector{32}; SURVEY 8(a) rows a4/a5/a7/a8 at d > 3).
+//
+// For d <= 3 a lane owns a path (bhip_path_kernel.h).  At d = 32 the state no longer fits a lane and
+// the work per step is five dense d x d mat-vecs
+//     r  = Hm_i (nu_i - x)      guide: Hm = inv(Hdiamond_i) (GuidedBridge, src/guip.jl:192-193) or H_i (nuH)
+//     bT = B (x - mu)           target LinPro drift            src/linpro.jl:80
+//     bA = B~ (x - mu~) + beta~ auxiliary drift                src/guip.jl:434
+//     g  = a r                  guiding term a*(...)           src/guip.jl:192
+//     s  = sigma dW             _scale(dW, sigma)              src/euler.jl:264
+// batched over paths they are a dense contraction, so a WAVE owns a 16-path tile and runs them on the
+// fp64 matrix cores:  Y(d x 16) = M(d x d) X(d x 16) as v_mfma_f64_16x16x4_f64 chains.
+//
+// Tile layout of every d x 16 operand (T = d/16 row tiles): lane (kq = lane>>4, j = lane&15) holds
+// v[t][r] = element (row 16t + 4r + kq, path j).  This is at once the MFMA C/D layout of a result and
+// the B-operand layout of the next mat-vec (K-slice ks = 4t + r), so chained products need no shuffles.
+// Matrices are pre-arranged on the host in A-operand fragment order
+//     Mf[(t'*4T + ks)*64 + lane] = M[16t' + (lane&15)][4ks + (lane>>4)]
+// The path-independent per-step matrix Hm_i (8 KiB at d = 32) is streamed global -> LDS once per block
+// and step (double-buffered, one barrier per step) and shared by the block's 4 waves; the four
+// constant matrices live in LDS for the whole kernel.  Noise: every lane needs 8 normals per step; a
+// Philox block yields the normals of rows 2m and 2m+1, which sit in partner lanes (lane ^ 16), so each
+// lane generates half of the pair's blocks and they exchange by shuffle.  The per-path log-weight is
+// reduced over the 4 row groups of a path with two wavefront shuffles.
+//
+// Numerics: MFMA accumulates with fused multiply-adds in k order and the guide solve is replaced by a
+// product with the pre-inverted matrix, so parity with the oracle is tolerance-based here
+// (tests: 1e-9 relative on paths, 1e-8 on ll), not bit-exact as for d <= 3.
+#pragma once
+#include "bhip_rng.h"
+#include <hip/hip_runtime.h>
+
+namespace bhip {
+
+typedef double double4v __attribute__((ext_vector_type(4)));
+
+struct TArgs {
+    const double *steps;   // [N-1][D*D + D]: Hm_i in fragment order, then nu_i (natural order)
+    const double *hdr;     // [N-1][2]: dt_i, sqrt(dt_i)
+    const double *cst;     // 4 fragment matrices (B, B~, a, sigma), then mu, mu~, beta~, vend, x0 (D each)
+    int N, skip, use_vend, noise;   // noise: 0 = external W, 1 = fresh Philox
+    long P;
+    const double *Win; long ldWin;
+    double *Wout; long ldWout;
+    double *X; long ldX;
+    double *ll;
+    uint32_t k0, k1, iter, path0;
+};
+
+template <int T>
+__device__ __forceinline__ void tile_mv(const double *__restrict__ Mf, const double (&v)[T][4], double (&out)[T][4], int lane)
+{
+    double4v acc[T];
+#pragma unroll
+    for (int tp = 0; tp < T; tp++) acc[tp] = double4v{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4 * T; ks++) {
+#pragma unroll
+        for (int tp = 0; tp < T; tp++)
+            acc[tp] = __builtin_amdgcn_mfma_f64_16x16x4f64(Mf[(tp * 4 * T + ks) * 64 + lane], v[ks >> 2][ks & 3], acc[tp], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tp = 0; tp < T; tp++) {
+        out[tp][0] = acc[tp][0]; out[tp][1] = acc[tp][1]; out[tp][2] = acc[tp][2]; out[tp][3] = acc[tp][3];
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_tile(const TArgs a)
+{
+    constexpr int T = D / 16;
+    constexpr int DD = D * D;
+    constexpr int STEP = DD + D;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *cm = lds;                  // 4*DD fragment matrices + 5*D vectors
+    double *hb = lds + 4 * DD + 5 * D; // 2 * STEP
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = lane >> 4, j = lane & 15;
+    const long p_raw = (long)blockIdx.x * 64 + wave * 16 + j;
+    const bool live = p_raw < a.P;
+    const long p = live ? p_raw : a.P - 1;
+    const int N = a.N, nsteps = N - 1, nll = N - 1 - a.skip;
+
+    for (int c = tid; c < 4 * DD + 5 * D; c += 256) cm[c] = a.cst[c];
+    for (int c = tid; c < STEP; c += 256) hb[c] = a.steps[c];
+    __syncthreads();
+    const double *Bf = cm, *Btf = cm + DD, *Af = cm + 2 * DD, *Sf = cm + 3 * DD;
+    const double *mu = cm + 4 * DD, *mua = mu + D, *beta = mu + 2 * D, *vend = mu + 3 * D, *x0 = mu + 4 * D;
+
+    double x[T][4], wprev[T][4];
+#pragma unroll
+    for (int t = 0; t < T; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 16 * t + 4 * r + kq;
+            x[t][r] = x0[row];
+            wprev[t][r] = a.noise == 0 ? a.Win[(size_t)row * a.ldWin + p] : 0.0;
+            if (a.noise == 1 && a.Wout && live) a.Wout[(size_t)row * a.ldWout + p] = 0.0;
+        }
+    double ll = 0.0;
+    const uint32_t path = a.path0 + (uint32_t)p;
+
+    for (int i = 0; i < nsteps; i++) {
+        const int cur = i & 1;
+        const double *hm = hb + cur * STEP, *nu = hm + DD;
+        // stage step i+1's matrix: global -> registers now, registers -> LDS after the compute
+        double stage[(STEP + 255) / 256];
+        const bool more = i + 1 < nsteps;
+        if (more) {
+#pragma unroll
+            for (int c = 0; c < (STEP + 255) / 256; c++) {
+                const int idx = tid + 256 * c;
+                stage[c] = idx < STEP ? a.steps[(size_t)(i + 1) * STEP + idx] : 0.0;
+            }
+        }
+        const double dt = a.hdr[2 * i], rdt = a.hdr[2 * i + 1];
+
+        // ---- the Wiener increment tile
+        double dw[T][4];
+        if (a.noise == 0) {
+#pragma unroll
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = 16 * t + 4 * r + kq;
+                    const double wn = a.Win[((size_t)(i + 1) * D + row) * a.ldWin + p];
+                    dw[t][r] = wn - wprev[t][r];
+                    wprev[t][r] = wn;
+                }
+        } else {
+            // normal index n = i*D + row; block n>>1 = i*D/2 + 2*ks + (kq>>1), element kq&1 (ks = 4t+r).
+            // lanes kq and kq^1 share blocks: the even lane draws ks = 0..2T-1, the odd one ks = 2T..4T-1.
+            const int odd = kq & 1;
+            double mine[4 * T];
+#pragma unroll
+            for (int h = 0; h < 2 * T; h++) {
+                const int ks = h + (odd ? 2 * T : 0);
+                double z0, z1;
+                normal_pair(a.k0, a.k1, path, a.iter, (uint32_t)(i * (D / 2) + 2 * ks + (kq >> 1)), z0, z1);
+                const double keep = odd ? z1 : z0, give = odd ? z0 : z1;
+                const double got = __shfl_xor(give, 16, 64);   // partner's block h + (partner odd ? 2T : 0)
+                mine[ks] = keep;
+                mine[h + (odd ? 0 : 2 * T)] = got;
+            }
+#pragma unroll
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double wn = wprev[t][r] + rdt * mine[4 * t + r];   // sample!: W[i+1] = W[i] + sqrt(dt)*xi
+                    dw[t][r] = wn - wprev[t][r];
+                    wprev[t][r] = wn;
+                    if (a.Wout && live) a.Wout[((size_t)(i + 1) * D + 16 * t + 4 * r + kq) * a.ldWout + p] = wn;
+                }
+        }
+
+        // ---- X[i] = x (before the update, src/euler.jl:263)
+        if (a.X && live) {
+#pragma unroll
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) a.X[((size_t)i * D + 16 * t + 4 * r + kq) * a.ldX + p] = x[t][r];
+        }
+
+        double w[T][4], xm[T][4], xa[T][4];
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 16 * t + 4 * r + kq;
+                w[t][r] = nu[row] - x[t][r];
+                xm[t][r] = x[t][r] - mu[row];
+                xa[t][r] = x[t][r] - mua[row];
+            }
+        double rr[T][4], bT[T][4], bA[T][4], g[T][4], s[T][4];
+        tile_mv<T>(hm, w, rr, lane);
+        tile_mv<T>(Bf, xm, bT, lane);
+        tile_mv<T>(Btf, xa, bA, lane);
+        tile_mv<T>(Af, rr, g, lane);
+        tile_mv<T>(Sf, dw, s, lane);
+
+        // ---- llikelihood: som += dot(b - b~, r)*dt, reduced over the path's 4 row groups
+        double part = 0.0;
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) part += (bT[t][r] - (bA[t][r] + beta[16 * t + 4 * r + kq])) * rr[t][r];
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        if (i < nll) ll += part * dt;
+
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) x[t][r] = x[t][r] + (bT[t][r] + g[t][r]) * dt + s[t][r];
+
+        if (more) {
+#pragma unroll
+            for (int c = 0; c < (STEP + 255) / 256; c++) {
+                const int idx = tid + 256 * c;
+                if (idx < STEP) hb[(cur ^ 1) * STEP + idx] = stage[c];
+            }
+        }
+        __syncthreads();
+    }
+
+    if (a.use_vend) {
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) x[t][r] = vend[16 * t + 4 * r + kq];
+    }
+    if (a.X && live) {
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) a.X[((size_t)(N - 1) * D + 16 * t + 4 * r + kq) * a.ldX + p] = x[t][r];
+    }
+    if (a.ll && live && kq == 0) a.ll[p] = ll;
+}
+
+template <int D>
+hipError_t launch_tile(const TArgs &a, hipStream_t st)
+{
+    const size_t lds = sizeof(double) * (4 * D * D + 5 * D + 2 * (D * D + D));
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_tile<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const long grid = (a.P + 63) / 64;
+    hipLaunchKernelGGL((k_tile<D>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace bhip

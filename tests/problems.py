@@ -164,6 +164,24 @@ def cases(N=201):
     return cs
 
 
+def linpro_big_case(d=32, N=201, kind=None):
+    """config C5: LinPro d=32, B = -I + 0.1 G, G ~ N(0,1)/sqrt(d) (seed 5), mu = 0,
+    sigma = 0.5 I + 0.05 G2 (dense a), auxiliary LinPro with B~ = -I and the same sigma; T = 1, u = 0, v = 0.5*1"""
+    rng = np.random.default_rng(5)
+    G = rng.standard_normal((d, d)) / math.sqrt(d)
+    G2 = rng.standard_normal((d, d)) / math.sqrt(d)
+    B = -np.eye(d) + 0.1 * G
+    sig = 0.5 * np.eye(d) + 0.05 * G2
+    par = o.linpro_par(B, np.zeros(d), sig)
+    apar = o.linpro_par(-np.eye(d), np.zeros(d), sig)
+    kind = o.GUIDE_HV if kind is None else kind
+    if kind == o.GUIDE_HV:
+        return Case(f"linpro{d}_guidedbridge", np.linspace(0, 1.0, N), np.zeros(d), o.MODEL_LINPRO, par, o.AUX_LINPRO, apar,
+                    o.GUIDE_HV, d, d, v=0.5 * np.ones(d), exact=False)
+    return Case(f"linpro{d}_nuh", np.linspace(0, 1.0, N), np.zeros(d), o.MODEL_LINPRO, par, o.AUX_LINPRO, apar,
+                o.GUIDE_NUH, d, d, m=d, L=np.eye(d), v=0.5 * np.ones(d), Sigma=0.01 * np.eye(d), eps=0.0, exact=False)
+
+
 def forward_cases(N=201):
     """unguided Euler-Maruyama (config C1 and test/euler.jl)"""
     return [

@@ -1,0 +1,84 @@
+"""GPU parity tests of the large-state-dimension path (config C5: LinPro d = 32 guided bridge on the
+fp64 MFMA tile kernel, bhip_tile_kernel.h), through the C ABI, against the CPU oracle.
+
+Tolerance (fp64): the oracle follows the reference literally -- an LU solve Hdiamond_i \\ (V_i - x) per
+step and unfused left-to-right dot products (src/guip.jl:192-193) -- while the device multiplies by the
+pre-inverted matrix and accumulates on the matrix cores with fused multiply-adds.  Stated tolerance:
+|X - X_oracle| <= 1e-9 * (1 + max|X|), |ll - ll_oracle| <= 1e-8 * (1 + |ll|) (SURVEY 7 "hard parts").
+The Wiener paths themselves are bit-exact (same generator, same operation order).
+"""
+import numpy as np
+import pytest
+import torch
+
+import bridgehip as bh
+import oracle as o
+import problems
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return bh.default_context(0)
+
+
+def _close(X, Xr, ll, llr):
+    assert np.abs(X - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max()), np.abs(X - Xr).max()
+    assert np.all(np.abs(ll - llr) <= 1e-8 * (1 + np.abs(llr))), np.abs(ll - llr).max()
+
+
+@pytest.mark.parametrize("kind", [o.GUIDE_HV, o.GUIDE_NUH], ids=["guidedbridge", "nuh"])
+@pytest.mark.parametrize("d", [32, 16])
+def test_tile_kernel_external_W_vs_oracle(ctx, d, kind):
+    c = problems.linpro_big_case(d, 151, kind)
+    P = 40                                     # neither a multiple of 64 nor of 16: tail lanes
+    Po, ref = c.bh_proposal(bh, ctx), c.oracle_proposal()
+    Wh = np.stack([o.wiener_sample(c.tt, d, 11, p, 0) for p in range(P)])
+    W = bh.EnsemblePath.from_paths(c.tt, Wh, ctx)
+    ll = ctx.empty(P)
+    X = bh.solve(bh.Euler(), c.x0, W, Po, ll=ll)
+    Xh = X.paths()
+    Xr = np.stack([o.solve_guided(ref, c.x0, Wh[p]) for p in range(P)])
+    llr = np.array([o.llikelihood(ref, Xr[p]) for p in range(P)])
+    _close(Xh, Xr, ll.cpu().numpy(), llr)
+    assert np.array_equal(Xh[:, 0, :], np.tile(c.x0, (P, 1)))
+    if kind == o.GUIDE_HV:
+        assert np.array_equal(Xh[:, -1, :], np.tile(c.v, (P, 1)))       # endpoint rule src/euler.jl:241-242
+    ll7 = ctx.empty(P)
+    bh.solve(bh.Euler(), c.x0, W, Po, ll=ll7, skip=7)
+    ref7 = np.array([o.llikelihood(ref, Xr[p], skip=7) for p in range(P)])
+    assert np.all(np.abs(ll7.cpu().numpy() - ref7) <= 1e-8 * (1 + np.abs(ref7)))
+
+
+def test_tile_kernel_fused_noise(ctx):
+    d, P = 32, 200
+    c = problems.linpro_big_case(d, 101)
+    Po, ref = c.bh_proposal(bh, ctx), c.oracle_proposal()
+    X, W, ll = bh.sample_solve(c.x0, Po, P, seed=5, iter=3, path0=1000, store_W=True)
+    Wh = W.paths()
+    for p in (0, 15, 16, 63, 64, 199):          # Wiener paths are bit-exact (Philox pair exchange between lanes)
+        assert np.array_equal(Wh[p], o.wiener_sample(c.tt, d, 5, 1000 + p, 3))
+    ll2 = ctx.empty(P)
+    X2 = bh.solve(bh.Euler(), c.x0, W, Po, ll=ll2)
+    assert torch.equal(X2.data, X.data) and torch.equal(ll2, ll)      # fused == separate passes, same arithmetic
+    Xh, llh = X.paths(), ll.cpu().numpy()
+    for p in (0, 77, 199):
+        Xr = o.solve_guided(ref, c.x0, Wh[p])
+        _close(Xh[p], Xr, llh[p:p + 1], np.array([o.llikelihood(ref, Xr)]))
+    # sharding invariance and ll-only mode
+    Xb, _, llb = bh.sample_solve(c.x0, Po, 100, seed=5, iter=3, path0=1100)
+    assert torch.equal(Xb.data, X.data[:, :, 100:]) and torch.equal(llb, ll[100:])
+    _, _, ll3 = bh.sample_solve(c.x0, Po, P, seed=5, iter=3, path0=1000, store_X=False)
+    assert torch.equal(ll3, ll)
+
+
+def test_large_d_unsupported_combinations_fail_loudly(ctx):
+    c = problems.linpro_big_case(32, 51)
+    P, Pt = c.bh_process(bh), c.bh_aux(bh)
+    with pytest.raises(bh.BridgeError, match="large-d"):
+        bh.PartialBridge(c.tt, P, Pt, np.eye(32)[:2], [0.1, 0.2], 0.01 * np.eye(2), ctx=ctx)
+    rng = np.random.default_rng(0)
+    P8 = bh.LinPro(-np.eye(8), np.zeros(8), np.eye(8))
+    with pytest.raises(bh.BridgeError, match="large-d"):
+        bh.GuidedBridge(c.tt, P8, P8, np.ones(8), ctx=ctx)
