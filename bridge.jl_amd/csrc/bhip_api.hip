@@ -386,7 +386,10 @@ static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const d
     a.N = (int)po->tt.size(); a.skip = skip; a.use_vend = po->use_vend; a.noise = noise; a.P = npaths;
     a.Win = W_in; a.ldWin = ldWin; a.Wout = W_out; a.ldWout = ldWout; a.X = X; a.ldX = ldX; a.ll = ll;
     a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.iter = iter; a.path0 = path0;
-    HIPCHK(ctx, d == 32 ? launch_tile<32>(a, ctx->stream) : launch_tile<16>(a, ctx->stream));
+    hipError_t le = hipSuccess;
+    if (d == 32) le = noise ? launch_tile<32, 1>(a, ctx->stream) : launch_tile<32, 0>(a, ctx->stream);
+    else le = noise ? launch_tile<16, 1>(a, ctx->stream) : launch_tile<16, 0>(a, ctx->stream);
+    HIPCHK(ctx, le);
     return BHIP_OK;
 }
 

@@ -65,8 +65,8 @@ __device__ __forceinline__ void tile_mv(const double *__restrict__ Mf, const dou
     }
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void k_tile(const TArgs a)
+template <int D, int NOISE>
+__global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per SIMD: <= 256 VGPR+AGPR
 {
     constexpr int T = D / 16;
     constexpr int DD = D * D;
@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256) void k_tile(const TArgs a)
         for (int r = 0; r < 4; r++) {
             const int row = 16 * t + 4 * r + kq;
             x[t][r] = x0[row];
-            wprev[t][r] = a.noise == 0 ? a.Win[(size_t)row * a.ldWin + p] : 0.0;
-            if (a.noise == 1 && a.Wout && live) a.Wout[(size_t)row * a.ldWout + p] = 0.0;
+            wprev[t][r] = NOISE == 0 ? a.Win[(size_t)row * a.ldWin + p] : 0.0;
+            if (NOISE == 1 && a.Wout && live) a.Wout[(size_t)row * a.ldWout + p] = 0.0;
         }
     double ll = 0.0;
     const uint32_t path = a.path0 + (uint32_t)p;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_tile(const TArgs a)
 
         // ---- the Wiener increment tile
         double dw[T][4];
-        if (a.noise == 0) {
+        if constexpr (NOISE == 0) {
 #pragma unroll
             for (int t = 0; t < T; t++)
 #pragma unroll
@@ -130,17 +130,17 @@ __global__ __launch_bounds__(256) void k_tile(const TArgs a)
         } else {
             // normal index n = i*D + row; block n>>1 = i*D/2 + 2*ks + (kq>>1), element kq&1 (ks = 4t+r).
             // lanes kq and kq^1 share blocks: the even lane draws ks = 0..2T-1, the odd one ks = 2T..4T-1.
-            const int odd = kq & 1;
-            double mine[4 * T];
+            const bool odd = (kq & 1) != 0;
+            double mine[4 * T];   // statically indexed (values are selected, never indices)
 #pragma unroll
             for (int h = 0; h < 2 * T; h++) {
                 const int ks = h + (odd ? 2 * T : 0);
                 double z0, z1;
                 normal_pair(a.k0, a.k1, path, a.iter, (uint32_t)(i * (D / 2) + 2 * ks + (kq >> 1)), z0, z1);
                 const double keep = odd ? z1 : z0, give = odd ? z0 : z1;
-                const double got = __shfl_xor(give, 16, 64);   // partner's block h + (partner odd ? 2T : 0)
-                mine[ks] = keep;
-                mine[h + (odd ? 0 : 2 * T)] = got;
+                const double got = __shfl_xor(give, 16, 64);   // partner's block: h (partner even) or h + 2T (partner odd)
+                mine[h] = odd ? got : keep;            // K-slice h       : drawn by the even lane
+                mine[h + 2 * T] = odd ? keep : got;    // K-slice h + 2T  : drawn by the odd lane
             }
 #pragma unroll
             for (int t = 0; t < T; t++)
@@ -218,18 +218,18 @@ __global__ __launch_bounds__(256) void k_tile(const TArgs a)
     if (a.ll && live && kq == 0) a.ll[p] = ll;
 }
 
-template <int D>
+template <int D, int NOISE>
 hipError_t launch_tile(const TArgs &a, hipStream_t st)
 {
     const size_t lds = sizeof(double) * (4 * D * D + 5 * D + 2 * (D * D + D));
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_tile<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_tile<D, NOISE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const long grid = (a.P + 63) / 64;
-    hipLaunchKernelGGL((k_tile<D>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_tile<D, NOISE>), dim3((unsigned)grid), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 

@@ -87,6 +87,26 @@ def test_host_guide_equals_oracle_bitwise(hctx, case):
     assert (N.value, d.value, mp.value, kind.value) == (len(case.tt), case.d, case.mp, case.kind)
 
 
+@pytest.mark.parametrize("kind", [o.GUIDE_HV, o.GUIDE_NUH], ids=["guidedbridge", "nuh"])
+def test_host_guide_d32_equals_oracle_bitwise(hctx, kind):
+    """config C5: the dimension-generic host side (LU inverse / solve for n > 3) against the oracle"""
+    c = problems.linpro_big_case(32, 101, kind)
+    g = c.oracle_guide()
+    Po = c.bh_proposal(bh, ctx=hctx)
+    if kind == o.GUIDE_HV:
+        assert np.array_equal(Po.Hd, g["Hd"]) and np.array_equal(Po.V, g["V"])
+        # closed form: Hdiamond(t) = phim*lam*phim' - lam for the auxiliary LinPro (src/linpro.jl:115-126)
+        from scipy.linalg import expm, solve_continuous_lyapunov
+        d = 32
+        B = o.uncm(c.apar[:d * d], d, d)
+        sig = o.uncm(c.apar[d * d + d:], d, d)
+        lam = solve_continuous_lyapunov(B, -sig @ sig.T)
+        phim = expm(-(1.0 - c.tt[50]) * B)
+        assert np.abs(Po.Hd[50] - (phim @ lam @ phim.T - lam)).max() < 1e-6
+    else:
+        assert np.array_equal(Po.nu, g["nu"]) and np.array_equal(Po.H, g["H"]) and Po.C == g["C"]
+
+
 def test_lptilde_matches_oracle(hctx):
     c = problems.cases(101)[0]
     Po = c.bh_proposal(bh, ctx=hctx)
