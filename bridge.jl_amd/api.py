@@ -240,6 +240,30 @@ class Pendulum(ContinuousTimeProcess):
         return np.array([self.theta2, self.gamma])
 
 
+class UserProcess(ContinuousTimeProcess):
+    """A user-defined target process: the body of `Bridge.b(t, x, P)` as HIP C++ text (compiled for
+    gfx950 with hipRTC on first use) + a constant diffusion matrix sigma [d, mp].
+
+        P = UserProcess(2, "o[0] = (x[0]-x[1]-x[0]*x[0]*x[0]+par[1])/par[0]; o[1] = par[2]*x[0]-x[1]+par[3];",
+                        par=[0.1, 0.0, 1.5, 0.8], sigma=[[0.0], [0.3]])
+
+    The text sees `double t`, `const double* x`, `const double* par` and writes `double* o`."""
+
+    def __init__(self, d, drift_src, par, sigma, ctx=None):
+        self.ctx = ctx or default_context()
+        self.d = int(d)
+        self.sigma = np.asarray(sigma, dtype=np.float64).reshape(self.d, -1)
+        self.mp = self.sigma.shape[1]
+        self.par = np.atleast_1d(np.asarray(par, dtype=np.float64)).ravel()
+        self.drift_src = drift_src
+        mid = C.c_int()
+        self.ctx.check(self.ctx.lib.bhip_model_define(self.ctx.h, self.d, self.mp, len(self.par), drift_src.encode(), C.byref(mid)))
+        self.model_id = mid.value
+
+    def params(self):
+        return np.concatenate([self.par, _cm(self.sigma)])
+
+
 # ---- auxiliary processes (Bridge.B / Bridge.beta / Bridge.sigma / Bridge.a 2-arg methods)
 class AffineAux:
     """constant B, beta, sigma;  b~(t,x) = B*x + beta  (e.g. FitzhughDiffusionAux "linearised_end",

@@ -4,6 +4,7 @@
 #include "bhip_host.hpp"
 #include "bhip_path_kernel.h"
 #include "bhip_tile_kernel.h"
+#include "bhip_rtc.hpp"
 #include "bhip_util_kernels.h"
 #include <algorithm>
 #include <cstdio>
@@ -246,6 +247,26 @@ int bhip_download_aos(bhip_ctx *ctx, const double *dev, int N, int dim, long ld,
     return BHIP_OK;
 }
 
+/* ------------------------------------------------------------------ user-defined drift (hipRTC) */
+int bhip_model_define(bhip_ctx *ctx, int d, int mp, int npar, const char *drift_src, int *model_id)
+{
+    if (!ctx || !drift_src || !model_id) return BHIP_EINVAL;
+    if (d < 1 || d > 3 || mp < 1 || mp > 3) return fail(ctx, BHIP_EUNSUPPORTED, "bhip_model_define: user drifts run on the path-per-lane kernel, d and m' in 1..3");
+    if (npar < 0 || npar + d * mp + d * d > 32) return fail(ctx, BHIP_EINVAL, "bhip_model_define: too many parameters (npar + d*mp + d*d <= 32)");
+    std::unique_ptr<UserModel> um(new UserModel());
+    um->d = d; um->mp = mp; um->npar = npar; um->drift = drift_src;
+    // validate the text now (compilation needs no GPU): plain Euler-Maruyama instantiation
+    std::vector<char> code;
+    std::string low;
+    const std::string log = rtc_compile(*um, BHIP_GUIDE_NONE, 1, NOISE_EXT, 1, code, low);
+    if (!log.empty()) return fail(ctx, BHIP_EINVAL, log);
+    std::lock_guard<std::mutex> lk(user_models_mutex());
+    um->id = USER_MODEL_BASE + (int)user_models().size();
+    *model_id = um->id;
+    user_models().push_back(std::move(um));
+    return BHIP_OK;
+}
+
 /* ------------------------------------------------------------------ proposal */
 int bhip_proposal_create(bhip_ctx *ctx, const double *tt, int N, int model, int d, const double *par, int npar, bhip_proposal **out)
 {
@@ -259,7 +280,24 @@ int bhip_proposal_create(bhip_ctx *ctx, const double *tt, int N, int model, int 
     po->ctx = ctx;
     po->tt.assign(tt, tt + N);
     std::string err;
-    int rc = model_setup(model, d, par, npar, po->mh, err);
+    int rc = BHIP_OK;
+    if (model >= USER_MODEL_BASE) {   // hipRTC-compiled drift: par = user parameters followed by sigma (d x m', column-major)
+        std::lock_guard<std::mutex> lk(user_models_mutex());
+        const UserModel *um = find_user_model(model);
+        if (!um) { rc = BHIP_EINVAL; err = "unknown user model id"; }
+        else if (d > 0 && d != um->d) { rc = BHIP_EINVAL; err = "dimension does not match the user model"; }
+        else if (npar != um->npar + um->d * um->mp) { rc = BHIP_EINVAL; err = "user model expects npar + d*mp parameters (drift parameters, then sigma)"; }
+        else {
+            ModelHost &mh = po->mh;
+            mh.id = model; mh.d = um->d; mh.mp = um->mp;
+            mh.par.assign(par, par + npar);
+            mh.a = outer(Mat(um->d, um->mp, par + um->npar));
+            mh.dpar = mh.par;
+            mh.dpar.insert(mh.dpar.end(), mh.a.a.begin(), mh.a.a.end());
+        }
+    } else {
+        rc = model_setup(model, d, par, npar, po->mh, err);
+    }
     if (rc) { delete po; return fail(ctx, rc, "bhip_proposal_create: " + err); }
     po->g.kind = BHIP_GUIDE_NONE;
     *out = po;
@@ -566,9 +604,31 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
     int fl = 0;
     if (noise == NOISE_PCN) fl = a.Xo ? 1 : 0;
     else fl = (a.X ? 1 : 0) | (a.Wout ? 2 : 0);
-    launch_fn f = find_launch(po->mh, gk_dispatch, gk == BHIP_GUIDE_LMMU ? po->g.m : 1, noise, fl);
-    if (!f) return fail(ctx, BHIP_EUNSUPPORTED, "no device kernel for this (model, guide, noise) combination");
     if (a.rs != row_stride(gk, po->mh.d, po->g.m)) return fail(ctx, BHIP_ESTATE, "row stride mismatch");
+    const int mo = gk == BHIP_GUIDE_LMMU ? po->g.m : 1;
+    if (po->mh.id >= USER_MODEL_BASE) {   // hipRTC-compiled user drift: compile this instantiation on first use
+        if (gk_dispatch == BHIP_GUIDE_NUH_INPLACE) fl |= 4;
+        hipFunction_t fn = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(user_models_mutex());
+            UserModel *um = find_user_model(po->mh.id);
+            if (!um) return fail(ctx, BHIP_EINVAL, "unknown user model id");
+            const std::vector<int> key = {gk, mo, noise, fl};
+            auto it = um->fns.find(key);
+            if (it == um->fns.end()) {
+                const std::string log = rtc_build(*um, gk, mo, noise, fl, &fn);
+                if (!log.empty()) return fail(ctx, BHIP_EHIP, log);
+                um->fns[key] = fn;
+            } else fn = it->second;
+        }
+        KArgs args = a;
+        void *params[] = {&args};
+        const long grid = (a.P + 255) / 256;
+        HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr));
+        return BHIP_OK;
+    }
+    launch_fn f = find_launch(po->mh, gk_dispatch, mo, noise, fl);
+    if (!f) return fail(ctx, BHIP_EUNSUPPORTED, "no device kernel for this (model, guide, noise) combination");
     HIPCHK(ctx, f(a, ctx->stream));
     return BHIP_OK;
 }

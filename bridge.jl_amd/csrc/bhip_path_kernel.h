@@ -425,6 +425,9 @@ __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
     }
 }
 
+// ---- BHIP_RTC_END  (everything above is device code and is also embedded, flattened, into the
+// library for hipRTC-compiled user models -- gen_rtc_src.py; below: host-side launch / dispatch)
+
 typedef hipError_t (*launch_fn)(const KArgs &, hipStream_t);
 
 template <class M, int GK, int MO, int NOISE, int FL>

@@ -1,0 +1,138 @@
+// bhip_rtc.hpp -- user-defined target drift b(t,x,P) compiled at run time with hipRTC.
+//
+// The reference lets users define a process by adding Julia methods Bridge.b / Bridge.sigma on their own
+// type (README.md:69-77, project_partialbridge/partialbridge_fitzhugh.jl:44-46).  A Julia closure
+// cannot run inside a pre-compiled kernel, so besides the registry of built-in functors a
+// user can hand the library the BODY of the drift as HIP C++ text:
+//
+//     "o[0] = (x[0] - x[1] - x[0]*x[0]*x[0] + par[1]) / par[0];  o[1] = par[2]*x[0] - x[1] + par[3];"
+//
+// (inputs: double t, const double* x, const double* par; output double* o).  The diffusion coefficient
+// is constant on this path and is passed as DATA (a d x m' matrix appended to the
+// parameters).  The text is spliced into a functor next to the embedded kernel source and every
+// kernel instantiation that is actually launched is compiled for gfx950 on first use and cached.
+#pragma once
+#include "bhip_path_kernel.h"
+#include <hip/hiprtc.h>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace bhip {
+
+static const char *const RTC_PREFIX =
+#include "bhip_rtc_src.inc"
+    ;
+
+struct UserModel {
+    int id = 0, d = 0, mp = 0, npar = 0;
+    std::string drift;
+    std::map<std::vector<int>, hipFunction_t> fns;   // (gk, mo, noise, fl) -> kernel
+    std::vector<hipModule_t> modules;
+};
+
+inline std::vector<std::unique_ptr<UserModel>> &user_models()
+{
+    static std::vector<std::unique_ptr<UserModel>> v;
+    return v;
+}
+inline std::mutex &user_models_mutex()
+{
+    static std::mutex m;
+    return m;
+}
+constexpr int USER_MODEL_BASE = 1000;
+
+inline UserModel *find_user_model(int id)
+{
+    const int k = id - USER_MODEL_BASE;
+    auto &v = user_models();
+    return (k >= 0 && k < (int)v.size()) ? v[k].get() : nullptr;
+}
+
+inline std::string rtc_source(const UserModel &um, int gk, int mo, int noise, int fl)
+{
+    std::string s = RTC_PREFIX;
+    s += "\nnamespace bhip {\nstruct MUser {\n";
+    s += "    static constexpr int D = " + std::to_string(um.d) + ", MP = " + std::to_string(um.mp) + ", NP = " + std::to_string(um.npar) + ", ID = 1000;\n";
+    s += "    static constexpr bool noisy(int) { return true; }\n    const double *p;\n";
+    s += "    BHIP_DEV explicit MUser(const double *p_) : p(p_) {}\n";
+    s += "    BHIP_DEV void b(double t, const double *x, double *o) const\n    {\n        const double *par = p; (void)par; (void)t;\n        " + um.drift + "\n    }\n";
+    s += R"(    BHIP_DEV void sdw(const double *dw, double *o) const
+    {
+        const double *S = p + NP;
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            double s = S[i] * dw[0];
+#pragma unroll
+            for (int j = 1; j < MP; j++) s += S[i + D * j] * dw[j];
+            o[i] = s;
+        }
+    }
+    BHIP_DEV void amul(const double *r, double *o) const
+    {
+        const double *A = p + NP + D * MP;
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            double s = A[i] * r[0];
+#pragma unroll
+            for (int j = 1; j < D; j++) s += A[i + D * j] * r[j];
+            o[i] = s;
+        }
+    }
+};
+)";
+    s += "template __global__ void k_paths<MUser, " + std::to_string(gk) + ", " + std::to_string(mo) + ", " + std::to_string(noise) + ", " +
+         std::to_string(fl) + ">(const KArgs);\n}\n";
+    return s;
+}
+
+// compile one instantiation (no GPU needed); returns "" on success, else the hipRTC log
+inline std::string rtc_compile(const UserModel &um, int gk, int mo, int noise, int fl, std::vector<char> &code, std::string &low)
+{
+    const std::string src = rtc_source(um, gk, mo, noise, fl);
+    const std::string name = "bhip::k_paths<bhip::MUser, " + std::to_string(gk) + ", " + std::to_string(mo) + ", " + std::to_string(noise) + ", " +
+                             std::to_string(fl) + ">";
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "bhip_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return "hiprtcCreateProgram failed";
+    hiprtcAddNameExpression(prog, name.c_str());
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+    const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, ' ');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return "hipRTC compilation of the user drift failed:\n" + log;
+    }
+    const char *lowered = nullptr;
+    hiprtcGetLoweredName(prog, name.c_str(), &lowered);
+    low = lowered ? lowered : "";
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    code.resize(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    return "";
+}
+
+// compile + load one instantiation
+inline std::string rtc_build(UserModel &um, int gk, int mo, int noise, int fl, hipFunction_t *out)
+{
+    std::vector<char> code;
+    std::string low;
+    const std::string log = rtc_compile(um, gk, mo, noise, fl, code, low);
+    if (!log.empty()) return log;
+    hipModule_t mod;
+    if (hipModuleLoadData(&mod, code.data()) != hipSuccess) return "hipModuleLoadData failed for the compiled user model";
+    hipFunction_t f;
+    if (hipModuleGetFunction(&f, mod, low.c_str()) != hipSuccess) return "kernel symbol not found in the compiled user model: " + low;
+    um.modules.push_back(mod);
+    *out = f;
+    return "";
+}
+
+}  // namespace bhip

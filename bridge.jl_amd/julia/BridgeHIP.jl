@@ -53,6 +53,22 @@ hipmodel(P::Bridge.Models.Pendulum) = (8, 2, [P.θ², P.γ])
 hipmodel(::Wiener{SVector{d,Float64}}) where {d} = (0, d, Float64[])
 hipmodel(::Wiener{Float64}) = (0, 1, Float64[])
 
+# A process WITHOUT a registry functor: give the body of its Bridge.b method as HIP C++ text; the
+# library compiles it for gfx950 with hipRTC (bhip_model_define).  sigma must be constant (d x m').
+#     struct DoubleWell <: ContinuousTimeProcess{Float64}; θ::Float64; σ::Float64; end
+#     BridgeHIP.hipmodel(P::DoubleWell) = BridgeHIP.userdrift(1, "o[0] = par[0]*(x[0] - x[0]*x[0]*x[0]);", [P.θ], fill(P.σ, 1, 1))
+const _user_ids = Dict{Tuple{Int,Int,Int,String},Cint}()
+function userdrift(d::Integer, src::String, par::Vector{Float64}, sigma::AbstractMatrix; c::Context = ctx())
+    key = (Int(d), size(sigma, 2), length(par), src)
+    id = get!(_user_ids, key) do
+        r = Ref{Cint}(0)
+        check(c, ccall((:bhip_model_define, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Cstring, Ref{Cint}),
+            c.h, d, size(sigma, 2), length(par), src, r))
+        r[]
+    end
+    (id, Int(d), vcat(par, vec(collect(Float64, sigma))))
+end
+
 # auxiliary process: constant coefficients by default, any Bridge.B/β/a methods through a C callback
 function aux_callback(t::Cdouble, B::Ptr{Cdouble}, beta::Ptr{Cdouble}, a::Ptr{Cdouble}, user::Ptr{Cvoid})::Cvoid
     Pt = unsafe_pointer_to_objref(user)[]

@@ -99,6 +99,16 @@ int bhip_memset(bhip_ctx *ctx, void *dev, int byte, size_t bytes);
 int bhip_upload_aos(bhip_ctx *ctx, double *dev, int N, int dim, long ld, long p0, long np, const double *aos);
 int bhip_download_aos(bhip_ctx *ctx, const double *dev, int N, int dim, long ld, long p0, long np, double *aos);
 
+/* ------------------------------------------------------------------ user-defined target drift
+ * The reference's extension point is "add a method Bridge.b(t, x, P::MyProcess)" (README.md:69-77).
+ * Here the BODY of that method is given as HIP C++ text and compiled for gfx950 at run time (hipRTC):
+ *     inputs  double t, const double* x (d), const double* par (npar);  output double* o (d), e.g.
+ *     "o[0] = (x[0]-x[1]-x[0]*x[0]*x[0]+par[1])/par[0]; o[1] = par[2]*x[0]-x[1]+par[3];"
+ * The (constant) diffusion coefficient is data: proposals on the returned model id take
+ * par = [npar drift parameters, sigma (d x mp, column-major)].  d, mp <= 3.  A syntax error returns
+ * BHIP_EINVAL with the compiler log in bhip_last_error().  Kernels are compiled on first use. */
+int bhip_model_define(bhip_ctx *ctx, int d, int mp, int npar, const char *drift_src, int *model_id);
+
 /* ------------------------------------------------------------------ proposal  ("Po")
  * A proposal holds the grid tt (Po.tt), the target P, the auxiliary Pt and the guide coefficient
  * rows; the latter are computed on the host by backward Ralston-3 (src/ode.jl:44-49,88-97) exactly
