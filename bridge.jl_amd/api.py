@@ -597,6 +597,78 @@ def llikelihood(rule, X, Po, skip=0):
     return out
 
 
+def innovations_(method, W, Y, P):
+    """innovations!(::EulerMaruyama, W, Y, P)  src/euler.jl:358-376: recover the driving W from the paths Y
+    (inverse of solve!); P is a PlainProcess or a guided proposal with a square, invertible sigma."""
+    if not isinstance(method, EulerMaruyama):
+        raise BridgeError("innovations!: only the Euler-Maruyama scheme runs on the device")
+    if len(W) != len(Y):
+        raise BridgeError("Y and W differ in length.")                  # src/euler.jl:361
+    if P.d != P.mp or W.dim != P.mp or Y.dim != P.d or W.npaths != Y.npaths:
+        raise BridgeError("innovations!: needs square sigma and matching ensembles")
+    W.tt[:] = Y.tt                                                       # :366
+    ctx = Y.ctx
+    ctx.check(ctx.lib.bhip_innovations(ctx.h, P.h, Y.ptr(), Y.ld, W.ptr(), W.ld, Y.npaths))
+    return W
+
+
+def innovations(method, Y, P):
+    """innovations(method, Y, P) = innovations!(method, copy(Y), Y, P)   src/euler.jl:357"""
+    return innovations_(method, EnsemblePath(Y.tt, P.mp, Y.npaths, Y.ctx), Y, P)
+
+
+def gpupdate(H, V, L=None, Sigma=None, v=None):
+    """gpupdate(Hd, V, L, Sigma, v) or gpupdate(P::GuidedBridge, L, Sigma, v)  src/guip.jl:221-243:
+    returns the updated (Hd, V) after observing v = L x + N(0, Sigma) at the left end of the segment."""
+    if isinstance(H, GuidedBridge):
+        P, L, Sigma, v = H, V, L, Sigma
+        H, V = P.Hd[0], P.V[0]
+    H = np.atleast_2d(np.asarray(H, dtype=np.float64))
+    d = H.shape[0]
+    L = np.asarray(L, dtype=np.float64).reshape(-1, d)
+    m = L.shape[0]
+    Sigma = np.asarray(Sigma, dtype=np.float64).reshape(m, m)
+    Vv = np.ascontiguousarray(np.atleast_1d(V), dtype=np.float64)
+    vv = np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64)
+    Ho, Vo = np.empty(d * d), np.empty(d)
+    rc = _lib.load().bhip_gpupdate(d, m, _dptr(_cm(H)), _dptr(Vv), _dptr(_cm(L)), _dptr(_cm(Sigma)), _dptr(vv), _dptr(Ho), _dptr(Vo))
+    if rc != 0:
+        raise BridgeError(f"bhip_gpupdate failed ({rc})")
+    return _uncm(Ho, d, d), Vo
+
+
+def write_iterates_csv(fn, XX, subsamples, tt, every=50):
+    """the script's CSV of MCMC iterates (partialbridge_fitzhugh.jl:180-189) for ONE chain:
+    header `iteration, time, component, value`, rows for d in 1:dim, j in 1:every:N, (i,s) in subsamples
+    (component fastest, then time, then iteration; 1-based component index)."""
+    with open(fn, "w") as f:
+        f.write("iteration, time, component, value \n")
+        for X, s in zip(XX, subsamples):
+            X = np.asarray(X)
+            for j in range(0, X.shape[0], every):
+                for dcomp in range(X.shape[1]):
+                    f.write(f"{s},{float(tt[j])!r},{dcomp + 1},{float(X[j, dcomp])!r}\n")
+
+
+def write_info(fn, aux_choice, endpoint, iterations, skip_it, x0, T, v, Sigma, L, dt, rho, acc):
+    """the script's info-*.txt (partialbridge_fitzhugh.jl:191-208)"""
+    ave_acc_perc = 100 * round(acc / iterations, 2)
+    with open(fn, "w") as f:
+        f.write(f"Choice of auxiliary process: {aux_choice}\n")
+        f.write(f"Choice of endpoint: {endpoint}\n\n")
+        f.write(f"Number of iterations: {iterations}\n")
+        f.write(f"Skip every {skip_it} iterations, when saving to csv\n\n")
+        f.write(f"Starting point: {list(np.atleast_1d(x0))}\n")
+        f.write(f"End time T: {T}\n")
+        f.write(f"Endpoint v: {v}\n")
+        f.write(f"Noise Sigma: {np.asarray(Sigma).tolist()}\n")
+        f.write(f"L: {np.asarray(L).tolist()}\n\n")
+        f.write(f"Mesh width: {dt}\n")
+        f.write(f"rho (Crank-Nicholsen parameter: {rho}\n")
+        f.write(f"Average acceptance percentage: {ave_acc_perc}\n")
+    return ave_acc_perc
+
+
 def sample_solve(u, Po, npaths, seed=0, iter=0, path0=0, store_W=False, store_X=True, skip=0, ctx=None):
     """fused  W = sample(tt, Wiener()); X = solve(Euler(), u, W, Po); ll = llikelihood(LeftRule(), X, Po)
     with in-kernel Philox noise.  Returns (X or None, W or None, ll or None)."""

@@ -252,7 +252,7 @@ int bhip_model_define(bhip_ctx *ctx, int d, int mp, int npar, const char *drift_
 {
     if (!ctx || !drift_src || !model_id) return BHIP_EINVAL;
     if (d < 1 || d > 3 || mp < 1 || mp > 3) return fail(ctx, BHIP_EUNSUPPORTED, "bhip_model_define: user drifts run on the path-per-lane kernel, d and m' in 1..3");
-    if (npar < 0 || npar + d * mp + d * d > 32) return fail(ctx, BHIP_EINVAL, "bhip_model_define: too many parameters (npar + d*mp + d*d <= 32)");
+    if (npar < 0 || npar + d * mp + 2 * d * d > 40) return fail(ctx, BHIP_EINVAL, "bhip_model_define: too many parameters (npar + d*mp + 2*d*d <= 40)");
     std::unique_ptr<UserModel> um(new UserModel());
     um->d = d; um->mp = mp; um->npar = npar; um->drift = drift_src;
     // validate the text now (compilation needs no GPU): plain Euler-Maruyama instantiation
@@ -294,6 +294,11 @@ int bhip_proposal_create(bhip_ctx *ctx, const double *tt, int N, int model, int 
             mh.a = outer(Mat(um->d, um->mp, par + um->npar));
             mh.dpar = mh.par;
             mh.dpar.insert(mh.dpar.end(), mh.a.a.begin(), mh.a.a.end());
+            if (um->mp == um->d) {   // square sigma: inv(sigma) for innovations (zero block if singular)
+                const Mat S(um->d, um->d, par + um->npar);
+                const Mat Si = det(S) != 0.0 ? inv(S) : Mat(um->d, um->d);
+                mh.dpar.insert(mh.dpar.end(), Si.a.begin(), Si.a.end());
+            }
         }
     } else {
         rc = model_setup(model, d, par, npar, po->mh, err);
@@ -591,7 +596,7 @@ static int fill_common(const bhip_proposal *po, KArgs &a, const double *x0, cons
         a.vend[k] = po->vend[k];
         a.mu_aux[k] = aux_linpro ? po->aux.mu()[k] : 0.0;
     }
-    if ((int)po->mh.dpar.size() > 32) return fail(ctx, BHIP_EINVAL, "model parameter block too large");
+    if ((int)po->mh.dpar.size() > 40) return fail(ctx, BHIP_EINVAL, "model parameter block too large");
     for (size_t k = 0; k < po->mh.dpar.size(); k++) a.mpar[k] = po->mh.dpar[k];
     return BHIP_OK;
 }
@@ -600,7 +605,7 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
 {
     bhip_ctx *ctx = po->ctx;
     const int gk = po->g.kind == BHIP_GUIDE_NUH_INPLACE ? BHIP_GUIDE_NUH : po->g.kind;
-    const int gk_dispatch = po->g.kind;   // NUH_INPLACE selects the two-dot log-likelihood instantiation
+    const int gk_dispatch = noise == NOISE_INNOV ? gk : po->g.kind;   // NUH_INPLACE selects the two-dot log-likelihood instantiation
     int fl = 0;
     if (noise == NOISE_PCN) fl = a.Xo ? 1 : 0;
     else fl = (a.X ? 1 : 0) | (a.Wout ? 2 : 0);
@@ -709,6 +714,35 @@ int bhip_llikelihood(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev
     if (ldX < npaths) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
     a.Win = X_dev; a.ldWin = ldX; a.ll = ll_dev;
     return do_launch(po, NOISE_LLONLY, a);
+}
+
+int bhip_innovations(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev, long ldX, double *W_dev, long ldW, long npaths)
+{
+    if (!ctx || !po || !X_dev || !W_dev) return BHIP_EINVAL;
+    if (po->mh.d != po->mh.mp) return fail(ctx, BHIP_EINVAL, "bhip_innovations: needs a square, invertible sigma (d == m')");
+    if (po->mh.d > 3) return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: innovations not built");
+    if (po->g.kind == BHIP_GUIDE_NONE) {
+        int rc = ensure_plain_rows(const_cast<bhip_proposal *>(po));
+        if (rc) return rc;
+    }
+    KArgs a;
+    const double zero[3] = {0, 0, 0};
+    int rc = fill_common(po, a, zero, nullptr, npaths, 0);
+    if (rc) return rc;
+    if (ldX < npaths || ldW < npaths) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
+    a.Win = X_dev; a.ldWin = ldX; a.Wout = W_dev; a.ldWout = ldW;
+    return do_launch(po, NOISE_INNOV, a);
+}
+
+int bhip_gpupdate(int d, int m, const double *Hd, const double *V, const double *L, const double *Sigma, const double *v,
+                  double *Hd_out, double *V_out)
+{
+    if (d < 1 || m < 1 || !Hd || !V || !L || !Sigma || !v || !Hd_out || !V_out) return BHIP_EINVAL;
+    Mat Ho, Vo;
+    gpupdate(Mat(d, d, Hd), Mat(d, 1, V), Mat(m, d, L), Mat(m, m, Sigma), Mat(m, 1, v), Ho, Vo);
+    std::memcpy(Hd_out, Ho.a.data(), sizeof(double) * d * d);
+    std::memcpy(V_out, Vo.a.data(), sizeof(double) * d);
+    return BHIP_OK;
 }
 
 /* ------------------------------------------------------------------ chains */

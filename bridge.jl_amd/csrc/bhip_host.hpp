@@ -370,6 +370,28 @@ inline void guide_nuh_inplace(const std::vector<double> &tt, const Aux &Pt, cons
     for (int i = 0; i < N; i++) g.H[i] = inv(St[i]);
 }
 
+// gpupdate(Hd, V, L, Sigma, v)  src/guip.jl:221-231 -- the backward link between chained GuidedBridge
+// segments (test/smoothing.jl:73-83): fold the observation v = L x + N(0, Sigma) into (Hdiamond, V).
+inline void gpupdate(const Mat &Hd, const Mat &V, const Mat &L, const Mat &Sigma, const Mat &v, Mat &Hd_out, Mat &V_out)
+{
+    const int d = Hd.r;
+    bool allinf = true;
+    for (int k = 0; k < d; k++) if (!(std::isinf(Hd(k, k)) && Hd(k, k) > 0)) allinf = false;
+    const Mat Si = inv(Sigma);
+    if (allinf) {
+        const Mat LtSi = tr(L) * Si;
+        const Mat A = LtSi * L;
+        Hd_out = inv(A);
+        V_out = solve(A, LtSi * v);
+        return;
+    }
+    const Mat S = Sigma + (L * Hd) * tr(L);
+    const Mat Z = eye(d) - ((Hd * tr(L)) * inv(S)) * L;
+    const Mat ZH = Z * Hd;
+    Hd_out = ZH;
+    V_out = ((ZH * tr(L)) * Si) * v + Z * V;
+}
+
 // ---- target model, host view
 struct ModelHost {
     int id = -1, d = 0, mp = 0;
@@ -413,12 +435,23 @@ inline int model_setup(int id, int d_hint, const double *par, int npar, ModelHos
     mh.a = outer(S);   // src/types.jl:32  a = outer(sigma);  src/linpro.jl:72  a = sigma*sigma'
     mh.dpar = mh.par;
     switch (id) {
-    case BHIP_MODEL_OU: mh.dpar.push_back(mh.a.a[0]); break;
-    case BHIP_MODEL_LINPRO: mh.dpar.insert(mh.dpar.end(), mh.a.a.begin(), mh.a.a.end()); break;
+    // models with a square sigma also carry inv(sigma) (innovations!, src/euler.jl:371): scalar inv(x) = 1/x,
+    // SMatrix inv (closed forms), SDiagonal inv = 1 ./ diag
+    case BHIP_MODEL_OU: mh.dpar.push_back(mh.a.a[0]); mh.dpar.push_back(1.0 / par[1]); break;
+    case BHIP_MODEL_LINPRO: {
+        mh.dpar.insert(mh.dpar.end(), mh.a.a.begin(), mh.a.a.end());
+        if (d <= 3) { const Mat Si = det(S) != 0.0 ? inv(S) : Mat(d, d); mh.dpar.insert(mh.dpar.end(), Si.a.begin(), Si.a.end()); }
+        break; }
     case BHIP_MODEL_FHN: case BHIP_MODEL_INTDIFF: case BHIP_MODEL_PENDULUM: mh.dpar.push_back(mh.a(1, 1)); break;
     case BHIP_MODEL_NCLAR: mh.dpar.push_back(mh.a(2, 2)); break;
-    case BHIP_MODEL_LORENZ: for (int k = 0; k < 3; k++) mh.dpar.push_back(mh.a(k, k)); break;
-    case BHIP_MODEL_FHN2: mh.dpar.push_back(mh.a(0, 0)); mh.dpar.push_back(mh.a(1, 1)); break;
+    case BHIP_MODEL_LORENZ:
+        for (int k = 0; k < 3; k++) mh.dpar.push_back(mh.a(k, k));
+        for (int k = 0; k < 3; k++) mh.dpar.push_back(1.0 / par[3 + k]);
+        break;
+    case BHIP_MODEL_FHN2:
+        mh.dpar.push_back(mh.a(0, 0)); mh.dpar.push_back(mh.a(1, 1));
+        mh.dpar.push_back(1.0 / par[4]); mh.dpar.push_back(1.0 / par[5]);
+        break;
     default: break;
     }
     return BHIP_OK;

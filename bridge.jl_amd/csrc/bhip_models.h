@@ -17,11 +17,12 @@ namespace bhip {
 struct MOU {
     static constexpr int D = 1, MP = 1, ID = BHIP_MODEL_OU;
     static constexpr bool noisy(int) { return true; }
-    double beta, sig, a;
-    BHIP_DEV explicit MOU(const double *p) : beta(p[0]), sig(p[1]), a(p[2]) {}
+    double beta, sig, a, isig;
+    BHIP_DEV explicit MOU(const double *p) : beta(p[0]), sig(p[1]), a(p[2]), isig(p[3]) {}
     BHIP_DEV void b(double, const double *x, double *o) const { o[0] = -beta * x[0]; }
     BHIP_DEV void sdw(const double *dw, double *o) const { o[0] = sig * dw[0]; }
     BHIP_DEV void amul(const double *r, double *o) const { o[0] = a * r[0]; }
+    BHIP_DEV void sinv_mul(const double *v, double *o) const { o[0] = isig * v[0]; }   // inv(sigma)*v
 };
 
 // ---- LinPro: b = B*(x - mu), sigma, a = sigma*sigma'       src/linpro.jl:65-87
@@ -64,6 +65,17 @@ struct MLinPro {
             double s = A[i] * r[0];
 #pragma unroll
             for (int j = 1; j < D; j++) s += A[i + D * j] * r[j];
+            o[i] = s;
+        }
+    }
+    BHIP_DEV void sinv_mul(const double *v, double *o) const   // inv(P.sigma)*v
+    {
+        const double *Si = p + 3 * D * D + D;
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            double s = Si[i] * v[0];
+#pragma unroll
+            for (int j = 1; j < D; j++) s += Si[i + D * j] * v[j];
             o[i] = s;
         }
     }
@@ -121,9 +133,10 @@ struct MIntDiff {
 struct MLorenz {
     static constexpr int D = 3, MP = 3, ID = BHIP_MODEL_LORENZ;
     static constexpr bool noisy(int) { return true; }
-    double t1, t2, t3, s1, s2, s3, a1, a2, a3;
+    double t1, t2, t3, s1, s2, s3, a1, a2, a3, i1, i2, i3;
     BHIP_DEV explicit MLorenz(const double *p)
-        : t1(p[0]), t2(p[1]), t3(p[2]), s1(p[3]), s2(p[4]), s3(p[5]), a1(p[6]), a2(p[7]), a3(p[8]) {}
+        : t1(p[0]), t2(p[1]), t3(p[2]), s1(p[3]), s2(p[4]), s3(p[5]), a1(p[6]), a2(p[7]), a3(p[8]), i1(p[9]), i2(p[10]), i3(p[11]) {}
+    BHIP_DEV void sinv_mul(const double *v, double *o) const { o[0] = i1 * v[0]; o[1] = i2 * v[1]; o[2] = i3 * v[2]; }
     BHIP_DEV void b(double, const double *x, double *o) const
     {
         o[0] = t1 * (x[1] - x[0]);
@@ -139,9 +152,10 @@ struct MLorenz {
 struct MFHN2 {
     static constexpr int D = 2, MP = 2, ID = BHIP_MODEL_FHN2;
     static constexpr bool noisy(int) { return true; }
-    double eps, s, gam, beta, s1, s2, a1, a2;
+    double eps, s, gam, beta, s1, s2, a1, a2, i1, i2;
     BHIP_DEV explicit MFHN2(const double *p)
-        : eps(p[0]), s(p[1]), gam(p[2]), beta(p[3]), s1(p[4]), s2(p[5]), a1(p[6]), a2(p[7]) {}
+        : eps(p[0]), s(p[1]), gam(p[2]), beta(p[3]), s1(p[4]), s2(p[5]), a1(p[6]), a2(p[7]), i1(p[8]), i2(p[9]) {}
+    BHIP_DEV void sinv_mul(const double *v, double *o) const { o[0] = i1 * v[0]; o[1] = i2 * v[1]; }
     BHIP_DEV void b(double, const double *x, double *o) const
     {
         o[0] = (x[0] - x[0] * x[0] * x[0] - x[1] + s) / eps;
@@ -183,6 +197,11 @@ struct MWiener {
     {
 #pragma unroll
         for (int k = 0; k < D; k++) o[k] = r[k];
+    }
+    BHIP_DEV void sinv_mul(const double *v, double *o) const
+    {
+#pragma unroll
+        for (int k = 0; k < D; k++) o[k] = v[k];
     }
 };
 

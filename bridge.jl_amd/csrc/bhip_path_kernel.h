@@ -23,7 +23,12 @@
 
 namespace bhip {
 
-enum { NOISE_EXT = 0, NOISE_FRESH = 1, NOISE_PCN = 2, NOISE_LLONLY = 3 };
+enum { NOISE_EXT = 0, NOISE_FRESH = 1, NOISE_PCN = 2, NOISE_LLONLY = 3, NOISE_INNOV = 4 };
+
+// does the model functor provide inv(sigma)*v (square, invertible diffusion coefficient)?
+template <class...> using bhip_void_t = void;
+template <class M, class = void> struct has_sinv { static constexpr bool value = false; };
+template <class M> struct has_sinv<M, bhip_void_t<decltype(&M::sinv_mul)>> { static constexpr bool value = true; };
 
 struct KArgs {
     const double *rows;   // [N-1][rs] packed per-step coefficients (device)
@@ -57,7 +62,7 @@ struct KArgs {
     double x0[3];
     double vend[3];
     double mu_aux[3];
-    double mpar[32];
+    double mpar[40];
 };
 
 typedef const __attribute__((address_space(4))) double *cptr_t;
@@ -182,6 +187,29 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, cptr_t row, int i, int n
     if constexpr (NOISE == NOISE_LLONLY) {
 #pragma unroll
         for (int k = 0; k < D; k++) st.y[k] = win_k[k];
+    }
+
+    if constexpr (NOISE == NOISE_INNOV) {
+        // innovations!(::EulerMaruyama, W, Y, P)  src/euler.jl:358-376 (the inverse map X -> W, square sigma):
+        //   ww[i] = w;  w = w + inv(sigma)*(yy[i+1] - yy[i] - _b((i,t),yy[i],P)*dt)      win_k = yy[i+1]
+        static_assert(D == MP, "innovations need a square, invertible sigma");
+#pragma unroll
+        for (int k = 0; k < D; k++) st_stream(&wout[((size_t)i * D + k) * ldwo], st.wprev[k]);
+        double bI[D];
+        model.b(t, st.y, bI);
+        if constexpr (GK != BHIP_GUIDE_NONE) {
+            double r[D], g[D];
+            guide_terms<M, GK, MO>(model, rw + RL::G, st.y, r, g);
+#pragma unroll
+            for (int k = 0; k < D; k++) bI[k] = bI[k] + g[k];
+        }
+        double df[D], inc[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) df[k] = win_k[k] - st.y[k] - bI[k] * dt;
+        model.sinv_mul(df, inc);
+#pragma unroll
+        for (int k = 0; k < D; k++) { st.wprev[k] = st.wprev[k] + inc[k]; st.y[k] = win_k[k]; }
+        return;
     }
 
     // ---- LOOP A / P: the Wiener increment of this step
@@ -313,6 +341,10 @@ __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
 #pragma unroll
         for (int k = 0; k < MP; k++) st.wprev[k] = win[k * ldwi];
     }
+    if constexpr (NOISE == NOISE_INNOV) {
+#pragma unroll
+        for (int k = 0; k < D; k++) st.y[k] = win[k * ldwi];   // yy[1]
+    }
     if constexpr (NOISE == NOISE_FRESH && (FL & 2) != 0) {
 #pragma unroll
         for (int k = 0; k < MP; k++) wout[k * ldwo] = 0.0;   // W[1] = 0
@@ -328,9 +360,9 @@ __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
     // flight and their latency overlaps arithmetic instead of being exposed once per step.  Stores are
     // fire-and-forget.  The loop is unrolled by two so that the Philox block parity is static.
     constexpr int PF = BHIP_KCH;
-    constexpr int NIN = NOISE == NOISE_LLONLY ? D : MP;
-    constexpr bool READS = NOISE == NOISE_EXT || NOISE == NOISE_LLONLY;
-    constexpr int OFF = NOISE == NOISE_LLONLY ? 0 : 1;
+    constexpr int NIN = (NOISE == NOISE_LLONLY || NOISE == NOISE_INNOV) ? D : MP;
+    constexpr bool READS = NOISE == NOISE_EXT || NOISE == NOISE_LLONLY || NOISE == NOISE_INNOV;
+    constexpr int OFF = NOISE == NOISE_LLONLY ? 0 : 1;   // INNOV reads X[i+1] (X[0] is loaded up front)
     const int nsteps = N - 1;
     double pf[PF][NIN];
     d2v pfs[PF][MP];
@@ -399,7 +431,11 @@ __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
         commit(i);
     }
 
-    if constexpr (NOISE != NOISE_LLONLY) {
+    if constexpr (NOISE == NOISE_INNOV) {
+#pragma unroll
+        for (int k = 0; k < D; k++) st_stream(&wout[((size_t)(N - 1) * D + k) * ldwo], st.wprev[k]);   // ww[N] = w
+    }
+    if constexpr (NOISE != NOISE_LLONLY && NOISE != NOISE_INNOV) {
         if (a.use_vend) {   // endpoint(y, P::GuidedBridge) src/euler.jl:241-242
 #pragma unroll
             for (int k = 0; k < D; k++) st.y[k] = a.vend[k];
@@ -459,6 +495,9 @@ launch_fn get_launch_gk(int noise, int fl)
         return nullptr;
     case NOISE_LLONLY:
         if constexpr (GK != BHIP_GUIDE_NONE) return launch_paths<M, GK, MO, NOISE_LLONLY, 0 | T>;
+        return nullptr;
+    case NOISE_INNOV:
+        if constexpr (has_sinv<M>::value && !TWO) return launch_paths<M, GK, MO, NOISE_INNOV, 2>;
         return nullptr;
     }
     return nullptr;

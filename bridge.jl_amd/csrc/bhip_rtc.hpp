@@ -82,8 +82,21 @@ inline std::string rtc_source(const UserModel &um, int gk, int mo, int noise, in
             o[i] = s;
         }
     }
-};
 )";
+    if (um.d == um.mp)   // square sigma: inv(sigma)*v for innovations!
+        s += R"(    BHIP_DEV void sinv_mul(const double *v, double *o) const
+    {
+        const double *Si = p + NP + D * MP + D * D;
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            double s = Si[i] * v[0];
+#pragma unroll
+            for (int j = 1; j < D; j++) s += Si[i + D * j] * v[j];
+            o[i] = s;
+        }
+    }
+)";
+    s += "};\n";
     s += "template __global__ void k_paths<MUser, " + std::to_string(gk) + ", " + std::to_string(mo) + ", " + std::to_string(noise) + ", " +
          std::to_string(fl) + ">(const KArgs);\n}\n";
     return s;

@@ -165,6 +165,19 @@ int bhip_sample_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, 
 int bhip_llikelihood(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev, long ldX, double *ll_dev,
                      int skip, long npaths);
 
+/* innovations!(EulerMaruyama(), W, X, P): the inverse map X -> W of the Euler scheme,
+ *   W[0] = 0,  W[i+1] = W[i] + inv(sigma)*(X[i+1] - X[i] - _b((i,t_i), X[i], P)*(t_{i+1}-t_i))
+ * for every path of the ensemble (P: the plain target or a guided proposal); needs a square,
+ * invertible sigma (d == m').  src/euler.jl:358-376 -- used by the non-centred parameter updates
+ * (example/fitzhugh_nagumo_full.jl:353). */
+int bhip_innovations(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev, long ldX, double *W_dev, long ldW, long npaths);
+
+/* gpupdate(Hd, V, L, Sigma, v) -> (Hd_out [d*d], V_out [d]): fold the observation v = L x + N(0,Sigma)
+ * at the left end of a segment into (Hdiamond, V), the backward link between chained GuidedBridge
+ * segments (host only).  src/guip.jl:221-231, test/smoothing.jl:73-83 */
+int bhip_gpupdate(int d, int m, const double *Hd, const double *V, const double *L, const double *Sigma, const double *v,
+                  double *Hd_out, double *V_out);
+
 /* ------------------------------------------------------------------ pCN Metropolis-Hastings ensemble
  * One chain per lane.  partialbridge_fitzhugh.jl:125-176, test/partialbridgenuH.jl:155-198
  * Chain state = (W, ll, parity): W and the proposal Wo share a 16-byte slot per (grid index, chain)

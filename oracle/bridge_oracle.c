@@ -609,6 +609,44 @@ void bo_gp_hv(const double *tt, int N, int d, int mp, int aux, const double *apa
     }
 }
 
+/* gpupdate(Hd, V, L, Sigma, v)  src/guip.jl:221-231: fold an observation v = L x + N(0,Sigma) at the left
+ * end of a segment into (Hdiamond, V) -- the backward link between chained GuidedBridge segments
+ * (test/smoothing.jl:73-83).  Z = I - Hd*L'*inv(Sigma + L*Hd*L')*L ; (Z*Hd, Z*Hd*L'*inv(Sigma)*v + Z*V);
+ * if all(diag(Hd) .== Inf): (inv(L'inv(Sigma)L), (L'inv(Sigma)L) \ (L'inv(Sigma)v)). */
+void bo_gpupdate(int d, int m, const double *Hd, const double *V, const double *L, const double *Sigma,
+                 const double *v, double *Hd_out, double *V_out)
+{
+    double Si[D2], LtSi[D2], T1[D2], T2[D2], T3[D2], Z[D2], ZH[D2], w1[BO_MAXD], w2[BO_MAXD];
+    int allinf = 1;
+    for (int k = 0; k < d; k++) if (!(isinf(Hd[k + d * k]) && Hd[k + d * k] > 0)) allinf = 0;
+    bo_inv(m, Sigma, Si);
+    if (allinf) {
+        mtm(d, m, m, L, Si, LtSi);            /* L'*inv(Sigma)        d x m */
+        mm(d, m, d, LtSi, L, T1);             /* (L'inv(Sigma))*L     d x d */
+        bo_inv(d, T1, Hd_out);
+        mv(d, m, LtSi, v, w1);                /* (L'inv(Sigma))*v           */
+        bo_solve(d, T1, w1, V_out);
+        return;
+    }
+    double LH[D2], S[D2], Sinv[D2];
+    mm(m, d, d, L, Hd, LH);                   /* L*Hd                 m x d */
+    mmt(m, d, m, LH, L, S);                   /* (L*Hd)*L'            m x m */
+    for (int k = 0; k < m * m; k++) S[k] = Sigma[k] + S[k];
+    bo_inv(m, S, Sinv);
+    mmt(d, d, m, Hd, L, T1);                  /* Hd*L'                d x m */
+    mm(d, m, m, T1, Sinv, T2);                /* (Hd*L')*inv(S)       d x m */
+    mm(d, m, d, T2, L, T3);                   /* (...)*L              d x d */
+    for (int j = 0; j < d; j++)
+        for (int i = 0; i < d; i++) Z[i + d * j] = (i == j ? 1.0 : 0.0) - T3[i + d * j];
+    mm(d, d, d, Z, Hd, ZH);
+    memcpy(Hd_out, ZH, sizeof(double) * d * d);
+    mmt(d, d, m, ZH, L, T1);                  /* (Z*Hd)*L'                  */
+    mm(d, m, m, T1, Si, T2);                  /* (...)*inv(Sigma)           */
+    mv(d, m, T2, v, w1);
+    mv(d, d, Z, V, w2);
+    for (int k = 0; k < d; k++) V_out[k] = w1[k] + w2[k];
+}
+
 /* forward R3 integration, src/ode.jl:178-184 solve(::R3, F, tt, x0, P);
  * what: 0 _F (gpmu), 1 _dK (gpK), 2 _dPhi (fundamental_matrix), 3 process drift b, 4 _dHinv */
 double bo_r3_forward(const double *tt, int N, int d, int mp, int aux, const double *apar, int what,
@@ -1064,3 +1102,34 @@ void bo_mcnext(int n_entries, int d, double *mean, double *m2, long *n, const do
     }
     *n = nn + 1;
 }
+
+/* innovations!(::EulerMaruyama, W, Y, P)  src/euler.jl:358-376: the inverse map X -> W,
+ *   w += inv(sigma(t_i, y_i)) * (y_{i+1} - y_i - _b((i,t_i), y_i, P)*(t_{i+1}-t_i)),  square sigma only.
+ * P may be the unguided target (kind NONE) or a guided proposal. */
+void bo_innovations_flat(int kind, int N, int d, int mp, int m, int model, const double *par,
+                         int aux, const double *apar, const double *tt,
+                         const double *A1, const double *A2, const double *A3, const double *A4,
+                         const double *X, double *W)
+{
+    bo_proposal P;
+    double S[D2], Sinv[D2], w[BO_MAXD], b[BO_MAXD], df[BO_MAXD], inc[BO_MAXD];
+    if (kind != BO_GUIDE_NONE) mk_prop(&P, kind, N, d, mp, m, model, par, aux, apar, tt, A1, A2, A3, A4);
+    model_sigma_mat(model, d, mp, par, S);
+    if (model == BO_MODEL_LORENZ || model == BO_MODEL_FHN2) {   /* inv(::SDiagonal) = SDiagonal(inv.(diag)) */
+        memset(Sinv, 0, sizeof(double) * d * d);
+        for (int k = 0; k < d; k++) Sinv[k + d * k] = 1.0 / S[k + d * k];
+    } else bo_inv(d, S, Sinv);
+    for (int k = 0; k < d; k++) w[k] = 0.0;
+    for (int i = 0; i < N - 1; i++) {
+        const double *y = X + (size_t)i * d, *yn = X + (size_t)(i + 1) * d;
+        memcpy(W + (size_t)i * d, w, sizeof(double) * d);
+        if (kind == BO_GUIDE_NONE) bo_b(model, d, par, tt[i], y, b);
+        else bo_guided_drift(&P, i, y, b);
+        double dt = tt[i + 1] - tt[i];
+        for (int k = 0; k < d; k++) df[k] = yn[k] - y[k] - b[k] * dt;
+        mv(d, d, Sinv, df, inc);
+        for (int k = 0; k < d; k++) w[k] = w[k] + inc[k];
+    }
+    memcpy(W + (size_t)(N - 1) * d, w, sizeof(double) * d);
+}
+

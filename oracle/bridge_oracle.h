@@ -161,6 +161,14 @@ double bo_ensemble_mcmc(int kind, int N, int d, int mp, int m, int model, const 
                         const double *x0, double rho, int iters, int nchains, uint32_t path0,
                         uint64_t seed, int threads, double *ll_out, long *acc_out);
 
+/* ---- chaining segments / inverse map ---- */
+void bo_gpupdate(int d, int m, const double *Hd, const double *V, const double *L, const double *Sigma,
+                 const double *v, double *Hd_out, double *V_out);
+void bo_innovations_flat(int kind, int N, int d, int mp, int m, int model, const double *par,
+                         int aux, const double *apar, const double *tt,
+                         const double *A1, const double *A2, const double *A3, const double *A4,
+                         const double *X, double *W);
+
 /* ---- online statistics (src/mclog.jl:22-56,89-93) ---- */
 void bo_mcnext(int n_entries, int d, double *mean, double *m2, long *n, const double *x);
 

@@ -330,6 +330,38 @@ def llikelihood(P, X, skip=0):
     return lib().bo_llikelihood_flat(*P._args(), px, C.c_int(skip))
 
 
+def gpupdate(Hd, V, L, Sigma, v):
+    Hd = np.atleast_2d(np.asarray(Hd, dtype=np.float64))
+    d = Hd.shape[0]
+    L = np.asarray(L, dtype=np.float64).reshape(-1, d)
+    m = L.shape[0]
+    a1, p1 = _d(cm(Hd))
+    a2, p2 = _d(np.atleast_1d(V))
+    a3, p3 = _d(cm(L))
+    a4, p4 = _d(cm(np.asarray(Sigma, dtype=np.float64).reshape(m, m)))
+    a5, p5 = _d(np.atleast_1d(v))
+    Ho, Vo = np.empty(d * d), np.empty(d)
+    lib().bo_gpupdate(C.c_int(d), C.c_int(m), p1, p2, p3, p4, p5, Ho.ctypes.data_as(dp), Vo.ctypes.data_as(dp))
+    return uncm(Ho, d, d), Vo
+
+
+def innovations(P, X, model=None, d=None, mp=None, par=None, tt=None):
+    """innovations!(EulerMaruyama(), W, X, P): P = Proposal, or None with (model, d, mp, par, tt) for the plain target"""
+    if P is not None:
+        xx, px = _d(np.asarray(X).reshape(P.N, P.d))
+        W = np.empty((P.N, P.d))
+        lib().bo_innovations_flat(*P._args(), px, W.ctypes.data_as(dp))
+        return W
+    tt = np.ascontiguousarray(tt, dtype=np.float64)
+    N = len(tt)
+    pp, p = _d(par)
+    xx, px = _d(np.asarray(X).reshape(N, d))
+    W = np.empty((N, d))
+    lib().bo_innovations_flat(C.c_int(GUIDE_NONE), C.c_int(N), C.c_int(d), C.c_int(mp), C.c_int(d), C.c_int(model), p,
+                              C.c_int(0), None, tt.ctypes.data_as(dp), None, None, None, None, px, W.ctypes.data_as(dp))
+    return W
+
+
 class _Res(C.Structure):
     _fields_ = [("acc", C.c_long), ("ll", C.c_double)]
 
