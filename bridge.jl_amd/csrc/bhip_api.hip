@@ -370,17 +370,22 @@ static int build_tile_data(bhip_proposal *po)
     if (po->g.kind == BHIP_GUIDE_NONE) return BHIP_OK;
     if (po->mh.id != BHIP_MODEL_LINPRO || (d != 16 && d != 32))
         return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: LinPro target with d = 16 or 32");
-    if (po->g.kind != BHIP_GUIDE_HV && po->g.kind != BHIP_GUIDE_NUH)
-        return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: GuidedBridge (Hdiamond,V) or (nu,H) guides");
     if (!po->has_aux || (po->aux.kind != BHIP_AUX_AFFINE && po->aux.kind != BHIP_AUX_LINPRO))
         return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: time-constant auxiliary process");
     const size_t DD = (size_t)d * d, STEP = DD + d;
     std::vector<double> steps((size_t)(N - 1) * STEP), hdr((size_t)(N - 1) * 2);
     for (int i = 0; i < N - 1; i++) {
-        // GuidedBridge: r = Hdiamond_i \ (V_i - x) evaluated as inv(Hdiamond_i)*(V_i - x) (path-independent
-        // inverse, LU with partial pivoting); nuH: r = H_i*(nu_i - x) as in the reference.
-        const Mat Hm = po->g.kind == BHIP_GUIDE_HV ? inv(po->g.Hd[i]) : po->g.H[i];
-        const Mat &nu = po->g.kind == BHIP_GUIDE_HV ? po->g.V[i] : po->g.nu[i];
+        // Every guide is brought to the form r = Hm_i (nu_i - x) the tile kernel evaluates:
+        //   GuidedBridge : Hdiamond_i \ (V_i - x)  ->  Hm = inv(Hdiamond_i) (LU, path-independent), nu = V_i
+        //   (nu,H)       : H_i (nu_i - x) as in the reference (PartialBridge! likewise)
+        //   PartialBridge: L'M(v - mu - Lx) = (L'ML)(nu - x) with any nu solving L nu = v - mu: nu = L'(LL')^-1 (v - mu)
+        Mat Hm, nu;
+        if (po->g.kind == BHIP_GUIDE_HV) { Hm = inv(po->g.Hd[i]); nu = po->g.V[i]; }
+        else if (po->g.kind == BHIP_GUIDE_LMMU) {
+            const Mat &L = po->g.L[i];
+            Hm = (tr(L) * po->g.M[i]) * L;
+            nu = tr(L) * solve(L * tr(L), po->g.v - po->g.mu[i]);
+        } else { Hm = po->g.H[i]; nu = po->g.nu[i]; }
         to_fragments(Hm, &steps[(size_t)i * STEP]);
         std::memcpy(&steps[(size_t)i * STEP + DD], nu.a.data(), sizeof(double) * d);
         hdr[2 * i] = po->tt[i + 1] - po->tt[i];

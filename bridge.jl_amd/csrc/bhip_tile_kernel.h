@@ -222,12 +222,9 @@ template <int D, int NOISE>
 hipError_t launch_tile(const TArgs &a, hipStream_t st)
 {
     const size_t lds = sizeof(double) * (4 * D * D + 5 * D + 2 * (D * D + D));
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_tile<D, NOISE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    // per device and cheap: set on every launch (a process may drive several devices)
+    hipError_t e = hipFuncSetAttribute((const void *)k_tile<D, NOISE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
     const long grid = (a.P + 63) / 64;
     hipLaunchKernelGGL((k_tile<D, NOISE>), dim3((unsigned)grid), dim3(256), lds, st, a);
     return hipGetLastError();

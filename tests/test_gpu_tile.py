@@ -73,12 +73,29 @@ def test_tile_kernel_fused_noise(ctx):
     assert torch.equal(ll3, ll)
 
 
+def test_partial_bridge_large_d_maps_onto_tile_kernel(ctx):
+    """PartialBridge (L,M,mu) at d = 32, two observed components: r = L'M(v - mu - Lx) is evaluated as
+    (L'ML)(nu - x) with nu = L'(LL')^-1 (v - mu); equal to the oracle's literal formula within tolerance"""
+    c = problems.linpro_big_case(32, 101)
+    L = np.zeros((2, 32))
+    L[0, 0] = 1.0
+    L[1, 3], L[1, 4] = 0.5, 0.5
+    v, Sig = [0.3, -0.2], 0.01 * np.eye(2)
+    Po = bh.PartialBridge(c.tt, c.bh_process(bh), c.bh_aux(bh), L, v, Sig, ctx=ctx)
+    Lt, Mt, mut = o.partialbridge_ode(c.tt, 32, 32, 2, c.aux, c.apar, L, Sig)
+    assert np.array_equal(Po.L, Lt) and np.array_equal(Po.M, Mt) and np.array_equal(Po.mu, mut)
+    ref = o.proposal_lmmu(c.tt, 32, 32, 2, c.model, c.par, c.aux, c.apar, Lt, Mt, mut, v)
+    P = 24
+    X, W, ll = bh.sample_solve(c.x0, Po, P, seed=2, store_W=True)
+    Xh, Wh, llh = X.paths(), W.paths(), ll.cpu().numpy()
+    for p in (0, 17, 23):
+        Xr = o.solve_guided(ref, c.x0, Wh[p])
+        _close(Xh[p], Xr, llh[p:p + 1], np.array([o.llikelihood(ref, Xr)]))
+    assert np.abs(Xh[:, -1] @ L.T - np.array(v)).max() < 0.5          # pulled towards the observation
+
+
 def test_large_d_unsupported_combinations_fail_loudly(ctx):
     c = problems.linpro_big_case(32, 51)
-    P, Pt = c.bh_process(bh), c.bh_aux(bh)
-    with pytest.raises(bh.BridgeError, match="large-d"):
-        bh.PartialBridge(c.tt, P, Pt, np.eye(32)[:2], [0.1, 0.2], 0.01 * np.eye(2), ctx=ctx)
-    rng = np.random.default_rng(0)
     P8 = bh.LinPro(-np.eye(8), np.zeros(8), np.eye(8))
     with pytest.raises(bh.BridgeError, match="large-d"):
         bh.GuidedBridge(c.tt, P8, P8, np.ones(8), ctx=ctx)
