@@ -87,6 +87,43 @@ def test_C3_fhn_partial_bridge_262144_paths(ctx):
     assert np.abs(X3.paths(4242, 1)[0] - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max())
 
 
+def _linpro_logdensity(B, mu, sig, u, T, v):
+    """log transition density of dX = B(X-mu)dt + sig dW from u at 0 to v at T (src/linpro.jl:98-113)"""
+    from scipy.linalg import expm, solve_continuous_lyapunov
+    a = sig @ sig.T
+    lam = solve_continuous_lyapunov(B, -a)
+    phi = expm(T * B)
+    m = phi @ (u - mu) + mu
+    K = lam - phi @ lam @ phi.T
+    r = v - m
+    return -0.5 * (r @ np.linalg.solve(K, r) + np.linalg.slogdet(K)[1] + len(v) * math.log(2 * math.pi))
+
+
+@pytest.mark.parametrize("d", [2, 3, 32])
+def test_K9_importance_weights_unbiased_multivariate(ctx, d):
+    """K9 (test/guip.jl:245-274) for vector LinPro targets, where the transition density is closed-form:
+    mean(exp(ll) * ptilde / p) = 1.  Exercises solve! + llikelihood + lptilde jointly at distribution
+    level for the path-per-lane kernel (d = 2, 3) and the MFMA tile kernel (d = 32)."""
+    if d == 32:
+        c = problems.linpro_big_case(32, 401)
+    else:
+        c = _case("linpro2_guidedbridge" if d == 2 else "linpro3_guidedbridge")
+    P = 65536
+    Po = c.bh_proposal(bh, ctx)
+    _, _, ll = bh.sample_solve(c.x0, Po, P, seed=10 + d, store_X=False)
+    llh = ll.cpu().numpy()
+    B = o.uncm(c.par[:d * d], d, d)
+    mu = np.asarray(c.par[d * d:d * d + d])
+    sig = o.uncm(c.par[d * d + d:], d, d)
+    lp = _linpro_logdensity(B, mu, sig, c.x0, c.tt[-1] - c.tt[0], np.asarray(c.v, dtype=float))
+    lw = llh + bh.lptilde(Po, c.x0) - lp
+    w = np.exp(lw)
+    se = np.std(w, ddof=1) / math.sqrt(P)
+    # discretisation bias of the Euler scheme is O(dt); allow it on top of 4 standard errors
+    assert abs(np.mean(w) - 1) < 4 * se + 0.03, (np.mean(w), se)
+    assert np.all(np.isfinite(llh))
+
+
 def test_C4_pcn_mcmc_262144_chains(ctx):
     """config C4's per-GPU shard: 262 144 pCN chains, a few iterations"""
     c = _case("fhn_partialbridge_extreme")
