@@ -264,3 +264,20 @@ def test_reference_error_messages(ctx):
     plain = bh.PlainProcess(c.tt, c.bh_process(bh), ctx=ctx)
     with pytest.raises(bh.BridgeError):
         bh.llikelihood(bh.LeftRule(), bh.solve(bh.Euler(), c.x0, W, plain), plain)
+
+
+def test_inline_philox_equals_rocrand_device_generator(tmp_path):
+    """the noise specification is rocRAND's default PHILOX4_32_10 with an explicit counter layout:
+    compile tests/rocrand_check.hip against rocRAND's device API and compare word for word"""
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "rocrand_check")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-I", os.path.join(root, "bridge.jl_amd", "csrc"),
+                           os.path.join(root, "tests", "rocrand_check.hip"), "-o", exe], stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
