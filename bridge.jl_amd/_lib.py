@@ -46,6 +46,7 @@ SIGNATURES = {
                                     C.c_uint64, C.c_uint32, C.c_uint32]),
     "bhip_llikelihood": (C.c_int, [vp, vp, vp, C.c_long, vp, C.c_int, C.c_long]),
     "bhip_innovations": (C.c_int, [vp, vp, vp, C.c_long, vp, C.c_long, C.c_long]),
+    "bhip_girsanov": (C.c_int, [vp, vp, dp, C.c_int, vp, C.c_long, vp, C.c_long]),
     "bhip_gpupdate": (C.c_int, [C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp]),
     "bhip_chains_create": (C.c_int, [vp, vp, C.c_long, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(vp)]),
     "bhip_chains_destroy": (None, [vp]),

@@ -617,6 +617,37 @@ def innovations(method, Y, P):
     return innovations_(method, EnsemblePath(Y.tt, P.mp, Y.npaths, Y.ctx), Y, P)
 
 
+def girsanov(X, P, Pt):
+    """girsanov(X::SamplePath, P, Pt)  src/diffusion.jl:109-123: the discretised log-likelihood ratio
+    dP/dPt of every path of the ensemble -> tensor [npaths].  P and Pt are two parameter sets of the same
+    process type (example/fitzhugh_nagumo_full.jl:313-321), or Pt = Wiener (test/guip.jl:72).
+    P may also be a PlainProcess / guided proposal already living on X's grid (its target is used)."""
+    ctx = X.ctx
+    if isinstance(P, _Proposal):
+        Po = P
+        if len(Po.tt) != len(X) or not np.array_equal(Po.tt, X.tt):
+            raise BridgeError("Time axis mismatch between X and P")
+        P = Po.Target
+    else:
+        Po = PlainProcess(X.tt, P, ctx)
+    if isinstance(Pt, _Proposal):
+        Pt = Pt.Target
+    if X.dim != P.d:
+        raise BridgeError("girsanov: dimension of X does not match P")
+    if isinstance(Pt, Wiener):
+        if Pt.d != P.d:
+            raise BridgeError("girsanov: dimension of Pt does not match P")
+        par_t, npar_t = None, 0
+    elif type(Pt) is type(P) and Pt.d == P.d:
+        pt = np.ascontiguousarray(Pt.params(), dtype=np.float64)
+        par_t, npar_t = _dptr(pt), len(pt)
+    else:
+        raise BridgeError("girsanov: Pt must be of the same process type as P, or Wiener")
+    out = ctx.empty(X.npaths)
+    ctx.check(ctx.lib.bhip_girsanov(ctx.h, Po.h, par_t, npar_t, X.ptr(), X.ld, vp(out.data_ptr()), X.npaths))
+    return out
+
+
 def gpupdate(H, V, L=None, Sigma=None, v=None):
     """gpupdate(Hd, V, L, Sigma, v) or gpupdate(P::GuidedBridge, L, Sigma, v)  src/guip.jl:221-243:
     returns the updated (Hd, V) after observing v = L x + N(0, Sigma) at the left end of the segment."""

@@ -4,6 +4,7 @@
 #include "bhip_host.hpp"
 #include "bhip_path_kernel.h"
 #include "bhip_tile_kernel.h"
+#include "bhip_girsanov_kernel.h"
 #include "bhip_rtc.hpp"
 #include "bhip_util_kernels.h"
 #include <algorithm>
@@ -737,6 +738,56 @@ int bhip_innovations(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev
     if (ldX < npaths || ldW < npaths) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
     a.Win = X_dev; a.ldWin = ldX; a.Wout = W_dev; a.ldWout = ldW;
     return do_launch(po, NOISE_INNOV, a);
+}
+
+int bhip_girsanov(bhip_ctx *ctx, const bhip_proposal *po, const double *par_t, int npar_t, const double *X_dev, long ldX,
+                  double *out_dev, long npaths)
+{
+    if (!ctx || !po || !X_dev || !out_dev) return BHIP_EINVAL;
+    NEED_DEVICE(ctx);
+    const ModelHost &mh = po->mh;
+    girsanov_fn f = nullptr;
+    switch (mh.id) {
+    case BHIP_MODEL_OU: f = launch_girsanov<MOU>; break;
+    case BHIP_MODEL_LINPRO: f = mh.d == 1 ? launch_girsanov<MLinPro<1>> : mh.d == 2 ? launch_girsanov<MLinPro<2>> : mh.d == 3 ? launch_girsanov<MLinPro<3>> : nullptr; break;
+    case BHIP_MODEL_LORENZ: f = launch_girsanov<MLorenz>; break;
+    case BHIP_MODEL_FHN2: f = launch_girsanov<MFHN2>; break;
+    default: break;
+    }
+    if (!f) return fail(ctx, BHIP_EUNSUPPORTED, "bhip_girsanov: needs a built-in target with invertible a (OU, LinPro d<=3, Lorenz, Models.FitzHughNagumo)");
+    if (npaths < 1) return fail(ctx, BHIP_EINVAL, "npaths must be positive");
+    if (ldX < npaths) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
+    if (po->g.kind == BHIP_GUIDE_NONE) {
+        int rc = ensure_plain_rows(const_cast<bhip_proposal *>(po));
+        if (rc) return rc;
+    }
+    if (!po->d_rows) return fail(ctx, BHIP_ESTATE, "proposal has no coefficient rows (compute a guide first)");
+    GirsArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.rows = po->d_rows; a.rs = po->rs; a.N = (int)po->tt.size(); a.P = npaths;
+    a.X = X_dev; a.ldX = ldX; a.out = out_dev;
+    if (mh.dpar.size() > 40) return fail(ctx, BHIP_EUNSUPPORTED, "parameter block too large");
+    std::copy(mh.dpar.begin(), mh.dpar.end(), a.mpar);
+    if (par_t) {
+        ModelHost mt;
+        std::string err;
+        int rc = model_setup(mh.id, mh.d, par_t, npar_t, mt, err);
+        if (rc) return fail(ctx, rc, "bhip_girsanov: Pt: " + err);
+        std::copy(mt.dpar.begin(), mt.dpar.end(), a.mpar_t);
+    } else {
+        a.zero_t = 1;
+        std::copy(mh.dpar.begin(), mh.dpar.end(), a.mpar_t);
+    }
+    // Gamma(t,x,P) = inv(a(t,x,P)), src/types.jl:33; sigma::SDiagonal (src/Models.jl:19,57) keeps a
+    // diagonal, whose inverse is taken entry by entry
+    if (mh.id == BHIP_MODEL_LORENZ || mh.id == BHIP_MODEL_FHN2) {
+        for (int k = 0; k < mh.d; k++) a.gam[k + mh.d * k] = 1.0 / mh.a(k, k);
+    } else {
+        const Mat G = inv(mh.a);
+        std::copy(G.a.begin(), G.a.end(), a.gam);
+    }
+    HIPCHK(ctx, f(a, ctx->stream));
+    return BHIP_OK;
 }
 
 int bhip_gpupdate(int d, int m, const double *Hd, const double *V, const double *L, const double *Sigma, const double *v,

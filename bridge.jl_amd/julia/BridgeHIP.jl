@@ -225,6 +225,23 @@ function llikelihood(::LeftRule, X::EnsemblePath, Po::HIPProposal; skip = 0)
     out
 end
 
+"""
+girsanov(X::EnsemblePath, Po::HIPProposal, Pt): src/diffusion.jl:109-123 for every stored path; P = the
+target of `Po`, `Pt` = the same process type with other parameters (example/fitzhugh_nagumo_full.jl:317)
+or `Wiener` (test/guip.jl:72).
+"""
+function Bridge.girsanov(X::EnsemblePath, Po::HIPProposal, Pt)
+    par = Pt isa Wiener ? Float64[] : hipmodel(Pt)[3]
+    out = Vector{Float64}(undef, X.npaths)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(X.ctx, ccall((:bhip_malloc, lib), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), X.ctx.h, 8 * X.npaths, r))
+    check(X.ctx, ccall((:bhip_girsanov, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Clong),
+        X.ctx.h, Po.h, Pt isa Wiener ? C_NULL : par, length(par), X.dev, X.npaths, r[], X.npaths))
+    check(X.ctx, ccall((:bhip_memcpy_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), X.ctx.h, out, r[], 8 * X.npaths))
+    ccall((:bhip_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), X.ctx.h, r[])
+    out
+end
+
 # ---------------------------------------------------------------- the MCMC loop of the scripts
 """
     mcmc(Po, x0, iterations; ρ, nchains, seed) -> (acc, ll, chains)

@@ -172,6 +172,15 @@ int bhip_llikelihood(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev
  * (example/fitzhugh_nagumo_full.jl:353). */
 int bhip_innovations(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev, long ldX, double *W_dev, long ldW, long npaths);
 
+/* girsanov(X, P, Pt): the discretised log-likelihood ratio dP/dPt of every stored path,
+ *   out[p] = sum_i dot( Gamma(P)*(B - Bt),  X[i+1] - X[i] - 0.5*(B + Bt)*(t_{i+1}-t_i) ),
+ *   B = b(t_i, X[i], P), Bt = b(t_i, X[i], Pt), Gamma(P) = inv(a(P))              src/diffusion.jl:109-123
+ * P = the target of `po` (grid = po's grid); Pt = the same process type with parameters par_t
+ * (the theta-update of example/fitzhugh_nagumo_full.jl:313-321), or Wiener (zero drift, test/guip.jl:72)
+ * when par_t == NULL.  Needs an invertible a: OU, LinPro (d <= 3), Lorenz, Models.FitzHughNagumo. */
+int bhip_girsanov(bhip_ctx *ctx, const bhip_proposal *po, const double *par_t, int npar_t, const double *X_dev, long ldX,
+                  double *out_dev, long npaths);
+
 /* gpupdate(Hd, V, L, Sigma, v) -> (Hd_out [d*d], V_out [d]): fold the observation v = L x + N(0,Sigma)
  * at the left end of a segment into (Hdiamond, V), the backward link between chained GuidedBridge
  * segments (host only).  src/guip.jl:221-231, test/smoothing.jl:73-83 */

@@ -1133,3 +1133,34 @@ void bo_innovations_flat(int kind, int N, int d, int mp, int m, int model, const
     memcpy(W + (size_t)(N - 1) * d, w, sizeof(double) * d);
 }
 
+
+/* girsanov(X, P, Pt): src/diffusion.jl:109-123.  P, Pt: the same model type with parameter sets
+ * par / par_t, or Pt = Wiener (b = 0, src/wiener.jl:143-145) when par_t == NULL (test/guip.jl:72).
+ * Gamma(s,x,P) = inv(a(s,x,P)) (src/types.jl:33); for the SDiagonal-sigma models (src/Models.jl:19,57)
+ * a stays diagonal and is inverted entry by entry. */
+double bo_girsanov(int model, int d, int mp, const double *par, const double *par_t,
+                   const double *tt, int N, const double *X)
+{
+    double A[D2], G[D2], B[BO_MAXD], Bt[BO_MAXD], df[BO_MAXD], g[BO_MAXD];
+    bo_a(model, d, mp, par, 0.0, X, A);
+    if (model == BO_MODEL_LORENZ || model == BO_MODEL_FHN2) {
+        memset(G, 0, sizeof(double) * d * d);
+        for (int k = 0; k < d; k++) G[k + d * k] = 1.0 / A[k + d * k];
+    } else bo_inv(d, A, G);
+    double som = 0.0;
+    for (int i = 0; i < N - 1; i++) {
+        const double *x = X + (size_t)i * d, *xn = X + (size_t)(i + 1) * d;
+        bo_b(model, d, par, tt[i], x, B);
+        if (par_t) bo_b(model, d, par_t, tt[i], x, Bt);
+        else for (int k = 0; k < d; k++) Bt[k] = 0.0;
+        for (int k = 0; k < d; k++) df[k] = B[k] - Bt[k];
+        mv(d, d, G, df, g);                                   /* DeltaBG = Gamma*(B - Bt) */
+        double dt = tt[i + 1] - tt[i], dot = 0.0;
+        for (int k = 0; k < d; k++) {
+            double inc = (xn[k] - x[k]) - (0.5 * (B[k] + Bt[k])) * dt;
+            dot = k == 0 ? g[0] * inc : dot + g[k] * inc;
+        }
+        som += dot;
+    }
+    return som;
+}

@@ -169,6 +169,10 @@ void bo_innovations_flat(int kind, int N, int d, int mp, int m, int model, const
                          const double *A1, const double *A2, const double *A3, const double *A4,
                          const double *X, double *W);
 
+/* girsanov(X, P, Pt), src/diffusion.jl:109-123; par_t == NULL: Pt = Wiener */
+double bo_girsanov(int model, int d, int mp, const double *par, const double *par_t,
+                   const double *tt, int N, const double *X);
+
 /* ---- online statistics (src/mclog.jl:22-56,89-93) ---- */
 void bo_mcnext(int n_entries, int d, double *mean, double *m2, long *n, const double *x);
 

@@ -41,6 +41,7 @@ def load():
     lib.bo_llikelihood_flat.restype = C.c_double
     lib.bo_ensemble_proposals.restype = C.c_double
     lib.bo_ensemble_mcmc.restype = C.c_double
+    lib.bo_girsanov.restype = C.c_double
     return lib
 
 
@@ -360,6 +361,16 @@ def innovations(P, X, model=None, d=None, mp=None, par=None, tt=None):
     lib().bo_innovations_flat(C.c_int(GUIDE_NONE), C.c_int(N), C.c_int(d), C.c_int(mp), C.c_int(d), C.c_int(model), p,
                               C.c_int(0), None, tt.ctypes.data_as(dp), None, None, None, None, px, W.ctypes.data_as(dp))
     return W
+
+
+def girsanov(model, d, mp, par, par_t, tt, X):
+    """girsanov(X, P, Pt) (src/diffusion.jl:109-123); par_t None -> Pt = Wiener"""
+    tt = np.ascontiguousarray(tt, dtype=np.float64)
+    N = len(tt)
+    pp, p = _d(par)
+    pt, ptp = _d(par_t)
+    xx, px = _d(np.asarray(X).reshape(N, d))
+    return lib().bo_girsanov(C.c_int(model), C.c_int(d), C.c_int(mp), p, ptp, tt.ctypes.data_as(dp), C.c_int(N), px)
 
 
 class _Res(C.Structure):

@@ -358,3 +358,54 @@ def test_models_against_reference_expressions():
     lp = o.linpro_par(B, mu, np.eye(2))
     assert np.array_equal(o.aux_b(o.AUX_LINPRO, 2, lp, 0.0, x), B @ (x - mu)) or np.allclose(o.aux_b(o.AUX_LINPRO, 2, lp, 0.0, x), B @ (x - mu), rtol=1e-15)
     assert np.allclose(o.aux_beta(o.AUX_LINPRO, 2, lp, 0.0), -B @ mu, rtol=1e-15)
+
+
+# --------------------------------------------------------------------------- K14: girsanov
+def test_K14_girsanov_identity_against_transition_densities():
+    """test/guip.jl:46-50,71-72: OU(2,1) on tt = 1:1/500:2, X by Euler-Maruyama from 0:
+    |girsanov(X, P1, Wiener) - llikelihood(X, P1) + llikelihood(X, Wiener)| < 0.5 with the exact
+    transition densities (src/diffusion.jl:15-21, test/guip.jl:25, src/wiener.jl)."""
+    n = 500
+    tt = 1.0 + np.arange(n + 1) / n
+    beta, sig = 2.0, 1.0
+    for path in range(8):
+        W = o.wiener_sample(tt, 1, 14, path, 0)
+        X = o.solve_em(o.MODEL_OU, 1, 1, [beta, sig], tt, [0.0], W)[:, 0]
+        g = o.girsanov(o.MODEL_OU, 1, 1, [beta, sig], None, tt, X)
+        dt = np.diff(tt)
+        var = 0.5 * sig ** 2 / beta * (1 - np.exp(-2 * beta * dt))
+        mean = X[:-1] * np.exp(-beta * dt)
+        ll_p = np.sum(-0.5 * ((X[1:] - mean) ** 2 / var + np.log(2 * math.pi * var)))
+        ll_w = np.sum(-0.5 * ((X[1:] - X[:-1]) ** 2 / dt + np.log(2 * math.pi * dt)))
+        assert abs(g - ll_p + ll_w) < 0.5
+        # the defining sum, evaluated independently
+        B = -beta * X[:-1]
+        ref = np.sum((B / sig ** 2) * (np.diff(X) - 0.5 * B * dt))
+        assert abs(g - ref) <= 1e-12 * max(1.0, abs(ref))
+
+
+def test_girsanov_antisymmetry_and_vector_models():
+    rng = np.random.default_rng(5)
+    tt = np.linspace(0, 1, 101)
+    # same sigma: girsanov(X,P,Pt) == -girsanov(X,Pt,P) exactly, and girsanov(X,P,P) == 0
+    for model, d, par, par_t in (
+        (o.MODEL_FHN2, 2, [0.1, 0.0, 1.5, 0.8, 0.3, 0.4], [0.12, 0.1, 1.4, 0.7, 0.3, 0.4]),
+        (o.MODEL_LORENZ, 3, [10.0, 28.0, 8 / 3, 3.0, 3.0, 3.0], [9.0, 27.0, 2.5, 3.0, 3.0, 3.0]),
+    ):
+        W = o.wiener_sample(tt, d, 15, 0, 0)
+        X = o.solve_em(model, d, d, par, tt, 0.1 * np.ones(d), 0.05 * W)
+        g1, g2 = o.girsanov(model, d, d, par, par_t, tt, X), o.girsanov(model, d, d, par_t, par, tt, X)
+        assert g1 == -g2 and g1 != 0.0
+        assert o.girsanov(model, d, d, par, par, tt, X) == 0.0
+    # dense LinPro d=2: Gamma = inv(sigma sigma') as a full matrix, against numpy
+    B = np.array([[-1.0, 0.3], [-0.2, -0.8]])
+    Bt = np.array([[-0.5, 0.1], [0.0, -1.2]])
+    mu, mut = np.array([0.1, -0.2]), np.array([0.0, 0.3])
+    sg = np.array([[0.8, 0.1], [-0.3, 0.6]])
+    X = np.cumsum(0.1 * rng.standard_normal((101, 2)), axis=0)
+    g = o.girsanov(o.MODEL_LINPRO, 2, 2, o.linpro_par(B, mu, sg), o.linpro_par(Bt, mut, sg), tt, X)
+    G = np.linalg.inv(sg @ sg.T)
+    bb, bt = (X[:-1] - mu) @ B.T, (X[:-1] - mut) @ Bt.T
+    dt = np.diff(tt)[:, None]
+    ref = np.sum(((bb - bt) @ G.T) * (np.diff(X, axis=0) - 0.5 * (bb + bt) * dt))
+    assert abs(g - ref) <= 1e-12 * max(1.0, abs(ref))
