@@ -16,7 +16,9 @@ pCN mix -> guided Euler step -> log-likelihood increment (+ the accept at the en
 All inputs are resident in HBM when the timed region starts.  The timed region ends with the
 device-side reduction of the acceptance / log-weight statistics and (N > 1) ONE RCCL all-gather.
 
-`--mode proposals` times independent fresh proposals instead (sample!+solve!+llikelihood, X stored).
+`--mode proposals` times independent fresh proposals instead (sample!+solve!+llikelihood, X stored),
+`--mode linpro32` config C5 (d = 32 on the fp64 matrix cores).  At N = 1 the default run appends the
+kernel-level figures of those two modes as `other_modes` (measured after the timed region).
 """
 import argparse
 import json
@@ -37,11 +39,13 @@ import bridgehip as bh
 from bridgehip import dist as bdist
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F64_PEAK_TF = 78.6    # dense fp64 matrix peak, same guide
 N_GRID = 1001
 FHN = (0.1, 0.0, 1.5, 0.8, 0.3)
 X0 = (-0.5, -0.6)
 V_END = 1.1
 RHO = 0.9
+FHN_WORKLOAD = "FitzHugh-Nagumo PartialBridge (d=2, scalar noise, L=[1 0], Sigma=1e-10, v=1.1), 1001-point tau-grid T=2, "
 
 
 def tau_grid(T, N):
@@ -116,6 +120,87 @@ def profiled_traffic(kernel_tag, tags=("r1_mcmc",)):
     return None, None
 
 
+class Workload:
+    """one bench mode: owns its device buffers; step() = one launch of the dominant kernel"""
+
+    def __init__(self, mode, ctx, chains, rank):
+        self.mode, self.ctx = mode, ctx
+        self.P = chains
+        self.flops_per_pathstep = None
+        self.chains = None
+        if mode == "linpro32":
+            # config C5 (SURVEY 8(d)): LinPro d=32 GuidedBridge on the fp64 MFMA tile kernel; 65 536 paths by default
+            d = 32
+            if chains == 262144:
+                self.P = 65536
+            rng = np.random.default_rng(5)
+            G, G2 = rng.standard_normal((d, d)) / np.sqrt(d), rng.standard_normal((d, d)) / np.sqrt(d)
+            sig = 0.5 * np.eye(d) + 0.05 * G2
+            self.Po = bh.GuidedBridge(np.linspace(0.0, 1.0, N_GRID), bh.LinPro(-np.eye(d) + 0.1 * G, np.zeros(d), sig),
+                                      bh.LinPro(-np.eye(d), np.zeros(d), sig), 0.5 * np.ones(d), ctx=ctx)
+            self._fresh(d, np.zeros(d), 5)
+            self.bytes_per_pathstep = 8 * d              # write X (8d)
+            self.flops_per_pathstep = 5 * 2 * d * d      # five d x d mat-vecs
+            self.kernel = "k_tile<32>"
+            self.workload = "LinPro d=32 GuidedBridge (dense sigma, pre-inverted Hdiamond), 1001-point grid T=1, independent fused proposals"
+        elif mode == "mcmc":
+            self.Po = build_proposal(ctx)
+            self.path0 = rank * self.P                   # contiguous shard of the global chain ids; RNG keyed by global id
+            self.chains = bh.Chains(self.Po, X0, self.P, seed=4, path0=self.path0, store_X=True)
+            self.step = lambda: self.chains.step(RHO, 1)
+            self.bytes_per_pathstep = 8 * 2 + 16 * 1     # write Xo (8d) + read W, write Wo (16 m')   SURVEY 8(d) mode M
+            self.kernel = "k_paths<MFHN, LMMU, 1, PCN>"
+            self.workload = FHN_WORKLOAD + "pCN-MCMC rho=0.9: one step = one MH iteration of every chain"
+        else:
+            self.Po = build_proposal(ctx)
+            self._fresh(2, np.array(X0), 4)
+            self.bytes_per_pathstep = 8 * 2              # write X (8d)                               SURVEY 8(d) mode E
+            self.kernel = "k_paths<MFHN, LMMU, 1, FRESH>"
+            self.workload = FHN_WORKLOAD + "independent fused proposals (sample!+solve!+llikelihood)"
+        self.path0 = rank * self.P
+
+    def _fresh(self, d, x0, seed):
+        ctx, P = self.ctx, self.P
+        self.X = bh.EnsemblePath(self.Po.tt, d, P, ctx)
+        self.ll = ctx.empty(P)
+        self.it = 0
+        self.x0 = np.ascontiguousarray(x0, dtype=np.float64)
+
+        def step():
+            self.it += 1
+            ctx.check(ctx.lib.bhip_sample_solve(ctx.h, self.Po.h, bh.api._dptr(self.x0), None, None, P, self.X.ptr(), P,
+                                                bh.api.vp(self.ll.data_ptr()), 0, P, seed, self.it, self.path0))
+        self.step = step
+
+    def roofline(self, kern_ms):
+        """achieved = algorithmic bytes (or flops) per launch / mean launch duration (HIP events)"""
+        avg_s = float(np.mean(kern_ms)) * 1e-3
+        per_launch = float(self.P) * (N_GRID - 1)
+        gbs = per_launch * self.bytes_per_pathstep / avg_s / 1e9
+        r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+             "kernel": self.kernel, "kernel_avg_ms": avg_s * 1e3, "kernel_min_ms": float(np.min(kern_ms)),
+             "kernel_max_ms": float(np.max(kern_ms)), "algorithmic_bytes_per_path_step": self.bytes_per_pathstep,
+             "path_steps_per_launch": self.P * (N_GRID - 1)}
+        if self.flops_per_pathstep:   # compute-bound kernel: report against the fp64 matrix-core peak
+            tf = per_launch * self.flops_per_pathstep / avg_s / 1e12
+            r.update({"bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TF,
+                      "algorithmic_flops_per_path_step": self.flops_per_pathstep, "hbm_algorithmic_GBs": gbs})
+        return r
+
+
+def kernel_times(w, steps, warmup):
+    """HIP-event duration of every launch (events on the stream the kernels go to: torch's current stream)"""
+    for _ in range(warmup):
+        w.step()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    for k in range(steps):
+        evs[k].record()
+        w.step()
+    evs[steps].record()
+    torch.cuda.synchronize()
+    return [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +209,7 @@ def main():
     ap.add_argument("--chains", type=int, default=262144, help="chains (paths) per GPU")
     ap.add_argument("--mode", choices=["mcmc", "proposals", "linpro32"], default="mcmc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-modes", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,65 +224,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     ctx = bh.Context(local)
-    P = args.chains
-    path0 = rank * P                      # contiguous shard of the global chain ids; RNG keyed by global id
+    w = Workload(args.mode, ctx, args.chains, rank)
+    P = w.P
     steps_per_unit = N_GRID - 1
     stats = ctx.empty(bh.STATS_LEN)
-    roof = None
-    workload = None
-
-    if args.mode == "linpro32":
-        # config C5: LinPro d=32 GuidedBridge on the fp64 MFMA tile kernel; 65 536 paths by default
-        d = 32
-        if args.chains == 262144:
-            P = 65536
-            path0 = rank * P
-        rng = np.random.default_rng(5)
-        G, G2 = rng.standard_normal((d, d)) / np.sqrt(d), rng.standard_normal((d, d)) / np.sqrt(d)
-        sig = 0.5 * np.eye(d) + 0.05 * G2
-        Po = bh.GuidedBridge(np.linspace(0.0, 1.0, N_GRID), bh.LinPro(-np.eye(d) + 0.1 * G, np.zeros(d), sig),
-                             bh.LinPro(-np.eye(d), np.zeros(d), sig), 0.5 * np.ones(d), ctx=ctx)
-        X = bh.EnsemblePath(Po.tt, d, P, ctx)
-        ll = ctx.empty(P)
-        it = [0]
-        x0 = np.zeros(d)
-
-        def step():
-            it[0] += 1
-            ctx.check(ctx.lib.bhip_sample_solve(ctx.h, Po.h, bh.api._dptr(x0), None, None, P, X.ptr(), P,
-                                                bh.api.vp(ll.data_ptr()), 0, P, 5, it[0], path0))
-
-        bytes_per_pathstep = 8 * d               # write X (8d)
-        flops_per_pathstep = 5 * 2 * d * d       # five d x d mat-vecs
-        kernel = "k_tile<32>"
-        roof = ("mfma", flops_per_pathstep, 78.6, "TFLOP/s")
-        workload = "LinPro d=32 GuidedBridge (dense sigma, pre-inverted Hdiamond), 1001-point grid T=1, independent fused proposals"
-    elif args.mode == "mcmc":
-        Po = build_proposal(ctx)
-        ch = bh.Chains(Po, X0, P, seed=4, path0=path0, store_X=True)
-
-        def step():
-            ch.step(RHO, 1)
-
-        bytes_per_pathstep = 8 * 2 + 16 * 1      # write Xo (8d) + read W, write Wo (16 m')   SURVEY 8(d) mode M
-        kernel = "k_paths<MFHN, LMMU, 1, PCN>"
-    else:
-        Po = build_proposal(ctx)
-        X = bh.EnsemblePath(Po.tt, 2, P, ctx)
-        ll = ctx.empty(P)
-        it = [0]
-        x0 = np.array(X0)
-
-        def step():
-            it[0] += 1
-            ctx.check(ctx.lib.bhip_sample_solve(ctx.h, Po.h, bh.api._dptr(x0), None, None, P, X.ptr(), P,
-                                                bh.api.vp(ll.data_ptr()), 0, P, 4, it[0], path0))
-
-        bytes_per_pathstep = 8 * 2               # write X (8d)                               SURVEY 8(d) mode E
-        kernel = "k_paths<MFHN, LMMU, 1, FRESH>"
 
     for _ in range(args.warmup):
-        step()
+        w.step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -206,10 +240,10 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         evs[k].record()
-        step()
+        w.step()
     evs[args.steps].record()
     if args.mode == "mcmc":
-        ch.stats(stats)
+        w.chains.stats(stats)
     else:
         stats.zero_()
     gathered = bdist.allgather_stats(stats, world)       # the ONE collective: acceptance / log-weight statistics
@@ -224,16 +258,12 @@ def main():
         elapsed = float(tmax.item())
 
     kern_ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps)]
-    kern_avg_s = float(np.mean(kern_ms)) * 1e-3
 
     if rank == 0:
         total_pathsteps = float(world) * P * steps_per_unit * args.steps
-        value = total_pathsteps / elapsed
-        alg_bytes_per_launch = float(P) * steps_per_unit * bytes_per_pathstep
-        achieved = alg_bytes_per_launch / kern_avg_s / 1e9
         out = {
             "metric": "guided-bridge path-steps/sec (whole node)",
-            "value": value,
+            "value": total_pathsteps / elapsed,
             "unit": "path-steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -244,18 +274,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": ("FitzHugh-Nagumo PartialBridge (d=2, scalar noise, L=[1 0], Sigma=1e-10, v=1.1), "
-                                    "1001-point tau-grid T=2, "
-                                    + ("pCN-MCMC rho=0.9: one step = one MH iteration of every chain"
-                                       if args.mode == "mcmc" else "independent fused proposals (sample!+solve!+llikelihood)")),
-                       "mode": args.mode, "paths_per_gpu": P, "grid_points": N_GRID, "path_steps_per_step": P * steps_per_unit * world,
+            "config": {"workload": w.workload, "mode": args.mode, "paths_per_gpu": P, "grid_points": N_GRID,
+                       "path_steps_per_step": P * steps_per_unit * world,
                        "parallelism": f"chains sharded over {world} GPU(s), one RCCL all-gather of the statistics block"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": kernel, "kernel_avg_ms": kern_avg_s * 1e3,
-                         "kernel_min_ms": float(np.min(kern_ms)), "kernel_max_ms": float(np.max(kern_ms)),
-                         "algorithmic_bytes_per_path_step": bytes_per_pathstep,
-                         "path_steps_per_launch": P * steps_per_unit},
+            "roofline": w.roofline(kern_ms),
         }
         if args.mode == "mcmc" and P == 262144:
             # measured once per round with rocprofv3 PMC passes on this exact command (scripts/gpu_profile.sh)
@@ -263,17 +285,24 @@ def main():
             if tr:
                 out["roofline"]["traffic"] = tr
                 out["roofline"]["traffic_source"] = src
-        if workload:
-            out["config"]["workload"] = workload
-        if roof:   # compute-bound kernel: report against the fp64 matrix-core peak
-            tf = float(P) * steps_per_unit * roof[1] / kern_avg_s / 1e12
-            out["roofline"].update({"bound": roof[0], "achieved": tf, "peak": roof[2], "unit": roof[3], "frac": tf / roof[2],
-                                    "algorithmic_flops_per_path_step": roof[1], "hbm_algorithmic_GBs": achieved})
         if args.mode == "mcmc":
             summary = bdist.combine_stats(gathered)
             out["config"]["acceptance_rate"] = summary["acceptance_rate"]
             out["config"]["mean_ll"] = summary["mean_ll"]
             out["config"]["chains_total"] = summary["chains"]
+        if world == 1 and args.mode == "mcmc" and args.chains == 262144 and not args.no_other_modes:
+            # kernel-level figures of the other two workloads (outside the timed region above)
+            others = []
+            del w
+            torch.cuda.empty_cache()
+            for mode in ("proposals", "linpro32"):
+                wo = Workload(mode, ctx, args.chains, rank)
+                ms = kernel_times(wo, args.steps, args.warmup)
+                others.append({"mode": mode, "workload": wo.workload, "paths": wo.P,
+                               "path_steps_per_s": wo.P * steps_per_unit / (float(np.mean(ms)) * 1e-3), "roofline": wo.roofline(ms)})
+                del wo
+                torch.cuda.empty_cache()
+            out["other_modes"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -4,7 +4,7 @@
 #   2. separate --pmc passes (never combined with other trace domains): FETCH_SIZE, WRITE_SIZE, SQ mix
 # Text summaries land in gpurun_out/<tag>_*.txt (copy the ones to be judged into profiles/).
 TAG=${1:-prof}; shift
-ARGS=${@:---steps 6 --warmup 2 --no-cpu-baseline}
+ARGS=${@:---steps 6 --warmup 2 --no-cpu-baseline --no-other-modes}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
