@@ -85,9 +85,21 @@ static int fail(bhip_ctx *ctx, int code, const std::string &msg)
         if (e_ != hipSuccess) return fail(ctx, BHIP_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// every entry point that touches the device: refuse host-only contexts and make the context's device
+// current for the calling thread (a process may drive several devices through several contexts)
 #define NEED_DEVICE(ctx)                                                                          \
     do {                                                                                          \
         if ((ctx)->host_only) return fail(ctx, BHIP_EHIP, "host-only context (device -1): no device work possible"); \
+        if (hipSetDevice((ctx)->device) != hipSuccess) return fail(ctx, BHIP_EHIP, "hipSetDevice failed for the context's device"); \
+    } while (0)
+#define SAME_CTX(ctx, po)                                                                         \
+    do {                                                                                          \
+        if ((po)->ctx != (ctx)) return fail(ctx, BHIP_EINVAL, "the proposal belongs to another context"); \
+    } while (0)
+// the Philox counter holds the global path id in 32 bits
+#define PATH_RANGE(ctx, path0, n)                                                                 \
+    do {                                                                                          \
+        if ((uint64_t)(path0) + (uint64_t)(n) > (1ull << 32)) return fail(ctx, BHIP_EINVAL, "path0 + npaths exceeds the 32-bit path id of the RNG counter"); \
     } while (0)
 
 static int ensure_scratch(bhip_ctx *ctx, size_t bytes)
@@ -274,6 +286,7 @@ int bhip_proposal_create(bhip_ctx *ctx, const double *tt, int N, int model, int 
     if (!ctx || !out) return BHIP_EINVAL;
     *out = nullptr;
     if (!tt || N < 2) return fail(ctx, BHIP_EINVAL, "bhip_proposal_create: need a grid with at least 2 points");
+    if (npar < 0 || (npar > 0 && !par)) return fail(ctx, BHIP_EINVAL, "bhip_proposal_create: parameter vector missing");
     for (int i = 0; i + 1 < N; i++)
         if (!(tt[i + 1] > tt[i])) return fail(ctx, BHIP_EINVAL, "bhip_proposal_create: grid must be strictly increasing");
     bhip_proposal *po = new (std::nothrow) bhip_proposal();
@@ -648,6 +661,7 @@ int bhip_wiener_sample(bhip_ctx *ctx, const double *tt, int N, int mp, double *W
 {
     if (!ctx || !tt || !W_dev || N < 2 || mp < 1 || npaths < 1 || ld < npaths) return fail(ctx, BHIP_EINVAL, "bhip_wiener_sample: bad argument");
     NEED_DEVICE(ctx);
+    PATH_RANGE(ctx, path0, npaths);
     std::vector<double> rdt(N - 1);
     for (int i = 0; i + 1 < N; i++) rdt[i] = std::sqrt(tt[i + 1] - tt[i]);
     int rc = ensure_scratch(ctx, sizeof(double) * (size_t)(N - 1));
@@ -667,6 +681,7 @@ int bhip_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, const d
                double *X_dev, long ldX, double *ll_dev, int skip, long npaths)
 {
     if (!ctx || !po) return BHIP_EINVAL;
+    SAME_CTX(ctx, po);
     if (!W_dev) return fail(ctx, BHIP_EINVAL, "bhip_solve: W_dev is required");
     if (po->g.kind == BHIP_GUIDE_NONE) {
         if (ll_dev) return fail(ctx, BHIP_EINVAL, "bhip_solve: llikelihood needs a guided proposal");
@@ -690,12 +705,14 @@ int bhip_sample_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, 
                       double *X_dev, long ldX, double *ll_dev, int skip, long npaths, uint64_t seed, uint32_t iter, uint32_t path0)
 {
     if (!ctx || !po) return BHIP_EINVAL;
+    SAME_CTX(ctx, po);
     if (po->g.kind == BHIP_GUIDE_NONE) {
         if (ll_dev) return fail(ctx, BHIP_EINVAL, "bhip_sample_solve: llikelihood needs a guided proposal");
         int rc = ensure_plain_rows(const_cast<bhip_proposal *>(po));
         if (rc) return rc;
     }
     if ((W_dev && ldW < npaths) || (X_dev && ldX < npaths)) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
+    PATH_RANGE(ctx, path0, npaths > 0 ? npaths : 0);
     if (po->mh.d > 3) {
         if (x0_dev) return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: shared starting point only");
         return launch_tile_path(po, x0, nullptr, 0, W_dev, ldW, X_dev, ldX, ll_dev, skip, npaths, 1, seed, iter, path0);
@@ -712,6 +729,7 @@ int bhip_sample_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, 
 int bhip_llikelihood(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev, long ldX, double *ll_dev, int skip, long npaths)
 {
     if (!ctx || !po || !X_dev || !ll_dev) return BHIP_EINVAL;
+    SAME_CTX(ctx, po);
     if (po->g.kind == BHIP_GUIDE_NONE) return fail(ctx, BHIP_EINVAL, "bhip_llikelihood: needs a guided proposal");
     KArgs a;
     const double zero[3] = {0, 0, 0};
@@ -725,6 +743,7 @@ int bhip_llikelihood(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev
 int bhip_innovations(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev, long ldX, double *W_dev, long ldW, long npaths)
 {
     if (!ctx || !po || !X_dev || !W_dev) return BHIP_EINVAL;
+    SAME_CTX(ctx, po);
     if (po->mh.d != po->mh.mp) return fail(ctx, BHIP_EINVAL, "bhip_innovations: needs a square, invertible sigma (d == m')");
     if (po->mh.d > 3) return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: innovations not built");
     if (po->g.kind == BHIP_GUIDE_NONE) {
@@ -744,6 +763,7 @@ int bhip_girsanov(bhip_ctx *ctx, const bhip_proposal *po, const double *par_t, i
                   double *out_dev, long npaths)
 {
     if (!ctx || !po || !X_dev || !out_dev) return BHIP_EINVAL;
+    SAME_CTX(ctx, po);
     NEED_DEVICE(ctx);
     const ModelHost &mh = po->mh;
     girsanov_fn f = nullptr;
@@ -805,9 +825,11 @@ int bhip_gpupdate(int d, int m, const double *Hd, const double *V, const double 
 int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uint32_t path0, uint64_t seed, int flags, bhip_chains **out)
 {
     if (!ctx || !po || !out) return BHIP_EINVAL;
+    SAME_CTX(ctx, po);
     *out = nullptr;
     NEED_DEVICE(ctx);
     if (nchains < 1) return fail(ctx, BHIP_EINVAL, "nchains must be positive");
+    PATH_RANGE(ctx, path0, nchains);
     if (po->g.kind == BHIP_GUIDE_NONE) return fail(ctx, BHIP_EINVAL, "chains need a guided proposal");
     if (po->mh.d > 3) return fail(ctx, BHIP_EUNSUPPORTED, "chains: d <= 3");
     bhip_chains *ch = new (std::nothrow) bhip_chains();
@@ -867,6 +889,7 @@ int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip)
     bhip_ctx *ctx = ch->ctx;
     if (!ch->inited) return fail(ctx, BHIP_ESTATE, "bhip_chains_step: call bhip_chains_init first");
     if (iters < 0) return fail(ctx, BHIP_EINVAL, "iters must be >= 0");
+    if (!(rho >= -1.0 && rho <= 1.0)) return fail(ctx, BHIP_EINVAL, "rho must lie in [-1, 1] (sqrt(1 - rho^2) is the weight of the fresh noise)");
     const bhip_proposal *po = ch->po;
     KArgs a;
     int rc = fill_common(po, a, ch->x0, nullptr, ch->n, skip);
@@ -888,6 +911,7 @@ int bhip_chains_stats(bhip_chains *ch, double *stats_dev)
     if (!ch || !stats_dev) return BHIP_EINVAL;
     bhip_ctx *ctx = ch->ctx;
     if (!ch->inited) return fail(ctx, BHIP_ESTATE, "bhip_chains_stats: chains not initialised");
+    NEED_DEVICE(ctx);
     const int nparts = (int)std::min<long>(256, (ch->n + 1023) / 1024);
     hipLaunchKernelGGL(k_chain_stats_partial, dim3(nparts), dim3(256), 0, ctx->stream, ch->llcur, ch->acc, ch->n, ch->statpart);
     HIPCHK(ctx, hipGetLastError());
@@ -900,6 +924,7 @@ int bhip_chains_get(bhip_chains *ch, double *ll, int64_t *acc)
 {
     if (!ch) return BHIP_EINVAL;
     bhip_ctx *ctx = ch->ctx;
+    NEED_DEVICE(ctx);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (ll) HIPCHK(ctx, hipMemcpy(ll, ch->llcur, sizeof(double) * ch->n, hipMemcpyDeviceToHost));
     if (acc) {
@@ -940,6 +965,7 @@ int bhip_chains_get_paths(bhip_chains *ch, long p0, long np, double *X_aos, doub
     if (!ch) return BHIP_EINVAL;
     bhip_ctx *ctx = ch->ctx;
     if (!ch->inited) return fail(ctx, BHIP_ESTATE, "chains not initialised");
+    NEED_DEVICE(ctx);
     if (p0 < 0 || np < 0 || p0 + np > ch->n) return fail(ctx, BHIP_EINVAL, "chain range out of bounds");
     if (np == 0 || (!X_aos && !W_aos)) return BHIP_OK;
     const long N = (long)ch->po->tt.size(), d = ch->po->mh.d, mp = ch->po->mh.mp;
@@ -959,6 +985,7 @@ int bhip_chains_current_X(bhip_chains *ch, double *X_dev, long ldX)
     if (!ch || !X_dev) return BHIP_EINVAL;
     bhip_ctx *ctx = ch->ctx;
     if (!ch->inited) return fail(ctx, BHIP_ESTATE, "chains not initialised");
+    NEED_DEVICE(ctx);
     if (ldX < ch->n) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than the number of chains");
     const long N = (long)ch->po->tt.size(), mp = ch->po->mh.mp;
     double *tmp = nullptr;
@@ -987,6 +1014,7 @@ int bhip_chains_pathstats(bhip_chains *ch, double *mean, double *m2)
     if (!ch || !mean || !m2) return BHIP_EINVAL;
     bhip_ctx *ctx = ch->ctx;
     if (!ch->inited) return fail(ctx, BHIP_ESTATE, "chains not initialised");
+    NEED_DEVICE(ctx);
     const int N = (int)ch->po->tt.size(), d = ch->po->mh.d;
     const size_t nm = (size_t)N * d, n2 = (size_t)N * d * d, nX = (size_t)N * d * ch->n;
     double *tmp = nullptr;

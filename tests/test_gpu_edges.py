@@ -85,6 +85,33 @@ def test_padded_leading_dimension_and_raw_pointers(ctx):
     assert lib.bhip_solve(h, Po.h, bh.api._dptr(x0), None, bh.api.vp(Wt.data_ptr()), ld, bh.api.vp(X2.data_ptr()), ld, None, -1, P) == -1
 
 
+def test_more_argument_checks(ctx):
+    c = _fhn_case(problems.tau_grid(2.0, 33))
+    Po = c.bh_proposal(bh, ctx)
+    lib, h = ctx.lib, ctx.h
+    ch = bh.Chains(Po, c.x0, 64, seed=1)
+    for rho in (1.5, -1.01, float("nan")):
+        with pytest.raises(bh.BridgeError, match="rho"):
+            ch.step(rho, 1)
+    ch.step(1.0, 1)                       # rho = 1: the proposal equals the current W, always accepted
+    assert np.array_equal(ch.acc(), np.ones(64, dtype=np.int64))
+    # the RNG counter holds the global path id in 32 bits
+    with pytest.raises(bh.BridgeError, match="32-bit"):
+        bh.Chains(Po, c.x0, 64, seed=1, path0=2 ** 32 - 10)
+    with pytest.raises(bh.BridgeError, match="32-bit"):
+        bh.sample_solve(c.x0, Po, 64, seed=1, path0=2 ** 32 - 63)
+    X, _, _ = bh.sample_solve(c.x0, Po, 64, seed=1, path0=2 ** 32 - 64)      # the last admissible shard
+    assert bool(torch.isfinite(X.data).all())
+    # a proposal is tied to the context that created it
+    other = bh.Context(0)
+    ll = ctx.empty(64)
+    assert lib.bhip_llikelihood(other.h, Po.h, X.ptr(), 64, bh.api.vp(ll.data_ptr()), 0, 64) == -1
+    assert b"another context" in lib.bhip_last_error(other.h)
+    # parameter vector missing
+    hh = bh.api.vp()
+    assert lib.bhip_proposal_create(h, bh.api._dptr(np.linspace(0, 1, 5)), 5, o.MODEL_OU, 1, None, 2, C.byref(hh)) == -1
+
+
 def test_script_grid_10001_points(ctx):
     """the paper scripts' grid: dt = 1/5000, T = 2, time-changed (partialbridge_fitzhugh.jl:11-14)"""
     T, dt = 2.0, 1 / 5000
