@@ -381,10 +381,10 @@ static int build_tile_data(bhip_proposal *po)
 {
     bhip_ctx *ctx = po->ctx;
     const int N = (int)po->tt.size(), d = po->mh.d;
-    if (po->g.kind == BHIP_GUIDE_NONE) return BHIP_OK;
+    const bool plain = po->g.kind == BHIP_GUIDE_NONE;   // forward Euler-Maruyama: the guide matrices are zero
     if (po->mh.id != BHIP_MODEL_LINPRO || (d != 16 && d != 32))
         return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: LinPro target with d = 16 or 32");
-    if (!po->has_aux || (po->aux.kind != BHIP_AUX_AFFINE && po->aux.kind != BHIP_AUX_LINPRO))
+    if (!plain && (!po->has_aux || (po->aux.kind != BHIP_AUX_AFFINE && po->aux.kind != BHIP_AUX_LINPRO)))
         return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: time-constant auxiliary process");
     const size_t DD = (size_t)d * d, STEP = DD + d;
     std::vector<double> steps((size_t)(N - 1) * STEP), hdr((size_t)(N - 1) * 2);
@@ -394,7 +394,8 @@ static int build_tile_data(bhip_proposal *po)
         //   (nu,H)       : H_i (nu_i - x) as in the reference (PartialBridge! likewise)
         //   PartialBridge: L'M(v - mu - Lx) = (L'ML)(nu - x) with any nu solving L nu = v - mu: nu = L'(LL')^-1 (v - mu)
         Mat Hm, nu;
-        if (po->g.kind == BHIP_GUIDE_HV) { Hm = inv(po->g.Hd[i]); nu = po->g.V[i]; }
+        if (plain) { Hm = Mat(d, d); nu = Mat(d, 1); }
+        else if (po->g.kind == BHIP_GUIDE_HV) { Hm = inv(po->g.Hd[i]); nu = po->g.V[i]; }
         else if (po->g.kind == BHIP_GUIDE_LMMU) {
             const Mat &L = po->g.L[i];
             Hm = (tr(L) * po->g.M[i]) * L;
@@ -409,13 +410,14 @@ static int build_tile_data(bhip_proposal *po)
     cst.assign(4 * DD + 5 * d, 0.0);
     const double *par = po->mh.par.data();
     to_fragments(Mat(d, d, par), &cst[0]);                               // B
-    to_fragments(po->aux.B(po->tt[0]), &cst[DD]);                        // B~
+    if (!plain) to_fragments(po->aux.B(po->tt[0]), &cst[DD]);            // B~
     to_fragments(po->mh.a, &cst[2 * DD]);                                // a = sigma*sigma'
     to_fragments(Mat(d, d, par + DD + d), &cst[3 * DD]);                 // sigma
     std::memcpy(&cst[4 * DD], par + DD, sizeof(double) * d);             // mu
-    const bool lin = po->aux.linpro_form();
-    if (lin) std::memcpy(&cst[4 * DD + d], po->aux.mu(), sizeof(double) * d);                        // mu~ (else 0)
-    else { const Mat be = po->aux.beta(po->tt[0]); std::memcpy(&cst[4 * DD + 2 * d], be.a.data(), sizeof(double) * d); }   // beta~ (else 0)
+    if (!plain) {
+        if (po->aux.linpro_form()) std::memcpy(&cst[4 * DD + d], po->aux.mu(), sizeof(double) * d);                        // mu~ (else 0)
+        else { const Mat be = po->aux.beta(po->tt[0]); std::memcpy(&cst[4 * DD + 2 * d], be.a.data(), sizeof(double) * d); }   // beta~ (else 0)
+    }
     if (po->g.kind == BHIP_GUIDE_HV) std::memcpy(&cst[4 * DD + 3 * d], po->g.V[N - 1].a.data(), sizeof(double) * d);       // vend
     for (double **q : {&po->d_steps, &po->d_hdr, &po->d_cst})
         if (*q) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(*q)); *q = nullptr; }
@@ -590,7 +592,7 @@ int bhip_proposal_info(const bhip_proposal *po, int *N, int *d, int *mp, int *m,
 static int ensure_plain_rows(bhip_proposal *po)
 {   // forward EM without a guide: rows = (t, dt, sqrt(dt))
     NEED_DEVICE(po->ctx);
-    if (po->d_rows) return BHIP_OK;
+    if (po->d_rows || po->d_steps) return BHIP_OK;
     return finish_guide(po);
 }
 

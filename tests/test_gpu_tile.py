@@ -99,3 +99,24 @@ def test_large_d_unsupported_combinations_fail_loudly(ctx):
     P8 = bh.LinPro(-np.eye(8), np.zeros(8), np.eye(8))
     with pytest.raises(bh.BridgeError, match="large-d"):
         bh.GuidedBridge(c.tt, P8, P8, np.ones(8), ctx=ctx)
+
+
+@pytest.mark.parametrize("d", [16, 32])
+def test_tile_kernel_forward_euler_maruyama(ctx, d):
+    """plain solve(EulerMaruyama(), u, W, P) of a LinPro{SVector{d}} (src/euler.jl:135-152): the tile kernel with
+    a zero guide; external W against the oracle, fused noise against the external-W run."""
+    c = problems.linpro_big_case(d, 121)
+    P = 70
+    proc = bh.PlainProcess(c.tt, c.bh_process(bh), ctx=ctx)
+    x0 = 0.3 * np.ones(d)
+    Wh = np.stack([o.wiener_sample(c.tt, d, 12, p, 0) for p in range(P)])
+    W = bh.EnsemblePath.from_paths(c.tt, Wh, ctx)
+    Xh = bh.solve(bh.EulerMaruyama(), x0, W, proc).paths()
+    Xr = np.stack([o.solve_em(o.MODEL_LINPRO, d, d, c.par, c.tt, x0, Wh[p]) for p in range(P)])
+    assert np.abs(Xh - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max())
+    assert np.array_equal(Xh[:, 0, :], np.tile(x0, (P, 1)))
+    X2, W2, ll = bh.sample_solve(x0, proc, P, seed=12, store_W=True)
+    assert ll is None and np.array_equal(W2.paths(), Wh)
+    assert np.abs(X2.paths() - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max())
+    with pytest.raises(bh.BridgeError):          # llikelihood needs a guided proposal
+        bh.solve(bh.EulerMaruyama(), x0, W, proc, ll=ctx.empty(P))
