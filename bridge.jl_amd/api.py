@@ -242,26 +242,41 @@ class Pendulum(ContinuousTimeProcess):
 
 class UserProcess(ContinuousTimeProcess):
     """A user-defined target process: the body of `Bridge.b(t, x, P)` as HIP C++ text (compiled for
-    gfx950 with hipRTC on first use) + a constant diffusion matrix sigma [d, mp].
+    gfx950 with hipRTC on first use) + a constant diffusion matrix sigma [d, mp],
 
         P = UserProcess(2, "o[0] = (x[0]-x[1]-x[0]*x[0]*x[0]+par[1])/par[0]; o[1] = par[2]*x[0]-x[1]+par[3];",
                         par=[0.1, 0.0, 1.5, 0.8], sigma=[[0.0], [0.3]])
 
-    The text sees `double t`, `const double* x`, `const double* par` and writes `double* o`."""
+    or, with `sigma_src`, the body of a state-dependent `Bridge.sigma(t, x, P)` that fills `s` (d x mp,
+    column-major, zero-initialised) -- then `constdiff(P)` is false:
 
-    def __init__(self, d, drift_src, par, sigma, ctx=None):
+        P = UserProcess(2, drift_src, par, sigma_src="s[0] = par[5]*sqrt(1.0 + x[0]*x[0]); s[3] = par[6];", mp=2)
+
+    The texts see `double t`, `const double* x`, `const double* par`; the drift writes `double* o`."""
+
+    def __init__(self, d, drift_src, par, sigma=None, ctx=None, sigma_src=None, mp=None):
         self.ctx = ctx or default_context()
         self.d = int(d)
-        self.sigma = np.asarray(sigma, dtype=np.float64).reshape(self.d, -1)
-        self.mp = self.sigma.shape[1]
         self.par = np.atleast_1d(np.asarray(par, dtype=np.float64)).ravel()
-        self.drift_src = drift_src
+        self.drift_src, self.sigma_src = drift_src, sigma_src
         mid = C.c_int()
-        self.ctx.check(self.ctx.lib.bhip_model_define(self.ctx.h, self.d, self.mp, len(self.par), drift_src.encode(), C.byref(mid)))
+        if sigma_src is None:
+            if sigma is None:
+                raise BridgeError("UserProcess: give a constant sigma matrix or a sigma_src text")
+            self.sigma = np.asarray(sigma, dtype=np.float64).reshape(self.d, -1)
+            self.mp = self.sigma.shape[1]
+            self.ctx.check(self.ctx.lib.bhip_model_define(self.ctx.h, self.d, self.mp, len(self.par), drift_src.encode(), C.byref(mid)))
+        else:
+            if sigma is not None:
+                raise BridgeError("UserProcess: sigma and sigma_src are exclusive")
+            self.sigma = None
+            self.mp = int(mp if mp is not None else d)
+            self.ctx.check(self.ctx.lib.bhip_model_define_sigma(self.ctx.h, self.d, self.mp, len(self.par), drift_src.encode(),
+                                                                sigma_src.encode(), C.byref(mid)))
         self.model_id = mid.value
 
     def params(self):
-        return np.concatenate([self.par, _cm(self.sigma)])
+        return self.par if self.sigma is None else np.concatenate([self.par, _cm(self.sigma)])
 
 
 # ---- auxiliary processes (Bridge.B / Bridge.beta / Bridge.sigma / Bridge.a 2-arg methods)

@@ -261,13 +261,18 @@ int bhip_download_aos(bhip_ctx *ctx, const double *dev, int N, int dim, long ld,
 }
 
 /* ------------------------------------------------------------------ user-defined drift (hipRTC) */
-int bhip_model_define(bhip_ctx *ctx, int d, int mp, int npar, const char *drift_src, int *model_id)
+static int model_define(bhip_ctx *ctx, int d, int mp, int npar, const char *drift_src, const char *sigma_src, int *model_id)
 {
     if (!ctx || !drift_src || !model_id) return BHIP_EINVAL;
-    if (d < 1 || d > 3 || mp < 1 || mp > 3) return fail(ctx, BHIP_EUNSUPPORTED, "bhip_model_define: user drifts run on the path-per-lane kernel, d and m' in 1..3");
-    if (npar < 0 || npar + d * mp + 2 * d * d > 40) return fail(ctx, BHIP_EINVAL, "bhip_model_define: too many parameters (npar + d*mp + 2*d*d <= 40)");
+    if (d < 1 || d > 3 || mp < 1 || mp > 3) return fail(ctx, BHIP_EUNSUPPORTED, "bhip_model_define: user processes run on the path-per-lane kernel, d and m' in 1..3");
+    const int derived = sigma_src ? 0 : d * mp + 2 * d * d;
+    if (npar < 0 || npar + derived > 40) return fail(ctx, BHIP_EINVAL, "bhip_model_define: too many parameters (npar + d*mp + 2*d*d <= 40)");
     std::unique_ptr<UserModel> um(new UserModel());
     um->d = d; um->mp = mp; um->npar = npar; um->drift = drift_src;
+    if (sigma_src) {
+        um->sigma = sigma_src;
+        if (um->sigma.find_first_not_of(" \t\r\n") == std::string::npos) return fail(ctx, BHIP_EINVAL, "bhip_model_define_sigma: empty sigma text");
+    }
     // validate the text now (compilation needs no GPU): plain Euler-Maruyama instantiation
     std::vector<char> code;
     std::string low;
@@ -278,6 +283,17 @@ int bhip_model_define(bhip_ctx *ctx, int d, int mp, int npar, const char *drift_
     *model_id = um->id;
     user_models().push_back(std::move(um));
     return BHIP_OK;
+}
+
+int bhip_model_define(bhip_ctx *ctx, int d, int mp, int npar, const char *drift_src, int *model_id)
+{
+    return model_define(ctx, d, mp, npar, drift_src, nullptr, model_id);
+}
+
+int bhip_model_define_sigma(bhip_ctx *ctx, int d, int mp, int npar, const char *drift_src, const char *sigma_src, int *model_id)
+{
+    if (!sigma_src) return ctx ? fail(ctx, BHIP_EINVAL, "bhip_model_define_sigma: sigma text missing") : BHIP_EINVAL;
+    return model_define(ctx, d, mp, npar, drift_src, sigma_src, model_id);
 }
 
 /* ------------------------------------------------------------------ proposal */
@@ -300,6 +316,16 @@ int bhip_proposal_create(bhip_ctx *ctx, const double *tt, int N, int model, int 
         const UserModel *um = find_user_model(model);
         if (!um) { rc = BHIP_EINVAL; err = "unknown user model id"; }
         else if (d > 0 && d != um->d) { rc = BHIP_EINVAL; err = "dimension does not match the user model"; }
+        else if (!um->sigma.empty()) {   // state-dependent sigma(t,x,P): nothing to derive on the host
+            if (npar != um->npar) { rc = BHIP_EINVAL; err = "user model with a sigma text expects exactly its npar parameters"; }
+            else {
+                ModelHost &mh = po->mh;
+                mh.id = model; mh.d = um->d; mh.mp = um->mp; mh.constdiff = false;
+                mh.par.assign(par, par + npar);
+                mh.a = Mat(um->d, um->d);
+                mh.dpar = mh.par;
+            }
+        }
         else if (npar != um->npar + um->d * um->mp) { rc = BHIP_EINVAL; err = "user model expects npar + d*mp parameters (drift parameters, then sigma)"; }
         else {
             ModelHost &mh = po->mh;
@@ -630,7 +656,15 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
     int fl = 0;
     if (noise == NOISE_PCN) fl = a.Xo ? 1 : 0;
     else fl = (a.X ? 1 : 0) | (a.Wout ? 2 : 0);
-    if (a.rs != row_stride(gk, po->mh.d, po->g.m)) return fail(ctx, BHIP_ESTATE, "row stride mismatch");
+    if (a.rs != row_stride(gk, po->mh.d, po->g.m, po->mh.constdiff)) return fail(ctx, BHIP_ESTATE, "row stride mismatch");
+    if (!po->mh.constdiff) {
+        // constdiff(P) == false.  The reference's extra log-likelihood terms exist for PartialBridge only
+        // (src/partialbridge.jl:79-84); its other !constdiff branches reference undefined names.
+        const bool wants_ll = a.ll != nullptr || noise == NOISE_PCN || noise == NOISE_LLONLY;
+        if (wants_ll && gk != BHIP_GUIDE_LMMU)
+            return fail(ctx, BHIP_EUNSUPPORTED, "llikelihood with a state-dependent sigma is defined for PartialBridge (L,M,mu) only");
+        if (noise == NOISE_INNOV) return fail(ctx, BHIP_EUNSUPPORTED, "innovations need a constant, invertible sigma");
+    }
     const int mo = gk == BHIP_GUIDE_LMMU ? po->g.m : 1;
     if (po->mh.id >= USER_MODEL_BASE) {   // hipRTC-compiled user drift: compile this instantiation on first use
         if (gk_dispatch == BHIP_GUIDE_NUH_INPLACE) fl |= 4;

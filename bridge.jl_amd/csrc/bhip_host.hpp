@@ -398,6 +398,7 @@ struct ModelHost {
     std::vector<double> par;   // user parameters
     std::vector<double> dpar;  // device parameter block (par + derived constants)
     Mat a;                     // a = sigma*sigma' (constant diffusivity)
+    bool constdiff = true;     // false: hipRTC user process with a state-dependent sigma(t,x,P)
 };
 
 inline int model_setup(int id, int d_hint, const double *par, int npar, ModelHost &mh, std::string &err)
@@ -458,12 +459,12 @@ inline int model_setup(int id, int d_hint, const double *par, int npar, ModelHos
 }
 
 // ---- per-step rows for the d <= 3 kernel (layout: RowLayout in bhip_path_kernel.h)
-inline int row_stride(int gk, int d, int mo)
+inline int row_stride(int gk, int d, int mo, bool constdiff = true)
 {
     if (gk == BHIP_GUIDE_NONE) return 4;
     int glen = 0;
     if (gk == BHIP_GUIDE_HV) glen = d == 1 ? 2 : d == 2 ? 7 : 13;
-    else if (gk == BHIP_GUIDE_LMMU) glen = mo * d + mo + 2 * d * mo;
+    else if (gk == BHIP_GUIDE_LMMU) glen = mo * d + mo + 2 * d * mo + (constdiff ? 0 : 2 * d * d);
     else glen = d * d + d;
     const int len = 3 + d * d + d + glen;
     return (len + 1) & ~1;
@@ -473,7 +474,7 @@ inline void pack_rows(const std::vector<double> &tt, const ModelHost &mh, const 
 {
     const int N = (int)tt.size(), d = mh.d;
     const int gk = g.kind == BHIP_GUIDE_NUH_INPLACE ? BHIP_GUIDE_NUH : g.kind;
-    rs = row_stride(gk, d, g.m);
+    rs = row_stride(gk, d, g.m, mh.constdiff);
     rows.assign((size_t)(N - 1) * rs, 0.0);
     for (int i = 0; i < N - 1; i++) {
         double *r = &rows[(size_t)i * rs];
@@ -504,9 +505,18 @@ inline void pack_rows(const std::vector<double> &tt, const ModelHost &mh, const 
             std::memcpy(q, L.a.data(), sizeof(double) * m * d);
             for (int j = 0; j < m; j++) q[m * d + j] = g.v.a[j] - g.mu[i].a[j];   // (v - mu[i])
             const Mat R = tr(L) * M;                 // r = L'*M*(...)            src/partialbridge.jl:57
-            const Mat G = (mh.a * tr(L)) * M;        // a*L'*M*(...)              src/partialbridge.jl:54
             std::memcpy(q + m * d + m, R.a.data(), sizeof(double) * d * m);
-            std::memcpy(q + m * d + m + d * m, G.a.data(), sizeof(double) * d * m);
+            if (mh.constdiff) {
+                const Mat G = (mh.a * tr(L)) * M;    // a*L'*M*(...)              src/partialbridge.jl:54
+                std::memcpy(q + m * d + m + d * m, G.a.data(), sizeof(double) * d * m);
+            } else {
+                // a(t,x) is evaluated in the kernel: the slot holds M; then H = L'*M*L (src/partialbridge.jl:58)
+                // and the auxiliary a~(t_i) for the extra log-likelihood terms (src/partialbridge.jl:79-84)
+                std::memcpy(q + m * d + m + d * m, M.a.data(), sizeof(double) * m * m);
+                const Mat H = R * L, at = Pt->a(tt[i]);
+                std::memcpy(q + m * d + m + 2 * d * m, H.a.data(), sizeof(double) * d * d);
+                std::memcpy(q + m * d + m + 2 * d * m + d * d, at.a.data(), sizeof(double) * d * d);
+            }
         } else {
             std::memcpy(q, g.H[i].a.data(), sizeof(double) * d * d);
             std::memcpy(q + d * d, g.nu[i].a.data(), sizeof(double) * d);

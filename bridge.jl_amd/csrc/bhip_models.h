@@ -5,6 +5,9 @@
 // derived constants the host computes once (a = sigma*sigma' in the reference's operation order).
 // Member functions follow the reference expressions literally (operation order matters: results
 // are compared bit-for-bit with the CPU oracle; device code is built with -ffp-contract=off).
+//   b(t, x, o)          o = b(t,x,P)
+//   sdw(t, x, dw, o)    o = sigma(t,x,P)*dw      (every built-in process has a constant sigma and ignores t, x;
+//   amul(t, x, r, o)    o = a(t,x,P)*r            user processes compiled by hipRTC may depend on them)
 #pragma once
 #include "../../include/bridgehip.h"
 #include <hip/hip_runtime.h>
@@ -20,8 +23,8 @@ struct MOU {
     double beta, sig, a, isig;
     BHIP_DEV explicit MOU(const double *p) : beta(p[0]), sig(p[1]), a(p[2]), isig(p[3]) {}
     BHIP_DEV void b(double, const double *x, double *o) const { o[0] = -beta * x[0]; }
-    BHIP_DEV void sdw(const double *dw, double *o) const { o[0] = sig * dw[0]; }
-    BHIP_DEV void amul(const double *r, double *o) const { o[0] = a * r[0]; }
+    BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const { o[0] = sig * dw[0]; }
+    BHIP_DEV void amul(double, const double *, const double *r, double *o) const { o[0] = a * r[0]; }
     BHIP_DEV void sinv_mul(const double *v, double *o) const { o[0] = isig * v[0]; }   // inv(sigma)*v
 };
 
@@ -46,7 +49,7 @@ struct MLinPro {
             o[i] = s;
         }
     }
-    BHIP_DEV void sdw(const double *dw, double *o) const
+    BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const
     {
         const double *S = p + D * D + D;
 #pragma unroll
@@ -57,7 +60,7 @@ struct MLinPro {
             o[i] = s;
         }
     }
-    BHIP_DEV void amul(const double *r, double *o) const
+    BHIP_DEV void amul(double, const double *, const double *r, double *o) const
     {
         const double *A = p + 2 * D * D + D;
 #pragma unroll
@@ -94,8 +97,8 @@ struct MFHN {
         o[0] = (x[0] - x[1] - x[0] * x[0] * x[0] + s) / eps;
         o[1] = gam * x[0] - x[1] + beta;
     }
-    BHIP_DEV void sdw(const double *dw, double *o) const { o[0] = 0.0; o[1] = sig * dw[0]; }
-    BHIP_DEV void amul(const double *r, double *o) const { o[0] = 0.0; o[1] = a22 * r[1]; }
+    BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const { o[0] = 0.0; o[1] = sig * dw[0]; }
+    BHIP_DEV void amul(double, const double *, const double *r, double *o) const { o[0] = 0.0; o[1] = a22 * r[1]; }
 };
 
 // ---- NclarDiffusion                   project_partialbridge/partialbridge_nclar.jl:52-61
@@ -109,8 +112,8 @@ struct MNCLAR {
     {
         o[0] = x[1]; o[1] = x[2]; o[2] = -al * sin(om * x[2]);
     }
-    BHIP_DEV void sdw(const double *dw, double *o) const { o[0] = 0.0; o[1] = 0.0; o[2] = sig * dw[0]; }
-    BHIP_DEV void amul(const double *r, double *o) const { o[0] = 0.0; o[1] = 0.0; o[2] = a33 * r[2]; }
+    BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const { o[0] = 0.0; o[1] = 0.0; o[2] = sig * dw[0]; }
+    BHIP_DEV void amul(double, const double *, const double *r, double *o) const { o[0] = 0.0; o[1] = 0.0; o[2] = a33 * r[2]; }
 };
 
 // ---- IntegratedDiffusion              test/partialbridge.jl:7-15
@@ -124,8 +127,8 @@ struct MIntDiff {
     {
         o[0] = x[1]; o[1] = -(x[1] + sin(x[1])) + 0.5;
     }
-    BHIP_DEV void sdw(const double *dw, double *o) const { o[0] = 0.0; o[1] = gam * dw[0]; }
-    BHIP_DEV void amul(const double *r, double *o) const { o[0] = 0.0; o[1] = a22 * r[1]; }
+    BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const { o[0] = 0.0; o[1] = gam * dw[0]; }
+    BHIP_DEV void amul(double, const double *, const double *r, double *o) const { o[0] = 0.0; o[1] = a22 * r[1]; }
 };
 
 // ---- Lorenz                           src/Models.jl:41-58 (test/euler.jl:45-50 with s = 3,3,3)
@@ -143,8 +146,8 @@ struct MLorenz {
         o[1] = x[0] * (t2 - x[2]) - x[1];
         o[2] = x[0] * x[1] - t3 * x[2];
     }
-    BHIP_DEV void sdw(const double *dw, double *o) const { o[0] = s1 * dw[0]; o[1] = s2 * dw[1]; o[2] = s3 * dw[2]; }
-    BHIP_DEV void amul(const double *r, double *o) const { o[0] = a1 * r[0]; o[1] = a2 * r[1]; o[2] = a3 * r[2]; }
+    BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const { o[0] = s1 * dw[0]; o[1] = s2 * dw[1]; o[2] = s3 * dw[2]; }
+    BHIP_DEV void amul(double, const double *, const double *r, double *o) const { o[0] = a1 * r[0]; o[1] = a2 * r[1]; o[2] = a3 * r[2]; }
 };
 
 // ---- Models.FitzHughNagumo            src/Models.jl:9-20  (diagonal 2-d noise)
@@ -161,8 +164,8 @@ struct MFHN2 {
         o[0] = (x[0] - x[0] * x[0] * x[0] - x[1] + s) / eps;
         o[1] = gam * x[0] - x[1] + beta;
     }
-    BHIP_DEV void sdw(const double *dw, double *o) const { o[0] = s1 * dw[0]; o[1] = s2 * dw[1]; }
-    BHIP_DEV void amul(const double *r, double *o) const { o[0] = a1 * r[0]; o[1] = a2 * r[1]; }
+    BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const { o[0] = s1 * dw[0]; o[1] = s2 * dw[1]; }
+    BHIP_DEV void amul(double, const double *, const double *r, double *o) const { o[0] = a1 * r[0]; o[1] = a2 * r[1]; }
 };
 
 // ---- Pendulum                         src/Models.jl:69-88
@@ -173,8 +176,8 @@ struct MPendulum {
     double th2, gam, a22;
     BHIP_DEV explicit MPendulum(const double *p) : th2(p[0]), gam(p[1]), a22(p[2]) {}
     BHIP_DEV void b(double, const double *x, double *o) const { o[0] = x[1]; o[1] = -th2 * sin(x[0]); }
-    BHIP_DEV void sdw(const double *dw, double *o) const { o[0] = 0.0; o[1] = gam * dw[0]; }
-    BHIP_DEV void amul(const double *r, double *o) const { o[0] = 0.0; o[1] = a22 * r[1]; }
+    BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const { o[0] = 0.0; o[1] = gam * dw[0]; }
+    BHIP_DEV void amul(double, const double *, const double *r, double *o) const { o[0] = 0.0; o[1] = a22 * r[1]; }
 };
 
 // ---- Wiener{SVector{D}}: b = 0, sigma = a = I            src/wiener.jl:143-167
@@ -188,12 +191,12 @@ struct MWiener {
 #pragma unroll
         for (int k = 0; k < D; k++) o[k] = 0.0;
     }
-    BHIP_DEV void sdw(const double *dw, double *o) const
+    BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const
     {
 #pragma unroll
         for (int k = 0; k < D; k++) o[k] = dw[k];
     }
-    BHIP_DEV void amul(const double *r, double *o) const
+    BHIP_DEV void amul(double, const double *, const double *r, double *o) const
     {
 #pragma unroll
         for (int k = 0; k < D; k++) o[k] = r[k];

@@ -30,6 +30,11 @@ template <class...> using bhip_void_t = void;
 template <class M, class = void> struct has_sinv { static constexpr bool value = false; };
 template <class M> struct has_sinv<M, bhip_void_t<decltype(&M::sinv_mul)>> { static constexpr bool value = true; };
 
+// constdiff(P) (src/types.jl:36): every built-in process has a constant sigma; a hipRTC user process with a
+// state-dependent sigma(t,x,P) declares `static constexpr bool STATE_SIGMA = true` and provides amat().
+template <class M, class = void> struct is_constdiff { static constexpr bool value = true; };
+template <class M> struct is_constdiff<M, bhip_void_t<decltype(M::STATE_SIGMA)>> { static constexpr bool value = !M::STATE_SIGMA; };
+
 struct KArgs {
     const double *rows;   // [N-1][rs] packed per-step coefficients (device)
     int rs, N, skip;
@@ -88,22 +93,26 @@ template <class T> BHIP_DEV T ld_stream(const T *p)
     else return *p;
 }
 
-template <int GK, int D, int MO>
+// CD = constant diffusivity.  With a state-dependent a(t,x) the PartialBridge row carries M (in place of
+// the pre-multiplied (aL')M) and, for the extra log-likelihood terms of src/partialbridge.jl:79-84,
+// H = L'ML and the auxiliary a~.
+template <int GK, int D, int MO, bool CD = true>
 struct RowLayout {
     static constexpr int T = 0, DT = 1, RDT = 2;
     static constexpr int B = 3;              // D*D col-major
     static constexpr int BETA = 3 + D * D;   // D
     static constexpr int G = 3 + D * D + D;  // guide part
     static constexpr int GLEN = GK == BHIP_GUIDE_HV ? (D == 1 ? 2 : D == 2 ? 7 : 13)
-                              : GK == BHIP_GUIDE_LMMU ? (MO * D + MO + 2 * D * MO)
+                              : GK == BHIP_GUIDE_LMMU ? (MO * D + MO + 2 * D * MO + (CD ? 0 : 2 * D * D))
                               : GK == BHIP_GUIDE_NUH ? (D * D + D) : 0;
+    static constexpr int LM_H = G + MO * D + MO + 2 * D * MO;   // LMMU, !CD: H (D*D), then a~ (D*D)
     static constexpr int LEN = GK == BHIP_GUIDE_NONE ? 3 : G + GLEN;
     static constexpr int RS = (LEN + 1) & ~1;
 };
 
 // r((i,t),x,Po) and g = a*L'*M*q | a*r, from the packed row
 template <class M, int GK, int MO>
-BHIP_DEV void guide_terms(const M &model, const double *g, const double *x, double *r, double *gd)
+BHIP_DEV void guide_terms(const M &model, double t, const double *g, const double *x, double *r, double *gd)
 {
     constexpr int D = M::D;
     if constexpr (GK == BHIP_GUIDE_HV) {
@@ -120,7 +129,7 @@ BHIP_DEV void guide_terms(const M &model, const double *g, const double *x, doub
             r[1] = (g[3] * w0 + g[4] * w1 + g[5] * w2) / g[9];
             r[2] = (g[6] * w0 + g[7] * w1 + g[8] * w2) / g[9];
         }
-        model.amul(r, gd);
+        model.amul(t, x, r, gd);
     } else if constexpr (GK == BHIP_GUIDE_LMMU) {
         // q = (v - mu[i]) - L[i]*x ; r = (L'M)q ; g = ((aL')M)q    src/partialbridge.jl:53-57
         double q[MO];
@@ -132,12 +141,43 @@ BHIP_DEV void guide_terms(const M &model, const double *g, const double *x, doub
             q[j] = g[MO * D + j] - s;
         }
         const double *R = g + MO * D + MO, *G = g + MO * D + MO + D * MO;
+        if constexpr (is_constdiff<M>::value) {
 #pragma unroll
-        for (int i = 0; i < D; i++) {
-            double sr = R[i] * q[0], sg = G[i] * q[0];
+            for (int i = 0; i < D; i++) {
+                double sr = R[i] * q[0], sg = G[i] * q[0];
 #pragma unroll
-            for (int j = 1; j < MO; j++) { sr += R[i + D * j] * q[j]; sg += G[i + D * j] * q[j]; }
-            r[i] = sr; gd[i] = sg;
+                for (int j = 1; j < MO; j++) { sr += R[i + D * j] * q[j]; sg += G[i + D * j] * q[j]; }
+                r[i] = sr; gd[i] = sg;
+            }
+        } else {
+            // a(t,x) depends on the state: ((a*L')*M)*q evaluated per step; the G slot holds M (MO x MO)
+            double A[D * D], AL[D * MO], ALM[D * MO];
+            model.amat(t, x, A);
+#pragma unroll
+            for (int i = 0; i < D; i++)
+#pragma unroll
+                for (int j = 0; j < MO; j++) {
+                    double sa = A[i] * g[j];                                   // (a*L')[i][j] = sum_k a[i][k]*L[j][k]
+#pragma unroll
+                    for (int k = 1; k < D; k++) sa += A[i + D * k] * g[j + MO * k];
+                    AL[i + D * j] = sa;
+                }
+#pragma unroll
+            for (int i = 0; i < D; i++)
+#pragma unroll
+                for (int j = 0; j < MO; j++) {
+                    double sa = AL[i] * G[MO * j];
+#pragma unroll
+                    for (int l = 1; l < MO; l++) sa += AL[i + D * l] * G[l + MO * j];
+                    ALM[i + D * j] = sa;
+                }
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+                double sr = R[i] * q[0], sg = ALM[i] * q[0];
+#pragma unroll
+                for (int j = 1; j < MO; j++) { sr += R[i + D * j] * q[j]; sg += ALM[i + D * j] * q[j]; }
+                r[i] = sr; gd[i] = sg;
+            }
         }
     } else if constexpr (GK == BHIP_GUIDE_NUH) {
         // r = H[i]*(nu[i] - x) ; g = a*r                            src/partialbridgenuH.jl:157-161
@@ -151,7 +191,7 @@ BHIP_DEV void guide_terms(const M &model, const double *g, const double *x, doub
             for (int j = 1; j < D; j++) s += g[i + D * j] * w[j];
             r[i] = s;
         }
-        model.amul(r, gd);
+        model.amul(t, x, r, gd);
     }
 }
 
@@ -177,7 +217,7 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, cptr_t row, int i, int n
                         double *wout, long ldwo, double *xout, long ldx, LaneState<M::D, M::MP> &st)
 {
     constexpr int D = M::D, MP = M::MP;
-    using RL = RowLayout<GK, D, MO>;
+    using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
     // the whole coefficient row through the scalar unit, one wait
     double rw[RL::RS];
 #pragma unroll
@@ -199,7 +239,7 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, cptr_t row, int i, int n
         model.b(t, st.y, bI);
         if constexpr (GK != BHIP_GUIDE_NONE) {
             double r[D], g[D];
-            guide_terms<M, GK, MO>(model, rw + RL::G, st.y, r, g);
+            guide_terms<M, GK, MO>(model, t, rw + RL::G, st.y, r, g);
 #pragma unroll
             for (int k = 0; k < D; k++) bI[k] = bI[k] + g[k];
         }
@@ -255,7 +295,7 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, cptr_t row, int i, int n
     model.b(t, st.y, bT);
     if constexpr (GK != BHIP_GUIDE_NONE) {
         double r[D], g[D];
-        guide_terms<M, GK, MO>(model, rw + RL::G, st.y, r, g);
+        guide_terms<M, GK, MO>(model, t, rw + RL::G, st.y, r, g);
         // ---- LOOP C: som += dot(b - b~, r)*dt ;  b~ = B~(x - mu~) + beta~  (mu~ = 0 for the affine form
         // B~x + beta~, beta~ = 0 for the LinPro form B~(x - mu~): adding/subtracting 0.0 is exact)
         double xm[D], bA[D];
@@ -281,13 +321,37 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, cptr_t row, int i, int n
         double lln;
         if constexpr ((FL & 4) != 0) lln = (st.ll + s1 * dt) - s2 * dt;   // PartialBridge!: src/partialbridgen!.jl:96-97
         else lln = st.ll + s0 * dt;                                        // src/partialbridge.jl:77
+        if constexpr (!is_constdiff<M>::value && GK == BHIP_GUIDE_LMMU) {
+            // A = a(t,x,P) - a~_i;  som -= 0.5*tr(A*H)*dt;  som += 0.5*(r'*A*r)*dt      src/partialbridge.jl:79-84
+            double A[D * D];
+            model.amat(t, st.y, A);
+#pragma unroll
+            for (int q = 0; q < D * D; q++) A[q] = A[q] - rw[RL::LM_H + D * D + q];
+            double trAH = 0.0, quad = 0.0;
+#pragma unroll
+            for (int ii = 0; ii < D; ii++) {
+                double e = A[ii] * rw[RL::LM_H + D * ii];                 // (A*H)[ii][ii] = sum_k A[ii][k]*H[k][ii]
+#pragma unroll
+                for (int k = 1; k < D; k++) e += A[ii + D * k] * rw[RL::LM_H + k + D * ii];
+                trAH = ii == 0 ? e : trAH + e;
+            }
+#pragma unroll
+            for (int jj = 0; jj < D; jj++) {
+                double e = r[0] * A[D * jj];                              // (r'*A)[jj] = sum_i r[i]*A[i][jj]
+#pragma unroll
+                for (int ii = 1; ii < D; ii++) e += r[ii] * A[ii + D * jj];
+                quad = jj == 0 ? e * r[0] : quad + e * r[jj];
+            }
+            lln = lln - (0.5 * trAH) * dt;
+            lln = lln + (0.5 * quad) * dt;
+        }
         st.ll = (i < nll) ? lln : st.ll;                                   // skip: only i < N-1-skip contribute
 #pragma unroll
         for (int k = 0; k < D; k++) bT[k] = bT[k] + g[k];       // _b = b + a*(...)
     }
     if constexpr (NOISE != NOISE_LLONLY) {
         double s[D];
-        model.sdw(dw, s);
+        model.sdw(t, st.y, dw, s);
 #pragma unroll
         for (int k = 0; k < D; k++)   // src/euler.jl:264; a structurally zero sigma row contributes an exact "+ 0.0"
             st.y[k] = M::noisy(k) ? st.y[k] + bT[k] * dt + s[k] : st.y[k] + bT[k] * dt;
@@ -305,7 +369,7 @@ template <class M, int GK, int MO, int NOISE, int FL>
 __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
 {
     constexpr int D = M::D, MP = M::MP;
-    using RL = RowLayout<GK, D, MO>;
+    using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.P) return;
     const M model(a.mpar);

@@ -29,6 +29,7 @@ static const char *const RTC_PREFIX =
 struct UserModel {
     int id = 0, d = 0, mp = 0, npar = 0;
     std::string drift;
+    std::string sigma;   // empty: constant sigma passed as data; else the body of sigma(t,x,P)
     std::map<std::vector<int>, hipFunction_t> fns;   // (gk, mo, noise, fl) -> kernel
     std::vector<hipModule_t> modules;
 };
@@ -60,7 +61,9 @@ inline std::string rtc_source(const UserModel &um, int gk, int mo, int noise, in
     s += "    static constexpr bool noisy(int) { return true; }\n    const double *p;\n";
     s += "    BHIP_DEV explicit MUser(const double *p_) : p(p_) {}\n";
     s += "    BHIP_DEV void b(double t, const double *x, double *o) const\n    {\n        const double *par = p; (void)par; (void)t;\n        " + um.drift + "\n    }\n";
-    s += R"(    BHIP_DEV void sdw(const double *dw, double *o) const
+    if (um.sigma.empty()) {
+        // constant sigma passed as data behind the drift parameters: sigma (D x MP), a = sigma*sigma' (D x D), [inv(sigma)]
+        s += R"(    BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const
     {
         const double *S = p + NP;
 #pragma unroll
@@ -71,7 +74,7 @@ inline std::string rtc_source(const UserModel &um, int gk, int mo, int noise, in
             o[i] = s;
         }
     }
-    BHIP_DEV void amul(const double *r, double *o) const
+    BHIP_DEV void amul(double, const double *, const double *r, double *o) const
     {
         const double *A = p + NP + D * MP;
 #pragma unroll
@@ -83,8 +86,8 @@ inline std::string rtc_source(const UserModel &um, int gk, int mo, int noise, in
         }
     }
 )";
-    if (um.d == um.mp)   // square sigma: inv(sigma)*v for innovations!
-        s += R"(    BHIP_DEV void sinv_mul(const double *v, double *o) const
+        if (um.d == um.mp)   // square sigma: inv(sigma)*v for innovations!
+            s += R"(    BHIP_DEV void sinv_mul(const double *v, double *o) const
     {
         const double *Si = p + NP + D * MP + D * D;
 #pragma unroll
@@ -96,6 +99,52 @@ inline std::string rtc_source(const UserModel &um, int gk, int mo, int noise, in
         }
     }
 )";
+    } else {
+        // state-dependent sigma(t,x,P): the user text fills s (D x MP, column-major, zero-initialised);
+        // a(t,x,P) = sigma*sigma' (src/types.jl:32), constdiff(P) = false
+        s += "    static constexpr bool STATE_SIGMA = true;\n";
+        s += "    BHIP_DEV void sig(double t, const double *x, double *s) const\n    {\n        const double *par = p; (void)par; (void)t; (void)x;\n";
+        s += "#pragma unroll\n        for (int k = 0; k < D * MP; k++) s[k] = 0.0;\n        " + um.sigma + "\n    }\n";
+        s += R"(    BHIP_DEV void sdw(double t, const double *x, const double *dw, double *o) const
+    {
+        double S[D * MP];
+        sig(t, x, S);
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            double s = S[i] * dw[0];
+#pragma unroll
+            for (int j = 1; j < MP; j++) s += S[i + D * j] * dw[j];
+            o[i] = s;
+        }
+    }
+    BHIP_DEV void amat(double t, const double *x, double *A) const
+    {
+        double S[D * MP];
+        sig(t, x, S);
+#pragma unroll
+        for (int i = 0; i < D; i++)
+#pragma unroll
+            for (int j = 0; j < D; j++) {
+                double s = S[i] * S[j];
+#pragma unroll
+                for (int k = 1; k < MP; k++) s += S[i + D * k] * S[j + D * k];
+                A[i + D * j] = s;
+            }
+    }
+    BHIP_DEV void amul(double t, const double *x, const double *r, double *o) const
+    {
+        double A[D * D];
+        amat(t, x, A);
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            double s = A[i] * r[0];
+#pragma unroll
+            for (int j = 1; j < D; j++) s += A[i + D * j] * r[j];
+            o[i] = s;
+        }
+    }
+)";
+    }
     s += "};\n";
     s += "template __global__ void k_paths<MUser, " + std::to_string(gk) + ", " + std::to_string(mo) + ", " + std::to_string(noise) + ", " +
          std::to_string(fl) + ">(const KArgs);\n}\n";
@@ -119,7 +168,7 @@ inline std::string rtc_compile(const UserModel &um, int gk, int mo, int noise, i
         std::string log(n, ' ');
         if (n) hiprtcGetProgramLog(prog, &log[0]);
         hiprtcDestroyProgram(&prog);
-        return "hipRTC compilation of the user drift failed:\n" + log;
+        return "hipRTC compilation of the user process failed:\n" + log;
     }
     const char *lowered = nullptr;
     hiprtcGetLoweredName(prog, name.c_str(), &lowered);

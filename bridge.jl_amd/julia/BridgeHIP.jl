@@ -69,6 +69,20 @@ function userdrift(d::Integer, src::String, par::Vector{Float64}, sigma::Abstrac
     (id, Int(d), vcat(par, vec(collect(Float64, sigma))))
 end
 
+# The same with a state-dependent Bridge.σ(t, x, P): `sigsrc` fills s (d x m', column-major, zero-initialised)
+#     BridgeHIP.hipmodel(P::MyDiff) = BridgeHIP.userprocess(1, 1, "o[0] = par[0]*(par[1] - x[0]);",
+#                                                           "s[0] = par[2]*sqrt(1.0 + x[0]*x[0]);", [P.κ, P.θ, P.s])
+function userprocess(d::Integer, mp::Integer, bsrc::String, sigsrc::String, par::Vector{Float64}; c::Context = ctx())
+    key = (Int(d), Int(mp), length(par), bsrc * "\0" * sigsrc)
+    id = get!(_user_ids, key) do
+        r = Ref{Cint}(0)
+        check(c, ccall((:bhip_model_define_sigma, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Cstring, Cstring, Ref{Cint}),
+            c.h, d, mp, length(par), bsrc, sigsrc, r))
+        r[]
+    end
+    (id, Int(d), par)
+end
+
 # auxiliary process: constant coefficients by default, any Bridge.B/β/a methods through a C callback
 function aux_callback(t::Cdouble, B::Ptr{Cdouble}, beta::Ptr{Cdouble}, a::Ptr{Cdouble}, user::Ptr{Cvoid})::Cvoid
     Pt = unsafe_pointer_to_objref(user)[]

@@ -108,6 +108,15 @@ int bhip_download_aos(bhip_ctx *ctx, const double *dev, int N, int dim, long ld,
  * par = [npar drift parameters, sigma (d x mp, column-major)].  d, mp <= 3.  A syntax error returns
  * BHIP_EINVAL with the compiler log in bhip_last_error().  Kernels are compiled on first use. */
 int bhip_model_define(bhip_ctx *ctx, int d, int mp, int npar, const char *drift_src, int *model_id);
+/* The same with a STATE-DEPENDENT diffusion coefficient sigma(t,x,P) (the other half of the reference's
+ * extension point, README.md:69-77; a = sigma*sigma' by src/types.jl:32; constdiff(P) = false):
+ * sigma_src fills `double* s` (d x mp, column-major, zero-initialised) from (t, x, par), e.g. for d = mp = 2
+ *     "s[0] = par[4]*sqrt(1.0 + x[0]*x[0]); s[2] = par[6]*x[1]; s[3] = par[5];"
+ * Proposals on the returned id take par = the npar parameters only.  Runs: plain Euler-Maruyama, guided
+ * solves of all three proposal kinds, and llikelihood / pCN chains for PartialBridge (L,M,mu), whose
+ * non-constant-diffusivity terms are src/partialbridge.jl:79-84; the reference's other !constdiff
+ * branches are undefined (they name unbound variables), those calls return BHIP_EUNSUPPORTED. */
+int bhip_model_define_sigma(bhip_ctx *ctx, int d, int mp, int npar, const char *drift_src, const char *sigma_src, int *model_id);
 
 /* ------------------------------------------------------------------ proposal  ("Po")
  * A proposal holds the grid tt (Po.tt), the target P, the auxiliary Pt and the guide coefficient

@@ -356,9 +356,14 @@ int bo_model_dims(int model, int d_hint, int *d, int *mp)
     case BO_MODEL_LORENZ: *d = 3; *mp = 3; return 0;
     case BO_MODEL_FHN2: *d = 2; *mp = 2; return 0;
     case BO_MODEL_PENDULUM: *d = 2; *mp = 1; return 0;
+    case BO_MODEL_SDIFF1: *d = 1; *mp = 1; return 0;
+    case BO_MODEL_SDIFF2: *d = 2; *mp = 2; return 0;
     }
     return -1;
 }
+
+/* constdiff(P), src/types.jl:36 */
+int bo_constdiff(int model) { return model != BO_MODEL_SDIFF1 && model != BO_MODEL_SDIFF2; }
 
 void bo_b(int model, int d, const double *p, double t, const double *x, double *o)
 {
@@ -398,14 +403,29 @@ void bo_b(int model, int d, const double *p, double t, const double *x, double *
     case BO_MODEL_PENDULUM: /* src/Models.jl:79  (x2, -theta2*sin(x1)) */
         o[0] = x[1]; o[1] = -p[0] * sin(x[0]);
         break;
+    case BO_MODEL_SDIFF1:
+        o[0] = p[0] * (p[1] - x[0]);
+        break;
+    case BO_MODEL_SDIFF2:
+        o[0] = p[0] * (p[1] - x[0]) + p[2] * x[1];
+        o[1] = p[3] * (p[4] - x[1]);
+        break;
     }
 }
 
 /* _scale(dw, sigma(t,x,P)) = sigma*dw, src/euler.jl:3-4 */
+static void model_sigma_mat(int model, int d, int mp, const double *p, double t, const double *x, double *S);
+
 void bo_sigma_apply(int model, int d, int mp, const double *p, double t, const double *x,
                     const double *dw, double *o)
 {
     (void)t; (void)x; (void)mp;
+    if (!bo_constdiff(model)) {   /* sigma(t,x,P)*dw with the full matrix */
+        double S[D2];
+        model_sigma_mat(model, d, mp, p, t, x, S);
+        mv(d, mp, S, dw, o);
+        return;
+    }
     switch (model) {
     case BO_MODEL_WIENER: for (int k = 0; k < d; k++) o[k] = dw[k]; break;  /* sigma = I */
     case BO_MODEL_OU: o[0] = p[1] * dw[0]; break;
@@ -420,10 +440,13 @@ void bo_sigma_apply(int model, int d, int mp, const double *p, double t, const d
 }
 
 /* sigma as a d x mp matrix (for a = sigma*sigma') */
-static void model_sigma_mat(int model, int d, int mp, const double *p, double *S)
+static void model_sigma_mat(int model, int d, int mp, const double *p, double t, const double *x, double *S)
 {
+    (void)t;
     memset(S, 0, sizeof(double) * d * mp);
     switch (model) {
+    case BO_MODEL_SDIFF1: S[0] = p[2] * sqrt(1.0 + x[0] * x[0]); break;
+    case BO_MODEL_SDIFF2: S[0] = p[5] * sqrt(1.0 + x[0] * x[0]); S[2] = p[7] * x[1]; S[3] = p[6]; break;
     case BO_MODEL_WIENER: for (int k = 0; k < d; k++) S[k + d * k] = 1.0; break;
     case BO_MODEL_OU: S[0] = p[1]; break;
     case BO_MODEL_LINPRO: memcpy(S, p + d * d + d, sizeof(double) * d * d); break;
@@ -440,9 +463,8 @@ static void model_sigma_mat(int model, int d, int mp, const double *p, double *S
  * LinPro: P.a = sigma*sigma' (src/linpro.jl:72,84) */
 void bo_a(int model, int d, int mp, const double *p, double t, const double *x, double *A)
 {
-    (void)t; (void)x;
     double S[D2];
-    model_sigma_mat(model, d, mp, p, S);
+    model_sigma_mat(model, d, mp, p, t, x, S);
     mmt(d, mp, d, S, S, A);
 }
 
@@ -946,6 +968,26 @@ double bo_llikelihood(const bo_proposal *P, const double *X, int skip)
             for (int k = 0; k < d; k++) df[k] = bt[k] - ba[k];
             som += dotv(d, df, r) * dt;
         }
+        if (!bo_constdiff(P->model)) {
+            /* src/partialbridge.jl:79-84 (the one !constdiff branch of the reference that is well defined):
+             *   H = L'*M*L (:58);  A = a((i,s),x,target) - a((i,s),auxiliary)
+             *   som -= 0.5*tr(A*H)*dt;  som += 0.5*(r'*A*r)*dt */
+            if (P->kind != BO_GUIDE_LMMU) return NAN;
+            int m = P->m;
+            const double *L = P->L + (size_t)i * m * d, *M = P->M + (size_t)i * m * m;
+            double LtM[D2], H[D2], A[D2], At[D2], AH[D2], rA[BO_MAXD] = {0};
+            mtm(d, m, m, L, M, LtM);
+            mm(d, m, d, LtM, L, H);
+            bo_a(P->model, d, P->mp, P->par, s, x, A);
+            bo_aux_a(P->aux, d, P->mp, P->apar, s, At);
+            for (int k = 0; k < d * d; k++) A[k] = A[k] - At[k];
+            mm(d, d, d, A, H, AH);
+            double trAH = AH[0];
+            for (int k = 1; k < d; k++) trAH += AH[k + d * k];
+            mtm(1, d, d, r, A, rA);                       /* r'*A */
+            som -= 0.5 * trAH * dt;
+            som += 0.5 * dotv(d, rA, r) * dt;
+        }
     }
     return som;
 }
@@ -1114,7 +1156,7 @@ void bo_innovations_flat(int kind, int N, int d, int mp, int m, int model, const
     bo_proposal P;
     double S[D2], Sinv[D2], w[BO_MAXD], b[BO_MAXD], df[BO_MAXD], inc[BO_MAXD];
     if (kind != BO_GUIDE_NONE) mk_prop(&P, kind, N, d, mp, m, model, par, aux, apar, tt, A1, A2, A3, A4);
-    model_sigma_mat(model, d, mp, par, S);
+    model_sigma_mat(model, d, mp, par, tt[0], X, S);
     if (model == BO_MODEL_LORENZ || model == BO_MODEL_FHN2) {   /* inv(::SDiagonal) = SDiagonal(inv.(diag)) */
         memset(Sinv, 0, sizeof(double) * d * d);
         for (int k = 0; k < d; k++) Sinv[k + d * k] = 1.0 / S[k + d * k];

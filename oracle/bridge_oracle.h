@@ -46,8 +46,14 @@ enum {
     BO_MODEL_INTDIFF = 5,     /* test/partialbridge.jl:7-15                               par: gamma        */
     BO_MODEL_LORENZ = 6,      /* src/Models.jl:41-58, test/euler.jl:45-50                 par: th1,th2,th3,s1,s2,s3 */
     BO_MODEL_FHN2 = 7,        /* src/Models.jl:9-20 (diagonal 2-d noise)                  par: eps,s,gamma,beta,s1,s2 */
-    BO_MODEL_PENDULUM = 8     /* src/Models.jl:69-88                                      par: theta2,gamma */
+    BO_MODEL_PENDULUM = 8,    /* src/Models.jl:69-88                                      par: theta2,gamma */
+    /* two processes with a STATE-DEPENDENT sigma(t,x) (constdiff = false), the shape of a user-defined
+     * Bridge.b / Bridge.sigma pair (README.md:69-77); used to check the hipRTC user-process path */
+    BO_MODEL_SDIFF1 = 9,      /* b = kappa*(theta - x), sigma = s*sqrt(1 + x^2)            par: kappa,theta,s */
+    BO_MODEL_SDIFF2 = 10      /* b = (th1*(m1-x1) + c*x2, th2*(m2-x2)),
+                                 sigma = [s1*sqrt(1+x1^2)  s3*x2; 0  s2]                   par: th1,m1,c,th2,m2,s1,s2,s3 */
 };
+int bo_constdiff(int model);
 
 /* auxiliary (linear) processes  dX = (B(t)X + beta(t))dt + sigma(t)dW */
 enum {

@@ -14,6 +14,7 @@ _ODIR = os.path.join(os.path.dirname(_HERE), "oracle")
 _SO = os.path.join(_ODIR, "libbridge_oracle.so")
 
 MODEL_WIENER, MODEL_OU, MODEL_LINPRO, MODEL_FHN, MODEL_NCLAR, MODEL_INTDIFF, MODEL_LORENZ, MODEL_FHN2, MODEL_PENDULUM = range(9)
+MODEL_SDIFF1, MODEL_SDIFF2 = 9, 10        # state-dependent sigma (oracle-side stand-ins for hipRTC user processes)
 AUX_AFFINE, AUX_LINPRO, AUX_FHN_STARTEND = range(3)
 GUIDE_NONE, GUIDE_HV, GUIDE_LMMU, GUIDE_NUH, GUIDE_NUH_INPLACE = range(5)
 
