@@ -64,7 +64,7 @@ struct bhip_chains {
     int flags = 0;
     uint32_t iter = 0;
     bool inited = false;
-    double x0[3] = {0, 0, 0};
+    std::vector<double> x0;   // shared starting point (d doubles)
     double *Wc = nullptr;   // W slots [N][mp][ld][2]
     double *Xo = nullptr;   // proposal paths [N][d][ld] (BHIP_CHAINS_STORE_X)
     int skip0 = 0;
@@ -457,7 +457,8 @@ static int build_tile_data(bhip_proposal *po)
 }
 
 static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const double *W_in, long ldWin, double *W_out, long ldWout,
-                            double *X, long ldX, double *ll, int skip, long npaths, int noise, uint64_t seed, uint32_t iter, uint32_t path0)
+                            double *X, long ldX, double *ll, int skip, long npaths, int noise, uint64_t seed, uint32_t iter, uint32_t path0,
+                            int wstride = 1, const bhip_chains *ch = nullptr, double rho = 0.0)
 {
     bhip_proposal *po = const_cast<bhip_proposal *>(po_c);
     bhip_ctx *ctx = po->ctx;
@@ -476,9 +477,14 @@ static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const d
     a.N = (int)po->tt.size(); a.skip = skip; a.use_vend = po->use_vend; a.noise = noise; a.P = npaths;
     a.Win = W_in; a.ldWin = ldWin; a.Wout = W_out; a.ldWout = ldWout; a.X = X; a.ldX = ldX; a.ll = ll;
     a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.iter = iter; a.path0 = path0;
+    a.wstride = wstride;
+    if (noise == 2) {   // pCN chain step
+        a.Wc = ch->Wc; a.ldC = ch->ld; a.cur = ch->cur; a.llcur = ch->llcur; a.acc = ch->acc;
+        a.rho = rho; a.srho = std::sqrt(1 - rho * rho);
+    }
     hipError_t le = hipSuccess;
-    if (d == 32) le = noise ? launch_tile<32, 1>(a, ctx->stream) : launch_tile<32, 0>(a, ctx->stream);
-    else le = noise ? launch_tile<16, 1>(a, ctx->stream) : launch_tile<16, 0>(a, ctx->stream);
+    if (d == 32) le = noise == 3 ? launch_tile<32, 3>(a, ctx->stream) : noise == 2 ? launch_tile<32, 2>(a, ctx->stream) : noise ? launch_tile<32, 1>(a, ctx->stream) : launch_tile<32, 0>(a, ctx->stream);
+    else le = noise == 3 ? launch_tile<16, 3>(a, ctx->stream) : noise == 2 ? launch_tile<16, 2>(a, ctx->stream) : noise ? launch_tile<16, 1>(a, ctx->stream) : launch_tile<16, 0>(a, ctx->stream);
     HIPCHK(ctx, le);
     return BHIP_OK;
 }
@@ -767,6 +773,11 @@ int bhip_llikelihood(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev
     if (!ctx || !po || !X_dev || !ll_dev) return BHIP_EINVAL;
     SAME_CTX(ctx, po);
     if (po->g.kind == BHIP_GUIDE_NONE) return fail(ctx, BHIP_EINVAL, "bhip_llikelihood: needs a guided proposal");
+    if (po->mh.d > 3) {
+        if (ldX < npaths) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
+        const std::vector<double> zero(po->mh.d, 0.0);
+        return launch_tile_path(po, zero.data(), X_dev, ldX, nullptr, 0, nullptr, 0, ll_dev, skip, npaths, 3, 0, 0, 0);
+    }
     KArgs a;
     const double zero[3] = {0, 0, 0};
     int rc = fill_common(po, a, zero, nullptr, npaths, skip);
@@ -867,7 +878,7 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     if (nchains < 1) return fail(ctx, BHIP_EINVAL, "nchains must be positive");
     PATH_RANGE(ctx, path0, nchains);
     if (po->g.kind == BHIP_GUIDE_NONE) return fail(ctx, BHIP_EINVAL, "chains need a guided proposal");
-    if (po->mh.d > 3) return fail(ctx, BHIP_EUNSUPPORTED, "chains: d <= 3");
+    if (po->mh.d > 3 && !po->d_steps) return fail(ctx, BHIP_ESTATE, "chains: the proposal has no large-d guide data");
     bhip_chains *ch = new (std::nothrow) bhip_chains();
     if (!ch) return fail(ctx, BHIP_EHIP, "out of host memory");
     ch->ctx = ctx; ch->po = po; ch->n = nchains; ch->ld = (nchains + 63) / 64 * 64;
@@ -903,12 +914,20 @@ int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
     if (!ch || !x0) return BHIP_EINVAL;
     bhip_ctx *ctx = ch->ctx;
     const bhip_proposal *po = ch->po;
+    NEED_DEVICE(ctx);
+    if (skip < 0) return fail(ctx, BHIP_EINVAL, "skip must be >= 0");
+    ch->x0.assign(x0, x0 + po->mh.d);
+    HIPCHK(ctx, hipMemsetAsync(ch->cur, 0, ch->ld, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ch->acc, 0, sizeof(unsigned int) * ch->ld, ctx->stream));
+    if (po->mh.d > 3) {   // MFMA tile kernel: fresh W into half 0 of every slot, X and ll of the initial state
+        int rct = launch_tile_path(po, x0, nullptr, 0, ch->Wc, ch->ld, ch->Xo, ch->ld, ch->llcur, skip, ch->n, 1, ch->seed, 0, ch->path0, 2);
+        if (rct) return rct;
+        ch->skip0 = skip; ch->iter = 0; ch->inited = true;
+        return BHIP_OK;
+    }
     KArgs a;
     int rc = fill_common(po, a, x0, nullptr, ch->n, skip);
     if (rc) return rc;
-    for (int k = 0; k < po->mh.d; k++) ch->x0[k] = x0[k];
-    HIPCHK(ctx, hipMemsetAsync(ch->cur, 0, ch->ld, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ch->acc, 0, sizeof(unsigned int) * ch->ld, ctx->stream));
     a.Wout = ch->Wc; a.ldWout = ch->ld; a.wstride = 2;   // half 0 of every slot, cur = 0
     a.X = ch->Xo; a.ldX = ch->ld; a.ll = ch->llcur;
     ch->skip0 = skip;
@@ -927,8 +946,17 @@ int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip)
     if (iters < 0) return fail(ctx, BHIP_EINVAL, "iters must be >= 0");
     if (!(rho >= -1.0 && rho <= 1.0)) return fail(ctx, BHIP_EINVAL, "rho must lie in [-1, 1] (sqrt(1 - rho^2) is the weight of the fresh noise)");
     const bhip_proposal *po = ch->po;
+    if (po->mh.d > 3) {
+        if (skip < 0) return fail(ctx, BHIP_EINVAL, "skip must be >= 0");
+        for (int it = 0; it < iters; it++) {
+            ++ch->iter;
+            int rct = launch_tile_path(po, ch->x0.data(), nullptr, 0, nullptr, 0, ch->Xo, ch->ld, nullptr, skip, ch->n, 2, ch->seed, ch->iter, ch->path0, 1, ch, rho);
+            if (rct) return rct;
+        }
+        return BHIP_OK;
+    }
     KArgs a;
-    int rc = fill_common(po, a, ch->x0, nullptr, ch->n, skip);
+    int rc = fill_common(po, a, ch->x0.data(), nullptr, ch->n, skip);
     if (rc) return rc;
     a.Wc = ch->Wc; a.Xo = ch->Xo; a.ldC = ch->ld;
     a.cur = ch->cur; a.llcur = ch->llcur; a.acc = ch->acc;
@@ -989,8 +1017,9 @@ static int current_X(bhip_chains *ch, long p0, long np, double *W_soa, double *X
 {
     int rc = gather_current_W(ch, p0, np, W_soa);
     if (rc) return rc;
+    if (ch->po->mh.d > 3) return launch_tile_path(ch->po, ch->x0.data(), W_soa, np, nullptr, 0, X_soa, np, nullptr, 0, np, 0, 0, 0, 0);
     KArgs a;
-    rc = fill_common(ch->po, a, ch->x0, nullptr, np, 0);
+    rc = fill_common(ch->po, a, ch->x0.data(), nullptr, np, 0);
     if (rc) return rc;
     a.Win = W_soa; a.ldWin = np; a.X = X_soa; a.ldX = np;
     return do_launch(ch->po, NOISE_EXT, a);
@@ -1027,9 +1056,10 @@ int bhip_chains_current_X(bhip_chains *ch, double *X_dev, long ldX)
     double *tmp = nullptr;
     HIPCHK(ctx, hipMalloc((void **)&tmp, sizeof(double) * (size_t)N * mp * ch->n));
     int rc = gather_current_W(ch, 0, ch->n, tmp);
-    if (!rc) {
+    if (!rc && ch->po->mh.d > 3) rc = launch_tile_path(ch->po, ch->x0.data(), tmp, ch->n, nullptr, 0, X_dev, ldX, nullptr, 0, ch->n, 0, 0, 0, 0);
+    else if (!rc) {
         KArgs a;
-        rc = fill_common(ch->po, a, ch->x0, nullptr, ch->n, 0);
+        rc = fill_common(ch->po, a, ch->x0.data(), nullptr, ch->n, 0);
         if (!rc) { a.Win = tmp; a.ldWin = ch->n; a.X = X_dev; a.ldX = ldX; rc = do_launch(ch->po, NOISE_EXT, a); }
     }
     (void)hipStreamSynchronize(ctx->stream);

@@ -38,14 +38,23 @@ struct TArgs {
     const double *steps;   // [N-1][D*D + D]: Hm_i in fragment order, then nu_i (natural order)
     const double *hdr;     // [N-1][2]: dt_i, sqrt(dt_i)
     const double *cst;     // 4 fragment matrices (B, B~, a, sigma), then mu, mu~, beta~, vend, x0 (D each)
-    int N, skip, use_vend, noise;   // noise: 0 = external W, 1 = fresh Philox
+    int N, skip, use_vend, noise;   // noise: 0 = external W, 1 = fresh Philox, 2 = pCN chain step, 3 = llikelihood of a stored X (Win = X)
     long P;
     const double *Win; long ldWin;
     double *Wout; long ldWout;
+    int wstride;           // fresh W store: 1 = plain SoA, 2 = half 0 of the chain slots (chain initialisation)
     double *X; long ldX;
     double *ll;
     uint32_t k0, k1, iter, path0;
+    // pCN chain state, same scheme as the path-per-lane kernel (bhip_path_kernel.h, KArgs): 16-byte slots
+    // Wc[((i*D + row)*ldC + p)*2 + half], parity cur[p] selects the current half, accept flips it
+    double *Wc; long ldC;
+    unsigned char *cur;
+    double *llcur;
+    unsigned int *acc;
+    double rho, srho;
 };
+typedef double tile_d2v __attribute__((ext_vector_type(2)));
 
 template <int T>
 __device__ __forceinline__ void tile_mv(const double *__restrict__ Mf, const double (&v)[T][4], double (&out)[T][4], int lane)
@@ -95,10 +104,25 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
             const int row = 16 * t + 4 * r + kq;
             x[t][r] = x0[row];
             wprev[t][r] = NOISE == 0 ? a.Win[(size_t)row * a.ldWin + p] : 0.0;
-            if (NOISE == 1 && a.Wout && live) a.Wout[(size_t)row * a.ldWout + p] = 0.0;
+            if (NOISE == 1 && a.Wout && live) a.Wout[((size_t)row * a.ldWout + p) * a.wstride] = 0.0;
         }
     double ll = 0.0;
     const uint32_t path = a.path0 + (uint32_t)p;
+    // pCN: W2 accumulates the fresh Wiener path, wprev the proposal Wo = rho*W + sqrt(1-rho^2)*W2
+    double w2prev[NOISE == 2 ? T : 1][4];
+    int cpar = 0;
+    tile_d2v *wslot = nullptr;
+    if constexpr (NOISE == 2) {
+        cpar = a.cur[p];
+        wslot = reinterpret_cast<tile_d2v *>(a.Wc) + p;
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                w2prev[t][r] = 0.0;
+                if (live) wslot[(size_t)(16 * t + 4 * r + kq) * a.ldC] = tile_d2v{0.0, 0.0};   // W[1] = Wo[1] = 0
+            }
+    }
 
     for (int i = 0; i < nsteps; i++) {
         const int cur = i & 1;
@@ -127,7 +151,24 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                     dw[t][r] = wn - wprev[t][r];
                     wprev[t][r] = wn;
                 }
+        } else if constexpr (NOISE == 3) {
+            // stand-alone llikelihood(LeftRule(), X, Po): x_i comes from the stored path, nothing is propagated
+#pragma unroll
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    x[t][r] = a.Win[((size_t)i * D + 16 * t + 4 * r + kq) * a.ldWin + p];
+                    dw[t][r] = 0.0;
+                }
         } else {
+            tile_d2v slot[NOISE == 2 ? T : 1][4];
+            if constexpr (NOISE == 2) {   // the chain's slots of step i+1: issued first, consumed after the normals
+#pragma unroll
+                for (int t = 0; t < T; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        slot[t][r] = __builtin_nontemporal_load(&wslot[((size_t)(i + 1) * D + 16 * t + 4 * r + kq) * a.ldC]);
+            }
             // normal index n = i*D + row; block n>>1 = i*D/2 + 2*ks + (kq>>1), element kq&1 (ks = 4t+r).
             // lanes kq and kq^1 share blocks: the even lane draws ks = 0..2T-1, the odd one ks = 2T..4T-1.
             const bool odd = (kq & 1) != 0;
@@ -146,10 +187,23 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
             for (int t = 0; t < T; t++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const double wn = wprev[t][r] + rdt * mine[4 * t + r];   // sample!: W[i+1] = W[i] + sqrt(dt)*xi
-                    dw[t][r] = wn - wprev[t][r];
-                    wprev[t][r] = wn;
-                    if (a.Wout && live) a.Wout[((size_t)(i + 1) * D + 16 * t + 4 * r + kq) * a.ldWout + p] = wn;
+                    if constexpr (NOISE == 2) {
+                        // sample!(W2); Wo = rho*W + sqrt(1-rho^2)*W2   partialbridge_fitzhugh.jl:145-147
+                        const double wc = cpar ? slot[t][r].y : slot[t][r].x;
+                        const double w2 = w2prev[t][r] + rdt * mine[4 * t + r];
+                        const double wo = a.rho * wc + a.srho * w2;
+                        dw[t][r] = wo - wprev[t][r];
+                        w2prev[t][r] = w2;
+                        wprev[t][r] = wo;
+                        if (live)
+                            __builtin_nontemporal_store(cpar ? tile_d2v{wo, slot[t][r].y} : tile_d2v{slot[t][r].x, wo},
+                                                        &wslot[((size_t)(i + 1) * D + 16 * t + 4 * r + kq) * a.ldC]);
+                    } else {
+                        const double wn = wprev[t][r] + rdt * mine[4 * t + r];   // sample!: W[i+1] = W[i] + sqrt(dt)*xi
+                        dw[t][r] = wn - wprev[t][r];
+                        wprev[t][r] = wn;
+                        if (a.Wout && live) a.Wout[(((size_t)(i + 1) * D + 16 * t + 4 * r + kq) * a.ldWout + p) * a.wstride] = wn;
+                    }
                 }
         }
 
@@ -175,8 +229,10 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
         tile_mv<T>(hm, w, rr, lane);
         tile_mv<T>(Bf, xm, bT, lane);
         tile_mv<T>(Btf, xa, bA, lane);
-        tile_mv<T>(Af, rr, g, lane);
-        tile_mv<T>(Sf, dw, s, lane);
+        if constexpr (NOISE != 3) {
+            tile_mv<T>(Af, rr, g, lane);
+            tile_mv<T>(Sf, dw, s, lane);
+        }
 
         // ---- llikelihood: som += dot(b - b~, r)*dt, reduced over the path's 4 row groups
         double part = 0.0;
@@ -188,10 +244,12 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
         part += __shfl_xor(part, 32, 64);
         if (i < nll) ll += part * dt;
 
+        if constexpr (NOISE != 3) {
 #pragma unroll
-        for (int t = 0; t < T; t++)
+            for (int t = 0; t < T; t++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) x[t][r] = x[t][r] + (bT[t][r] + g[t][r]) * dt + s[t][r];
+                for (int r = 0; r < 4; r++) x[t][r] = x[t][r] + (bT[t][r] + g[t][r]) * dt + s[t][r];
+        }
 
         if (more) {
 #pragma unroll
@@ -209,11 +267,22 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 #pragma unroll
             for (int r = 0; r < 4; r++) x[t][r] = vend[16 * t + 4 * r + kq];
     }
-    if (a.X && live) {
+    if (NOISE != 3 && a.X && live) {
 #pragma unroll
         for (int t = 0; t < T; t++)
 #pragma unroll
             for (int r = 0; r < 4; r++) a.X[((size_t)(N - 1) * D + 16 * t + 4 * r + kq) * a.ldX + p] = x[t][r];
+    }
+    if constexpr (NOISE == 2) {
+        // if log(rand()) <= llo - ll: W <- Wo (parity flip), ll <- llo, acc += 1     partialbridge_fitzhugh.jl:160-167
+        if (live && kq == 0) {
+            const double u = accept_uniform(a.k0, a.k1, path, a.iter);
+            if (det_log(u) <= ll - a.llcur[p]) {
+                a.cur[p] = (unsigned char)(cpar ^ 1);
+                a.llcur[p] = ll;
+                a.acc[p] += 1u;
+            }
+        }
     }
     if (a.ll && live && kq == 0) a.ll[p] = ll;
 }

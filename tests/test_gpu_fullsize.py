@@ -144,3 +144,28 @@ def test_C4_pcn_mcmc_262144_chains(ctx):
     for k, p in enumerate((1234, 1235)):
         r = o.mcmc(ref, c.x0, 0.9, iters, 4, 7 * P + p)
         assert acc[p] == r["acc"] and ll[p] == r["ll"] and np.array_equal(W[k], r["W"]) and np.array_equal(X[k], r["X"])
+
+
+def test_C5_linpro32_guided_bridge_65536_paths(ctx):
+    """config C5: LinPro d = 32 GuidedBridge, 1001 steps, 65 536 paths on the MFMA tile kernel"""
+    d, P = 32, 65536
+    c = problems.linpro_big_case(d, N)
+    Po = c.bh_proposal(bh, ctx)
+    X, _, ll = bh.sample_solve(c.x0, Po, P, seed=5)
+    assert bool(torch.isfinite(ll).all())
+    assert bool((X.data[0] == 0).all())                                                   # x0 = 0 stored first
+    assert bool((X.data[-1] == torch.as_tensor(c.v, device=X.data.device)[:, None]).all())  # endpoint rule src/euler.jl:241-242
+    # checksum of checksums: the stand-alone llikelihood of the stored ensemble reproduces the fused values
+    ll2 = bh.llikelihood(bh.LeftRule(), X, Po)
+    assert float((ll2 - ll).abs().max()) <= 1e-9 * (1 + float(ll.abs().max()))
+    # sharding invariance: the last quarter as its own launch
+    Xq, _, llq = bh.sample_solve(c.x0, Po, P // 4, seed=5, path0=3 * P // 4)
+    assert torch.equal(llq, ll[3 * P // 4:]) and torch.equal(Xq.data, X.data[:, :, 3 * P // 4:])
+    del Xq
+    # spot check against the oracle (stated MFMA tolerance)
+    ref = c.oracle_proposal()
+    for p in (0, P - 1):
+        Xr = o.solve_guided(ref, c.x0, o.wiener_sample(c.tt, d, 5, p, 0))
+        assert np.abs(X.paths(p, 1)[0] - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max())
+        llr = o.llikelihood(ref, Xr)
+        assert abs(float(ll[p]) - llr) <= 1e-8 * (1 + abs(llr))

@@ -120,3 +120,40 @@ def test_tile_kernel_forward_euler_maruyama(ctx, d):
     assert np.abs(X2.paths() - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max())
     with pytest.raises(bh.BridgeError):          # llikelihood needs a guided proposal
         bh.solve(bh.EulerMaruyama(), x0, W, proc, ll=ctx.empty(P))
+
+
+@pytest.mark.parametrize("d,kind", [(32, o.GUIDE_HV), (16, o.GUIDE_NUH)], ids=["d32_guidedbridge", "d16_nuh"])
+def test_tile_kernel_pcn_chains(ctx, d, kind):
+    """pCN Metropolis-Hastings chains at large d (SURVEY 8(d) mode M, C5 column): same slot/parity scheme as the
+    path-per-lane kernel.  The Wiener state is bit-exact as long as the accept decisions agree; X and ll follow
+    the stated MFMA tolerance."""
+    c = problems.linpro_big_case(d, 81, kind)
+    Po, ref = c.bh_proposal(bh, ctx), c.oracle_proposal()
+    n, iters, rho = 40, 6, 0.95
+    ch = bh.Chains(Po, c.x0, n, seed=9, path0=50)
+    ll0 = ch.ll()
+    r0 = o.mcmc(ref, c.x0, rho, 0, 9, 50 + 3)
+    assert abs(ll0[3] - r0["ll"]) <= 1e-8 * (1 + abs(r0["ll"]))
+    ch.step(rho, iters)
+    acc, ll = ch.acc(), ch.ll()
+    assert 0 < acc.sum() < n * iters
+    X, W = ch.paths(0, n)
+    for p in (0, 15, 16, 39):
+        r = o.mcmc(ref, c.x0, rho, iters, 9, 50 + p)
+        assert acc[p] == r["acc"]
+        assert np.array_equal(W[p], r["W"])                                  # same accept history -> same W, bit for bit
+        _close(X[p], r["X"], np.array([ll[p]]), np.array([r["ll"]]))
+    # the statistics block and the re-materialised current X
+    st = ch.stats().cpu().numpy()
+    assert st[0] == n and st[1] == iters and st[2] == acc.sum() and st[5] == ll.min() and st[6] == ll.max()
+    Xc = ch.current_X()
+    assert np.array_equal(Xc.paths(5, 1)[0], X[5])
+    llc = bh.llikelihood(bh.LeftRule(), Xc, Po).cpu().numpy()                 # stand-alone llikelihood on the tile kernel
+    assert np.all(np.abs(llc - ll) <= 1e-8 * (1 + np.abs(ll)))
+    # the proposal buffer of the last iteration holds solve!(Xo, Wo): finite, starts at x0
+    Xo = ch.proposal_X()
+    assert bool(torch.isfinite(Xo).all()) and bool((Xo[0] == torch.as_tensor(c.x0, device=Xo.device)[:, None]).all())
+    nn, mean, m2 = ch.pathstats()
+    Xall = X
+    assert nn == n and np.abs(mean - Xall.mean(0)).max() < 1e-12
+    assert np.abs(m2[40] - (Xall[:, 40] - mean[40]).T @ (Xall[:, 40] - mean[40])).max() < 1e-10
