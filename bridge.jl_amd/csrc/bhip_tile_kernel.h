@@ -34,6 +34,12 @@ namespace bhip {
 
 typedef double double4v __attribute__((ext_vector_type(4)));
 
+// Timing experiments only (results become WRONG): bit0 no per-step barrier / matrix staging, bit1 no normal
+// generation, bit2 no MFMA products.  scripts/gpu_tile_probe.py runs the variants (profiles/r1_tile_breakdown.txt).
+#ifndef BHIP_TILE_EXP
+#define BHIP_TILE_EXP 0
+#endif
+
 struct TArgs {
     const double *steps;   // [N-1][D*D + D]: Hm_i in fragment order, then nu_i (natural order)
     const double *hdr;     // [N-1][2]: dt_i, sqrt(dt_i)
@@ -59,6 +65,13 @@ typedef double tile_d2v __attribute__((ext_vector_type(2)));
 template <int T>
 __device__ __forceinline__ void tile_mv(const double *__restrict__ Mf, const double (&v)[T][4], double (&out)[T][4], int lane)
 {
+    if constexpr ((BHIP_TILE_EXP & 4) != 0) {
+#pragma unroll
+        for (int tp = 0; tp < T; tp++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[tp][r] = v[tp][r] * Mf[lane];
+        return;
+    }
     double4v acc[T];
 #pragma unroll
     for (int tp = 0; tp < T; tp++) acc[tp] = double4v{0.0, 0.0, 0.0, 0.0};
@@ -125,11 +138,11 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     }
 
     for (int i = 0; i < nsteps; i++) {
-        const int cur = i & 1;
+        const int cur = (BHIP_TILE_EXP & 1) ? 0 : i & 1;
         const double *hm = hb + cur * STEP, *nu = hm + DD;
         // stage step i+1's matrix: global -> registers now, registers -> LDS after the compute
         double stage[(STEP + 255) / 256];
-        const bool more = i + 1 < nsteps;
+        const bool more = (BHIP_TILE_EXP & 1) ? false : i + 1 < nsteps;
         if (more) {
 #pragma unroll
             for (int c = 0; c < (STEP + 255) / 256; c++) {
@@ -177,7 +190,8 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
             for (int h = 0; h < 2 * T; h++) {
                 const int ks = h + (odd ? 2 * T : 0);
                 double z0, z1;
-                normal_pair(a.k0, a.k1, path, a.iter, (uint32_t)(i * (D / 2) + 2 * ks + (kq >> 1)), z0, z1);
+                if constexpr ((BHIP_TILE_EXP & 2) != 0) { z0 = 1e-3 * (double)(lane + ks); z1 = -z0; }
+                else normal_pair(a.k0, a.k1, path, a.iter, (uint32_t)(i * (D / 2) + 2 * ks + (kq >> 1)), z0, z1);
                 const double keep = odd ? z1 : z0, give = odd ? z0 : z1;
                 const double got = __shfl_xor(give, 16, 64);   // partner's block: h (partner even) or h + 2T (partner odd)
                 mine[h] = odd ? got : keep;            // K-slice h       : drawn by the even lane
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 if (idx < STEP) hb[(cur ^ 1) * STEP + idx] = stage[c];
             }
         }
-        __syncthreads();
+        if constexpr ((BHIP_TILE_EXP & 1) == 0) __syncthreads();
     }
 
     if (a.use_vend) {
