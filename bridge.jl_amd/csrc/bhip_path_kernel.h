@@ -198,6 +198,11 @@ BHIP_DEV void guide_terms(const M &model, double t, const double *g, const doubl
 #ifndef BHIP_KCH
 #define BHIP_KCH 4
 #endif
+// depth of the prefetch window of the pCN kernel (a 16-byte slot per step in flight): with 4 the kernel
+// needs 129+ VGPRs and spills inside the time loop under the 128-register cap of 4 waves per SIMD
+#ifndef BHIP_KCH_PCN
+#define BHIP_KCH_PCN 3
+#endif
 
 // per-lane state carried through the time loop
 template <int D, int MP>
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
     // for the stand-alone llikelihood) is issued while step i is computed, so PF loads per lane are in
     // flight and their latency overlaps arithmetic instead of being exposed once per step.  Stores are
     // fire-and-forget.  The loop is unrolled by two so that the Philox block parity is static.
-    constexpr int PF = BHIP_KCH;
+    constexpr int PF = NOISE == NOISE_PCN ? BHIP_KCH_PCN : BHIP_KCH;
     constexpr int NIN = (NOISE == NOISE_LLONLY || NOISE == NOISE_INNOV) ? D : MP;
     constexpr bool READS = NOISE == NOISE_EXT || NOISE == NOISE_LLONLY || NOISE == NOISE_INNOV;
     constexpr int OFF = NOISE == NOISE_LLONLY ? 0 : 1;   // INNOV reads X[i+1] (X[0] is loaded up front)

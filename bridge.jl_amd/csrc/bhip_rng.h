@@ -44,6 +44,50 @@ BHIP_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, 
 
 BHIP_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Device forms of the three fixed-range operations below.  They produce the SAME bits as the portable
+// expressions (checked exhaustively-at-random on the GPU by tests/rng_device_forms.hip) with fewer VALU
+// instructions: the noise is the largest share of the proposal kernels' issue slots.
+//   (a >> 11) * 2^-53 : k = a >> 11 = kh*2^32 + kl; a double whose mantissa field holds kl (kh) under a fixed
+//   exponent equals c + kl*2^-53 (c + kh*2^-21) exactly, so two subtractions and one exact addition replace
+//   the integer->double conversions.
+BHIP_HD double u53_bits(uint32_t lo, uint32_t hi, double lo_magic)
+{
+    const uint32_t kl = (hi << 21) | (lo >> 11), kh = hi >> 11;
+    union { uint64_t u; double d; } a, b;
+    a.u = 0x3FE0000000000000ULL | kl;             // 0.5   + kl * 2^-53
+    b.u = 0x41E0000000000000ULL | kh;             // 2^31  + kh * 2^-21
+    return (b.d - 0x1.0p31) + (a.d - lo_magic);   // both differences and the sum are exact
+}
+BHIP_HD double u53_open0(uint32_t lo, uint32_t hi) { return u53_bits(lo, hi, 0.5 - 0x1.0p-53); }   // (k+1)*2^-53 in (0,1]
+BHIP_HD double u53_open1(uint32_t lo, uint32_t hi) { return u53_bits(lo, hi, 0.5); }               // k*2^-53 in [0,1)
+// a / b and sqrt(x) as the compiler expands them (reciprocal / reciprocal-square-root seed, Newton steps on
+// fma, final residual correction = correctly rounded), WITHOUT the exponent pre-scaling and special-value
+// fix-ups that only matter outside the ranges used here: b in [1.7, 2.5], |a| < 1;  x in [0, 1500].
+BHIP_HD double div_fixed_range(double a, double b)
+{
+    const double y0 = __builtin_amdgcn_rcp(b);
+    const double e0 = __builtin_fma(-b, y0, 1.0);
+    const double y1 = __builtin_fma(y0, e0, y0);
+    const double e1 = __builtin_fma(-b, y1, 1.0);
+    const double y2 = __builtin_fma(y1, e1, y1);
+    const double q0 = a * y2;
+    const double r = __builtin_fma(-b, q0, a);
+    return __builtin_fma(r, y2, q0);
+}
+BHIP_HD double sqrt_fixed_range(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g0 = x * y, h0 = y * 0.5;
+    const double r0 = __builtin_fma(-h0, g0, 0.5);
+    const double g1 = __builtin_fma(g0, r0, g0), h1 = __builtin_fma(h0, r0, h0);
+    const double d0 = __builtin_fma(-g1, g1, x);
+    const double g2 = __builtin_fma(d0, h1, g1);
+    const double d1 = __builtin_fma(-g2, g2, x);
+    const double g3 = __builtin_fma(d1, h1, g2);
+    return x == 0.0 ? 0.0 : g3;
+}
+#else
 BHIP_HD double u53_open0(uint32_t lo, uint32_t hi)   // (0,1]
 {
     const uint64_t a = ((uint64_t)hi << 32) | lo;
@@ -54,6 +98,9 @@ BHIP_HD double u53_open1(uint32_t lo, uint32_t hi)   // [0,1)
     const uint64_t a = ((uint64_t)hi << 32) | lo;
     return (double)(a >> 11) * 0x1.0p-53;
 }
+BHIP_HD double div_fixed_range(double a, double b) { return a / b; }
+BHIP_HD double sqrt_fixed_range(double x) { return __builtin_sqrt(x); }
+#endif
 
 // natural log for x in (0,1], normal doubles:  x = 2^e m, m in [sqrt(1/2), sqrt(2));
 // log m = 2 atanh(s), s = (m-1)/(m+1), odd Taylor series in s up to s^23 (|s| <= 0.1716).
@@ -65,7 +112,7 @@ BHIP_HD double det_log(double x)
     v.u = (v.u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
     double m = v.d;
     if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
-    const double s = (m - 1.0) / (m + 1.0);
+    const double s = div_fixed_range(m - 1.0, m + 1.0);
     const double z = s * s;
     double p = 1.0 / 23.0;
     p = fma_(p, z, 1.0 / 21.0);
@@ -124,7 +171,7 @@ BHIP_HD void normal_pair(uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter,
     const u32x4 r = philox4x32_10(path, 0u, iter, blk, k0, k1);
     const double u1 = u53_open0(r.x, r.y);
     const double u2 = u53_open1(r.z, r.w);
-    const double rad = __builtin_sqrt(-2.0 * det_log(u1));
+    const double rad = sqrt_fixed_range(-2.0 * det_log(u1));
     double s, c;
     det_sincos2pi(u2, s, c);
     z0 = rad * c;

@@ -281,3 +281,21 @@ def test_inline_philox_equals_rocrand_device_generator(tmp_path):
                            os.path.join(root, "tests", "rocrand_check.hip"), "-o", exe], stderr=subprocess.DEVNULL)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
+
+
+def test_device_forms_of_the_generator_are_bit_identical(tmp_path):
+    """bhip_rng.h evaluates the uniforms, the division inside det_log and the square root of Box-Muller with
+    shorter device sequences; tests/rng_device_forms.hip compares them with the portable expressions
+    (integer->double conversion, IEEE division, IEEE sqrt) on 2^32 inputs from the ranges used"""
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "rng_device_forms")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-I", os.path.join(root, "bridge.jl_amd", "csrc"),
+                           os.path.join(root, "tests", "rng_device_forms.hip"), "-o", exe], stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
