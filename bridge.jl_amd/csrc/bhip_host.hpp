@@ -419,6 +419,10 @@ inline int model_setup(int id, int d_hint, const double *par, int npar, ModelHos
     if (d < 1) { err = "model needs a positive dimension"; return BHIP_EINVAL; }
     if (d_hint > 0 && d_hint != d) { err = "dimension does not match the model"; return BHIP_EINVAL; }
     if (npar != need) { err = "wrong number of model parameters"; return BHIP_EINVAL; }
+    if (id == BHIP_MODEL_FHN || id == BHIP_MODEL_FHN2) {   // the kernels divide by eps with a hoisted reciprocal (UniformDivisor)
+        const double ae = std::fabs(par[0]);
+        if (!(ae > 0x1.0p-200 && ae < 0x1.0p200)) { err = "FitzHugh-Nagumo: eps must satisfy 2^-200 < |eps| < 2^200"; return BHIP_EINVAL; }
+    }
     mh.id = id; mh.d = d; mh.mp = mp;
     mh.par.assign(par, par + npar);
     Mat S(d, mp);
