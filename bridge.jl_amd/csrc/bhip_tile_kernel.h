@@ -109,32 +109,50 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     const double *Bf = cm, *Btf = cm + DD, *Af = cm + 2 * DD, *Sf = cm + 3 * DD;
     const double *mu = cm + 4 * DD, *mua = mu + D, *beta = mu + 2 * D, *vend = mu + 3 * D, *x0 = mu + 4 * D;
 
+    // Addressing: the lane's element (t, r) of grid row i lives at  base + i*D*ld + (4t + r)*(4*ld), base = array +
+    // kq*ld + p.  One running pointer per array is advanced once per step and the 4T elements are reached by a
+    // chain of additions of the wave-uniform stride 4*ld (one VALU each) instead of a 64-bit multiply per access.
+    // Lanes beyond the ensemble (p_raw >= P) replicate path P-1 exactly (same path id, same loads), so their
+    // stores write identical values to identical addresses and need no execution mask.
+    const size_t rsWin = 4 * (size_t)a.ldWin, rsX = 4 * (size_t)a.ldX, rsWo = 4 * (size_t)a.ldWout * a.wstride, rsC = 4 * (size_t)a.ldC;
+    const double *winp = (NOISE == 0 || NOISE == 3) ? a.Win + (size_t)kq * a.ldWin + p : nullptr;
+    double *xp = a.X ? a.X + (size_t)kq * a.ldX + p : nullptr;
+    double *wop = (NOISE == 1 && a.Wout) ? a.Wout + ((size_t)kq * a.ldWout + p) * a.wstride : nullptr;
+    tile_d2v *wsp = NOISE == 2 ? reinterpret_cast<tile_d2v *>(a.Wc) + (size_t)kq * a.ldC + p : nullptr;
+
     double x[T][4], wprev[T][4];
+    {
+        const double *q = winp;
+        double *qo = wop;
 #pragma unroll
-    for (int t = 0; t < T; t++)
+        for (int t = 0; t < T; t++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = 16 * t + 4 * r + kq;
-            x[t][r] = x0[row];
-            wprev[t][r] = NOISE == 0 ? a.Win[(size_t)row * a.ldWin + p] : 0.0;
-            if (NOISE == 1 && a.Wout && live) a.Wout[((size_t)row * a.ldWout + p) * a.wstride] = 0.0;
-        }
+            for (int r = 0; r < 4; r++) {
+                x[t][r] = x0[16 * t + 4 * r + kq];
+                wprev[t][r] = NOISE == 0 ? *q : 0.0;
+                if (NOISE == 0) q += rsWin;
+                if (NOISE == 1 && a.Wout) { *qo = 0.0; qo += rsWo; }
+            }
+    }
+    if (NOISE == 0) winp += (size_t)D * a.ldWin;                       // -> W[1]
+    if (NOISE == 1 && a.Wout) wop += (size_t)D * a.ldWout * a.wstride;
     double ll = 0.0;
     const uint32_t path = a.path0 + (uint32_t)p;
     // pCN: W2 accumulates the fresh Wiener path, wprev the proposal Wo = rho*W + sqrt(1-rho^2)*W2
     double w2prev[NOISE == 2 ? T : 1][4];
     int cpar = 0;
-    tile_d2v *wslot = nullptr;
     if constexpr (NOISE == 2) {
         cpar = a.cur[p];
-        wslot = reinterpret_cast<tile_d2v *>(a.Wc) + p;
+        tile_d2v *q = wsp;
 #pragma unroll
         for (int t = 0; t < T; t++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 w2prev[t][r] = 0.0;
-                if (live) wslot[(size_t)(16 * t + 4 * r + kq) * a.ldC] = tile_d2v{0.0, 0.0};   // W[1] = Wo[1] = 0
+                *q = tile_d2v{0.0, 0.0};   // W[1] = Wo[1] = 0
+                q += rsC;
             }
+        wsp += (size_t)D * a.ldC;          // -> slots of W[1]
     }
 
     for (int i = 0; i < nsteps; i++) {
@@ -155,32 +173,40 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
         // ---- the Wiener increment tile
         double dw[T][4];
         if constexpr (NOISE == 0) {
+            const double *q = winp;
 #pragma unroll
             for (int t = 0; t < T; t++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int row = 16 * t + 4 * r + kq;
-                    const double wn = a.Win[((size_t)(i + 1) * D + row) * a.ldWin + p];
+                    const double wn = *q;
+                    q += rsWin;
                     dw[t][r] = wn - wprev[t][r];
                     wprev[t][r] = wn;
                 }
+            winp += (size_t)D * a.ldWin;
         } else if constexpr (NOISE == 3) {
             // stand-alone llikelihood(LeftRule(), X, Po): x_i comes from the stored path, nothing is propagated
+            const double *q = winp;
 #pragma unroll
             for (int t = 0; t < T; t++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    x[t][r] = a.Win[((size_t)i * D + 16 * t + 4 * r + kq) * a.ldWin + p];
+                    x[t][r] = *q;
+                    q += rsWin;
                     dw[t][r] = 0.0;
                 }
+            winp += (size_t)D * a.ldWin;
         } else {
             tile_d2v slot[NOISE == 2 ? T : 1][4];
             if constexpr (NOISE == 2) {   // the chain's slots of step i+1: issued first, consumed after the normals
+                const tile_d2v *q = wsp;
 #pragma unroll
                 for (int t = 0; t < T; t++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        slot[t][r] = __builtin_nontemporal_load(&wslot[((size_t)(i + 1) * D + 16 * t + 4 * r + kq) * a.ldC]);
+                    for (int r = 0; r < 4; r++) {
+                        slot[t][r] = __builtin_nontemporal_load(q);
+                        q += rsC;
+                    }
             }
             // normal index n = i*D + row; block n>>1 = i*D/2 + 2*ks + (kq>>1), element kq&1 (ks = 4t+r).
             // lanes kq and kq^1 share blocks: the even lane draws ks = 0..2T-1, the odd one ks = 2T..4T-1.
@@ -197,6 +223,8 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 mine[h] = odd ? got : keep;            // K-slice h       : drawn by the even lane
                 mine[h + 2 * T] = odd ? keep : got;    // K-slice h + 2T  : drawn by the odd lane
             }
+            tile_d2v *qs = wsp;
+            double *qo = wop;
 #pragma unroll
             for (int t = 0; t < T; t++)
 #pragma unroll
@@ -209,24 +237,32 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                         dw[t][r] = wo - wprev[t][r];
                         w2prev[t][r] = w2;
                         wprev[t][r] = wo;
-                        if (live)
-                            __builtin_nontemporal_store(cpar ? tile_d2v{wo, slot[t][r].y} : tile_d2v{slot[t][r].x, wo},
-                                                        &wslot[((size_t)(i + 1) * D + 16 * t + 4 * r + kq) * a.ldC]);
+                        __builtin_nontemporal_store(cpar ? tile_d2v{wo, slot[t][r].y} : tile_d2v{slot[t][r].x, wo}, qs);
+                        qs += rsC;
                     } else {
                         const double wn = wprev[t][r] + rdt * mine[4 * t + r];   // sample!: W[i+1] = W[i] + sqrt(dt)*xi
                         dw[t][r] = wn - wprev[t][r];
                         wprev[t][r] = wn;
-                        if (a.Wout && live) a.Wout[(((size_t)(i + 1) * D + 16 * t + 4 * r + kq) * a.ldWout + p) * a.wstride] = wn;
                     }
                 }
+            if (NOISE == 2) wsp += (size_t)D * a.ldC;
+            if (NOISE == 1 && a.Wout) {   // one wave-uniform test for the whole row group
+#pragma unroll
+                for (int t = 0; t < T; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { *qo = wprev[t][r]; qo += rsWo; }
+                wop += (size_t)D * a.ldWout * a.wstride;
+            }
         }
 
         // ---- X[i] = x (before the update, src/euler.jl:263)
-        if (a.X && live) {
+        if (NOISE != 3 && a.X) {   // wave-uniform test (xp itself is a per-lane value)
+            double *q = xp;
 #pragma unroll
             for (int t = 0; t < T; t++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) a.X[((size_t)i * D + 16 * t + 4 * r + kq) * a.ldX + p] = x[t][r];
+                for (int r = 0; r < 4; r++) { *q = x[t][r]; q += rsX; }
+            xp += (size_t)D * a.ldX;
         }
 
         double w[T][4], xm[T][4], xa[T][4];
@@ -281,11 +317,12 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 #pragma unroll
             for (int r = 0; r < 4; r++) x[t][r] = vend[16 * t + 4 * r + kq];
     }
-    if (NOISE != 3 && a.X && live) {
+    if (NOISE != 3 && a.X) {   // xp has advanced to row N-1
+        double *q = xp;
 #pragma unroll
         for (int t = 0; t < T; t++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) a.X[((size_t)(N - 1) * D + 16 * t + 4 * r + kq) * a.ldX + p] = x[t][r];
+            for (int r = 0; r < 4; r++) { *q = x[t][r]; q += rsX; }
     }
     if constexpr (NOISE == 2) {
         // if log(rand()) <= llo - ll: W <- Wo (parity flip), ll <- llo, acc += 1     partialbridge_fitzhugh.jl:160-167
