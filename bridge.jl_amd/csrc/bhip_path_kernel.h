@@ -198,10 +198,11 @@ BHIP_DEV void guide_terms(const M &model, double t, const double *g, const doubl
 #ifndef BHIP_KCH
 #define BHIP_KCH 4
 #endif
-// depth of the prefetch window of the pCN kernel (a 16-byte slot per step in flight): with 4 the kernel
-// needs 129+ VGPRs and spills inside the time loop under the 128-register cap of 4 waves per SIMD
+// depth of the prefetch window of the pCN kernel (a 16-byte slot per step in flight).  Measured on the bench
+// workload: 1, 2, 3 and 4 steps ahead run within 2 % of each other; 2 keeps the kernel at 118 VGPRs, 3 and 4 sit
+// on the 128-register cap of 4 waves per SIMD and spill a few loop-invariant values to scratch.
 #ifndef BHIP_KCH_PCN
-#define BHIP_KCH_PCN 3
+#define BHIP_KCH_PCN 2
 #endif
 
 // per-lane state carried through the time loop
