@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Writes tests/golden/guided_paths_v1.npz: for every problem of tests/problems.py (N = 101) the Wiener paths of
+the noise specification bhip-philox-v1, the guided paths, the log-likelihoods and a short pCN chain, as computed by
+the CPU oracle (oracle/bridge_oracle.c) AFTER it passed its pins (tests/test_oracle.py, K1..K14).
+
+The reference (Julia) stores no guided paths or llikelihood values and cannot run here, so these
+vectors do not come from Bridge.jl: they freeze the oracle + noise specification of round 1, so that a later
+change to BOTH the oracle and the kernels cannot drift unnoticed.  Regenerate only with a new version suffix.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle as o          # noqa: E402
+import problems             # noqa: E402
+
+N, NPATHS, SEED, CHAIN_ITERS, RHO = 101, 3, 2026, 5, 0.9
+
+
+def build():
+    out = {"meta": np.array([N, NPATHS, SEED, CHAIN_ITERS], dtype=np.int64), "rho": np.array(RHO)}
+    for c in problems.cases(N) + problems.forward_cases(N):
+        W = np.stack([o.wiener_sample(c.tt, c.mp, SEED, p, 0) for p in range(NPATHS)])
+        out[c.name + "/W"] = W
+        if c.kind == o.GUIDE_NONE:
+            out[c.name + "/X"] = np.stack([o.solve_em(c.model, c.d, c.mp, c.par, c.tt, c.x0, W[p]) for p in range(NPATHS)])
+            continue
+        ref = c.oracle_proposal()
+        X = np.stack([o.solve_guided(ref, c.x0, W[p]) for p in range(NPATHS)])
+        out[c.name + "/X"] = X
+        out[c.name + "/ll"] = np.array([o.llikelihood(ref, X[p]) for p in range(NPATHS)])
+        r = o.mcmc(ref, c.x0, RHO, CHAIN_ITERS, SEED, 1)
+        out[c.name + "/chain_W"], out[c.name + "/chain_X"] = r["W"], r["X"]
+        out[c.name + "/chain_ll_acc"] = np.array([r["ll"], float(r["acc"])])
+    return out
+
+
+if __name__ == "__main__":
+    data = build()
+    fn = os.path.join(HERE, "guided_paths_v1.npz")
+    np.savez_compressed(fn, **data)
+    print(fn, os.path.getsize(fn), "bytes,", len(data), "arrays")

@@ -299,3 +299,26 @@ def test_device_forms_of_the_generator_are_bit_identical(tmp_path):
                            os.path.join(root, "tests", "rng_device_forms.hip"), "-o", exe], stderr=subprocess.DEVNULL)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("case", problems.cases(101) + problems.forward_cases(101), ids=lambda c: c.name)
+def test_committed_golden_vectors_on_device(ctx, case):
+    """the frozen round-1 vectors (tests/golden/guided_paths_v1.npz) through the C ABI: in-kernel noise, guided
+    solve, fused log-likelihood and a pCN chain reproduce them without the oracle being involved"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "guided_paths_v1.npz"))
+    N, npaths, seed, iters = (int(v) for v in g["meta"])
+    rho = float(g["rho"])
+    Po = case.bh_proposal(bh, ctx)
+    X, W, ll = bh.sample_solve(case.x0, Po, npaths, seed=seed, store_W=True)
+    assert np.array_equal(W.paths(), g[case.name + "/W"])
+    check_paths(case, X.paths(), g[case.name + "/X"])
+    if case.kind == o.GUIDE_NONE:
+        return
+    check_ll(case, ll.cpu().numpy(), g[case.name + "/ll"])
+    if case.exact:
+        ch = bh.Chains(Po, case.x0, 2, seed=seed)
+        ch.step(rho, iters)
+        Xc, Wc = ch.paths(1, 1)
+        assert np.array_equal(Wc[0], g[case.name + "/chain_W"]) and np.array_equal(Xc[0], g[case.name + "/chain_X"])
+        assert ch.ll()[1] == g[case.name + "/chain_ll_acc"][0] and ch.acc()[1] == g[case.name + "/chain_ll_acc"][1]

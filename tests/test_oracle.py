@@ -409,3 +409,36 @@ def test_girsanov_antisymmetry_and_vector_models():
     dt = np.diff(tt)[:, None]
     ref = np.sum(((bb - bt) @ G.T) * (np.diff(X, axis=0) - 0.5 * (bb + bt) * dt))
     assert abs(g - ref) <= 1e-12 * max(1.0, abs(ref))
+
+
+# --------------------------------------------------------------------------- frozen vectors of round 1
+def test_oracle_reproduces_committed_golden_vectors():
+    """tests/golden/guided_paths_v1.npz (written by tests/golden/make_golden.py) freezes the oracle and the noise
+    specification: Wiener paths, guided paths, log-likelihoods and a short pCN chain for every test problem."""
+    import problems
+    sys_path = os.path.join(GOLD, "make_golden.py")
+    assert os.path.exists(sys_path)
+    g = np.load(os.path.join(GOLD, "guided_paths_v1.npz"))
+    N, npaths, seed, iters = (int(v) for v in g["meta"])
+    rho = float(g["rho"])
+    names = set()
+    for c in problems.cases(N) + problems.forward_cases(N):
+        names.add(c.name)
+        W = np.stack([o.wiener_sample(c.tt, c.mp, seed, p, 0) for p in range(npaths)])
+        assert np.array_equal(W, g[c.name + "/W"]), c.name
+        if c.kind == o.GUIDE_NONE:
+            X = np.stack([o.solve_em(c.model, c.d, c.mp, c.par, c.tt, c.x0, W[p]) for p in range(npaths)])
+            assert np.array_equal(X, g[c.name + "/X"]), c.name
+            continue
+        ref = c.oracle_proposal()
+        X = np.stack([o.solve_guided(ref, c.x0, W[p]) for p in range(npaths)])
+        ll = np.array([o.llikelihood(ref, X[p]) for p in range(npaths)])
+        # sin/cos-based drifts go through libm: allow its last-bit differences between builds
+        tol = 0.0 if c.exact else 1e-12
+        assert np.abs(X - g[c.name + "/X"]).max() <= tol * (1 + np.abs(X).max()), c.name
+        assert np.abs(ll - g[c.name + "/ll"]).max() <= tol * (1 + np.abs(ll).max()), c.name
+        if c.exact:
+            r = o.mcmc(ref, c.x0, rho, iters, seed, 1)
+            assert np.array_equal(r["W"], g[c.name + "/chain_W"]) and np.array_equal(r["X"], g[c.name + "/chain_X"]), c.name
+            assert r["ll"] == g[c.name + "/chain_ll_acc"][0] and r["acc"] == g[c.name + "/chain_ll_acc"][1], c.name
+    assert {k.split("/")[0] for k in g.files if "/" in k} == names
