@@ -711,8 +711,11 @@ int bhip_wiener_sample(bhip_ctx *ctx, const double *tt, int N, int mp, double *W
     HIPCHK(ctx, hipMemcpyAsync(ctx->scratch, rdt.data(), sizeof(double) * (N - 1), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // rdt is a stack-lifetime host buffer
     const dim3 grid((unsigned)((npaths + 255) / 256)), block(256);
-    if (mp <= 4)
-        hipLaunchKernelGGL(k_wiener, grid, block, 0, ctx->stream, ctx->scratch, N, mp, W_dev, ld, npaths, (uint32_t)seed, (uint32_t)(seed >> 32), iter, path0);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if (mp == 1) hipLaunchKernelGGL(k_wiener<1>, grid, block, 0, ctx->stream, ctx->scratch, N, W_dev, ld, npaths, k0, k1, iter, path0);
+    else if (mp == 2) hipLaunchKernelGGL(k_wiener<2>, grid, block, 0, ctx->stream, ctx->scratch, N, W_dev, ld, npaths, k0, k1, iter, path0);
+    else if (mp == 3) hipLaunchKernelGGL(k_wiener<3>, grid, block, 0, ctx->stream, ctx->scratch, N, W_dev, ld, npaths, k0, k1, iter, path0);
+    else if (mp == 4) hipLaunchKernelGGL(k_wiener<4>, grid, block, 0, ctx->stream, ctx->scratch, N, W_dev, ld, npaths, k0, k1, iter, path0);
     else
         hipLaunchKernelGGL(k_wiener_big, grid, block, 0, ctx->stream, ctx->scratch, N, mp, W_dev, ld, npaths, (uint32_t)seed, (uint32_t)(seed >> 32), iter, path0);
     HIPCHK(ctx, hipGetLastError());

@@ -35,25 +35,41 @@ __global__ void k_slots_to_soa(const double *__restrict__ slots, const unsigned 
 
 // sample!(W, Wiener{SVector{mp}}()):  W[0] = 0; W[i+1] = W[i] + rootdt[i]*xi   (time-major,
 // component-minor normals, src/wiener.jl:24-35; test/with_srand.jl)
-__global__ __launch_bounds__(256) void k_wiener(const double *__restrict__ rootdt, int N, int mp, double *__restrict__ W, long ld, long P,
+template <int MP>
+__global__ __launch_bounds__(256) void k_wiener(const double *__restrict__ rootdt, int N, double *__restrict__ W, long ld, long P,
                                                 uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const uint32_t path = path0 + (uint32_t)p;
-    double w[4] = {0.0, 0.0, 0.0, 0.0};
-    double zc = 0.0;
-    for (int k = 0; k < mp; k++) W[(size_t)k * ld + p] = 0.0;
-    for (int i = 0; i < N - 1; i++) {
-        const double rdt = rootdt[i];
-        for (int k = 0; k < mp; k++) {
-            const int n = i * mp + k;
-            double z;
-            if ((n & 1) == 0) normal_pair(k0, k1, path, iter, (uint32_t)(n >> 1), z, zc);
-            else z = zc;
-            const double wn = w[k & 3] + rdt * z;
-            w[k & 3] = wn;
-            W[((size_t)(i + 1) * mp + k) * ld + p] = wn;
+    double w[MP];
+    double *out = W + p;
+#pragma unroll
+    for (int k = 0; k < MP; k++) { w[k] = 0.0; out[(size_t)k * ld] = 0.0; }
+    out += (size_t)MP * ld;
+    // two grid steps per iteration = 2*MP normals = MP whole Philox blocks: the block parity is static
+    int i = 0;
+    for (; i + 1 < N - 1; i += 2) {
+        const double rdt0 = rootdt[i], rdt1 = rootdt[i + 1];
+        double z[2 * MP];
+#pragma unroll
+        for (int b = 0; b < MP; b++) normal_pair(k0, k1, path, iter, (uint32_t)(i / 2 * MP + b), z[2 * b], z[2 * b + 1]);
+#pragma unroll
+        for (int k = 0; k < MP; k++) { w[k] = w[k] + rdt0 * z[k]; __builtin_nontemporal_store(w[k], out + (size_t)k * ld); }
+        out += (size_t)MP * ld;
+#pragma unroll
+        for (int k = 0; k < MP; k++) { w[k] = w[k] + rdt1 * z[MP + k]; __builtin_nontemporal_store(w[k], out + (size_t)k * ld); }
+        out += (size_t)MP * ld;
+    }
+    if (i < N - 1) {   // odd number of steps: the last step takes the first MP normals of the following blocks
+        const double rdt0 = rootdt[i];
+#pragma unroll
+        for (int k = 0; k < MP; k++) {
+            const int n = i * MP + k;
+            double z0, z1;
+            normal_pair(k0, k1, path, iter, (uint32_t)(n >> 1), z0, z1);
+            w[k] = w[k] + rdt0 * ((n & 1) ? z1 : z0);
+            out[(size_t)k * ld] = w[k];
         }
     }
 }
