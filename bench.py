@@ -231,12 +231,15 @@ def main():
 
     for _ in range(args.warmup):
         w.step()
+    if world > 1:   # untimed: the first collective of each kind sets up RCCL's channels over xGMI
+        stats.zero_()
+        bdist.allgather_stats(stats, world)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
 
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    evs =[torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         evs[k].record()
