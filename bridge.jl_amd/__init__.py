@@ -7,3 +7,5 @@ from .api import *  # noqa: F401,F403
 from .api import _cm, _uncm  # noqa: F401
 from . import _lib  # noqa: F401
 from . import dist  # noqa: F401
+from . import coeffs  # noqa: F401
+from .coeffs import b, sigma, a, Gamma, constdiff, B, beta, r, H, guided_b  # noqa: F401

@@ -1206,3 +1206,15 @@ double bo_girsanov(int model, int d, int mp, const double *par, const double *pa
     }
     return som;
 }
+
+/* r((i,t),x,Po) and _b((i,t),x,Po) at one point, flat arguments for ctypes */
+void bo_guided_terms_flat(int kind, int N, int d, int mp, int m, int model, const double *par,
+                          int aux, const double *apar, const double *tt,
+                          const double *A1, const double *A2, const double *A3, const double *A4,
+                          int i, const double *x, double *r_out, double *drift_out)
+{
+    bo_proposal P;
+    mk_prop(&P, kind, N, d, mp, m, model, par, aux, apar, tt, A1, A2, A3, A4);
+    if (r_out) bo_guided_r(&P, i, x, r_out);
+    if (drift_out) bo_guided_drift(&P, i, x, drift_out);
+}

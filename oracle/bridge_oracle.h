@@ -144,6 +144,11 @@ double bo_llikelihood_flat(int kind, int N, int d, int mp, int m, int model, con
                            const double *A1, const double *A2, const double *A3, const double *A4,
                            const double *X, int skip);
 
+void bo_guided_terms_flat(int kind, int N, int d, int mp, int m, int model, const double *par,
+                          int aux, const double *apar, const double *tt,
+                          const double *A1, const double *A2, const double *A3, const double *A4,
+                          int i, const double *x, double *r_out, double *drift_out);
+
 /* ---- pCN Metropolis-Hastings chain (partialbridge_fitzhugh.jl:125-176) ---- */
 typedef struct { long acc; double ll; } bo_mcmc_result;
 void bo_mcmc_flat(int kind, int N, int d, int mp, int m, int model, const double *par,

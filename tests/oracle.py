@@ -332,6 +332,22 @@ def llikelihood(P, X, skip=0):
     return lib().bo_llikelihood_flat(*P._args(), px, C.c_int(skip))
 
 
+def guided_r(P, i, x):
+    """r((i,t), x, Po) at grid index i (0-based)"""
+    xx, px = _d(np.atleast_1d(x))
+    out = np.empty(P.d)
+    lib().bo_guided_terms_flat(*P._args(), C.c_int(i), px, out.ctypes.data_as(dp), None)
+    return out
+
+
+def guided_drift(P, i, x):
+    """_b((i,t), x, Po) = b + a*r"""
+    xx, px = _d(np.atleast_1d(x))
+    out = np.empty(P.d)
+    lib().bo_guided_terms_flat(*P._args(), C.c_int(i), px, None, out.ctypes.data_as(dp))
+    return out
+
+
 def gpupdate(Hd, V, L, Sigma, v):
     Hd = np.atleast_2d(np.asarray(Hd, dtype=np.float64))
     d = Hd.shape[0]

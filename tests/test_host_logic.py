@@ -207,3 +207,35 @@ def test_welford_merge_equals_sequential_mcnext():
     for x in xs:
         no = o.mcnext(mo, m2o, no, x)
     assert np.allclose(mo, mc[0], atol=1e-15) and np.allclose(o.uncm(m2o, 2, 2), mc[1], atol=1e-13)
+
+
+def test_coefficient_accessors_against_the_oracle():
+    """bridgehip.b / sigma / a / Gamma / B / beta / r / H / guided_b (the reference's small accessor methods, evaluated on the
+    host from the product's own parameters and guide arrays) against the oracle's restatement of the same methods"""
+    h = bh.Context(-1)
+    rng = np.random.default_rng(11)
+    for c in problems.cases(41):
+        P = c.bh_process(bh)
+        Po = c.bh_proposal(bh, h)
+        ref = c.oracle_proposal()
+        for i in (0, 7, len(c.tt) - 2):
+            x = np.asarray(c.x0) + 0.1 * rng.standard_normal(c.d)
+            t = float(c.tt[i])
+            assert np.allclose(bh.b(t, x, P), o.b(c.model, c.d, c.par, t, x), rtol=1e-14, atol=0), c.name
+            assert np.allclose(bh.a(t, x, P), o.a(c.model, c.d, c.mp, c.par), rtol=1e-14, atol=0), c.name
+            Pt = c.bh_aux(bh)
+            assert np.allclose(bh.B(t, Pt), o.aux_B(c.aux, c.d, c.apar, t), rtol=1e-15, atol=0), c.name
+            assert np.allclose(bh.beta(t, Pt), o.aux_beta(c.aux, c.d, c.apar, t), rtol=1e-14, atol=1e-300), c.name
+            assert np.allclose(bh.a(t, Pt), o.aux_a(c.aux, c.d, c.mp, c.apar, t), rtol=1e-14, atol=0), c.name
+            assert np.allclose(bh.b(t, x, Pt), o.aux_b(c.aux, c.d, c.apar, t, x), rtol=1e-12, atol=1e-14), c.name
+            rr = o.guided_r(ref, i, x)
+            assert np.allclose(bh.r(i, x, Po), rr, rtol=1e-9, atol=1e-12 * (1 + np.abs(rr).max())), c.name
+            gb = o.guided_drift(ref, i, x)
+            assert np.allclose(bh.guided_b(i, x, Po), gb, rtol=1e-9, atol=1e-12 * (1 + np.abs(gb).max())), c.name
+        assert bh.constdiff(Po) and bh.constdiff(P)
+        Hh = bh.H(3, Po)
+        assert Hh.shape == (c.d, c.d) and np.allclose(Hh, Hh.T, rtol=1e-9, atol=1e-9 * np.abs(Hh).max())
+    P = bh.OrnsteinUhlenbeck(2.0, 0.5)
+    assert np.allclose(bh.Gamma(0.0, [0.3], P), [[4.0]]) and np.allclose(bh.sigma(0.0, [0.3], P), [[0.5]])
+    with pytest.raises(bh.BridgeError):
+        bh.b(0.0, [0.1, 0.2], bh.UserProcess(2, "o[0] = x[0]; o[1] = x[1];", [], [[1.0], [1.0]], ctx=h))
