@@ -127,3 +127,31 @@ def test_script_grid_10001_points(ctx):
     X, W = ch.paths(100, 1)
     assert ch.acc()[100] == r["acc"] and ch.ll()[100] == r["ll"] and np.array_equal(X[0], r["X"]) and np.array_equal(W[0], r["W"])
     assert abs(X[0, -1, 0] - 1.1) < 1e-3                                           # the bridge ends at the observation
+
+
+def test_handles_release_their_device_memory(ctx):
+    """proposals, chains and ensembles are created and dropped repeatedly: the free device memory must come back"""
+    import gc
+    c = _fhn_case(problems.tau_grid(2.0, 257))
+
+    def cycle(rep):
+        Po = c.bh_proposal(bh, ctx)
+        ch = bh.Chains(Po, c.x0, 4096, seed=rep)
+        ch.step(0.9, 1)
+        ch.pathstats()
+        ch.paths(0, 8)
+        X, _, _ = bh.sample_solve(c.x0, Po, 4096, seed=rep)
+        del ch, Po, X
+
+    def free():
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        return torch.cuda.mem_get_info()[0]
+
+    cycle(0)        # first use loads the kernels' code objects and the runtime's pools (~150 MB, once)
+    free0 = free()
+    for rep in range(40):
+        cycle(rep)
+    free1 = free()
+    assert free0 - free1 < 64 << 20, (free0, free1)          # each repetition allocates > 50 MB: a leak would show as GBs
