@@ -953,7 +953,8 @@ int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip)
         if (skip < 0) return fail(ctx, BHIP_EINVAL, "skip must be >= 0");
         for (int it = 0; it < iters; it++) {
             ++ch->iter;
-            int rct = launch_tile_path(po, ch->x0.data(), nullptr, 0, nullptr, 0, ch->Xo, ch->ld, nullptr, skip, ch->n, 2, ch->seed, ch->iter, ch->path0, 1, ch, rho);
+            double *Xo = it == iters - 1 ? ch->Xo : nullptr;   // see below
+            int rct = launch_tile_path(po, ch->x0.data(), nullptr, 0, nullptr, 0, Xo, ch->ld, nullptr, skip, ch->n, 2, ch->seed, ch->iter, ch->path0, 1, ch, rho);
             if (rct) return rct;
         }
         return BHIP_OK;
@@ -965,8 +966,11 @@ int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip)
     a.cur = ch->cur; a.llcur = ch->llcur; a.acc = ch->acc;
     a.rho = rho; a.srho = std::sqrt(1 - rho * rho);
     a.k0 = (uint32_t)ch->seed; a.k1 = (uint32_t)(ch->seed >> 32); a.path0 = ch->path0;
+    // The proposal buffer Xo is overwritten by every iteration, so within one call only the LAST iteration's
+    // store can ever be observed: the earlier iterations run the instantiation without the store.
     for (int it = 0; it < iters; it++) {
         a.iter = ++ch->iter;
+        a.Xo = it == iters - 1 ? ch->Xo : nullptr;
         rc = do_launch(po, NOISE_PCN, a);
         if (rc) return rc;
     }

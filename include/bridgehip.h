@@ -200,11 +200,13 @@ int bhip_gpupdate(int d, int m, const double *Hd, const double *V, const double 
  * One chain per lane.  partialbridge_fitzhugh.jl:125-176, test/partialbridgenuH.jl:155-198
  * Chain state = (W, ll, parity): W and the proposal Wo share a 16-byte slot per (grid index, chain)
  * and an accept flips the chain's parity bit -- the reference's `W, Wo = Wo, W` swap
- * (test/partialbridgenuH.jl:186-187) without its copies.  Every iteration writes the proposal path
- * Xo (solve!(Euler(), Xo, x0, Wo, Po)) when BHIP_CHAINS_STORE_X is set; the CURRENT path X is a
+ * (test/partialbridgenuH.jl:186-187) without its copies.  With BHIP_CHAINS_STORE_X the proposal path
+ * Xo (solve!(Euler(), Xo, x0, Wo, Po)) of the last iteration of every bhip_chains_step call is kept in
+ * the proposal buffer (earlier iterations of the same call would be overwritten unseen and skip the
+ * store; call with iters = 1 to have every iteration's Xo); the CURRENT path X is a
  * deterministic function of the current W and is re-materialised on demand, bit-identical to the Xo
  * stored when that W was accepted (bhip_chains_current_X / bhip_chains_get_paths). */
-#define BHIP_CHAINS_STORE_X 1   /* write the proposal paths Xo every iteration (the SamplePath contract) */
+#define BHIP_CHAINS_STORE_X 1   /* keep the proposal paths Xo (the SamplePath contract) */
 int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uint32_t path0, uint64_t seed,
                        int flags, bhip_chains **out);
 void bhip_chains_destroy(bhip_chains *ch);

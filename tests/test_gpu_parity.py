@@ -322,3 +322,17 @@ def test_committed_golden_vectors_on_device(ctx, case):
         Xc, Wc = ch.paths(1, 1)
         assert np.array_equal(Wc[0], g[case.name + "/chain_W"]) and np.array_equal(Xc[0], g[case.name + "/chain_X"])
         assert ch.ll()[1] == g[case.name + "/chain_ll_acc"][0] and ch.acc()[1] == g[case.name + "/chain_ll_acc"][1]
+
+
+def test_batched_chain_steps_equal_single_steps(ctx):
+    """bhip_chains_step(iters = k) skips the proposal-path store of all but its last iteration (the buffer would be
+    overwritten unseen): the chain state, the statistics and the final Xo must equal k calls with iters = 1"""
+    c = [k for k in problems.cases(201) if k.name == "fhn_partialbridge_extreme"][0]
+    Po = c.bh_proposal(bh, ctx)
+    a, b = bh.Chains(Po, c.x0, 300, seed=12), bh.Chains(Po, c.x0, 300, seed=12)
+    a.step(0.9, 7)
+    for _ in range(7):
+        b.step(0.9, 1)
+    assert np.array_equal(a.ll(), b.ll()) and np.array_equal(a.acc(), b.acc())
+    assert torch.equal(a.proposal_X(), b.proposal_X()) and torch.equal(a.current_X().data, b.current_X().data)
+    assert torch.equal(a.stats(), b.stats())
