@@ -309,8 +309,8 @@ class FitzhughDiffusionAuxStartEnd:
 
 def fitzhugh_aux_linearised_end(P, v):
     """Bridge.B/beta of FitzhughDiffusionAux, aux_choice == "linearised_end" (partialbridge_fitzhugh.jl:99-100)"""
-    B = [[1 / P.eps - 3 * v ** 2 / P.eps, -1 / P.eps], [P.gamma, -1.0]]
-    beta = [P.s / P.eps + 2 * v ** 3 / P.eps, P.beta]
+    B = [[1 / P.eps - 3 * (v * v) / P.eps, -1 / P.eps], [P.gamma, -1.0]]       # Julia lowers v^2, v^3 to products
+    beta = [P.s / P.eps + 2 * (v * v * v) / P.eps, P.beta]
     return AffineAux(B, beta, [[0.0], [P.sigma]])
 
 

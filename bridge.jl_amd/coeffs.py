@@ -38,7 +38,7 @@ def b(t, x, P):
     if isinstance(P, _api.LinPro):                       # src/linpro.jl:80
         return P.B @ (x - P.mu)
     if isinstance(P, _api.FitzhughDiffusion):            # partialbridge_fitzhugh.jl:44
-        return np.array([(x[0] - x[1] - x[0] ** 3 + P.s) / P.eps, P.gamma * x[0] - x[1] + P.beta])
+        return np.array([(x[0] - x[1] - x[0] * x[0] * x[0] + P.s) / P.eps, P.gamma * x[0] - x[1] + P.beta])
     if isinstance(P, _api.NclarDiffusion):               # partialbridge_nclar.jl:58
         return np.array([x[1], x[2], -P.alpha * math.sin(P.omega * x[2])])
     if isinstance(P, _api.IntegratedDiffusion):          # test/partialbridge.jl:11-12
@@ -48,7 +48,7 @@ def b(t, x, P):
         return np.array([th[0] * (x[1] - x[0]), x[0] * (th[1] - x[2]) - x[1], x[0] * x[1] - th[2] * x[2]])
     if isinstance(P, _api.FitzHughNagumo):               # src/Models.jl:18
         eps, s, gam, bet = P.p[:4]
-        return np.array([(x[0] - x[0] ** 3 - x[1] + s) / eps, gam * x[0] - x[1] + bet])
+        return np.array([(x[0] - x[0] * x[0] * x[0] - x[1] + s) / eps, gam * x[0] - x[1] + bet])
     if isinstance(P, _api.Pendulum):                     # src/Models.jl:79
         return np.array([x[1], -P.theta2 * math.sin(x[0])])
     raise _api.BridgeError(f"b(t, x, P): no host method for {type(P).__name__} (user texts only run on the device)")
@@ -117,7 +117,7 @@ def B(t, Pt):
         eps, s, gam, bet, sig, t0, u, T, v = Pt.p
         lam = (t - t0) / (T - t0)
         uv = v * lam + u * (1 - lam)
-        return np.array([[1 / eps - 3 * uv ** 2 / eps, -1 / eps], [gam, -1.0]])
+        return np.array([[1 / eps - 3 * (uv * uv) / eps, -1 / eps], [gam, -1.0]])
     if isinstance(Pt, _api.CallbackAux):
         return np.atleast_2d(np.asarray(Pt.fn(t)[0], dtype=np.float64))
     raise _api.BridgeError(f"B(t, Pt): {type(Pt).__name__} is not an auxiliary process")
@@ -133,7 +133,7 @@ def beta(t, Pt):
         eps, s, gam, bet, sig, t0, u, T, v = Pt.p
         lam = (t - t0) / (T - t0)
         uv = v * lam + u * (1 - lam)
-        return np.array([s / eps + 2 * uv ** 3 / eps, bet])
+        return np.array([s / eps + 2 * (uv * uv * uv) / eps, bet])
     if isinstance(Pt, _api.CallbackAux):
         return np.atleast_1d(np.asarray(Pt.fn(t)[1], dtype=np.float64))
     raise _api.BridgeError(f"beta(t, Pt): {type(Pt).__name__} is not an auxiliary process")

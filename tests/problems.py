@@ -88,8 +88,8 @@ class Case:
 
 def fhn_aux_end(eps, s, gamma, beta, sigma, v):
     """Bridge.B / Bridge.beta of FitzhughDiffusionAux "linearised_end" (partialbridge_fitzhugh.jl:99-100)"""
-    B = [[1 / eps - 3 * v ** 2 / eps, -1 / eps], [gamma, -1.0]]
-    be = [s / eps + 2 * v ** 3 / eps, beta]
+    B = [[1 / eps - 3 * (v * v) / eps, -1 / eps], [gamma, -1.0]]
+    be = [s / eps + 2 * (v * v * v) / eps, beta]
     return o.affine_par(B, be, [[0.0], [sigma]])
 
 
