@@ -169,3 +169,28 @@ def test_C5_linpro32_guided_bridge_65536_paths(ctx):
         assert np.abs(X.paths(p, 1)[0] - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max())
         llr = o.llikelihood(ref, Xr)
         assert abs(float(ll[p]) - llr) <= 1e-8 * (1 + abs(llr))
+
+
+def test_C4_full_run_1000_iterations_of_32768_chains(ctx):
+    """config C4 as specified: one GPU's shard (32 768 chains) for the full 1000 pCN iterations, rho = 0.9;
+    after 10^9 path-steps per ... chain-step the spot-checked chains still agree with the oracle bit for bit"""
+    c = _case("fhn_partialbridge_extreme")
+    P, iters = 32768, 1000
+    ch = bh.Chains(c.bh_proposal(bh, ctx), c.x0, P, seed=4, path0=3 * P, store_X=False)      # rank 3's shard
+    marks = []
+    for n in (100, 400, 250, 250):
+        ch.step(0.9, n)
+        marks.append(ch.acc().sum())
+    ll, acc = ch.ll(), ch.acc()
+    assert np.all(np.isfinite(ll)) and acc.min() >= 1 and acc.max() < iters                # K10: 1 < acc < iterations
+    # the acceptance rate falls during burn-in (the chains climb in ll) and then settles: the last two quarters agree
+    r = [marks[0] / (P * 100), (marks[1] - marks[0]) / (P * 400), (marks[2] - marks[1]) / (P * 250), (marks[3] - marks[2]) / (P * 250)]
+    assert r[0] > r[1] > r[2] - 0.01 and abs(r[2] - r[3]) < 0.02 and 0.1 < r[3] < 0.7, r
+    st = ch.stats().cpu().numpy()
+    assert st[1] == iters and st[2] == acc.sum()
+    ref = c.oracle_proposal()
+    X, W = ch.paths(777, 1)
+    r = o.mcmc(ref, c.x0, 0.9, iters, 4, 3 * P + 777)
+    assert acc[777] == r["acc"] and ll[777] == r["ll"] and np.array_equal(W[0], r["W"]) and np.array_equal(X[0], r["X"])
+    r = o.mcmc(ref, c.x0, 0.9, iters, 4, 3 * P + P - 1)
+    assert acc[P - 1] == r["acc"] and ll[P - 1] == r["ll"]
