@@ -194,3 +194,29 @@ def test_C4_full_run_1000_iterations_of_32768_chains(ctx):
     assert acc[777] == r["acc"] and ll[777] == r["ll"] and np.array_equal(W[0], r["W"]) and np.array_equal(X[0], r["X"])
     r = o.mcmc(ref, c.x0, 0.9, iters, 4, 3 * P + P - 1)
     assert acc[P - 1] == r["acc"] and ll[P - 1] == r["ll"]
+
+
+def test_K13_noise_moments_and_tails_at_scale(ctx):
+    """K13 (test/wiener.jl:33-47, moments of W_T) sharpened: 2.6e8 in-kernel normals (262 144 paths x 1000 steps on a unit
+    grid, so the increments ARE the normals): mean, variance, skewness, kurtosis and tail frequencies within 5 standard
+    errors of the N(0,1) values, and no correlation between consecutive draws or neighbouring paths"""
+    P, N = 262144, 1001
+    tt = np.arange(N, dtype=np.float64)
+    W = bh.sample(tt, bh.Wiener(1), npaths=P, seed=77, ctx=ctx)
+    z = (W.data[1:, 0, :] - W.data[:-1, 0, :])
+    n = z.numel()
+    m1 = float(z.mean())
+    m2 = float((z * z).mean())
+    m3 = float((z ** 3).mean())
+    m4 = float((z ** 4).mean())
+    se = 1 / math.sqrt(n)
+    assert abs(m1) < 5 * se and abs(m2 - 1) < 5 * math.sqrt(2) * se
+    assert abs(m3) < 5 * math.sqrt(15) * se and abs(m4 - 3) < 5 * math.sqrt(96) * se
+    for thr, p in ((1.0, 0.31731050786291415), (3.0, 0.0026997960632601866), (4.5, 6.795346249460121e-06)):
+        cnt = float((z.abs() > thr).sum())
+        assert abs(cnt - n * p) < 5 * math.sqrt(n * p), (thr, cnt, n * p)
+    assert float(z.abs().max()) < 7.5                                                  # P(|z| > 7.5) * 2.6e8 = 1.7e-5
+    # serial correlation along a path (normals 2j, 2j+1 come from one Box-Muller pair) and across neighbouring paths
+    c_time = float((z[1:] * z[:-1]).mean())
+    c_path = float((z[:, 1:] * z[:, :-1]).mean())
+    assert abs(c_time) < 5 * se and abs(c_path) < 5 * se
