@@ -3,6 +3,7 @@
 // bhip_path_kernel.h (instantiated per model in bhip_inst.hip) and bhip_util_kernels.h.
 #include "bhip_host.hpp"
 #include "bhip_path_kernel.h"
+#include "bhip_chain_kernel.h"
 #include "bhip_tile_kernel.h"
 #include "bhip_girsanov_kernel.h"
 #include "bhip_rtc.hpp"
@@ -65,7 +66,9 @@ struct bhip_chains {
     uint32_t iter = 0;
     bool inited = false;
     std::vector<double> x0;   // shared starting point (d doubles)
-    double *Wc = nullptr;   // W slots [N][mp][ld][2]
+    bool lines = false;     // scalar noise, d <= 3: W in the line layout of bhip_chain_kernel.h, else 16-byte slots
+    int nch = 0;            // lines per chain and parity half = ceil(N / 16)
+    double *Wc = nullptr;   // W slots [N][mp][ld][2]  |  lines [2][nch][ld][16]
     double *Xo = nullptr;   // proposal paths [N][d][ld] (BHIP_CHAINS_STORE_X)
     int skip0 = 0;
     unsigned char *cur = nullptr;
@@ -660,13 +663,13 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
     const int gk = po->g.kind == BHIP_GUIDE_NUH_INPLACE ? BHIP_GUIDE_NUH : po->g.kind;
     const int gk_dispatch = noise == NOISE_INNOV ? gk : po->g.kind;   // NUH_INPLACE selects the two-dot log-likelihood instantiation
     int fl = 0;
-    if (noise == NOISE_PCN) fl = a.Xo ? 1 : 0;
+    if (noise == NOISE_PCN || noise == NOISE_PCN_LINES) fl = a.Xo ? 1 : 0;
     else fl = (a.X ? 1 : 0) | (a.Wout ? 2 : 0);
     if (a.rs != row_stride(gk, po->mh.d, po->g.m, po->mh.constdiff)) return fail(ctx, BHIP_ESTATE, "row stride mismatch");
     if (!po->mh.constdiff) {
         // constdiff(P) == false.  The reference's extra log-likelihood terms exist for PartialBridge only
         // (src/partialbridge.jl:79-84); its other !constdiff branches reference undefined names.
-        const bool wants_ll = a.ll != nullptr || noise == NOISE_PCN || noise == NOISE_LLONLY;
+        const bool wants_ll = a.ll != nullptr || noise == NOISE_PCN || noise == NOISE_PCN_LINES || noise == NOISE_LLONLY;
         if (wants_ll && gk != BHIP_GUIDE_LMMU)
             return fail(ctx, BHIP_EUNSUPPORTED, "llikelihood with a state-dependent sigma is defined for PartialBridge (L,M,mu) only");
         if (noise == NOISE_INNOV) return fail(ctx, BHIP_EUNSUPPORTED, "innovations need a constant, invertible sigma");
@@ -690,7 +693,8 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         KArgs args = a;
         void *params[] = {&args};
         const long grid = (a.P + 255) / 256;
-        HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr));
+        const unsigned lds = noise == NOISE_PCN_LINES ? (unsigned)CHAIN_LINES_LDS : 0u;
+        HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, lds, ctx->stream, params, nullptr));
         return BHIP_OK;
     }
     launch_fn f = find_launch(po->mh, gk_dispatch, mo, noise, fl);
@@ -887,7 +891,10 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     ch->ctx = ctx; ch->po = po; ch->n = nchains; ch->ld = (nchains + 63) / 64 * 64;
     ch->path0 = path0; ch->seed = seed; ch->flags = flags;
     const size_t N = po->tt.size();
-    const size_t wbytes = sizeof(double) * 2 * N * po->mh.mp * ch->ld, xbytes = sizeof(double) * N * po->mh.d * ch->ld;
+    ch->lines = po->mh.d <= 3 && po->mh.mp == 1;
+    ch->nch = (int)((N + LINE_DOUBLES - 1) / LINE_DOUBLES);
+    const size_t wbytes = ch->lines ? sizeof(double) * 2 * ch->nch * ch->ld * LINE_DOUBLES : sizeof(double) * 2 * N * po->mh.mp * ch->ld;
+    const size_t xbytes = sizeof(double) * N * po->mh.d * ch->ld;
     hipError_t e = hipMalloc((void **)&ch->Wc, wbytes);
     if (e == hipSuccess && (flags & BHIP_CHAINS_STORE_X)) e = hipMalloc((void **)&ch->Xo, xbytes);
     if (e == hipSuccess) e = hipMalloc((void **)&ch->cur, ch->ld);
@@ -931,11 +938,24 @@ int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
     KArgs a;
     int rc = fill_common(po, a, x0, nullptr, ch->n, skip);
     if (rc) return rc;
-    a.Wout = ch->Wc; a.ldWout = ch->ld; a.wstride = 2;   // half 0 of every slot, cur = 0
+    double *tmpW = nullptr;
+    if (ch->lines) {   // the fresh W goes to a plain SoA scratch array and is re-arranged into half 0 of the lines
+        HIPCHK(ctx, hipMalloc((void **)&tmpW, sizeof(double) * po->tt.size() * ch->ld));
+        a.Wout = tmpW; a.ldWout = ch->ld; a.wstride = 1;
+    } else {
+        a.Wout = ch->Wc; a.ldWout = ch->ld; a.wstride = 2;   // half 0 of every slot, cur = 0
+    }
     a.X = ch->Xo; a.ldX = ch->ld; a.ll = ch->llcur;
     ch->skip0 = skip;
     a.k0 = (uint32_t)ch->seed; a.k1 = (uint32_t)(ch->seed >> 32); a.iter = 0; a.path0 = ch->path0;
     rc = do_launch(po, NOISE_FRESH, a);
+    if (!rc && ch->lines) {
+        const long total = (long)ch->nch * ch->ld * LINE_DOUBLES;
+        hipLaunchKernelGGL(k_soa_to_lines, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, tmpW, ch->ld, (int)po->tt.size(), ch->nch,
+                           ch->Wc, ch->ld, ch->n);
+        if (hipGetLastError() != hipSuccess) rc = fail(ctx, BHIP_EHIP, "k_soa_to_lines launch failed");
+    }
+    if (tmpW) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(tmpW); }
     if (rc) return rc;
     ch->iter = 0; ch->inited = true;
     return BHIP_OK;
@@ -971,7 +991,7 @@ int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip)
     for (int it = 0; it < iters; it++) {
         a.iter = ++ch->iter;
         a.Xo = it == iters - 1 ? ch->Xo : nullptr;
-        rc = do_launch(po, NOISE_PCN, a);
+        rc = do_launch(po, ch->lines ? NOISE_PCN_LINES : NOISE_PCN, a);
         if (rc) return rc;
     }
     return BHIP_OK;
@@ -1010,6 +1030,13 @@ int bhip_chains_get(bhip_chains *ch, double *ll, int64_t *acc)
 static int gather_current_W(bhip_chains *ch, long p0, long np, double *W_soa)
 {
     bhip_ctx *ctx = ch->ctx;
+    if (ch->lines) {
+        const int N = (int)ch->po->tt.size();
+        const long total = (long)N * np;
+        hipLaunchKernelGGL(k_lines_to_soa, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ch->Wc, ch->cur, N, ch->nch, ch->ld, p0, np, W_soa);
+        HIPCHK(ctx, hipGetLastError());
+        return BHIP_OK;
+    }
     const long E = (long)ch->po->tt.size() * ch->po->mh.mp;
     const long tot = E * np;
     hipLaunchKernelGGL(k_slots_to_soa, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ch->Wc, ch->cur, W_soa, E, ch->ld, p0, np);

@@ -1,0 +1,173 @@
+// bhip_chain_kernel.h -- the pCN Metropolis-Hastings iteration for scalar noise (m' = 1) on the LINE layout.
+//
+// Same arithmetic as k_paths<..., NOISE_PCN, ...> (it calls the same path_step), different chain-state layout.
+// The slot layout of bhip_path_kernel.h keeps a chain's current W and its proposal Wo side by side (16 bytes per
+// grid point) because neighbouring chains have different accept/reject parities; every iteration then moves the
+// unchanged half as well: 16 B read + 16 B written per path-step for 8 + 8 algorithmic bytes.  This memory system
+// moves whole 128-byte lines (profiles/r1_microbench.txt), so the waste can only be avoided if a chain's values of
+// ONE parity half fill whole lines:
+//
+//     Wl[((h*nch + k)*ld + p)*16 + s] = W[16k + s] of chain p in half h        (a 128-byte line per (h, k, p))
+//
+// A wave owns 64 chains.  Per 16-step chunk it reads, for every chain, only the line of that chain's CURRENT half
+// -- cooperatively, 8 lanes per line, 8 instructions for the 64 lines, exactly as coalesced as a plain stream --
+// transposes through a padded LDS tile so that each chain's lane finds its own 16 values, overwrites them in
+// place with the proposal values as the steps are computed, and writes the tile cooperatively to the lines of
+// the OTHER halves.  An accept flips the chain's parity bit as before.  HBM traffic per path-step: 8 B read +
+// 8 B written for W (+ 8d for the proposal path) = the algorithmic bytes of SURVEY 8(d) mode M.
+// Cost: a 64 x 17 double LDS tile per wave and 32 staging registers => 2 waves per SIMD (VGPRs are then plentiful).
+#pragma once
+#include "bhip_path_kernel.h"
+
+namespace bhip {
+
+constexpr int LINE_DOUBLES = 16;              // one 128-byte line
+constexpr int LINE_ROW = LINE_DOUBLES + 1;    // padded LDS row: lane L reads column s of row L without bank conflicts
+
+BHIP_DEV size_t line_index(int h, int k, long chain, int nch, long ld)
+{
+    return (((size_t)h * nch + k) * ld + chain) * LINE_DOUBLES;
+}
+
+template <class M, int GK, int MO, int FL>
+__global__ __launch_bounds__(256, 2) void k_chain_lines(const KArgs a)
+{
+    constexpr int D = M::D;
+    static_assert(M::MP == 1, "the line layout is built for scalar noise");
+    using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
+    extern __shared__ __attribute__((aligned(16))) double lds_tiles[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long c0 = ((long)blockIdx.x * 4 + wave) * 64;
+    if (c0 >= a.P) return;                         // no block-level synchronisation anywhere below
+    const bool live = c0 + lane < a.P;
+    // lanes beyond the ensemble replicate chain P-1 exactly (same row of the tile, same stream): their stores
+    // write identical values to identical addresses and need no execution mask
+    const int row = live ? lane : (int)(a.P - 1 - c0);
+    const long p = c0 + row;
+    double *tile = lds_tiles + (size_t)wave * 64 * LINE_ROW;
+    double *mine = tile + row * LINE_ROW;
+
+    const M model(a.mpar);
+    const int N = a.N, nsteps = N - 1, nll = N - 1 - a.skip;
+    const int nch = (N + LINE_DOUBLES - 1) / LINE_DOUBLES;
+    const cptr_t rows = (cptr_t)(uintptr_t)a.rows;
+    LaneState<D, 1> st;
+#pragma unroll
+    for (int k = 0; k < D; k++) st.y[k] = a.x0[k];
+    st.ll = 0.0; st.zc = 0.0; st.wprev[0] = 0.0; st.w2prev[0] = 0.0;
+    double *xout = nullptr;
+    long ldx = 0;
+    if constexpr ((FL & 1) != 0) { xout = a.Xo + p; ldx = a.ldC; }
+    const uint32_t path = a.path0 + (uint32_t)p;
+    const int c = a.cur[p];
+
+    // cooperative mapping: instruction q moves the lines of chains c0 + 8q + lane/8; lane%8 selects 16 bytes of a line
+    const int sub = lane >> 3, part = 2 * (lane & 7);
+    int par[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) par[q] = a.cur[c0 + 8 * q + sub];   // cur[] is allocated (and zeroed) up to ld
+    d2v stage[8];
+    auto fetch = [&](int k) {
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            stage[q] = ld_stream((const d2v *)(a.Wc + line_index(par[q], k, c0 + 8 * q + sub, nch, a.ldC) + part));
+    };
+    fetch(0);
+
+    // one Euler step i (grid value j = i + 1 = 16k + s): the chain's current W[j] comes from the tile, the proposal goes back
+    auto step = [&](int i, int s) {
+        double wc = mine[s];
+        path_step<M, GK, MO, NOISE_PCN, FL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, &wc, nullptr, 0, xout, ldx, st);
+        mine[s] = st.wprev[0];
+    };
+
+    for (int k = 0; k < nch; k++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {   // staged lines -> tile
+            double *d = tile + (8 * q + sub) * LINE_ROW + part;
+            d[0] = stage[q].x; d[1] = stage[q].y;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (k + 1 < nch) fetch(k + 1);   // in flight while this chunk is computed
+        const int j0 = k * LINE_DOUBLES;
+        if (k > 0 && j0 + LINE_DOUBLES <= N) {
+            // interior chunk: 16 valid steps; pairs (i odd, i even) so that the Philox block parity is static
+#pragma unroll 1
+            for (int s = 0; s < LINE_DOUBLES; s += 2) {
+                step(j0 + s - 1, s);
+                step(j0 + s, s + 1);
+            }
+        } else {
+            // first chunk (grid value 0 is W[0] = Wo[0] = 0, no step) and the ragged last chunk
+#pragma unroll 1
+            for (int s = 0; s < LINE_DOUBLES; s += 2) {
+                const int i0 = j0 + s - 1;
+                if (i0 < 0) mine[s] = 0.0;
+                else if (i0 < nsteps) step(i0, s);
+                if (i0 + 1 < nsteps) step(i0 + 1, s + 1);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 8; q++) {   // tile -> the lines of the other halves
+            const double *d = tile + (8 * q + sub) * LINE_ROW + part;
+            st_stream((d2v *)(a.Wc + line_index(par[q] ^ 1, k, c0 + 8 * q + sub, nch, a.ldC) + part), d2v{d[0], d[1]});
+        }
+        __builtin_amdgcn_wave_barrier();   // the tile is overwritten by the next chunk only after these reads
+    }
+
+    if (a.use_vend) {   // endpoint(y, P::GuidedBridge) src/euler.jl:241-242
+#pragma unroll
+        for (int k = 0; k < D; k++) st.y[k] = a.vend[k];
+    }
+    if constexpr ((FL & 1) != 0) {
+#pragma unroll
+        for (int k = 0; k < D; k++) st_stream(&xout[((size_t)(N - 1) * D + k) * ldx], st.y[k]);
+    }
+    // if log(rand()) <= llo - ll: W <- Wo (parity flip), ll <- llo, acc += 1
+    if (live) {
+        const double u = accept_uniform(a.k0, a.k1, path, a.iter);
+        if (det_log(u) <= st.ll - a.llcur[p]) {
+            a.cur[p] = (unsigned char)(c ^ 1);
+            a.llcur[p] = st.ll;
+            a.acc[p] += 1u;
+        }
+        if (a.ll) a.ll[p] = st.ll;
+    }
+}
+
+// ---- BHIP_RTC_END  (above: device code, also embedded for hipRTC user models; below: host launch + layout conversion)
+
+constexpr size_t CHAIN_LINES_LDS = sizeof(double) * 4 * 64 * LINE_ROW;   // one tile per wave, 4 waves per block: 34 KiB
+
+template <class M, int GK, int MO, int FL>
+hipError_t launch_chain_lines(const KArgs &a, hipStream_t st)
+{
+    const long grid = (a.P + 255) / 256;
+    hipLaunchKernelGGL((k_chain_lines<M, GK, MO, FL>), dim3((unsigned)grid), dim3(256), CHAIN_LINES_LDS, st, a);
+    return hipGetLastError();
+}
+
+// plain SoA W [N][ld] -> half 0 of the line layout (chain initialisation), and the current halves back to SoA
+static __global__ __launch_bounds__(256) void k_soa_to_lines(const double *__restrict__ W, long ldW, int N, int nch, double *__restrict__ Wl, long ld, long P)
+{
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;   // one thread per (chunk, chain, s): s fastest
+    const long total = (long)nch * ld * LINE_DOUBLES;
+    if (t >= total) return;
+    const int s = (int)(t % LINE_DOUBLES);
+    const long pc = t / LINE_DOUBLES, p = pc % ld;
+    const int k = (int)(pc / ld), j = k * LINE_DOUBLES + s;
+    Wl[t] = (p < P && j < N) ? W[(size_t)j * ldW + p] : 0.0;
+}
+static __global__ __launch_bounds__(256) void k_lines_to_soa(const double *__restrict__ Wl, const unsigned char *__restrict__ cur, int N, int nch, long ld,
+                                                      long p0, long np, double *__restrict__ W)
+{
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;   // one thread per (j, local chain): chain fastest
+    if (t >= (long)N * np) return;
+    const long q = t % np;
+    const int j = (int)(t / np);
+    const long p = p0 + q;
+    W[(size_t)j * np + q] = Wl[line_index(cur[p], j / LINE_DOUBLES, p, nch, ld) + j % LINE_DOUBLES];
+}
+
+}  // namespace bhip

@@ -1,6 +1,7 @@
 // bhip_inst.hip -- instantiates the fused path kernel for ONE target model per translation unit
 // (compiled once per model with -DBHIP_INST=<n> so the build parallelises).
 #include "bhip_path_kernel.h"
+#include "bhip_chain_kernel.h"
 
 namespace bhip {
 #if BHIP_INST == 0

@@ -146,8 +146,11 @@ inline std::string rtc_source(const UserModel &um, int gk, int mo, int noise, in
 )";
     }
     s += "};\n";
-    s += "template __global__ void k_paths<MUser, " + std::to_string(gk) + ", " + std::to_string(mo) + ", " + std::to_string(noise) + ", " +
-         std::to_string(fl) + ">(const KArgs);\n}\n";
+    if (noise == NOISE_PCN_LINES)
+        s += "template __global__ void k_chain_lines<MUser, " + std::to_string(gk) + ", " + std::to_string(mo) + ", " + std::to_string(fl) + ">(const KArgs);\n}\n";
+    else
+        s += "template __global__ void k_paths<MUser, " + std::to_string(gk) + ", " + std::to_string(mo) + ", " + std::to_string(noise) + ", " +
+             std::to_string(fl) + ">(const KArgs);\n}\n";
     return s;
 }
 
@@ -155,8 +158,10 @@ inline std::string rtc_source(const UserModel &um, int gk, int mo, int noise, in
 inline std::string rtc_compile(const UserModel &um, int gk, int mo, int noise, int fl, std::vector<char> &code, std::string &low)
 {
     const std::string src = rtc_source(um, gk, mo, noise, fl);
-    const std::string name = "bhip::k_paths<bhip::MUser, " + std::to_string(gk) + ", " + std::to_string(mo) + ", " + std::to_string(noise) + ", " +
-                             std::to_string(fl) + ">";
+    const std::string name = noise == NOISE_PCN_LINES
+                                 ? "bhip::k_chain_lines<bhip::MUser, " + std::to_string(gk) + ", " + std::to_string(mo) + ", " + std::to_string(fl) + ">"
+                                 : "bhip::k_paths<bhip::MUser, " + std::to_string(gk) + ", " + std::to_string(mo) + ", " + std::to_string(noise) + ", " +
+                                       std::to_string(fl) + ">";
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "bhip_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return "hiprtcCreateProgram failed";
     hiprtcAddNameExpression(prog, name.c_str());
