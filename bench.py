@@ -149,7 +149,7 @@ class Workload:
             self.chains = bh.Chains(self.Po, X0, self.P, seed=4, path0=self.path0, store_X=True)
             self.step = lambda: self.chains.step(RHO, 1)
             self.bytes_per_pathstep = 8 * 2 + 16 * 1     # write Xo (8d) + read W, write Wo (16 m')   SURVEY 8(d) mode M
-            self.kernel = "k_paths<MFHN, LMMU, 1, PCN>"
+            self.kernel = "k_chain_lines<MFHN, LMMU, 1, store X>"
             self.workload = FHN_WORKLOAD + "pCN-MCMC rho=0.9: one step = one MH iteration of every chain"
         else:
             self.Po = build_proposal(ctx)
@@ -284,7 +284,7 @@ def main():
         }
         if args.mode == "mcmc" and P == 262144:
             # measured once per round with rocprofv3 PMC passes on this exact command (scripts/gpu_profile.sh)
-            tr, src = profiled_traffic("MFHN, 2, 1, 2, 1")
+            tr, src = profiled_traffic("k_chain_lines<bhip::MFHN, 2, 1, 1>")
             if tr:
                 out["roofline"]["traffic"] = tr
                 out["roofline"]["traffic_source"] = src

@@ -29,8 +29,15 @@ BHIP_DEV size_t line_index(int h, int k, long chain, int nch, long ld)
     return (((size_t)h * nch + k) * ld + chain) * LINE_DOUBLES;
 }
 
+// BHIP_LINES_STAGE 1: the next chunk's lines are fetched into 32 staging registers while the current chunk is
+// computed (2 waves per SIMD, latency hidden inside the wave); 0: fetched at the chunk boundary (fits the 128
+// registers of 4 waves per SIMD, latency hidden by the other waves).
+#ifndef BHIP_LINES_STAGE
+#define BHIP_LINES_STAGE 1
+#endif
+
 template <class M, int GK, int MO, int FL>
-__global__ __launch_bounds__(256, 2) void k_chain_lines(const KArgs a)
+__global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(const KArgs a)
 {
     constexpr int D = M::D;
     static_assert(M::MP == 1, "the line layout is built for scalar noise");
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void k_chain_lines(const KArgs a)
         for (int q = 0; q < 8; q++)
             stage[q] = ld_stream((const d2v *)(a.Wc + line_index(par[q], k, c0 + 8 * q + sub, nch, a.ldC) + part));
     };
-    fetch(0);
+    if (BHIP_LINES_STAGE) fetch(0);
 
     // one Euler step i (grid value j = i + 1 = 16k + s): the chain's current W[j] comes from the tile, the proposal goes back
     auto step = [&](int i, int s) {
@@ -82,17 +89,21 @@ __global__ __launch_bounds__(256, 2) void k_chain_lines(const KArgs a)
     };
 
     for (int k = 0; k < nch; k++) {
+        if (!BHIP_LINES_STAGE) fetch(k);
 #pragma unroll
         for (int q = 0; q < 8; q++) {   // staged lines -> tile
             double *d = tile + (8 * q + sub) * LINE_ROW + part;
             d[0] = stage[q].x; d[1] = stage[q].y;
         }
         __builtin_amdgcn_wave_barrier();
-        if (k + 1 < nch) fetch(k + 1);   // in flight while this chunk is computed
+        if (BHIP_LINES_STAGE && k + 1 < nch) fetch(k + 1);   // in flight while this chunk is computed
         const int j0 = k * LINE_DOUBLES;
         if (k > 0 && j0 + LINE_DOUBLES <= N) {
             // interior chunk: 16 valid steps; pairs (i odd, i even) so that the Philox block parity is static
-#pragma unroll 1
+#ifndef BHIP_LINES_UNROLL
+#define BHIP_LINES_UNROLL 1
+#endif
+#pragma unroll BHIP_LINES_UNROLL
             for (int s = 0; s < LINE_DOUBLES; s += 2) {
                 step(j0 + s - 1, s);
                 step(j0 + s, s + 1);
