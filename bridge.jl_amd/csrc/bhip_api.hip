@@ -950,8 +950,7 @@ int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
     a.k0 = (uint32_t)ch->seed; a.k1 = (uint32_t)(ch->seed >> 32); a.iter = 0; a.path0 = ch->path0;
     rc = do_launch(po, NOISE_FRESH, a);
     if (!rc && ch->lines) {
-        const long total = (long)ch->nch * ch->ld * LINE_DOUBLES;
-        hipLaunchKernelGGL(k_soa_to_lines, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, tmpW, ch->ld, (int)po->tt.size(), ch->nch,
+        hipLaunchKernelGGL(k_soa_to_lines, dim3((unsigned)(ch->ld / 64), (unsigned)ch->nch), dim3(256), 0, ctx->stream, tmpW, ch->ld, (int)po->tt.size(), ch->nch,
                            ch->Wc, ch->ld, ch->n);
         if (hipGetLastError() != hipSuccess) rc = fail(ctx, BHIP_EHIP, "k_soa_to_lines launch failed");
     }
@@ -1032,8 +1031,7 @@ static int gather_current_W(bhip_chains *ch, long p0, long np, double *W_soa)
     bhip_ctx *ctx = ch->ctx;
     if (ch->lines) {
         const int N = (int)ch->po->tt.size();
-        const long total = (long)N * np;
-        hipLaunchKernelGGL(k_lines_to_soa, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ch->Wc, ch->cur, N, ch->nch, ch->ld, p0, np, W_soa);
+        hipLaunchKernelGGL(k_lines_to_soa, dim3((unsigned)((np + 63) / 64), (unsigned)ch->nch), dim3(256), 0, ctx->stream, ch->Wc, ch->cur, N, ch->nch, ch->ld, p0, np, W_soa);
         HIPCHK(ctx, hipGetLastError());
         return BHIP_OK;
     }

@@ -159,26 +159,51 @@ hipError_t launch_chain_lines(const KArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-// plain SoA W [N][ld] -> half 0 of the line layout (chain initialisation), and the current halves back to SoA
+// Layout conversion, both directions as a tiled transpose: a block owns 64 chains x one 16-value chunk, so that the
+// SoA side is accessed 64 chains (512 bytes) at a time and the line side a whole line (8 lanes x 16 bytes) at a time.
+//   k_soa_to_lines: plain SoA W [N][ldW] -> half 0 of the line layout (chain initialisation)
+//   k_lines_to_soa: the CURRENT halves of chains p0..p0+np -> plain SoA [N][np]
 static __global__ __launch_bounds__(256) void k_soa_to_lines(const double *__restrict__ W, long ldW, int N, int nch, double *__restrict__ Wl, long ld, long P)
 {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;   // one thread per (chunk, chain, s): s fastest
-    const long total = (long)nch * ld * LINE_DOUBLES;
-    if (t >= total) return;
-    const int s = (int)(t % LINE_DOUBLES);
-    const long pc = t / LINE_DOUBLES, p = pc % ld;
-    const int k = (int)(pc / ld), j = k * LINE_DOUBLES + s;
-    Wl[t] = (p < P && j < N) ? W[(size_t)j * ldW + p] : 0.0;
+    __shared__ double tile[64 * LINE_ROW];
+    const int k = blockIdx.y, t = threadIdx.x;
+    const long c0 = (long)blockIdx.x * 64;
+#pragma unroll
+    for (int rep = 0; rep < 4; rep++) {   // SoA rows j = 16k + 4*rep + t/64, chain c0 + t%64
+        const int sl = 4 * rep + (t >> 6), j = k * LINE_DOUBLES + sl;
+        const long p = c0 + (t & 63);
+        tile[(t & 63) * LINE_ROW + sl] = (p < P && j < N) ? W[(size_t)j * ldW + p] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {   // 16-byte pieces: chain (rep*256 + t)/8, part (rep*256 + t)%8
+        const int idx = rep * 256 + t, cr = idx >> 3, part = 2 * (idx & 7);
+        const double *d = tile + cr * LINE_ROW + part;
+        *(d2v *)(Wl + line_index(0, k, c0 + cr, nch, ld) + part) = d2v{d[0], d[1]};
+    }
 }
 static __global__ __launch_bounds__(256) void k_lines_to_soa(const double *__restrict__ Wl, const unsigned char *__restrict__ cur, int N, int nch, long ld,
-                                                      long p0, long np, double *__restrict__ W)
+                                                             long p0, long np, double *__restrict__ W)
 {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;   // one thread per (j, local chain): chain fastest
-    if (t >= (long)N * np) return;
-    const long q = t % np;
-    const int j = (int)(t / np);
-    const long p = p0 + q;
-    W[(size_t)j * np + q] = Wl[line_index(cur[p], j / LINE_DOUBLES, p, nch, ld) + j % LINE_DOUBLES];
+    __shared__ double tile[64 * LINE_ROW];
+    const int k = blockIdx.y, t = threadIdx.x;
+    const long q0 = (long)blockIdx.x * 64;   // local chain index of the block's first chain
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+        const int idx = rep * 256 + t, cr = idx >> 3, part = 2 * (idx & 7);
+        if (q0 + cr < np) {
+            const long p = p0 + q0 + cr;
+            const d2v v = *(const d2v *)(Wl + line_index(cur[p], k, p, nch, ld) + part);
+            tile[cr * LINE_ROW + part] = v.x; tile[cr * LINE_ROW + part + 1] = v.y;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rep = 0; rep < 4; rep++) {
+        const int sl = 4 * rep + (t >> 6), j = k * LINE_DOUBLES + sl;
+        const long q = q0 + (t & 63);
+        if (q < np && j < N) W[(size_t)j * np + q] = tile[(t & 63) * LINE_ROW + sl];
+    }
 }
 
 }  // namespace bhip
