@@ -145,10 +145,17 @@ BHIP_DEV void guide_terms(const M &model, double t, const double *g, const doubl
         if constexpr (is_constdiff<M>::value) {
 #pragma unroll
             for (int i = 0; i < D; i++) {
-                double sr = R[i] * q[0], sg = G[i] * q[0];
+                double sr = R[i] * q[0];
 #pragma unroll
-                for (int j = 1; j < MO; j++) { sr += R[i + D * j] * q[j]; sg += G[i + D * j] * q[j]; }
-                r[i] = sr; gd[i] = sg;
+                for (int j = 1; j < MO; j++) sr += R[i + D * j] * q[j];
+                r[i] = sr;
+                // a structurally zero row of sigma makes row i of a*L'*M an exact zero (+-0): not computed, not added
+                if (M::noisy(i)) {   // folds after unrolling
+                    double sg = G[i] * q[0];
+#pragma unroll
+                    for (int j = 1; j < MO; j++) sg += G[i + D * j] * q[j];
+                    gd[i] = sg;
+                } else gd[i] = 0.0;
             }
         } else {
             // a(t,x) depends on the state: ((a*L')*M)*q evaluated per step; the G slot holds M (MO x MO)
@@ -248,7 +255,8 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, cptr_t row, int i, int n
             double r[D], g[D];
             guide_terms<M, GK, MO>(model, t, rw + RL::G, st.y, r, g);
 #pragma unroll
-            for (int k = 0; k < D; k++) bI[k] = bI[k] + g[k];
+            for (int k = 0; k < D; k++)
+                if (M::noisy(k)) bI[k] = bI[k] + g[k];
         }
         double df[D], inc[D];
 #pragma unroll
@@ -354,7 +362,8 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, cptr_t row, int i, int n
         }
         st.ll = (i < nll) ? lln : st.ll;                                   // skip: only i < N-1-skip contribute
 #pragma unroll
-        for (int k = 0; k < D; k++) bT[k] = bT[k] + g[k];       // _b = b + a*(...)
+        for (int k = 0; k < D; k++)                                // _b = b + a*(...); exact zeros of a are not added
+            if (M::noisy(k)) bT[k] = bT[k] + g[k];
     }
     if constexpr (NOISE != NOISE_LLONLY) {
         double s[D];
