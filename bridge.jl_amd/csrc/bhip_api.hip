@@ -66,7 +66,7 @@ struct bhip_chains {
     uint32_t iter = 0;
     bool inited = false;
     std::vector<double> x0;   // shared starting point (d doubles)
-    bool lines = false;     // scalar noise, d <= 3: W in the line layout of bhip_chain_kernel.h, else 16-byte slots
+    bool lines = false;     // noise dimension 1 or 2, d <= 3: W in the line layout of bhip_chain_kernel.h, else 16-byte slots
     int nch = 0;            // lines per chain and parity half = ceil(N / 16)
     double *Wc = nullptr;   // W slots [N][mp][ld][2]  |  lines [2][nch][ld][16]
     double *Xo = nullptr;   // proposal paths [N][d][ld] (BHIP_CHAINS_STORE_X)
@@ -891,8 +891,9 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     ch->ctx = ctx; ch->po = po; ch->n = nchains; ch->ld = (nchains + 63) / 64 * 64;
     ch->path0 = path0; ch->seed = seed; ch->flags = flags;
     const size_t N = po->tt.size();
-    ch->lines = po->mh.d <= 3 && po->mh.mp == 1;
-    ch->nch = (int)((N + LINE_DOUBLES - 1) / LINE_DOUBLES);
+    ch->lines = po->mh.d <= 3 && (po->mh.mp == 1 || po->mh.mp == 2);
+    const size_t spc = LINE_DOUBLES / (ch->lines ? po->mh.mp : 1);   // grid points per line
+    ch->nch = (int)((N + spc - 1) / spc);
     const size_t wbytes = ch->lines ? sizeof(double) * 2 * ch->nch * ch->ld * LINE_DOUBLES : sizeof(double) * 2 * N * po->mh.mp * ch->ld;
     const size_t xbytes = sizeof(double) * N * po->mh.d * ch->ld;
     hipError_t e = hipMalloc((void **)&ch->Wc, wbytes);
@@ -940,7 +941,7 @@ int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
     if (rc) return rc;
     double *tmpW = nullptr;
     if (ch->lines) {   // the fresh W goes to a plain SoA scratch array and is re-arranged into half 0 of the lines
-        HIPCHK(ctx, hipMalloc((void **)&tmpW, sizeof(double) * po->tt.size() * ch->ld));
+        HIPCHK(ctx, hipMalloc((void **)&tmpW, sizeof(double) * po->tt.size() * po->mh.mp * ch->ld));
         a.Wout = tmpW; a.ldWout = ch->ld; a.wstride = 1;
     } else {
         a.Wout = ch->Wc; a.ldWout = ch->ld; a.wstride = 2;   // half 0 of every slot, cur = 0
@@ -950,7 +951,7 @@ int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
     a.k0 = (uint32_t)ch->seed; a.k1 = (uint32_t)(ch->seed >> 32); a.iter = 0; a.path0 = ch->path0;
     rc = do_launch(po, NOISE_FRESH, a);
     if (!rc && ch->lines) {
-        hipLaunchKernelGGL(k_soa_to_lines, dim3((unsigned)(ch->ld / 64), (unsigned)ch->nch), dim3(256), 0, ctx->stream, tmpW, ch->ld, (int)po->tt.size(), ch->nch,
+        hipLaunchKernelGGL(k_soa_to_lines, dim3((unsigned)(ch->ld / 64), (unsigned)ch->nch), dim3(256), 0, ctx->stream, tmpW, ch->ld, (int)po->tt.size(), po->mh.mp, ch->nch,
                            ch->Wc, ch->ld, ch->n);
         if (hipGetLastError() != hipSuccess) rc = fail(ctx, BHIP_EHIP, "k_soa_to_lines launch failed");
     }
@@ -1031,7 +1032,7 @@ static int gather_current_W(bhip_chains *ch, long p0, long np, double *W_soa)
     bhip_ctx *ctx = ch->ctx;
     if (ch->lines) {
         const int N = (int)ch->po->tt.size();
-        hipLaunchKernelGGL(k_lines_to_soa, dim3((unsigned)((np + 63) / 64), (unsigned)ch->nch), dim3(256), 0, ctx->stream, ch->Wc, ch->cur, N, ch->nch, ch->ld, p0, np, W_soa);
+        hipLaunchKernelGGL(k_lines_to_soa, dim3((unsigned)((np + 63) / 64), (unsigned)ch->nch), dim3(256), 0, ctx->stream, ch->Wc, ch->cur, N, ch->po->mh.mp, ch->nch, ch->ld, p0, np, W_soa);
         HIPCHK(ctx, hipGetLastError());
         return BHIP_OK;
     }

@@ -1,4 +1,4 @@
-// bhip_chain_kernel.h -- the pCN Metropolis-Hastings iteration for scalar noise (m' = 1) on the LINE layout.
+// bhip_chain_kernel.h -- the pCN Metropolis-Hastings iteration on the LINE layout (noise dimension m' = 1 or 2).
 //
 // Same arithmetic as k_paths<..., NOISE_PCN, ...> (it calls the same path_step), different chain-state layout.
 // The slot layout of bhip_path_kernel.h keeps a chain's current W and its proposal Wo side by side (16 bytes per
@@ -7,9 +7,10 @@
 // moves whole 128-byte lines (profiles/r1_microbench.txt), so the waste can only be avoided if a chain's values of
 // ONE parity half fill whole lines:
 //
-//     Wl[((h*nch + k)*ld + p)*16 + s] = W[16k + s] of chain p in half h        (a 128-byte line per (h, k, p))
+//     Wl[((h*nch + k)*ld + p)*16 + s*m' + c] = component c of W[(16/m')k + s] of chain p in half h
+//                                                                      (a 128-byte line per (h, k, p): 16/m' grid points)
 //
-// A wave owns 64 chains.  Per 16-step chunk it reads, for every chain, only the line of that chain's CURRENT half
+// A wave owns 64 chains.  Per chunk of 16/m' steps it reads, for every chain, only the line of that chain's CURRENT half
 // -- cooperatively, 8 lanes per line, 8 instructions for the 64 lines, exactly as coalesced as a plain stream --
 // transposes through a padded LDS tile so that each chain's lane finds its own 16 values, overwrites them in
 // place with the proposal values as the steps are computed, and writes the tile cooperatively to the lines of
@@ -39,8 +40,9 @@ BHIP_DEV size_t line_index(int h, int k, long chain, int nch, long ld)
 template <class M, int GK, int MO, int FL>
 __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(const KArgs a)
 {
-    constexpr int D = M::D;
-    static_assert(M::MP == 1, "the line layout is built for scalar noise");
+    constexpr int D = M::D, MP = M::MP;
+    static_assert(MP == 1 || MP == 2, "a line holds 16/m' grid points: m' must divide 16 (and the tile budget allows 1 and 2)");
+    constexpr int SPC = LINE_DOUBLES / MP;   // grid points (steps) per chunk
     using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
     extern __shared__ __attribute__((aligned(16))) double lds_tiles[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -56,12 +58,14 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
 
     const M model(a.mpar);
     const int N = a.N, nsteps = N - 1, nll = N - 1 - a.skip;
-    const int nch = (N + LINE_DOUBLES - 1) / LINE_DOUBLES;
+    const int nch = (N + SPC - 1) / SPC;
     const cptr_t rows = (cptr_t)(uintptr_t)a.rows;
-    LaneState<D, 1> st;
+    LaneState<D, MP> st;
 #pragma unroll
     for (int k = 0; k < D; k++) st.y[k] = a.x0[k];
-    st.ll = 0.0; st.zc = 0.0; st.wprev[0] = 0.0; st.w2prev[0] = 0.0;
+    st.ll = 0.0; st.zc = 0.0;
+#pragma unroll
+    for (int k = 0; k < MP; k++) { st.wprev[k] = 0.0; st.w2prev[k] = 0.0; }
     double *xout = nullptr;
     long ldx = 0;
     if constexpr ((FL & 1) != 0) { xout = a.Xo + p; ldx = a.ldC; }
@@ -81,11 +85,14 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
     };
     if (BHIP_LINES_STAGE) fetch(0);
 
-    // one Euler step i (grid value j = i + 1 = 16k + s): the chain's current W[j] comes from the tile, the proposal goes back
+    // one Euler step i (grid point j = i + 1 = SPC*k + s): the chain's current W[j] comes from the tile, the proposal goes back
     auto step = [&](int i, int s) {
-        double wc = mine[s];
-        path_step<M, GK, MO, NOISE_PCN, FL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, &wc, nullptr, 0, xout, ldx, st);
-        mine[s] = st.wprev[0];
+        double wc[MP];
+#pragma unroll
+        for (int cc = 0; cc < MP; cc++) wc[cc] = mine[s * MP + cc];
+        path_step<M, GK, MO, NOISE_PCN, FL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wc, nullptr, 0, xout, ldx, st);
+#pragma unroll
+        for (int cc = 0; cc < MP; cc++) mine[s * MP + cc] = st.wprev[cc];
     };
 
     for (int k = 0; k < nch; k++) {
@@ -97,24 +104,26 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
         }
         __builtin_amdgcn_wave_barrier();
         if (BHIP_LINES_STAGE && k + 1 < nch) fetch(k + 1);   // in flight while this chunk is computed
-        const int j0 = k * LINE_DOUBLES;
-        if (k > 0 && j0 + LINE_DOUBLES <= N) {
-            // interior chunk: 16 valid steps; pairs (i odd, i even) so that the Philox block parity is static
+        const int j0 = k * SPC;
+        if (k > 0 && j0 + SPC <= N) {
+            // interior chunk: SPC valid steps; pairs (i odd, i even) so that the Philox block parity is static
 #ifndef BHIP_LINES_UNROLL
 #define BHIP_LINES_UNROLL 1
 #endif
 #pragma unroll BHIP_LINES_UNROLL
-            for (int s = 0; s < LINE_DOUBLES; s += 2) {
+            for (int s = 0; s < SPC; s += 2) {
                 step(j0 + s - 1, s);
                 step(j0 + s, s + 1);
             }
         } else {
-            // first chunk (grid value 0 is W[0] = Wo[0] = 0, no step) and the ragged last chunk
+            // first chunk (grid point 0 is W[0] = Wo[0] = 0, no step) and the ragged last chunk
 #pragma unroll 1
-            for (int s = 0; s < LINE_DOUBLES; s += 2) {
+            for (int s = 0; s < SPC; s += 2) {
                 const int i0 = j0 + s - 1;
-                if (i0 < 0) mine[s] = 0.0;
-                else if (i0 < nsteps) step(i0, s);
+                if (i0 < 0) {
+#pragma unroll
+                    for (int cc = 0; cc < MP; cc++) mine[cc] = 0.0;
+                } else if (i0 < nsteps) step(i0, s);
                 if (i0 + 1 < nsteps) step(i0 + 1, s + 1);
             }
         }
@@ -161,18 +170,19 @@ hipError_t launch_chain_lines(const KArgs &a, hipStream_t st)
 
 // Layout conversion, both directions as a tiled transpose: a block owns 64 chains x one 16-value chunk, so that the
 // SoA side is accessed 64 chains (512 bytes) at a time and the line side a whole line (8 lanes x 16 bytes) at a time.
-//   k_soa_to_lines: plain SoA W [N][ldW] -> half 0 of the line layout (chain initialisation)
-//   k_lines_to_soa: the CURRENT halves of chains p0..p0+np -> plain SoA [N][np]
-static __global__ __launch_bounds__(256) void k_soa_to_lines(const double *__restrict__ W, long ldW, int N, int nch, double *__restrict__ Wl, long ld, long P)
+//   k_soa_to_lines: plain SoA W [N][m'][ldW] -> half 0 of the line layout (chain initialisation)
+//   k_lines_to_soa: the CURRENT halves of chains p0..p0+np -> plain SoA [N][m'][np]
+// (the SoA row index v = j*m' + c is also the position in the chain's sequence of line values: v = 16k + s)
+static __global__ __launch_bounds__(256) void k_soa_to_lines(const double *__restrict__ W, long ldW, int N, int mp, int nch, double *__restrict__ Wl, long ld, long P)
 {
     __shared__ double tile[64 * LINE_ROW];
     const int k = blockIdx.y, t = threadIdx.x;
     const long c0 = (long)blockIdx.x * 64;
 #pragma unroll
-    for (int rep = 0; rep < 4; rep++) {   // SoA rows j = 16k + 4*rep + t/64, chain c0 + t%64
-        const int sl = 4 * rep + (t >> 6), j = k * LINE_DOUBLES + sl;
+    for (int rep = 0; rep < 4; rep++) {   // line position sl = 4*rep + t/64 <-> SoA row (grid point, component), chain c0 + t%64
+        const int sl = 4 * rep + (t >> 6), v = k * LINE_DOUBLES + sl;   // v = j*mp + c
         const long p = c0 + (t & 63);
-        tile[(t & 63) * LINE_ROW + sl] = (p < P && j < N) ? W[(size_t)j * ldW + p] : 0.0;
+        tile[(t & 63) * LINE_ROW + sl] = (p < P && v < N * mp) ? W[(size_t)v * ldW + p] : 0.0;
     }
     __syncthreads();
 #pragma unroll
@@ -182,7 +192,7 @@ static __global__ __launch_bounds__(256) void k_soa_to_lines(const double *__res
         *(d2v *)(Wl + line_index(0, k, c0 + cr, nch, ld) + part) = d2v{d[0], d[1]};
     }
 }
-static __global__ __launch_bounds__(256) void k_lines_to_soa(const double *__restrict__ Wl, const unsigned char *__restrict__ cur, int N, int nch, long ld,
+static __global__ __launch_bounds__(256) void k_lines_to_soa(const double *__restrict__ Wl, const unsigned char *__restrict__ cur, int N, int mp, int nch, long ld,
                                                              long p0, long np, double *__restrict__ W)
 {
     __shared__ double tile[64 * LINE_ROW];
@@ -200,9 +210,9 @@ static __global__ __launch_bounds__(256) void k_lines_to_soa(const double *__res
     __syncthreads();
 #pragma unroll
     for (int rep = 0; rep < 4; rep++) {
-        const int sl = 4 * rep + (t >> 6), j = k * LINE_DOUBLES + sl;
+        const int sl = 4 * rep + (t >> 6), v = k * LINE_DOUBLES + sl;
         const long q = q0 + (t & 63);
-        if (q < np && j < N) W[(size_t)j * np + q] = tile[(t & 63) * LINE_ROW + sl];
+        if (q < np && v < N * mp) W[(size_t)v * np + q] = tile[(t & 63) * LINE_ROW + sl];
     }
 }
 

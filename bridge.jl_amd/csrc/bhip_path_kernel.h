@@ -24,7 +24,7 @@
 namespace bhip {
 
 enum { NOISE_EXT = 0, NOISE_FRESH = 1, NOISE_PCN = 2, NOISE_LLONLY = 3, NOISE_INNOV = 4,
-       NOISE_PCN_LINES = 5 /* pCN step on the line layout, k_chain_lines in bhip_chain_kernel.h (scalar noise) */ };
+       NOISE_PCN_LINES = 5 /* pCN step on the line layout, k_chain_lines in bhip_chain_kernel.h (m' = 1, 2) */ };
 
 // does the model functor provide inv(sigma)*v (square, invertible diffusion coefficient)?
 template <class...> using bhip_void_t = void;
@@ -577,7 +577,7 @@ launch_fn get_launch_gk(int noise, int fl)
         if constexpr (GK != BHIP_GUIDE_NONE) return (fl & 1) ? launch_paths<M, GK, MO, NOISE_PCN, 1 | T> : launch_paths<M, GK, MO, NOISE_PCN, 0 | T>;
         return nullptr;
     case NOISE_PCN_LINES:
-        if constexpr (GK != BHIP_GUIDE_NONE && M::MP == 1) return (fl & 1) ? launch_chain_lines<M, GK, MO, 1 | T> : launch_chain_lines<M, GK, MO, 0 | T>;
+        if constexpr (GK != BHIP_GUIDE_NONE && (M::MP == 1 || M::MP == 2)) return (fl & 1) ? launch_chain_lines<M, GK, MO, 1 | T> : launch_chain_lines<M, GK, MO, 0 | T>;
         return nullptr;
     case NOISE_LLONLY:
         if constexpr (GK != BHIP_GUIDE_NONE) return launch_paths<M, GK, MO, NOISE_LLONLY, 0 | T>;

@@ -189,7 +189,8 @@ def test_results_do_not_depend_on_launch_geometry_or_sharding(ctx):
 # --------------------------------------------------------------------------- pCN MCMC
 @pytest.mark.parametrize("case", [c for c in problems.cases(151) if c.name in
                                   ("fhn_partialbridge_first", "fhn_partialbridge_extreme", "fhn_startend", "ou_guidedbridge",
-                                   "fhn_inplace", "nclar_firstcomponent", "intdiff_partialbridge", "linpro3_partial_m2")],
+                                   "fhn_inplace", "nclar_firstcomponent", "intdiff_partialbridge", "linpro3_partial_m2",
+                                   "linpro2_guidedbridge", "fhn2_nuh_full")],        # noise dimension 1 and 2: line layout; 3: slots
                          ids=lambda c: c.name)
 def test_mcmc_chains_match_oracle(ctx, case):
     nch, iters = 70, 25
