@@ -220,3 +220,37 @@ def test_K13_noise_moments_and_tails_at_scale(ctx):
     c_time = float((z[1:] * z[:-1]).mean())
     c_path = float((z[:, 1:] * z[:, :-1]).mean())
     assert abs(c_time) < 5 * se and abs(c_path) < 5 * se
+
+
+def test_mcmc_reaches_the_exact_ou_bridge_law(ctx):
+    """End-to-end, distribution level: the target is an Ornstein-Uhlenbeck process (beta = 0.8, a = 0.7), the auxiliary a
+    DIFFERENT linear process, so proposals are wrong by the Girsanov weight and only the Metropolis-Hastings correction
+    (llikelihood + accept, rows a8 + a10) makes the chains sample the true bridge.  The OU bridge given X_0 = u, X_T = v
+    is Gaussian with closed-form mean and variance; 65 536 chains after 300 pCN iterations must match them at every
+    grid point up to Monte-Carlo error and the O(dt) bias of the Euler scheme; the raw proposals must NOT."""
+    c = _case("ou_guidedbridge")
+    beta, a, T, u, v = 0.8, 0.7, 2.0, float(c.x0[0]), float(c.v[0])
+    tt = c.tt
+    var_t = a * (1 - np.exp(-2 * beta * tt)) / (2 * beta)                      # Var(X_t | X_0)
+    var_T = var_t[-1]
+    cov = np.exp(-beta * (T - tt)) * var_t                                     # Cov(X_t, X_T | X_0)
+    mean_exact = u * np.exp(-beta * tt) + cov / var_T * (v - u * math.exp(-beta * T))
+    var_exact = var_t - cov ** 2 / var_T
+    P = 65536
+    Po = c.bh_proposal(bh, ctx)
+    ch = bh.Chains(Po, c.x0, P, seed=91, store_X=False)
+    X0 = ch.current_X().data[:, 0, :]
+    prop_mean = X0.mean(1).cpu().numpy()
+    ch.step(0.7, 300)
+    X = ch.current_X().data[:, 0, :]
+    m, s2 = X.mean(1).cpu().numpy(), X.var(1).cpu().numpy()
+    inner = slice(1, -1)
+    se = np.sqrt(var_exact[inner] / P)
+    # pCN chains are autocorrelated across iterations but the 65 536 chains are independent: plain standard errors apply
+    assert np.abs(m[inner] - mean_exact[inner]).max() < 6 * se.max() + 4e-3, np.abs(m[inner] - mean_exact[inner]).max()
+    far = (tt > 0.04) & (tt < T - 0.2)          # the Euler scheme's relative variance error grows like dt/(T-t) towards the pinned end
+    assert np.abs(s2[far] / var_exact[far] - 1).max() < 0.03 and np.abs(s2 - var_exact).max() < 4e-3
+    # the uncorrected proposals are visibly off (otherwise this test would not test the MH step)
+    assert np.abs(prop_mean[inner] - mean_exact[inner]).max() > 5 * np.abs(m[inner] - mean_exact[inner]).max()
+    acc = ch.acc().sum() / (P * 300)
+    assert 0.2 < acc < 0.95
