@@ -59,6 +59,9 @@ SIGNATURES = {
     "bhip_chains_current_X": (C.c_int, [vp, vp, C.c_long]),
     "bhip_chains_proposal_X": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_long)]),
     "bhip_chains_pathstats": (C.c_int, [vp, dp, dp]),
+    "bhip_chains_state_bytes": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "bhip_chains_save": (C.c_int, [vp, vp]),
+    "bhip_chains_load": (C.c_int, [vp, vp]),
     "bhip_welford_merge": (C.c_int, [C.c_long, C.c_int, dp, dp, dp, C.c_double, dp, dp]),
     "bhip_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "bhip_normals_host": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, dp]),

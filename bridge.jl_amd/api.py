@@ -801,6 +801,22 @@ class Chains:
         self.ctx.check(self.ctx.lib.bhip_chains_pathstats(self.h, _dptr(mean), _dptr(m2)))
         return self.n, mean, _uncm(m2, d, d)
 
+    def save(self):
+        """checkpoint: the chain state (current W, ll, acceptance counts, iteration counter) as a numpy byte array"""
+        nb = C.c_size_t()
+        self.ctx.check(self.ctx.lib.bhip_chains_state_bytes(self.h, C.byref(nb)))
+        buf = np.empty(nb.value, dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.bhip_chains_save(self.h, buf.ctypes.data_as(vp)))
+        return buf
+
+    def load(self, buf):
+        """resume from Chains.save() of an ensemble with the same proposal shape, chains, seed and path0: the following
+        iterations are bit-identical to those the saved ensemble would have run (counter-based noise)"""
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.bhip_chains_load(self.h, buf.ctypes.data_as(vp)))
+        self.iterations = int(self.stats().cpu()[1])
+        return self
+
     def __del__(self):
         try:
             if getattr(self, "h", None):

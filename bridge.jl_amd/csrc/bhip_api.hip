@@ -1100,6 +1100,92 @@ int bhip_chains_current_X(bhip_chains *ch, double *X_dev, long ldX)
     return rc;
 }
 
+/* ---- checkpoint / resume */
+namespace {
+struct ChainStateHeader {
+    uint64_t magic;      // "BHIPCHN1"
+    int64_t n, N, mp, d;
+    uint64_t seed;
+    uint32_t path0, iter;
+    int32_t skip0, reserved;
+};
+constexpr uint64_t CHAIN_MAGIC = 0x314E484350494842ULL;   // "BHIPCHN1" little endian
+}  // namespace
+
+int bhip_chains_state_bytes(const bhip_chains *ch, size_t *bytes)
+{
+    if (!ch || !bytes) return BHIP_EINVAL;
+    const size_t N = ch->po->tt.size();
+    *bytes = sizeof(ChainStateHeader) + sizeof(double) * N * ch->po->mh.mp * ch->n + sizeof(double) * ch->n + sizeof(unsigned int) * ch->n;
+    return BHIP_OK;
+}
+
+int bhip_chains_save(bhip_chains *ch, void *host_buf)
+{
+    if (!ch || !host_buf) return BHIP_EINVAL;
+    bhip_ctx *ctx = ch->ctx;
+    NEED_DEVICE(ctx);
+    if (!ch->inited) return fail(ctx, BHIP_ESTATE, "bhip_chains_save: chains not initialised");
+    const size_t N = ch->po->tt.size(), nW = N * ch->po->mh.mp * ch->n;
+    ChainStateHeader h{};
+    h.magic = CHAIN_MAGIC; h.n = ch->n; h.N = (int64_t)N; h.mp = ch->po->mh.mp; h.d = ch->po->mh.d;
+    h.seed = ch->seed; h.path0 = ch->path0; h.iter = ch->iter; h.skip0 = ch->skip0;
+    char *out = static_cast<char *>(host_buf);
+    std::memcpy(out, &h, sizeof(h));
+    double *tmp = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&tmp, sizeof(double) * nW));
+    int rc = gather_current_W(ch, 0, ch->n, tmp);
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMemcpyAsync(out + sizeof(h), tmp, sizeof(double) * nW, hipMemcpyDeviceToHost, ctx->stream);
+    if (!rc && e == hipSuccess) e = hipMemcpyAsync(out + sizeof(h) + sizeof(double) * nW, ch->llcur, sizeof(double) * ch->n, hipMemcpyDeviceToHost, ctx->stream);
+    if (!rc && e == hipSuccess)
+        e = hipMemcpyAsync(out + sizeof(h) + sizeof(double) * (nW + ch->n), ch->acc, sizeof(unsigned int) * ch->n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(ctx, BHIP_EHIP, hipGetErrorString(e));
+    return BHIP_OK;
+}
+
+int bhip_chains_load(bhip_chains *ch, const void *host_buf)
+{
+    if (!ch || !host_buf) return BHIP_EINVAL;
+    bhip_ctx *ctx = ch->ctx;
+    NEED_DEVICE(ctx);
+    const bhip_proposal *po = ch->po;
+    const size_t N = po->tt.size(), nW = N * po->mh.mp * ch->n;
+    ChainStateHeader h;
+    const char *in = static_cast<const char *>(host_buf);
+    std::memcpy(&h, in, sizeof(h));
+    if (h.magic != CHAIN_MAGIC) return fail(ctx, BHIP_EINVAL, "bhip_chains_load: not a chain state buffer");
+    if (h.n != ch->n || h.N != (int64_t)N || h.mp != po->mh.mp || h.d != po->mh.d)
+        return fail(ctx, BHIP_EINVAL, "bhip_chains_load: the state was saved for another ensemble shape (chains, grid, dimensions)");
+    if (h.seed != ch->seed || h.path0 != ch->path0)
+        return fail(ctx, BHIP_EINVAL, "bhip_chains_load: seed / path0 differ from the ensemble the state was saved from");
+    if (!ch->inited && ch->x0.empty()) return fail(ctx, BHIP_ESTATE, "bhip_chains_load: call bhip_chains_init once first (it fixes the starting point)");
+    double *tmp = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&tmp, sizeof(double) * nW));
+    hipError_t e = hipMemcpyAsync(tmp, in + sizeof(h), sizeof(double) * nW, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ch->llcur, in + sizeof(h) + sizeof(double) * nW, sizeof(double) * ch->n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ch->acc, in + sizeof(h) + sizeof(double) * (nW + ch->n), sizeof(unsigned int) * ch->n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ch->cur, 0, ch->ld, ctx->stream);   // the restored W goes to half 0
+    if (e == hipSuccess) {
+        if (ch->lines) {
+            hipLaunchKernelGGL(k_soa_to_lines, dim3((unsigned)(ch->ld / 64), (unsigned)ch->nch), dim3(256), 0, ctx->stream, tmp, ch->n, (int)N, po->mh.mp, ch->nch,
+                               ch->Wc, ch->ld, ch->n);
+        } else {
+            const long E = (long)N * po->mh.mp, tot = E * ch->n;
+            hipLaunchKernelGGL(k_soa_to_slots, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, tmp, ch->Wc, E, ch->ld, ch->n);
+        }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(ctx, BHIP_EHIP, hipGetErrorString(e));
+    ch->iter = h.iter; ch->skip0 = h.skip0; ch->inited = true;
+    return BHIP_OK;
+}
+
 int bhip_chains_proposal_X(bhip_chains *ch, double **Xo_dev, long *ld)
 {
     if (!ch || !Xo_dev || !ld) return BHIP_EINVAL;

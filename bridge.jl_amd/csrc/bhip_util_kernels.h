@@ -33,6 +33,15 @@ __global__ void k_slots_to_soa(const double *__restrict__ slots, const unsigned 
     soa[e * np + p] = slots[(e * ld + p0 + p) * 2 + cur[p0 + p]];
 }
 
+// plain SoA [E][np] -> half 0 of the slots of all np = n chains (restoring a saved chain state: parity 0 everywhere)
+__global__ void k_soa_to_slots(const double *__restrict__ soa, double *__restrict__ slots, long E, long ld, long np)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= E * np) return;
+    const long p = idx % np, e = idx / np;
+    slots[(e * ld + p) * 2] = soa[e * np + p];
+}
+
 // sample!(W, Wiener{SVector{mp}}()):  W[0] = 0; W[i+1] = W[i] + rootdt[i]*xi   (time-major,
 // component-minor normals, src/wiener.jl:24-35; test/with_srand.jl)
 template <int MP>

@@ -232,6 +232,14 @@ int bhip_chains_proposal_X(bhip_chains *ch, double **Xo_dev, long *ld);
 /* pointwise online mean/covariance of the current X over the chain ensemble (mcstart/mcnext!
  * semantics, src/mclog.jl:22-56): mean [N][d], m2 [N][d*d] (column-major), host pointers */
 int bhip_chains_pathstats(bhip_chains *ch, double *mean, double *m2);
+/* Checkpoint / resume.  A chain ensemble is fully described by (current W, ll, acceptance counts, iteration counter)
+ * plus the creation arguments (seed, path0): the noise is counter based, so a restored ensemble continues with
+ * exactly the iterations the original would have run.  bhip_chains_save writes bhip_chains_state_bytes(ch) bytes to
+ * a host buffer; bhip_chains_load restores them into an ensemble created with the same proposal shape, number of
+ * chains, seed and path0 (checked against the header). */
+int bhip_chains_state_bytes(const bhip_chains *ch, size_t *bytes);
+int bhip_chains_save(bhip_chains *ch, void *host_buf);
+int bhip_chains_load(bhip_chains *ch, const void *host_buf);
 /* merge two (n, mean, m2) Welford states in place into a: parallel form of src/mclog.jl:31-38 */
 int bhip_welford_merge(long entries, int d, double *na, double *mean_a, double *m2_a, double nb,
                        const double *mean_b, const double *m2_b);

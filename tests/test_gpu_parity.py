@@ -337,3 +337,30 @@ def test_batched_chain_steps_equal_single_steps(ctx):
     assert np.array_equal(a.ll(), b.ll()) and np.array_equal(a.acc(), b.acc())
     assert torch.equal(a.proposal_X(), b.proposal_X()) and torch.equal(a.current_X().data, b.current_X().data)
     assert torch.equal(a.stats(), b.stats())
+
+
+@pytest.mark.parametrize("name", ["fhn_partialbridge_extreme", "fhn2_nuh_full", "linpro3_partial_m2"])
+def test_chain_checkpoint_and_resume(ctx, name):
+    """Chains.save() / load(): (current W, ll, acceptance counts, iteration counter) + the counter-based noise make a
+    resumed ensemble continue with exactly the iterations the original runs (line layout, m' = 1 and 2; slots, m' = 3)"""
+    c = [k for k in problems.cases(121) if k.name == name][0]
+    Po = c.bh_proposal(bh, ctx)
+    a = bh.Chains(Po, c.x0, 200, seed=21, path0=9)
+    a.step(0.9, 7)
+    state = a.save()
+    a.step(0.9, 6)
+    b = bh.Chains(Po, c.x0, 200, seed=21, path0=9)          # a fresh ensemble (iteration 0) ...
+    b.load(state)                                            # ... put into the saved state
+    assert b.iterations == 7
+    b.step(0.9, 6)
+    Xa, Wa = a.paths(0, 200)
+    Xb, Wb = b.paths(0, 200)
+    assert np.array_equal(a.ll(), b.ll()) and np.array_equal(a.acc(), b.acc())
+    assert np.array_equal(Wa, Wb) and np.array_equal(Xa, Xb) and torch.equal(a.stats(), b.stats())
+    # a state only fits the ensemble it came from
+    with pytest.raises(bh.BridgeError, match="seed"):
+        bh.Chains(Po, c.x0, 200, seed=22, path0=9).load(state)
+    with pytest.raises(bh.BridgeError, match="shape"):
+        bh.Chains(Po, c.x0, 100, seed=21, path0=9).load(state)
+    with pytest.raises(bh.BridgeError, match="not a chain state"):
+        b.load(np.zeros(len(state), dtype=np.uint8))
