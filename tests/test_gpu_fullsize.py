@@ -254,3 +254,24 @@ def test_mcmc_reaches_the_exact_ou_bridge_law(ctx):
     assert np.abs(prop_mean[inner] - mean_exact[inner]).max() > 5 * np.abs(m[inner] - mean_exact[inner]).max()
     acc = ch.acc().sum() / (P * 300)
     assert 0.2 < acc < 0.95
+
+
+def test_C1_ou_euler_maruyama_65536_paths(ctx):
+    """config C1 (README.md:69-83): OU(beta = 2, sigma = 1), Euler-Maruyama on 0:0.01:10 from x0 = 0.1 -- 65 536 paths at
+    once.  The scheme's own law is known exactly: x_N = (1 - beta dt)^N x0 + noise with variance
+    sigma^2 dt (1 - r^(2N)) / (1 - r^2), r = 1 - beta dt."""
+    N, P = 1001, 65536
+    tt = np.arange(N) * 0.01
+    proc = bh.PlainProcess(tt, bh.OrnsteinUhlenbeck(2.0, 1.0), ctx=ctx)
+    X, W, _ = bh.sample_solve([0.1], proc, P, seed=1, store_W=True)
+    xT = X.data[-1, 0]
+    r = 1 - 2.0 * 0.01
+    var = 0.01 * (1 - r ** (2 * (N - 1))) / (1 - r * r)
+    mean = 0.1 * r ** (N - 1)
+    assert abs(float(xT.mean()) - mean) < 5 * math.sqrt(var / P)
+    assert abs(float(xT.var()) / var - 1) < 5 * math.sqrt(2 / P)
+    assert bool((X.data[0, 0] == 0.1).all())
+    for p in (0, P - 1):
+        Wr = o.wiener_sample(tt, 1, 1, p, 0)
+        assert np.array_equal(W.paths(p, 1)[0], Wr)
+        assert np.array_equal(X.paths(p, 1)[0], o.solve_em(o.MODEL_OU, 1, 1, [2.0, 1.0], tt, [0.1], Wr))
