@@ -894,6 +894,10 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     ch->lines = po->mh.d <= 3 && (po->mh.mp == 1 || po->mh.mp == 2);
     const size_t spc = LINE_DOUBLES / (ch->lines ? po->mh.mp : 1);   // grid points per line
     ch->nch = (int)((N + spc - 1) / spc);
+    if (ch->nch > 65535) {   // the layout-conversion kernels index the chunks with gridDim.y: very long grids stay on the slots
+        ch->lines = false;
+        ch->nch = 0;
+    }
     const size_t wbytes = ch->lines ? sizeof(double) * 2 * ch->nch * ch->ld * LINE_DOUBLES : sizeof(double) * 2 * N * po->mh.mp * ch->ld;
     const size_t xbytes = sizeof(double) * N * po->mh.d * ch->ld;
     hipError_t e = hipMalloc((void **)&ch->Wc, wbytes);
