@@ -9,6 +9,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -89,3 +90,29 @@ def test_shard_partitions_any_world_size():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_equal_one_rank_with_twice_the_chains(tmp_path):
+    """bench.py's N > 1 path end to end on a one-GPU box (BENCH_SINGLE_DEVICE=1: both ranks on GPU 0, gloo collectives):
+    rank r owns the global chain ids [r*P, (r+1)*P) and the noise is keyed by the global id, so 2 ranks x 4096 chains must
+    report exactly the acceptance rate and mean log-weight of 1 rank x 8192 chains."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_SINGLE_DEVICE="1")
+    common = ["--steps", "4", "--warmup", "0", "--no-cpu-baseline", "--no-other-modes"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29561", os.path.join(root, "bench.py"), "--gpus", "2", "--chains", "4096"] + common,
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--chains", "8192"] + common,
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j2["config"]["chains_total"] == 8192 and j1["config"]["chains_total"] == 8192
+    assert j2["config"]["acceptance_rate"] == j1["config"]["acceptance_rate"]
+    assert abs(j2["config"]["mean_ll"] - j1["config"]["mean_ll"]) <= 1e-12 * abs(j1["config"]["mean_ll"])
+    assert j2["scaling"] == "weak" and j2["config"]["path_steps_per_step"] == 8192 * 1000
