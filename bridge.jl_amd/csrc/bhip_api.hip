@@ -406,17 +406,30 @@ static void to_fragments(const Mat &M, double *out)
             for (int l = 0; l < 64; l++) out[((size_t)t * 4 * T + ks) * 64 + l] = M(16 * t + (l & 15), 4 * ks + (l >> 4));
 }
 
+// zero padding of a d x d matrix / d-vector to the tile kernel's dimension
+static Mat pad_mat(const Mat &M, int Dp)
+{
+    Mat R(Dp, Dp);
+    for (int j = 0; j < M.c; j++)
+        for (int i = 0; i < M.r; i++) R(i, j) = M(i, j);
+    return R;
+}
+static int tile_dim(int d) { return d <= 16 ? 16 : 32; }
+
 static int build_tile_data(bhip_proposal *po)
 {
     bhip_ctx *ctx = po->ctx;
     const int N = (int)po->tt.size(), d = po->mh.d;
     const bool plain = po->g.kind == BHIP_GUIDE_NONE;   // forward Euler-Maruyama: the guide matrices are zero
-    if (po->mh.id != BHIP_MODEL_LINPRO || (d != 16 && d != 32))
-        return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: LinPro target with d = 16 or 32");
+    // The tile kernel is instantiated for 16 and 32 components; other EVEN dimensions 4..30 run zero padded (an even
+    // dimension keeps a Philox block inside one grid point, which the lane-pair exchange of the normals relies on).
+    if (po->mh.id != BHIP_MODEL_LINPRO || d > 32 || (d & 1))
+        return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: LinPro target with an even dimension 4 <= d <= 32");
     if (!plain && (!po->has_aux || (po->aux.kind != BHIP_AUX_AFFINE && po->aux.kind != BHIP_AUX_LINPRO)))
         return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: time-constant auxiliary process");
-    const size_t DD = (size_t)d * d, STEP = DD + d;
-    std::vector<double> steps((size_t)(N - 1) * STEP), hdr((size_t)(N - 1) * 2);
+    const int Dp = tile_dim(d);
+    const size_t DD = (size_t)Dp * Dp, STEP = DD + Dp, dd = (size_t)d * d;
+    std::vector<double> steps((size_t)(N - 1) * STEP, 0.0), hdr((size_t)(N - 1) * 2);
     for (int i = 0; i < N - 1; i++) {
         // Every guide is brought to the form r = Hm_i (nu_i - x) the tile kernel evaluates:
         //   GuidedBridge : Hdiamond_i \ (V_i - x)  ->  Hm = inv(Hdiamond_i) (LU, path-independent), nu = V_i
@@ -430,24 +443,24 @@ static int build_tile_data(bhip_proposal *po)
             Hm = (tr(L) * po->g.M[i]) * L;
             nu = tr(L) * solve(L * tr(L), po->g.v - po->g.mu[i]);
         } else { Hm = po->g.H[i]; nu = po->g.nu[i]; }
-        to_fragments(Hm, &steps[(size_t)i * STEP]);
+        to_fragments(pad_mat(Hm, Dp), &steps[(size_t)i * STEP]);
         std::memcpy(&steps[(size_t)i * STEP + DD], nu.a.data(), sizeof(double) * d);
         hdr[2 * i] = po->tt[i + 1] - po->tt[i];
         hdr[2 * i + 1] = std::sqrt(po->tt[i + 1] - po->tt[i]);
     }
     std::vector<double> &cst = po->cst_host;
-    cst.assign(4 * DD + 5 * d, 0.0);
+    cst.assign(4 * DD + 5 * Dp, 0.0);
     const double *par = po->mh.par.data();
-    to_fragments(Mat(d, d, par), &cst[0]);                               // B
-    if (!plain) to_fragments(po->aux.B(po->tt[0]), &cst[DD]);            // B~
-    to_fragments(po->mh.a, &cst[2 * DD]);                                // a = sigma*sigma'
-    to_fragments(Mat(d, d, par + DD + d), &cst[3 * DD]);                 // sigma
-    std::memcpy(&cst[4 * DD], par + DD, sizeof(double) * d);             // mu
+    to_fragments(pad_mat(Mat(d, d, par), Dp), &cst[0]);                          // B
+    if (!plain) to_fragments(pad_mat(po->aux.B(po->tt[0]), Dp), &cst[DD]);       // B~
+    to_fragments(pad_mat(po->mh.a, Dp), &cst[2 * DD]);                           // a = sigma*sigma'
+    to_fragments(pad_mat(Mat(d, d, par + dd + d), Dp), &cst[3 * DD]);            // sigma
+    std::memcpy(&cst[4 * DD], par + dd, sizeof(double) * d);                     // mu
     if (!plain) {
-        if (po->aux.linpro_form()) std::memcpy(&cst[4 * DD + d], po->aux.mu(), sizeof(double) * d);                        // mu~ (else 0)
-        else { const Mat be = po->aux.beta(po->tt[0]); std::memcpy(&cst[4 * DD + 2 * d], be.a.data(), sizeof(double) * d); }   // beta~ (else 0)
+        if (po->aux.linpro_form()) std::memcpy(&cst[4 * DD + Dp], po->aux.mu(), sizeof(double) * d);                        // mu~ (else 0)
+        else { const Mat be = po->aux.beta(po->tt[0]); std::memcpy(&cst[4 * DD + 2 * Dp], be.a.data(), sizeof(double) * d); }   // beta~ (else 0)
     }
-    if (po->g.kind == BHIP_GUIDE_HV) std::memcpy(&cst[4 * DD + 3 * d], po->g.V[N - 1].a.data(), sizeof(double) * d);       // vend
+    if (po->g.kind == BHIP_GUIDE_HV) std::memcpy(&cst[4 * DD + 3 * Dp], po->g.V[N - 1].a.data(), sizeof(double) * d);       // vend
     for (double **q : {&po->d_steps, &po->d_hdr, &po->d_cst})
         if (*q) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(*q)); *q = nullptr; }
     HIPCHK(ctx, hipMalloc((void **)&po->d_steps, sizeof(double) * steps.size()));
@@ -466,17 +479,18 @@ static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const d
     bhip_proposal *po = const_cast<bhip_proposal *>(po_c);
     bhip_ctx *ctx = po->ctx;
     NEED_DEVICE(ctx);
-    const int d = po->mh.d;
+    const int d = po->mh.d, Dp = tile_dim(d);
     if (!po->d_steps) return fail(ctx, BHIP_ESTATE, "proposal has no large-d guide data (compute a guide first)");
     if (!x0) return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: shared starting point only");
     if (npaths < 1 || skip < 0) return fail(ctx, BHIP_EINVAL, "bad npaths/skip");
-    const size_t DD = (size_t)d * d;
+    const size_t DD = (size_t)Dp * Dp;
     // x0 lives in the constant block (read by every lane by row index)
-    std::memcpy(&po->cst_host[4 * DD + 4 * d], x0, sizeof(double) * d);
-    HIPCHK(ctx, hipMemcpyAsync(po->d_cst + 4 * DD + 4 * d, &po->cst_host[4 * DD + 4 * d], sizeof(double) * d, hipMemcpyHostToDevice, ctx->stream));
+    std::memcpy(&po->cst_host[4 * DD + 4 * Dp], x0, sizeof(double) * d);
+    HIPCHK(ctx, hipMemcpyAsync(po->d_cst + 4 * DD + 4 * Dp, &po->cst_host[4 * DD + 4 * Dp], sizeof(double) * d, hipMemcpyHostToDevice, ctx->stream));
     TArgs a;
     std::memset(&a, 0, sizeof(a));
     a.steps = po->d_steps; a.hdr = po->d_hdr; a.cst = po->d_cst;
+    a.dtrue = d;
     a.N = (int)po->tt.size(); a.skip = skip; a.use_vend = po->use_vend; a.noise = noise; a.P = npaths;
     a.Win = W_in; a.ldWin = ldWin; a.Wout = W_out; a.ldWout = ldWout; a.X = X; a.ldX = ldX; a.ll = ll;
     a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.iter = iter; a.path0 = path0;
@@ -486,8 +500,10 @@ static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const d
         a.rho = rho; a.srho = std::sqrt(1 - rho * rho);
     }
     hipError_t le = hipSuccess;
-    if (d == 32) le = noise == 3 ? launch_tile<32, 3>(a, ctx->stream) : noise == 2 ? launch_tile<32, 2>(a, ctx->stream) : noise ? launch_tile<32, 1>(a, ctx->stream) : launch_tile<32, 0>(a, ctx->stream);
-    else le = noise == 3 ? launch_tile<16, 3>(a, ctx->stream) : noise == 2 ? launch_tile<16, 2>(a, ctx->stream) : noise ? launch_tile<16, 1>(a, ctx->stream) : launch_tile<16, 0>(a, ctx->stream);
+    if (d == 32) le = launch_tile_noise<32, false>(a, noise, ctx->stream);
+    else if (d == 16) le = launch_tile_noise<16, false>(a, noise, ctx->stream);
+    else if (Dp == 32) le = launch_tile_noise<32, true>(a, noise, ctx->stream);
+    else le = launch_tile_noise<16, true>(a, noise, ctx->stream);
     HIPCHK(ctx, le);
     return BHIP_OK;
 }

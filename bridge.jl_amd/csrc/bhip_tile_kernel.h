@@ -44,6 +44,7 @@ struct TArgs {
     const double *steps;   // [N-1][D*D + D]: Hm_i in fragment order, then nu_i (natural order)
     const double *hdr;     // [N-1][2]: dt_i, sqrt(dt_i)
     const double *cst;     // 4 fragment matrices (B, B~, a, sigma), then mu, mu~, beta~, vend, x0 (D each)
+    int dtrue;             // state dimension of the process (<= the kernel's D; the rest is zero padding, template PAD)
     int N, skip, use_vend, noise;   // noise: 0 = external W, 1 = fresh Philox, 2 = pCN chain step, 3 = llikelihood of a stored X (Win = X)
     long P;
     const double *Win; long ldWin;
@@ -87,7 +88,7 @@ __device__ __forceinline__ void tile_mv(const double *__restrict__ Mf, const dou
     }
 }
 
-template <int D, int NOISE>
+template <int D, int NOISE, bool PAD = false>
 __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per SIMD: <= 256 VGPR+AGPR
 {
     constexpr int T = D / 16;
@@ -102,6 +103,10 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     const bool live = p_raw < a.P;
     const long p = live ? p_raw : a.P - 1;
     const int N = a.N, nsteps = N - 1, nll = N - 1 - a.skip;
+    // PAD: the process has dtr < D components (even, so that a Philox block never straddles two grid points); rows
+    // dtr..D-1 are zero padding of every matrix and vector, hold no data in the ensembles and are never loaded or stored
+    const int dtr = PAD ? a.dtrue : D;
+    auto ok = [&](int t, int r) { return !PAD || 16 * t + 4 * r + kq < dtr; };
 
     for (int c = tid; c < 4 * DD + 5 * D; c += 256) cm[c] = a.cst[c];
     for (int c = tid; c < STEP; c += 256) hb[c] = a.steps[c];
@@ -129,13 +134,13 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 x[t][r] = x0[16 * t + 4 * r + kq];
-                wprev[t][r] = NOISE == 0 ? *q : 0.0;
+                wprev[t][r] = (NOISE == 0 && ok(t, r)) ? *q : 0.0;
                 if (NOISE == 0) q += rsWin;
-                if (NOISE == 1 && a.Wout) { *qo = 0.0; qo += rsWo; }
+                if (NOISE == 1 && a.Wout) { if (ok(t, r)) *qo = 0.0; qo += rsWo; }
             }
     }
-    if (NOISE == 0) winp += (size_t)D * a.ldWin;                       // -> W[1]
-    if (NOISE == 1 && a.Wout) wop += (size_t)D * a.ldWout * a.wstride;
+    if (NOISE == 0) winp += (size_t)dtr * a.ldWin;                       // -> W[1]
+    if (NOISE == 1 && a.Wout) wop += (size_t)dtr * a.ldWout * a.wstride;
     double ll = 0.0;
     const uint32_t path = a.path0 + (uint32_t)p;
     // pCN: W2 accumulates the fresh Wiener path, wprev the proposal Wo = rho*W + sqrt(1-rho^2)*W2
@@ -149,10 +154,10 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 w2prev[t][r] = 0.0;
-                *q = tile_d2v{0.0, 0.0};   // W[1] = Wo[1] = 0
+                if (ok(t, r)) *q = tile_d2v{0.0, 0.0};   // W[1] = Wo[1] = 0
                 q += rsC;
             }
-        wsp += (size_t)D * a.ldC;          // -> slots of W[1]
+        wsp += (size_t)dtr * a.ldC;          // -> slots of W[1]
     }
 
     for (int i = 0; i < nsteps; i++) {
@@ -178,12 +183,12 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
             for (int t = 0; t < T; t++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const double wn = *q;
+                    const double wn = ok(t, r) ? *q : 0.0;
                     q += rsWin;
                     dw[t][r] = wn - wprev[t][r];
                     wprev[t][r] = wn;
                 }
-            winp += (size_t)D * a.ldWin;
+            winp += (size_t)dtr * a.ldWin;
         } else if constexpr (NOISE == 3) {
             // stand-alone llikelihood(LeftRule(), X, Po): x_i comes from the stored path, nothing is propagated
             const double *q = winp;
@@ -191,11 +196,11 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
             for (int t = 0; t < T; t++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    x[t][r] = *q;
+                    x[t][r] = ok(t, r) ? *q : 0.0;
                     q += rsWin;
                     dw[t][r] = 0.0;
                 }
-            winp += (size_t)D * a.ldWin;
+            winp += (size_t)dtr * a.ldWin;
         } else {
             tile_d2v slot[NOISE == 2 ? T : 1][4];
             if constexpr (NOISE == 2) {   // the chain's slots of step i+1: issued first, consumed after the normals
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 for (int t = 0; t < T; t++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        slot[t][r] = __builtin_nontemporal_load(q);
+                        slot[t][r] = ok(t, r) ? __builtin_nontemporal_load(q) : tile_d2v{0.0, 0.0};
                         q += rsC;
                     }
             }
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 const int ks = h + (odd ? 2 * T : 0);
                 double z0, z1;
                 if constexpr ((BHIP_TILE_EXP & 2) != 0) { z0 = 1e-3 * (double)(lane + ks); z1 = -z0; }
-                else normal_pair(a.k0, a.k1, path, a.iter, (uint32_t)(i * (D / 2) + 2 * ks + (kq >> 1)), z0, z1);
+                else normal_pair(a.k0, a.k1, path, a.iter, (uint32_t)(i * (dtr / 2) + 2 * ks + (kq >> 1)), z0, z1);
                 const double keep = odd ? z1 : z0, give = odd ? z0 : z1;
                 const double got = __shfl_xor(give, 16, 64);   // partner's block: h (partner even) or h + 2T (partner odd)
                 mine[h] = odd ? got : keep;            // K-slice h       : drawn by the even lane
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                         dw[t][r] = wo - wprev[t][r];
                         w2prev[t][r] = w2;
                         wprev[t][r] = wo;
-                        __builtin_nontemporal_store(cpar ? tile_d2v{wo, slot[t][r].y} : tile_d2v{slot[t][r].x, wo}, qs);
+                        if (ok(t, r)) __builtin_nontemporal_store(cpar ? tile_d2v{wo, slot[t][r].y} : tile_d2v{slot[t][r].x, wo}, qs);
                         qs += rsC;
                     } else {
                         const double wn = wprev[t][r] + rdt * mine[4 * t + r];   // sample!: W[i+1] = W[i] + sqrt(dt)*xi
@@ -245,13 +250,13 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                         wprev[t][r] = wn;
                     }
                 }
-            if (NOISE == 2) wsp += (size_t)D * a.ldC;
+            if (NOISE == 2) wsp += (size_t)dtr * a.ldC;
             if (NOISE == 1 && a.Wout) {   // one wave-uniform test for the whole row group
 #pragma unroll
                 for (int t = 0; t < T; t++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { *qo = wprev[t][r]; qo += rsWo; }
-                wop += (size_t)D * a.ldWout * a.wstride;
+                    for (int r = 0; r < 4; r++) { if (ok(t, r)) *qo = wprev[t][r]; qo += rsWo; }
+                wop += (size_t)dtr * a.ldWout * a.wstride;
             }
         }
 
@@ -261,8 +266,8 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 #pragma unroll
             for (int t = 0; t < T; t++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) { *q = x[t][r]; q += rsX; }
-            xp += (size_t)D * a.ldX;
+                for (int r = 0; r < 4; r++) { if (ok(t, r)) *q = x[t][r]; q += rsX; }
+            xp += (size_t)dtr * a.ldX;
         }
 
         double w[T][4], xm[T][4], xa[T][4];
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 #pragma unroll
         for (int t = 0; t < T; t++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) { *q = x[t][r]; q += rsX; }
+            for (int r = 0; r < 4; r++) { if (ok(t, r)) *q = x[t][r]; q += rsX; }
     }
     if constexpr (NOISE == 2) {
         // if log(rand()) <= llo - ll: W <- Wo (parity flip), ll <- llo, acc += 1     partialbridge_fitzhugh.jl:160-167
@@ -338,16 +343,22 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     if (a.ll && live && kq == 0) a.ll[p] = ll;
 }
 
-template <int D, int NOISE>
+template <int D, int NOISE, bool PAD = false>
 hipError_t launch_tile(const TArgs &a, hipStream_t st)
 {
     const size_t lds = sizeof(double) * (4 * D * D + 5 * D + 2 * (D * D + D));
     // per device and cheap: set on every launch (a process may drive several devices)
-    hipError_t e = hipFuncSetAttribute((const void *)k_tile<D, NOISE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)k_tile<D, NOISE, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const long grid = (a.P + 63) / 64;
-    hipLaunchKernelGGL((k_tile<D, NOISE>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_tile<D, NOISE, PAD>), dim3((unsigned)grid), dim3(256), lds, st, a);
     return hipGetLastError();
+}
+
+template <int D, bool PAD>
+hipError_t launch_tile_noise(const TArgs &a, int noise, hipStream_t st)
+{
+    return noise == 3 ? launch_tile<D, 3, PAD>(a, st) : noise == 2 ? launch_tile<D, 2, PAD>(a, st) : noise ? launch_tile<D, 1, PAD>(a, st) : launch_tile<D, 0, PAD>(a, st);
 }
 
 }  // namespace bhip

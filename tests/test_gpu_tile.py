@@ -97,8 +97,8 @@ def test_partial_bridge_large_d_maps_onto_tile_kernel(ctx):
 def test_large_d_unsupported_combinations_fail_loudly(ctx):
     c = problems.linpro_big_case(32, 51)
     P8 = bh.LinPro(-np.eye(8), np.zeros(8), np.eye(8))
-    with pytest.raises(bh.BridgeError, match="large-d"):
-        bh.GuidedBridge(c.tt, P8, P8, np.ones(8), ctx=ctx)
+    with pytest.raises(bh.BridgeError, match="large-d"):         # only LinPro targets run on the tile kernel
+        bh.GuidedBridge(c.tt, bh.Wiener(8), P8, np.ones(8), ctx=ctx)
 
 
 @pytest.mark.parametrize("d", [16, 32])
@@ -157,3 +157,45 @@ def test_tile_kernel_pcn_chains(ctx, d, kind):
     Xall = X
     assert nn == n and np.abs(mean - Xall.mean(0)).max() < 1e-12
     assert np.abs(m2[40] - (Xall[:, 40] - mean[40]).T @ (Xall[:, 40] - mean[40])).max() < 1e-10
+
+
+@pytest.mark.parametrize("d", [4, 6, 10, 24, 30])
+def test_tile_kernel_other_even_dimensions_run_zero_padded(ctx, d):
+    """LinPro targets of any even dimension 4..30 run on the 16- or 32-component instantiation with zero padding: the
+    noise keeps the d-component counter layout (Wiener paths bit-exact), the ensembles hold d rows, results agree with
+    the oracle to the MFMA tolerance; odd dimensions are refused."""
+    c = problems.linpro_big_case(d, 81)
+    P = 40
+    Po, ref = c.bh_proposal(bh, ctx), c.oracle_proposal()
+    X, W, ll = bh.sample_solve(c.x0, Po, P, seed=6, iter=2, path0=100, store_W=True)
+    assert X.data.shape[1] == d and W.data.shape[1] == d
+    Xh, Wh, llh = X.paths(), W.paths(), ll.cpu().numpy()
+    for p in (0, 15, 16, 39):
+        Wr = o.wiener_sample(c.tt, d, 6, 100 + p, 2)
+        assert np.array_equal(Wh[p], Wr), (d, p)
+        Xr = o.solve_guided(ref, c.x0, Wr)
+        _close(Xh[p], Xr, llh[p:p + 1], np.array([o.llikelihood(ref, Xr)]))
+    assert np.array_equal(Xh[:, -1, :], np.tile(c.v, (P, 1)))                     # endpoint rule, d components
+    # external W, stand-alone llikelihood, plain Euler-Maruyama, pCN chains: the same padded kernel in its other modes
+    ll2 = ctx.empty(P)
+    X2 = bh.solve(bh.Euler(), c.x0, W, Po, ll=ll2)
+    assert torch.equal(X2.data, X.data) and torch.equal(ll2, ll)
+    ll3 = bh.llikelihood(bh.LeftRule(), X, Po)
+    assert float((ll3 - ll).abs().max()) <= 1e-9 * (1 + float(ll.abs().max()))
+    proc = bh.PlainProcess(c.tt, c.bh_process(bh), ctx=ctx)
+    Xf = bh.solve(bh.EulerMaruyama(), 0.2 * np.ones(d), W, proc).paths()
+    Xfr = o.solve_em(o.MODEL_LINPRO, d, d, c.par, c.tt, 0.2 * np.ones(d), Wh[7])
+    assert np.abs(Xf[7] - Xfr).max() <= 1e-9 * (1 + np.abs(Xfr).max())
+    ch = bh.Chains(Po, c.x0, P, seed=8)
+    ch.step(0.9, 4)
+    r = o.mcmc(ref, c.x0, 0.9, 4, 8, 17)
+    Xc, Wc = ch.paths(17, 1)
+    assert ch.acc()[17] == r["acc"] and np.array_equal(Wc[0], r["W"])
+    assert abs(ch.ll()[17] - r["ll"]) <= 1e-8 * (1 + abs(r["ll"]))
+
+
+def test_tile_kernel_refuses_odd_and_too_large_dimensions(ctx):
+    for d in (5, 33):
+        B, sig = -np.eye(d), 0.5 * np.eye(d)
+        with pytest.raises(bh.BridgeError, match="even dimension"):
+            bh.GuidedBridge(np.linspace(0, 1, 11), bh.LinPro(B, np.zeros(d), sig), bh.LinPro(B, np.zeros(d), sig), np.zeros(d), ctx=ctx)
