@@ -309,8 +309,13 @@ def main():
             for mode in ("proposals", "linpro32"):
                 wo = Workload(mode, ctx, args.chains, rank)
                 ms = kernel_times(wo, args.steps, args.warmup)
+                roof = wo.roofline(ms)
+                tr, src = profiled_traffic(*{"proposals": ("k_paths<bhip::MFHN, 2, 1, 1, 1>", ("r1_prop",)),
+                                             "linpro32": ("k_tile<32, 1, false>", ("r1_lin32",))}[mode])
+                if tr and wo.P == (262144 if mode == "proposals" else 65536):
+                    roof["traffic"], roof["traffic_source"] = tr, src
                 others.append({"mode": mode, "workload": wo.workload, "paths": wo.P,
-                               "path_steps_per_s": wo.P * steps_per_unit / (float(np.mean(ms)) * 1e-3), "roofline": wo.roofline(ms)})
+                               "path_steps_per_s": wo.P * steps_per_unit / (float(np.mean(ms)) * 1e-3), "roofline": roof})
                 del wo
                 torch.cuda.empty_cache()
             out["other_modes"] = others
