@@ -275,3 +275,46 @@ def test_C1_ou_euler_maruyama_65536_paths(ctx):
         Wr = o.wiener_sample(tt, 1, 1, p, 0)
         assert np.array_equal(W.paths(p, 1)[0], Wr)
         assert np.array_equal(X.paths(p, 1)[0], o.solve_em(o.MODEL_OU, 1, 1, [2.0, 1.0], tt, [0.1], Wr))
+
+
+def test_mcmc_reaches_the_exact_partially_observed_linear_law(ctx):
+    """The vector twin of the OU test: a 2-d linear target with coupled components, ONE component observed with noise at T
+    (PartialBridge, L = [1 0]), an auxiliary with a different drift matrix.  X_t | X_0, L X_T + eps = v is Gaussian with
+    a Kalman-type closed form (exact transition via matrix exponentials); the chains (noise dimension 2: line layout)
+    must reach its mean vector and covariance matrix at every tested time, the uncorrected proposals must not."""
+    from scipy.linalg import expm, solve_continuous_lyapunov
+    B = np.array([[-1.0, 0.8], [-0.6, -0.7]])
+    sig = np.array([[0.6, 0.0], [0.2, 0.5]])
+    a = sig @ sig.T
+    T, u, v, Sig = 1.5, np.array([0.4, -0.3]), np.array([0.9]), np.array([[0.01]])
+    L = np.array([[1.0, 0.0]])
+    tt = problems.tau_grid(T, 1001)
+    P = bh.LinPro(B, np.zeros(2), sig)
+    Pt = bh.LinPro(np.array([[-0.3, 0.0], [0.0, -0.3]]), np.zeros(2), sig)
+    Po = bh.PartialBridge(tt, P, Pt, L, v, Sig, ctx=ctx)
+    n = 65536
+    ch = bh.Chains(Po, u, n, seed=92, store_X=False)
+    X0 = ch.current_X().data
+    ch.step(0.7, 300)
+    X = ch.current_X().data                                   # [N, 2, n]
+    lam = solve_continuous_lyapunov(B, -a)
+
+    def law(t):
+        Pt_, Ps_ = expm(t * B), expm((T - t) * B)
+        Qt, Qs = lam - Pt_ @ lam @ Pt_.T, lam - Ps_ @ lam @ Ps_.T
+        m = Pt_ @ u
+        H = L @ Ps_
+        S = H @ Qt @ H.T + L @ Qs @ L.T + Sig
+        G = Qt @ H.T @ np.linalg.inv(S)
+        return m + (G @ (v - H @ m)), Qt - G @ H @ Qt
+
+    worst_prop = 0.0
+    for i in (200, 500, 800, 950):
+        mean, cov = law(tt[i])
+        xi = X[i].cpu().numpy()                               # [2, n]
+        se = np.sqrt(np.diag(cov) / n)
+        assert np.all(np.abs(xi.mean(1) - mean) < 6 * se + 4e-3), (i, xi.mean(1), mean)
+        assert np.abs(np.cov(xi) - cov).max() < 0.03 * np.abs(cov).max() + 2e-3, (i, np.cov(xi), cov)
+        worst_prop = max(worst_prop, np.abs(X0[i].cpu().numpy().mean(1) - mean).max())
+    assert worst_prop > 0.03                                  # the proposals alone are biased: the MH step does the work
+    assert 0.15 < ch.acc().sum() / (n * 300) < 0.95
