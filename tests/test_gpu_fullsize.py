@@ -318,3 +318,35 @@ def test_mcmc_reaches_the_exact_partially_observed_linear_law(ctx):
         worst_prop = max(worst_prop, np.abs(X0[i].cpu().numpy().mean(1) - mean).max())
     assert worst_prop > 0.03                                  # the proposals alone are biased: the MH step does the work
     assert 0.15 < ch.acc().sum() / (n * 300) < 0.95
+
+
+def test_mcmc_reaches_the_exact_linear_bridge_law_d32(ctx):
+    """Distribution-level check of the MFMA tile kernel's chains: LinPro d = 32 target, auxiliary with another drift matrix,
+    endpoint conditioned exactly (GuidedBridge).  X_t | X_0 = u, X_T = v is Gaussian in closed form; after 150 pCN
+    iterations 16 384 chains must reproduce its mean vector and the diagonal of its covariance at mid-time."""
+    from scipy.linalg import expm, solve_continuous_lyapunov
+    d = 32
+    c = problems.linpro_big_case(d, 401)
+    B = o.uncm(c.par[:d * d], d, d)
+    sig = o.uncm(c.par[d * d + d:], d, d)
+    a = sig @ sig.T
+    T, u, v = float(c.tt[-1]), np.asarray(c.x0, dtype=float), np.asarray(c.v, dtype=float)
+    Po = c.bh_proposal(bh, ctx)
+    n = 16384
+    ch = bh.Chains(Po, u, n, seed=93, store_X=False)
+    ch.step(0.8, 150)
+    X = ch.current_X().data
+    lam = solve_continuous_lyapunov(B, -a)
+    i = 200
+    t = float(c.tt[i])
+    Pt_, Ps_ = expm(t * B), expm((T - t) * B)
+    Qt, Qs = lam - Pt_ @ lam @ Pt_.T, lam - Ps_ @ lam @ Ps_.T
+    S = Ps_ @ Qt @ Ps_.T + Qs                                  # Var(X_T | X_0)
+    G = Qt @ Ps_.T @ np.linalg.inv(S)
+    mean = Pt_ @ u + G @ (v - Ps_ @ Pt_ @ u)
+    cov = Qt - G @ Ps_ @ Qt
+    xi = X[i].cpu().numpy()                                    # [32, n]
+    se = np.sqrt(np.diag(cov) / n)
+    assert np.all(np.abs(xi.mean(1) - mean) < 6 * se + 5e-3), np.abs(xi.mean(1) - mean).max()
+    assert np.abs(xi.var(1) / np.diag(cov) - 1).max() < 0.08
+    assert 0.05 < ch.acc().sum() / (n * 150) < 0.99
