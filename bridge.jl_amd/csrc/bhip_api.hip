@@ -53,7 +53,6 @@ struct bhip_proposal {
     double vend[3] = {0, 0, 0};
     // large-d (tile kernel) data: per-step fragment matrices, step header, constants
     double *d_steps = nullptr, *d_hdr = nullptr, *d_cst = nullptr;
-    std::vector<double> cst_host;   // kept so that x0 can be patched per call
 };
 
 struct bhip_chains {
@@ -448,8 +447,7 @@ static int build_tile_data(bhip_proposal *po)
         hdr[2 * i] = po->tt[i + 1] - po->tt[i];
         hdr[2 * i + 1] = std::sqrt(po->tt[i + 1] - po->tt[i]);
     }
-    std::vector<double> &cst = po->cst_host;
-    cst.assign(4 * DD + 5 * Dp, 0.0);
+    std::vector<double> cst(4 * DD + 5 * Dp, 0.0);
     const double *par = po->mh.par.data();
     to_fragments(pad_mat(Mat(d, d, par), Dp), &cst[0]);                          // B
     if (!plain) to_fragments(pad_mat(po->aux.B(po->tt[0]), Dp), &cst[DD]);       // B~
@@ -476,19 +474,16 @@ static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const d
                             double *X, long ldX, double *ll, int skip, long npaths, int noise, uint64_t seed, uint32_t iter, uint32_t path0,
                             int wstride = 1, const bhip_chains *ch = nullptr, double rho = 0.0)
 {
-    bhip_proposal *po = const_cast<bhip_proposal *>(po_c);
+    const bhip_proposal *po = po_c;
     bhip_ctx *ctx = po->ctx;
     NEED_DEVICE(ctx);
-    const int d = po->mh.d, Dp = tile_dim(d);
+    const int d = po->mh.d;
     if (!po->d_steps) return fail(ctx, BHIP_ESTATE, "proposal has no large-d guide data (compute a guide first)");
     if (!x0) return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: shared starting point only");
     if (npaths < 1 || skip < 0) return fail(ctx, BHIP_EINVAL, "bad npaths/skip");
-    const size_t DD = (size_t)Dp * Dp;
-    // x0 lives in the constant block (read by every lane by row index)
-    std::memcpy(&po->cst_host[4 * DD + 4 * Dp], x0, sizeof(double) * d);
-    HIPCHK(ctx, hipMemcpyAsync(po->d_cst + 4 * DD + 4 * Dp, &po->cst_host[4 * DD + 4 * Dp], sizeof(double) * d, hipMemcpyHostToDevice, ctx->stream));
     TArgs a;
     std::memset(&a, 0, sizeof(a));
+    std::memcpy(a.x0, x0, sizeof(double) * d);   // by value in the kernel arguments (rows d..Dp-1 stay zero)
     a.steps = po->d_steps; a.hdr = po->d_hdr; a.cst = po->d_cst;
     a.dtrue = d;
     a.N = (int)po->tt.size(); a.skip = skip; a.use_vend = po->use_vend; a.noise = noise; a.P = npaths;
@@ -502,7 +497,7 @@ static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const d
     hipError_t le = hipSuccess;
     if (d == 32) le = launch_tile_noise<32, false>(a, noise, ctx->stream);
     else if (d == 16) le = launch_tile_noise<16, false>(a, noise, ctx->stream);
-    else if (Dp == 32) le = launch_tile_noise<32, true>(a, noise, ctx->stream);
+    else if (tile_dim(d) == 32) le = launch_tile_noise<32, true>(a, noise, ctx->stream);
     else le = launch_tile_noise<16, true>(a, noise, ctx->stream);
     HIPCHK(ctx, le);
     return BHIP_OK;

@@ -43,7 +43,8 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 struct TArgs {
     const double *steps;   // [N-1][D*D + D]: Hm_i in fragment order, then nu_i (natural order)
     const double *hdr;     // [N-1][2]: dt_i, sqrt(dt_i)
-    const double *cst;     // 4 fragment matrices (B, B~, a, sigma), then mu, mu~, beta~, vend, x0 (D each)
+    const double *cst;     // 4 fragment matrices (B, B~, a, sigma), then mu, mu~, beta~, vend (D each; a fifth D-slot is unused)
+    double x0[32];         // shared starting point (zero padded), passed by value: launches on one proposal do not interfere
     int dtrue;             // state dimension of the process (<= the kernel's D; the rest is zero padding, template PAD)
     int N, skip, use_vend, noise;   // noise: 0 = external W, 1 = fresh Philox, 2 = pCN chain step, 3 = llikelihood of a stored X (Win = X)
     long P;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     for (int c = tid; c < STEP; c += 256) hb[c] = a.steps[c];
     __syncthreads();
     const double *Bf = cm, *Btf = cm + DD, *Af = cm + 2 * DD, *Sf = cm + 3 * DD;
-    const double *mu = cm + 4 * DD, *mua = mu + D, *beta = mu + 2 * D, *vend = mu + 3 * D, *x0 = mu + 4 * D;
+    const double *mu = cm + 4 * DD, *mua = mu + D, *beta = mu + 2 * D, *vend = mu + 3 * D;
 
     // Addressing: the lane's element (t, r) of grid row i lives at  base + i*D*ld + (4t + r)*(4*ld), base = array +
     // kq*ld + p.  One running pointer per array is advanced once per step and the 4T elements are reached by a
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
         for (int t = 0; t < T; t++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                x[t][r] = x0[16 * t + 4 * r + kq];
+                x[t][r] = a.x0[16 * t + 4 * r + kq];
                 wprev[t][r] = (NOISE == 0 && ok(t, r)) ? *q : 0.0;
                 if (NOISE == 0) q += rsWin;
                 if (NOISE == 1 && a.Wout) { if (ok(t, r)) *qo = 0.0; qo += rsWo; }
