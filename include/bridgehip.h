@@ -208,6 +208,7 @@ int bhip_gpupdate(int d, int m, const double *Hd, const double *V, const double 
  * deterministic function of the current W and is re-materialised on demand, bit-identical to the Xo
  * stored when that W was accepted (bhip_chains_current_X / bhip_chains_get_paths). */
 #define BHIP_CHAINS_STORE_X 1   /* keep the proposal paths Xo (the SamplePath contract) */
+/* A chains object borrows `po` (it must outlive the chains) and is bound to po's context. */
 int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uint32_t path0, uint64_t seed,
                        int flags, bhip_chains **out);
 void bhip_chains_destroy(bhip_chains *ch);
