@@ -38,6 +38,9 @@ CHAINS_STORE_X = 1
 STATS_LEN = 8
 
 
+OPT_WAVE_SPECIALISED = 1   # BHIP_OPT_WAVE_SPECIALISED
+
+
 class BridgeError(RuntimeError):
     """error(...) of the reference / non-zero BHIP_E* code of the library"""
 
@@ -96,6 +99,10 @@ class Context:
 
     def sync(self):
         self.check(self.lib.bhip_ctx_sync(self.h))
+
+    def set_option(self, option, value):
+        """bhip_ctx_set_option: OPT_WAVE_SPECIALISED 1 (default) / 0"""
+        self.check(self.lib.bhip_ctx_set_option(self.h, int(option), int(value)))
 
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float64, device=self.device)
@@ -746,7 +753,10 @@ class Chains:
         self.iterations = 0
         self.ctx.check(self.ctx.lib.bhip_chains_init(h, _dptr(_x0(x0, Po.d)), skip))
 
-    def step(self, rho, iters=1, skip=0):
+    def step(self, rho, iters=1, skip=None):
+        """`iters` pCN iterations.  skip = None: the skip the ensemble was initialised with, so that llo and ll always
+        sum the same terms (partialbridge_nclar.jl:121 passes it to both)."""
+        skip = self.skip if skip is None else int(skip)
         self.ctx.check(self.ctx.lib.bhip_chains_step(self.h, float(rho), int(iters), skip))
         self.iterations += iters
 

@@ -4,6 +4,7 @@
 #include "bhip_host.hpp"
 #include "bhip_path_kernel.h"
 #include "bhip_chain_kernel.h"
+#include "bhip_pc_kernel.h"
 #include "bhip_tile_kernel.h"
 #include "bhip_girsanov_kernel.h"
 #include "bhip_rtc.hpp"
@@ -31,6 +32,10 @@ launch_fn get_launch_wiener2(int, int, int, int);
 launch_fn get_launch_wiener3(int, int, int, int);
 }  // namespace bhip
 
+#ifndef PC_FRESH_MAX_PATHS
+#define PC_FRESH_MAX_PATHS 98304
+#endif
+
 struct bhip_ctx {
     int device = 0;
     bool host_only = false;   // device == -1: guide pre-computation only, every launch is refused
@@ -38,6 +43,7 @@ struct bhip_ctx {
     std::string err;
     double *scratch = nullptr;
     size_t scratch_bytes = 0;
+    bool wave_specialised = true;   // BHIP_OPT_WAVE_SPECIALISED: producer/consumer kernels (bhip_pc_kernel.h) where they exist
 };
 
 struct bhip_proposal {
@@ -49,6 +55,7 @@ struct bhip_proposal {
     Guide g;
     double *d_rows = nullptr;
     int rs = 0;
+    double *d_rdtp = nullptr;   // rdtp[j] = sqrt(tt[j] - tt[j-1]), rdtp[0] = 0, zero padded to a multiple of 16 (bhip_pc_kernel.h)
     bool use_vend = false;
     double vend[3] = {0, 0, 0};
     // large-d (tile kernel) data: per-step fragment matrices, step header, constants
@@ -188,6 +195,13 @@ int bhip_ctx_sync(bhip_ctx *ctx)
 }
 
 const char *bhip_last_error(const bhip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int bhip_ctx_set_option(bhip_ctx *ctx, int option, int value)
+{
+    if (!ctx) return BHIP_EINVAL;
+    if (option == BHIP_OPT_WAVE_SPECIALISED) { ctx->wave_specialised = value != 0; return BHIP_OK; }
+    return fail(ctx, BHIP_EINVAL, "bhip_ctx_set_option: unknown option");
+}
 
 int bhip_malloc(bhip_ctx *ctx, size_t bytes, void **dev)
 {
@@ -357,6 +371,7 @@ void bhip_proposal_destroy(bhip_proposal *po)
     if (!po->ctx->host_only) {
         (void)hipStreamSynchronize(po->ctx->stream);
         if (po->d_rows) (void)hipFree(po->d_rows);
+        if (po->d_rdtp) (void)hipFree(po->d_rdtp);
         if (po->d_steps) (void)hipFree(po->d_steps);
         if (po->d_hdr) (void)hipFree(po->d_hdr);
         if (po->d_cst) (void)hipFree(po->d_cst);
@@ -525,6 +540,14 @@ static int finish_guide(bhip_proposal *po)
     HIPCHK(ctx, hipMalloc((void **)&po->d_rows, sizeof(double) * rows.size()));
     HIPCHK(ctx, hipMemcpy(po->d_rows, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice));
     po->rs = rs;
+    {   // the Wiener increment scale INTO grid point j -- the very values of the rows (producer waves, bhip_pc_kernel.h)
+        const size_t np = ((size_t)N + 15) / 16 * 16;
+        std::vector<double> rdtp(np, 0.0);
+        for (int j = 1; j < N; j++) rdtp[j] = rows[(size_t)(j - 1) * rs + 2];
+        if (po->d_rdtp) { HIPCHK(ctx, hipFree(po->d_rdtp)); po->d_rdtp = nullptr; }
+        HIPCHK(ctx, hipMalloc((void **)&po->d_rdtp, np * sizeof(double)));
+        HIPCHK(ctx, hipMemcpy(po->d_rdtp, rdtp.data(), np * sizeof(double), hipMemcpyHostToDevice));
+    }
     return BHIP_OK;
 }
 
@@ -654,6 +677,7 @@ static int fill_common(const bhip_proposal *po, KArgs &a, const double *x0, cons
     if (skip < 0) return fail(ctx, BHIP_EINVAL, "skip must be >= 0");
     if (!x0 && !x0_dev) return fail(ctx, BHIP_EINVAL, "need a starting point");
     a.rows = po->d_rows; a.rs = po->rs; a.N = (int)po->tt.size(); a.skip = skip;
+    a.rdtp = po->d_rdtp;
     a.P = npaths;
     a.wstride = 1;
     const bool aux_linpro = po->has_aux && po->aux.linpro_form();   // b~ = B(x - mu~); else b~ = B x + beta~ (mu~ = 0)
@@ -708,7 +732,15 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, lds, ctx->stream, params, nullptr));
         return BHIP_OK;
     }
-    launch_fn f = find_launch(po->mh, gk_dispatch, mo, noise, fl);
+    launch_fn f = nullptr;
+    if (ctx->wave_specialised && a.rdtp && (po->mh.mp == 1 || po->mh.mp == 2) && a.wstride == 1) {
+        // producer/consumer waves (bhip_pc_kernel.h): same results, the kernel of choice wherever it is instantiated
+        // Fresh proposals: with 4 waves per SIMD the one-lane-does-everything kernel already issues at ~85 % of the VALU
+        // rate and the hand-over only costs; the split pays below that (profiles/r2_small_configs.txt).
+        if (noise == NOISE_FRESH && a.P <= PC_FRESH_MAX_PATHS) f = find_launch(po->mh, gk_dispatch, mo, NOISE_FRESH_PC, fl);
+        else if (noise == NOISE_PCN_LINES) f = find_launch(po->mh, gk_dispatch, mo, NOISE_PCN_LINES_PC, fl);
+    }
+    if (!f) f = find_launch(po->mh, gk_dispatch, mo, noise, fl);
     if (!f) return fail(ctx, BHIP_EUNSUPPORTED, "no device kernel for this (model, guide, noise) combination");
     HIPCHK(ctx, f(a, ctx->stream));
     return BHIP_OK;

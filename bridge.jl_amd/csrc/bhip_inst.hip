@@ -2,6 +2,7 @@
 // (compiled once per model with -DBHIP_INST=<n> so the build parallelises).
 #include "bhip_path_kernel.h"
 #include "bhip_chain_kernel.h"
+#include "bhip_pc_kernel.h"
 
 namespace bhip {
 #if BHIP_INST == 0

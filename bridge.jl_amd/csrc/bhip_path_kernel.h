@@ -26,6 +26,9 @@ namespace bhip {
 enum { NOISE_EXT = 0, NOISE_FRESH = 1, NOISE_PCN = 2, NOISE_LLONLY = 3, NOISE_INNOV = 4,
        NOISE_PCN_LINES = 5 /* pCN step on the line layout, k_chain_lines in bhip_chain_kernel.h (m' = 1, 2) */ };
 
+template <bool C, class A, class B> struct bhip_cond { typedef A type; };   // (no <type_traits> under hipRTC)
+template <class A, class B> struct bhip_cond<false, A, B> { typedef B type; };
+
 // does the model functor provide inv(sigma)*v (square, invertible diffusion coefficient)?
 template <class...> using bhip_void_t = void;
 template <class M, class = void> struct has_sinv { static constexpr bool value = false; };
@@ -38,6 +41,7 @@ template <class M> struct is_constdiff<M, bhip_void_t<decltype(M::STATE_SIGMA)>>
 
 struct KArgs {
     const double *rows;   // [N-1][rs] packed per-step coefficients (device)
+    const double *rdtp;   // rdtp[j] = sqrt(tt[j] - tt[j-1]) (0 for j = 0), zero padded to a multiple of 16 (bhip_pc_kernel.h)
     int rs, N, skip;
     int use_vend;         // GuidedBridge endpoint rule: X[N-1] = V[N-1]
     long P;               // paths
@@ -226,9 +230,12 @@ struct LaneState {
 // the state-independent work -- Philox, Box-Muller, address arithmetic -- with the dependent chain).
 //   win_k : EXT: W[i+1] ; PCN: current chain W[i+1] ; LLONLY: X[i]       (already in registers)
 //   FL    : bit0 store X, bit1 store W, bit2 PartialBridge!-style log-likelihood (two dots)
-template <class M, int GK, int MO, int NOISE, int FL>
-BHIP_DEV void path_step(const M &model, const KArgs &a, cptr_t row, int i, int nll, uint32_t path, const double *win_k,
-                        double *wout, long ldwo, double *xout, long ldx, LaneState<M::D, M::MP> &st)
+//   RowPtr: where the step's coefficient row is read from -- cptr_t (constant address space: scalar loads into SGPRs)
+//           or an LDS pointer (the consumer waves of bhip_pc_kernel.h at small ensembles: broadcast ds_reads)
+//   Tab   : where the generator's tables are read from (TabConst, or TabLDS when the kernel keeps a copy in LDS)
+template <class M, int GK, int MO, int NOISE, int FL, class RowPtr = cptr_t, class Tab = TabConst>
+BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int nll, uint32_t path, const double *win_k,
+                        double *wout, long ldwo, double *xout, long ldx, LaneState<M::D, M::MP> &st, const Tab &tab = Tab())
 {
     constexpr int D = M::D, MP = M::MP;
     using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
@@ -282,7 +289,7 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, cptr_t row, int i, int n
         for (int k = 0; k < MP; k++) {
             const int n = i * MP + k;
             double z;
-            if ((n & 1) == 0) normal_pair(a.k0, a.k1, path, a.iter, (uint32_t)(n >> 1), z, st.zc);
+            if ((n & 1) == 0) normal_pair(tab, a.k0, a.k1, path, a.iter, (uint32_t)(n >> 1), z, st.zc);
             else z = st.zc;
             if constexpr (NOISE == NOISE_FRESH) {
                 const double wn = st.wprev[k] + rdt * z;          // yy[i] = yy[i-1] + rootdt*randn
@@ -386,6 +393,15 @@ __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
 {
     constexpr int D = M::D, MP = M::MP;
     using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
+    // the instantiations that draw normals keep the generator's tables in LDS (2.5 KB per block)
+    constexpr bool DRAWS = NOISE == NOISE_FRESH || NOISE == NOISE_PCN;
+    __shared__ __attribute__((aligned(16))) double rng_tab[DRAWS ? RNG_TAB_DOUBLES : 2];
+    if constexpr (DRAWS) {
+        TabLDS::load(rng_tab, threadIdx.x, blockDim.x);
+        __syncthreads();
+    }
+    using TabT = typename bhip_cond<DRAWS, TabLDS, TabConst>::type;
+    const TabT tab = [&]() { if constexpr (DRAWS) return TabLDS(rng_tab); else return TabConst(); }();
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.P) return;
     const M model(a.mpar);
@@ -498,16 +514,16 @@ __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
     for (; i + 1 < nsteps; i += 2) {
         double cur[NIN];
         advance(i, cur);
-        path_step<M, GK, MO, NOISE, FL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, cur, wout, ldwo, xout, ldx, st);
+        path_step<M, GK, MO, NOISE, FL, cptr_t, TabT>(model, a, rows + (size_t)i * RL::RS, i, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
         commit(i);
         advance(i + 1, cur);
-        path_step<M, GK, MO, NOISE, FL>(model, a, rows + (size_t)(i + 1) * RL::RS, i + 1, nll, path, cur, wout, ldwo, xout, ldx, st);
+        path_step<M, GK, MO, NOISE, FL, cptr_t, TabT>(model, a, rows + (size_t)(i + 1) * RL::RS, i + 1, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
         commit(i + 1);
     }
     if (i < nsteps) {
         double cur[NIN];
         advance(i, cur);
-        path_step<M, GK, MO, NOISE, FL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, cur, wout, ldwo, xout, ldx, st);
+        path_step<M, GK, MO, NOISE, FL, cptr_t, TabT>(model, a, rows + (size_t)i * RL::RS, i, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
         commit(i);
     }
 
@@ -530,7 +546,7 @@ __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
         // if log(rand()) <= llo - ll: X<-Xo, W<-Wo (parity flip), ll<-llo, acc+=1
         const double u = accept_uniform(a.k0, a.k1, path, a.iter);
         const double llc = a.llcur[p];
-        if (det_log(u) <= st.ll - llc) {
+        if (det_log(u, tab) <= st.ll - llc) {
             a.cur[p] = (unsigned char)(c ^ 1);
             a.llcur[p] = st.ll;
             a.acc[p] += 1u;
@@ -548,6 +564,8 @@ typedef hipError_t (*launch_fn)(const KArgs &, hipStream_t);
 
 template <class M, int GK, int MO, int FL>
 hipError_t launch_chain_lines(const KArgs &a, hipStream_t st);   // bhip_chain_kernel.h
+template <class M, int GK, int MO, int MODE, int FL>
+hipError_t launch_pc(const KArgs &a, hipStream_t st);            // bhip_pc_kernel.h
 
 template <class M, int GK, int MO, int NOISE, int FL>
 hipError_t launch_paths(const KArgs &a, hipStream_t st)
@@ -578,6 +596,19 @@ launch_fn get_launch_gk(int noise, int fl)
         return nullptr;
     case NOISE_PCN_LINES:
         if constexpr (GK != BHIP_GUIDE_NONE && (M::MP == 1 || M::MP == 2)) return (fl & 1) ? launch_chain_lines<M, GK, MO, 1 | T> : launch_chain_lines<M, GK, MO, 0 | T>;
+        return nullptr;
+    case 6 /* NOISE_FRESH_PC */:
+        if constexpr (M::MP == 1 || M::MP == 2) {
+            switch (fl & 3) {
+            case 0: return launch_pc<M, GK, MO, 6, 0 | T>;
+            case 1: return launch_pc<M, GK, MO, 6, 1 | T>;
+            case 2: return launch_pc<M, GK, MO, 6, 2 | T>;
+            default: return launch_pc<M, GK, MO, 6, 3 | T>;
+            }
+        }
+        return nullptr;
+    case 7 /* NOISE_PCN_LINES_PC */:
+        if constexpr (GK != BHIP_GUIDE_NONE && (M::MP == 1 || M::MP == 2)) return (fl & 1) ? launch_pc<M, GK, MO, 7, 1 | T> : launch_pc<M, GK, MO, 7, 0 | T>;
         return nullptr;
     case NOISE_LLONLY:
         if constexpr (GK != BHIP_GUIDE_NONE) return launch_paths<M, GK, MO, NOISE_LLONLY, 0 | T>;

@@ -1,0 +1,323 @@
+// bhip_pc_kernel.h -- the fused path kernel with wave specialisation (d <= 3, noise dimension m' = 1 or 2).
+//
+// Same arithmetic as k_paths<.., NOISE_FRESH, ..> / k_chain_lines (it calls the same path_step), different division of
+// labour.  In those kernels one lane does everything for its path: the Philox / Box-Muller normal (state-independent,
+// about half of the instructions) and the Euler recurrence (sequential in time).  With one path per lane the named
+// small ensembles starve the chip -- 65 536 paths are one wave per SIMD, 32 768 chains leave half of the SIMDs idle -- and
+// a lone wave cannot hide the latency of its own dependent chain.  Here a 128-thread workgroup owns 64 paths and splits
+// the work BY WAVE:
+//
+//   wave 0, the PRODUCER: everything that does not depend on the state -- sample!(W2, Wiener())  (src/wiener.jl:24-58),
+//           the pCN mix Wo = rho*W + sqrt(1-rho^2)*W2 (partialbridge_fitzhugh.jl:147) and the whole chain-state traffic
+//           (the 128-byte lines of bhip_chain_kernel.h, read, mixed in an LDS tile, written to the other parity half).
+//           Eight independent Philox blocks per 16-value chunk: instruction-level parallelism instead of a dependent chain.
+//           The generator's tables live in LDS (TabLDS).
+//   wave 1, the CONSUMER: solve!(Euler(), Xo, x0, Wo, Po) + llikelihood (src/euler.jl:247-268, src/partialbridge.jl:67-77
+//           ...) exactly as path_step<.., NOISE_EXT, ..> does them, with the driving Wiener values read from the
+//           producer's LDS tile instead of HBM; stores Xo; Metropolis-Hastings accept at the end.
+//
+// Hand-over: two 64 x 17 double tiles (a chunk = 16 values = 16/m' grid points per chain); the producer fills tile t&1
+// with chunk t while the consumer works on chunk t-1 in the other tile; one workgroup barrier per chunk.  Twice the
+// waves for the same paths (every SIMD busy at 32 768 chains, two waves per SIMD at 65 536), each with half the
+// instructions, its own register budget (the generator's constants in the producer, the coefficient rows in the
+// consumer: no scalar-register spills) -- and bit-identical results (tests/test_gpu_pc.py: == the monolithic kernels).
+//
+// RLDS (small ensembles, NPAIR > 1: LDS and registers to spare): the coefficient rows of a chunk travel through LDS
+// as well.  A consumer wave that is alone on its SIMD otherwise exposes one scalar-load round trip to L2 per time step
+// (the 128 KB of rows do not fit the scalar cache, and nothing else is there to issue meanwhile): measured ~640 cycles
+// per step for ~50 VALU instructions.  The producer fetches the next chunk's rows with two vector loads per lane a
+// whole chunk ahead and the consumer reads each row with broadcast ds_reads (~100 cycles, no scalar traffic).
+#pragma once
+#include "bhip_chain_kernel.h"
+
+namespace bhip {
+
+enum { NOISE_FRESH_PC = 6, NOISE_PCN_LINES_PC = 7 };
+
+#ifndef PC_BLOCK_UNROLL
+#define PC_BLOCK_UNROLL 2   // Philox blocks in flight per producer lane (instruction-level parallelism vs registers)
+#endif
+#ifndef PC_WPE
+#define PC_WPE 4            // minimum waves per SIMD the register allocation must allow (8 workgroups per CU by LDS)
+#endif
+constexpr int PC_TILE = 64 * LINE_ROW;                          // doubles per hand-over tile
+constexpr size_t PC_LDS = sizeof(double) * (RNG_TAB_DOUBLES + 2 * PC_TILE);   // 19 984 bytes: 8 workgroups per CU
+typedef const __attribute__((address_space(3))) double *ldsrow_t;
+
+// KArgs::rdtp (device): rdtp[j] = sqrt(tt[j] - tt[j-1]) for 1 <= j <= N-1, rdtp[0] = 0, zero padded to a multiple of 16:
+// the Wiener increment INTO grid point j, so that a chunk reads 16/m' consecutive, aligned values and grid point 0
+// (W[0] = 0 + 0*z = 0) needs no special case.
+
+template <class M, int GK, int MO, int MODE, int FL, int NPAIR>
+__global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(const KArgs a)
+{
+    constexpr int D = M::D, MP = M::MP;
+    static_assert(MP == 1 || MP == 2, "a chunk holds 16/m' grid points");
+    static_assert(MODE == NOISE_FRESH_PC || MODE == NOISE_PCN_LINES_PC, "producer/consumer kernel: fresh proposals or pCN on the line layout");
+    constexpr bool PCN = MODE == NOISE_PCN_LINES_PC;
+    constexpr int SPC = LINE_DOUBLES / MP;   // grid points per chunk
+    using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
+    // Workgroup = NPAIR producer/consumer pairs.  Small ensembles run 2 or 4 pairs per workgroup (and then RLDS): a
+    // workgroup's waves are dealt to the four SIMDs of its CU in turn, so 4 waves sit on 4 different SIMDs and the 8 waves
+    // of a 4-pair workgroup put one producer and one consumer on every SIMD, whereas the waves of independent 128-thread
+    // workgroups may share a SIMD while another one idles (measured at 32 768 chains: producer-only 0.21 ms,
+    // consumer-only 0.21 ms, both 0.31 ms in 128-thread workgroups, 0.25 ms in 256-thread ones).
+    constexpr bool RLDS = NPAIR > 1;
+    extern __shared__ __attribute__((aligned(16))) double pc_lds_all[];
+    double *tab = pc_lds_all;                                           // [RNG_TAB_DOUBLES], shared by the pairs
+    constexpr int CROW = SPC * RL::RS;                                  // doubles of coefficient rows per chunk
+    const int wave = threadIdx.x >> 6, pair = wave % NPAIR, role = wave / NPAIR;   // waves 0..NPAIR-1 produce, the others consume
+    double *pc_lds = pc_lds_all + RNG_TAB_DOUBLES + pair * (2 * PC_TILE + (RLDS ? 2 * CROW : 0));   // [2][PC_TILE] then (RLDS) [2][CROW]
+    double *crow = pc_lds + 2 * PC_TILE;
+    TabLDS::load(tab, threadIdx.x, 128 * NPAIR);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    long c0 = ((long)blockIdx.x * NPAIR + pair) * 64;
+    // a second pair without chains (odd number of 64-chain groups) re-runs the last group -- identical values to
+    // identical addresses -- so that it takes part in every barrier; it commits nothing (no lane is live)
+    const bool dup = c0 >= a.P;
+    if (dup) c0 = (a.P - 1) / 64 * 64;
+    const bool live = !dup && c0 + lane < a.P;
+    // lanes beyond the ensemble replicate path P-1 exactly (same tile row, same stream): their stores write identical
+    // values to identical addresses and need no execution mask
+    const int row = c0 + lane < a.P ? lane : (int)(a.P - 1 - c0);
+    const long p = c0 + row;
+    const int N = a.N, nsteps = N - 1;
+    const int nch = (N + SPC - 1) / SPC;
+    const uint32_t path = a.path0 + (uint32_t)p;
+
+    if (role == 0) {
+        // ------------------------------------------------------------------ producer
+        const TabLDS rtab(tab);
+        const cptr_t rdtp = (cptr_t)(uintptr_t)a.rdtp;
+        double wprev[MP], w2prev[MP];
+#pragma unroll
+        for (int c = 0; c < MP; c++) { wprev[c] = 0.0; w2prev[c] = 0.0; }
+        double carry = 0.0;   // m' = 1: second normal of the block that straddles the chunk boundary
+        // cooperative line moves (pCN): instruction q moves the lines of chains c0 + 8q + lane/8; lane%8 selects 16 bytes
+        const int sub = lane >> 3, part = 2 * (lane & 7);
+        int par[8];
+        d2v stage[8];
+        auto fetch = [&](int k) {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                stage[q] = ld_stream((const d2v *)(a.Wc + line_index(par[q], k, c0 + 8 * q + sub, nch, a.ldC) + part));
+        };
+        if constexpr (PCN) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) par[q] = a.cur[c0 + 8 * q + sub];   // cur[] is allocated (and zeroed) up to ld
+            fetch(0);
+        }
+        double *wout = nullptr;
+        long ldwo = 0;
+        if constexpr (!PCN && (FL & 2) != 0) { wout = a.Wout + (size_t)p * a.wstride; ldwo = a.ldWout * a.wstride; }
+        // RLDS: chunk k needs the rows of steps i = SPC*k - 1 .. SPC*k + SPC - 2, contiguous in memory; every lane moves
+        // 16-byte pieces (RS is even and the rows are 256-byte aligned), clamped into the array at both ends
+        constexpr int NRV = (CROW + 127) / 128;
+        d2v rstage[NRV];
+        const long rlast = (long)nsteps * RL::RS - 2;
+        auto fetch_rows = [&](int k) {
+#pragma unroll
+            for (int q = 0; q < NRV; q++) {
+                long e = ((long)SPC * k - 1) * RL::RS + (q * 64 + lane) * 2;
+                e = e < 0 ? 0 : (e > rlast ? rlast : e);
+                rstage[q] = *(const d2v *)(a.rows + e);
+            }
+        };
+        if constexpr (RLDS) fetch_rows(0);
+
+        for (int k = 0; k <= nch; k++) {
+            if (k < nch) {
+                double *tile = pc_lds + (k & 1) * PC_TILE;
+                double *mine = tile + row * LINE_ROW;
+                if constexpr (RLDS) {
+#pragma unroll
+                    for (int q = 0; q < NRV; q++) {
+                        const int e = (q * 64 + lane) * 2;
+                        if (e < CROW) *(d2v *)(crow + (k & 1) * CROW + e) = rstage[q];
+                    }
+                    if (k + 1 < nch) fetch_rows(k + 1);
+                }
+                if constexpr (PCN) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {   // staged lines -> tile
+                        double *d = tile + (8 * q + sub) * LINE_ROW + part;
+                        d[0] = stage[q].x; d[1] = stage[q].y;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (k + 1 < nch) fetch(k + 1);   // in flight while this chunk is mixed
+                }
+                // value v = s*MP + c of the chunk (grid point j = SPC*k + s, component c) takes normal n = (j-1)*MP + c:
+                //   m' = 1: v = 2q   <- second normal of block 8k+q-1 (the carry), v = 2q+1 <- first normal of block 8k+q
+                //   m' = 2: v = 2q, 2q+1 <- both normals of block 8k+q-1   (k = 0, q = 0: block "-1", multiplied by rdtp[0] = 0)
+                // RLDS (a producer that is alone on its SIMD): the chunk's 16/m' scales in one scalar load up front and the
+                // eight blocks fully unrolled -- otherwise every value waits for its own scalar load
+                double rd[SPC];
+                if constexpr (RLDS) {
+#pragma unroll
+                    for (int s = 0; s < SPC; s++) rd[s] = rdtp[(size_t)k * SPC + s];
+                }
+                auto value = [&](int v, double zz) {
+                    const int s = v / MP, c = v % MP, j = k * SPC + s;
+                    double rdt;
+                    if constexpr (RLDS) rdt = rd[s];
+                    else rdt = rdtp[j];                                           // wave-uniform: scalar load
+                    if constexpr (!PCN) {
+                        const double wn = wprev[c] + rdt * zz;                 // yy[i] = yy[i-1] + rootdt*randn   src/wiener.jl:55
+                        wprev[c] = wn;
+                        mine[v] = wn;
+                        if constexpr ((FL & 2) != 0) {
+                            if (j < N) st_stream(&wout[((size_t)j * MP + c) * ldwo], wn);
+                        }
+                    } else {
+                        const double wc = mine[v];
+                        const double w2 = w2prev[c] + rdt * zz;
+                        w2prev[c] = w2;
+                        mine[v] = a.rho * wc + a.srho * w2;                      // Wo = rho*W + sqrt(1-rho^2)*W2
+                    }
+                };
+                const uint32_t b0 = (uint32_t)(8 * k) - (MP == 2 ? 1u : 0u);
+                auto block = [&](int q) {
+                    double z0, z1;
+#ifdef PC_KNOCKOUT_NOISE   /* measurement only: what the consumer alone costs */
+                    z0 = 0.25; z1 = -0.5;
+#else
+                    normal_pair(rtab, a.k0, a.k1, path, a.iter, b0 + q, z0, z1);
+#endif
+                    if constexpr (MP == 1) { value(2 * q, carry); value(2 * q + 1, z0); carry = z1; }
+                    else { value(2 * q, z0); value(2 * q + 1, z1); }
+                };
+                if constexpr (RLDS) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) block(q);
+                } else {
+#pragma unroll PC_BLOCK_UNROLL
+                    for (int q = 0; q < 8; q++) block(q);
+                }
+                if constexpr (PCN) {
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {   // tile -> the lines of the other halves
+                        const double *d = tile + (8 * q + sub) * LINE_ROW + part;
+                        st_stream((d2v *)(a.Wc + line_index(par[q] ^ 1, k, c0 + 8 * q + sub, nch, a.ldC) + part), d2v{d[0], d[1]});
+                    }
+                }
+            }
+            __syncthreads();   // chunk k is complete; the consumer has finished chunk k-1 (the tile written next)
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer
+    const M model(a.mpar);
+    const int nll = N - 1 - a.skip;
+    const cptr_t rows = (cptr_t)(uintptr_t)a.rows;
+    LaneState<D, MP> st;
+#pragma unroll
+    for (int k = 0; k < D; k++) st.y[k] = a.x0_dev ? a.x0_dev[k * a.ldx0 + p] : a.x0[k];
+    st.ll = 0.0; st.zc = 0.0;
+#pragma unroll
+    for (int k = 0; k < MP; k++) { st.wprev[k] = 0.0; st.w2prev[k] = 0.0; }
+    double *xout = nullptr;
+    long ldx = 0;
+    if constexpr ((FL & 1) != 0) {
+        if constexpr (PCN) { xout = a.Xo + p; ldx = a.ldC; }
+        else { xout = a.X + p; ldx = a.ldX; }
+    }
+    constexpr int CFL = FL & ~2;   // the W store belongs to the producer
+    for (int k = 0; k <= nch; k++) {
+        if (k > 0) {
+            const int kc = k - 1;
+            const double *mine = pc_lds + (kc & 1) * PC_TILE + row * LINE_ROW;
+            const ldsrow_t lrows = (ldsrow_t)(__attribute__((address_space(3))) double *)(crow + (kc & 1) * CROW);   // row of step j0 + s - 1 at s*RS
+            const int j0 = kc * SPC;
+            if (kc > 0 && j0 + SPC <= N) {
+                // interior chunk: SPC steps  i = j - 1
+#pragma unroll 2
+                for (int s = 0; s < SPC; s++) {
+                    double wn[MP];
+#pragma unroll
+                    for (int c = 0; c < MP; c++) wn[c] = mine[s * MP + c];
+                    const int i = j0 + s - 1;
+#ifdef PC_KNOCKOUT_STEP   /* measurement only: what the producer alone costs */
+                    st.ll += wn[0];
+#else
+                    if constexpr (RLDS) path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, lrows + s * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st);
+                    else path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st);
+#endif
+                }
+            } else {
+                // first chunk (grid point 0 has no step) and the ragged last chunk
+#pragma unroll 1
+                for (int s = 0; s < SPC; s++) {
+                    const int i = j0 + s - 1;
+                    if (i < 0 || i >= nsteps) continue;
+                    double wn[MP];
+#pragma unroll
+                    for (int c = 0; c < MP; c++) wn[c] = mine[s * MP + c];
+                    if constexpr (RLDS) path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, lrows + s * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st);
+                    else path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (a.use_vend) {   // endpoint(y, P::GuidedBridge) src/euler.jl:241-242
+#pragma unroll
+        for (int k = 0; k < D; k++) st.y[k] = a.vend[k];
+    }
+    if constexpr ((FL & 1) != 0) {
+#pragma unroll
+        for (int k = 0; k < D; k++) st_stream(&xout[((size_t)(N - 1) * D + k) * ldx], st.y[k]);
+    }
+    if constexpr (PCN) {
+        // if log(rand()) <= llo - ll: W <- Wo (parity flip), ll <- llo, acc += 1      partialbridge_fitzhugh.jl:160-167
+        if (live) {
+            const double u = accept_uniform(a.k0, a.k1, path, a.iter);
+            if (det_log(u, TabLDS(tab)) <= st.ll - a.llcur[p]) {
+                a.cur[p] = (unsigned char)(a.cur[p] ^ 1);
+                a.llcur[p] = st.ll;
+                a.acc[p] += 1u;
+            }
+            if (a.ll) a.ll[p] = st.ll;
+        }
+    } else {
+        if (live && a.ll) a.ll[p] = st.ll;
+    }
+}
+
+// ---- BHIP_RTC_END  (above: device code, also embedded for hipRTC user models; below: host launch)
+
+// Small ensembles: up to 512 groups of 64 chains (32 768 chains) as 2-pair workgroups -- one wave per SIMD on up to 256
+// CUs --, up to 1024 groups (65 536) as 4-pair workgroups -- one producer and one consumer per SIMD; both RLDS (LDS and
+// 256 registers per lane are free at two waves per SIMD).  Larger ensembles: one pair per 128-thread workgroup, 8 per CU.
+#ifndef PC_MAX_GROUPS_2PAIR
+#define PC_MAX_GROUPS_2PAIR 512
+#endif
+#ifndef PC_MAX_GROUPS_4PAIR
+#define PC_MAX_GROUPS_4PAIR 1024
+#endif
+template <class M, int GK, int MO, int MODE, int FL, int NPAIR>
+void launch_pc_n(const KArgs &a, hipStream_t st, long groups)
+{
+    using RL = RowLayout<GK, M::D, MO, is_constdiff<M>::value>;
+    const size_t lds = NPAIR == 1 ? PC_LDS : sizeof(double) * (RNG_TAB_DOUBLES + NPAIR * (2 * PC_TILE + 2 * (LINE_DOUBLES / M::MP) * RL::RS));
+    if (lds > 65536) {   // more than the default 64 KB of dynamic LDS: opt in (once per instantiation)
+        static bool raised = false;
+        if (!raised) { (void)hipFuncSetAttribute((const void *)k_pc<M, GK, MO, MODE, FL, NPAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
+    }
+    hipLaunchKernelGGL((k_pc<M, GK, MO, MODE, FL, NPAIR>), dim3((unsigned)((groups + NPAIR - 1) / NPAIR)), dim3(128 * NPAIR), lds, st, a);
+}
+template <class M, int GK, int MO, int MODE, int FL>
+hipError_t launch_pc(const KArgs &a, hipStream_t st)
+{
+    const long groups = (a.P + 63) / 64;
+    if (groups <= PC_MAX_GROUPS_2PAIR) launch_pc_n<M, GK, MO, MODE, FL, 2>(a, st, groups);
+    else if (groups <= PC_MAX_GROUPS_4PAIR) launch_pc_n<M, GK, MO, MODE, FL, 4>(a, st, groups);
+    else launch_pc_n<M, GK, MO, MODE, FL, 1>(a, st, groups);
+    return hipGetLastError();
+}
+
+}  // namespace bhip

@@ -1,4 +1,4 @@
-// bhip_rng.h -- RNG specification "bhip-philox-v1" (host + device).
+// bhip_rng.h -- RNG specification "bhip-philox-v2" (host + device).
 //
 // Replaces the reference's global randn() (src/wiener.jl:31,44,55), which is not reproducible
 // outside Julia, with a counter-based generator whose output depends only on
@@ -11,10 +11,18 @@
 //             u1 = (bits53(r0,r1)+1)*2^-53 in (0,1],  u2 = bits53(r2,r3)*2^-53 in [0,1)
 //   stream 1: block 0 -> the Metropolis-Hastings uniform U = (bits53(r0,r1)+1)*2^-53
 //
-// log and sin/cos(2*pi*u) are built from +,-,*,/ and fma only, so that every host and device
-// evaluates bit-identical normals (no libm / ocml dependence).
+// -2*log(u1) and sin/cos(2*pi*u2) are built from integer operations, +, -, *, fma and two small constant
+// tables (bhip_rng_tables.h, generated correctly rounded by scripts/gen_rng_tables.py), so that every host and
+// device evaluates bit-identical normals (no libm / ocml dependence).
+//
+// v1 -> v2 (round 2): v1 evaluated log as 2*atanh((m-1)/(m+1)) (a division and an 11-term series) and sin/cos
+// by quadrant reduction and 7 + 8 Taylor terms: ~147 VALU instructions per Philox block, the largest single
+// share of every path kernel.  v2 reduces the arguments by table lookup (129 x 16 B for the log, 32 x 16 B
+// for the rotation) so that 6 + 4 + 5 polynomial terms suffice: ~119 per block.  Same Philox counters, same
+// uniforms; the normals differ from v1 in the last bits only (both are accurate to ~1 ulp).
 #pragma once
 #include <stdint.h>
+#include "bhip_rng_tables.h"
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define BHIP_HD __host__ __device__ __forceinline__
@@ -45,7 +53,7 @@ BHIP_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, 
 BHIP_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// Device forms of the three fixed-range operations below.  They produce the SAME bits as the portable
+// Device forms of the fixed-range operations below.  They produce the SAME bits as the portable
 // expressions (checked exhaustively-at-random on the GPU by tests/rng_device_forms.hip) with fewer VALU
 // instructions: the noise is the largest share of the proposal kernels' issue slots.
 //   (a >> 11) * 2^-53 : k = a >> 11 = kh*2^32 + kl; a double whose mantissa field holds kl (kh) under a fixed
@@ -61,20 +69,9 @@ BHIP_HD double u53_bits(uint32_t lo, uint32_t hi, double lo_magic)
 }
 BHIP_HD double u53_open0(uint32_t lo, uint32_t hi) { return u53_bits(lo, hi, 0.5 - 0x1.0p-53); }   // (k+1)*2^-53 in (0,1]
 BHIP_HD double u53_open1(uint32_t lo, uint32_t hi) { return u53_bits(lo, hi, 0.5); }               // k*2^-53 in [0,1)
-// a / b and sqrt(x) as the compiler expands them (reciprocal / reciprocal-square-root seed, Newton steps on
-// fma, final residual correction = correctly rounded), WITHOUT the exponent pre-scaling and special-value
-// fix-ups that only matter outside the ranges used here: b in [1.7, 2.5], |a| < 1;  x in [0, 1500].
-BHIP_HD double div_fixed_range(double a, double b)
-{
-    const double y0 = __builtin_amdgcn_rcp(b);
-    const double e0 = __builtin_fma(-b, y0, 1.0);
-    const double y1 = __builtin_fma(y0, e0, y0);
-    const double e1 = __builtin_fma(-b, y1, 1.0);
-    const double y2 = __builtin_fma(y1, e1, y1);
-    const double q0 = a * y2;
-    const double r = __builtin_fma(-b, q0, a);
-    return __builtin_fma(r, y2, q0);
-}
+// sqrt(x) as the compiler expands it (reciprocal-square-root seed, Newton steps on fma, final residual
+// correction = correctly rounded), WITHOUT the exponent pre-scaling and special-value fix-ups that only matter
+// outside the range used here: x in [0, 1500].
 BHIP_HD double sqrt_fixed_range(double x)
 {
     const double y = __builtin_amdgcn_rsq(x);
@@ -98,84 +95,132 @@ BHIP_HD double u53_open1(uint32_t lo, uint32_t hi)   // [0,1)
     const uint64_t a = ((uint64_t)hi << 32) | lo;
     return (double)(a >> 11) * 0x1.0p-53;
 }
-BHIP_HD double div_fixed_range(double a, double b) { return a / b; }
 BHIP_HD double sqrt_fixed_range(double x) { return __builtin_sqrt(x); }
 #endif
 
-// natural log for x in (0,1], normal doubles:  x = 2^e m, m in [sqrt(1/2), sqrt(2));
-// log m = 2 atanh(s), s = (m-1)/(m+1), odd Taylor series in s up to s^23 (|s| <= 0.1716).
-BHIP_HD double det_log(double x)
+// Where the two constant tables are read from.  TabConst: constant memory on the device (per-lane loads, served by
+// the vector L1 / L2 -- used by the kernels that draw few normals), plain arrays on the host.  TabLDS: a copy in
+// LDS (the producer waves of bhip_pc_kernel.h and the d = 16/32 tile kernel, which draw normals at full rate).
+alignas(16) static const double logtab_host[2 * BHIP_LOGTAB_N] = BHIP_LOGTAB_INIT;
+alignas(16) static const double sctab_host[2 * BHIP_SCTAB_N] = BHIP_SCTAB_INIT;
+#if defined(__HIPCC__)
+alignas(16) static __device__ const double logtab_dev[2 * BHIP_LOGTAB_N] = BHIP_LOGTAB_INIT;
+alignas(16) static __device__ const double sctab_dev[2 * BHIP_SCTAB_N] = BHIP_SCTAB_INIT;
+typedef double rng_d2v __attribute__((ext_vector_type(2)));
+#endif
+struct TabConst {
+    BHIP_HD void lg(uint32_t k, double &A, double &B) const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const rng_d2v v = *reinterpret_cast<const rng_d2v *>(logtab_dev + 2 * k);
+        A = v.x; B = v.y;
+#else
+        A = logtab_host[2 * k]; B = logtab_host[2 * k + 1];
+#endif
+    }
+    BHIP_HD void sc(uint32_t j, double &c, double &s) const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const rng_d2v v = *reinterpret_cast<const rng_d2v *>(sctab_dev + 2 * j);
+        c = v.x; s = v.y;
+#else
+        c = sctab_host[2 * j]; s = sctab_host[2 * j + 1];
+#endif
+    }
+};
+#if defined(__HIPCC__)
+constexpr int RNG_TAB_DOUBLES = 2 * (BHIP_LOGTAB_N + BHIP_SCTAB_N);   // 322 doubles = 2576 bytes of LDS
+struct TabLDS {
+    typedef const __attribute__((address_space(3))) rng_d2v *lds_t;
+    lds_t lgp, scp;
+    // `base` points to RNG_TAB_DOUBLES doubles of LDS (16-byte aligned), filled by load() + a barrier
+    __device__ __forceinline__ explicit TabLDS(double *base)
+        : lgp((lds_t)(__attribute__((address_space(3))) double *)base),
+          scp((lds_t)(__attribute__((address_space(3))) double *)(base + 2 * BHIP_LOGTAB_N)) {}
+    // cooperative fill by `nthreads` threads (thread index tid); the caller synchronises afterwards
+    static __device__ __forceinline__ void load(double *base, int tid, int nthreads)
+    {
+        for (int q = tid; q < 2 * BHIP_LOGTAB_N; q += nthreads) base[q] = logtab_dev[q];
+        for (int q = tid; q < 2 * BHIP_SCTAB_N; q += nthreads) base[2 * BHIP_LOGTAB_N + q] = sctab_dev[q];
+    }
+    __device__ __forceinline__ void lg(uint32_t k, double &A, double &B) const { const rng_d2v v = lgp[k]; A = v.x; B = v.y; }
+    __device__ __forceinline__ void sc(uint32_t j, double &c, double &s) const { const rng_d2v v = scp[j]; c = v.x; s = v.y; }
+};
+#endif
+
+// L = -2*ln(x) for x in (0,1], normal doubles.  x = 2^e * m0, m0 in [1,2);  k = round(128*m0) - 128 selects the
+// table row {A, B}: s = fma(m0, A, 2) = -2*(m/c - 1) with |s| <= 2^-7, and
+//     L = e'*(-2 ln2) + B + (s + s^2/4 + s^3/12 + s^4/32 + s^5/80 + s^6/192 + s^7/448)      (= -2*log1p(-s/2))
+// The rows k = 0 and k = 128 have c = 1, B = 0: L(1) = 0 exactly and x -> 1 suffers no cancellation (L >= 0 always,
+// so the square root below never sees a negative argument).
+template <class Tab>
+BHIP_HD double det_m2log(double x, const Tab &tab)
 {
     union { double d; uint64_t u; } v;
     v.d = x;
-    int e = (int)((v.u >> 52) & 0x7ff) - 1023;
+    const uint32_t hi = (uint32_t)(v.u >> 32);
+    const uint32_t k = (((hi >> 12) & 0xffu) + 1u) >> 1;
+    const int e = (int)(hi >> 20) - 1023 + (k > 53u ? 1 : 0);   // rows k > 53 work on m = m0/2
     v.u = (v.u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
-    double m = v.d;
-    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
-    const double s = div_fixed_range(m - 1.0, m + 1.0);
-    const double z = s * s;
-    double p = 1.0 / 23.0;
-    p = fma_(p, z, 1.0 / 21.0);
-    p = fma_(p, z, 1.0 / 19.0);
-    p = fma_(p, z, 1.0 / 17.0);
-    p = fma_(p, z, 1.0 / 15.0);
-    p = fma_(p, z, 1.0 / 13.0);
-    p = fma_(p, z, 1.0 / 11.0);
-    p = fma_(p, z, 1.0 / 9.0);
-    p = fma_(p, z, 1.0 / 7.0);
-    p = fma_(p, z, 1.0 / 5.0);
-    p = fma_(p, z, 1.0 / 3.0);
-    const double t = s * z;
-    double lm = fma_(t, p, s);
-    lm = lm + lm;
+    double A, B;
+    tab.lg(k, A, B);
+    const double s = fma_(v.d, A, 2.0);
+    double q = 1.0 / 448.0;
+    q = fma_(q, s, 1.0 / 192.0);
+    q = fma_(q, s, 1.0 / 80.0);
+    q = fma_(q, s, 1.0 / 32.0);
+    q = fma_(q, s, 1.0 / 12.0);
+    q = fma_(q, s, 0.25);
+    const double l1 = fma_(s * s, q, s);
     const double de = (double)e;
-    return fma_(de, 6.93147180369123816490e-01, fma_(de, 1.90821492927058770002e-10, lm));
+    // -2*ln2 split: the high part has 32 significant bits so de*hi is exact
+    return fma_(de, -2.0 * 6.93147180369123816490e-01, fma_(de, -2.0 * 1.90821492927058770002e-10, B + l1));
 }
+template <class Tab> BHIP_HD double det_log(double x, const Tab &tab) { return -0.5 * det_m2log(x, tab); }
+BHIP_HD double det_log(double x) { return det_log(x, TabConst()); }
 
-// sin/cos(2*pi*u), u in [0,1): q = round(4u), f = u - q/4 (exact), theta = 2*pi*f, Taylor to
-// theta^15 / theta^16, quadrant rotation.
-BHIP_HD void det_sincos2pi(double u, double &sn, double &cs)
+// sin/cos(2*pi*u), u = K*2^-53 in [0,1) whose top 32 source bits are `w`: jr = round(32u) (from the top 6 bits),
+// f = u - jr/32 (exact), x = 2*pi*f with |x| <= pi/32; Taylor sin/cos of x, rotated by the table row jr mod 32.
+template <class Tab>
+BHIP_HD void det_sincos2pi(double u, uint32_t w, const Tab &tab, double &sn, double &cs)
 {
-    const double q = __builtin_floor(fma_(u, 4.0, 0.5));
-    const double f = fma_(q, -0.25, u);
-    const double th = f * 6.283185307179586;
-    const double z = th * th;
-    double ps = -1.0 / 1307674368000.0;
-    ps = fma_(ps, z, 1.0 / 6227020800.0);
-    ps = fma_(ps, z, -1.0 / 39916800.0);
-    ps = fma_(ps, z, 1.0 / 362880.0);
+    const uint32_t jr = ((w >> 26) + 1u) >> 1;
+    const double f = fma_((double)jr, -0.03125, u);
+    double ck, sk;
+    tab.sc(jr & 31u, ck, sk);
+    const double x = f * 6.283185307179586;
+    const double z = x * x;
+    double ps = 1.0 / 362880.0;
     ps = fma_(ps, z, -1.0 / 5040.0);
     ps = fma_(ps, z, 1.0 / 120.0);
     ps = fma_(ps, z, -1.0 / 6.0);
-    const double s0 = fma_(th * z, ps, th);
-    double pc = 1.0 / 20922789888000.0;
-    pc = fma_(pc, z, -1.0 / 87178291200.0);
-    pc = fma_(pc, z, 1.0 / 479001600.0);
-    pc = fma_(pc, z, -1.0 / 3628800.0);
+    const double sf = fma_(x * z, ps, x);
+    double pc = -1.0 / 3628800.0;
     pc = fma_(pc, z, 1.0 / 40320.0);
     pc = fma_(pc, z, -1.0 / 720.0);
     pc = fma_(pc, z, 1.0 / 24.0);
     pc = fma_(pc, z, -0.5);
-    const double c0 = fma_(z, pc, 1.0);
-    // quadrant rotation without branches: q odd swaps sin/cos; sin is negated for q in {2,3}, cos for q in {1,2}
-    const int qi = (int)q & 3;
-    const bool swp = (qi & 1) != 0;
-    const double sb = swp ? c0 : s0, cb = swp ? s0 : c0;
-    sn = (qi & 2) ? -sb : sb;
-    cs = ((qi + 1) & 2) ? -cb : cb;
+    const double cf = fma_(z, pc, 1.0);
+    cs = fma_(-sk, sf, ck * cf);
+    sn = fma_(ck, sf, sk * cf);
 }
 
 // block `blk` of stream 0 -> normals 2*blk (z0) and 2*blk+1 (z1)
-BHIP_HD void normal_pair(uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t blk, double &z0, double &z1)
+template <class Tab>
+BHIP_HD void normal_pair(const Tab &tab, uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t blk, double &z0, double &z1)
 {
     const u32x4 r = philox4x32_10(path, 0u, iter, blk, k0, k1);
     const double u1 = u53_open0(r.x, r.y);
     const double u2 = u53_open1(r.z, r.w);
-    const double rad = sqrt_fixed_range(-2.0 * det_log(u1));
+    const double rad = sqrt_fixed_range(det_m2log(u1, tab));
     double s, c;
-    det_sincos2pi(u2, s, c);
+    det_sincos2pi(u2, r.w, tab, s, c);
     z0 = rad * c;
     z1 = rad * s;
+}
+BHIP_HD void normal_pair(uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t blk, double &z0, double &z1)
+{
+    normal_pair(TabConst(), k0, k1, path, iter, blk, z0, z1);
 }
 
 BHIP_HD double accept_uniform(uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter)

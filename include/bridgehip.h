@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BHIP_VERSION 100
+#define BHIP_VERSION 200
 
 /* error codes */
 #define BHIP_OK 0
@@ -88,6 +88,12 @@ int bhip_device_count(void);
 int bhip_ctx_create(int device, void *stream, bhip_ctx **out);
 void bhip_ctx_destroy(bhip_ctx *ctx);
 int bhip_ctx_sync(bhip_ctx *ctx);
+/* Options.  BHIP_OPT_WAVE_SPECIALISED (default 1): run fresh proposals and pCN iterations (noise dimension 1 or 2) on
+ * the producer/consumer kernels -- one wave draws the Wiener noise and moves the chain state, its partner wave runs the
+ * Euler recurrence and the log-likelihood; 0 selects the one-lane-does-everything kernels.  Results are bit-identical;
+ * the switch exists for A/B measurements and for the test that proves the identity. */
+#define BHIP_OPT_WAVE_SPECIALISED 1
+int bhip_ctx_set_option(bhip_ctx *ctx, int option, int value);
 const char *bhip_last_error(const bhip_ctx *ctx);
 /* device memory helpers for callers without their own allocator */
 int bhip_malloc(bhip_ctx *ctx, size_t bytes, void **dev);
@@ -246,8 +252,8 @@ int bhip_welford_merge(long entries, int d, double *na, double *mean_a, double *
                        const double *mean_b, const double *m2_b);
 
 /* ------------------------------------------------------------------ RNG specification helpers (host)
- * bhip-philox-v1: Philox4x32-10, key=(seed lo,hi), counter=(path, stream, iter, block); block j of
- * stream 0 yields the normals 2j, 2j+1 (Box-Muller with the library's deterministic log/sincos). */
+ * bhip-philox-v2: Philox4x32-10, key=(seed lo,hi), counter=(path, stream, iter, block); block j of
+ * stream 0 yields the normals 2j, 2j+1 (Box-Muller with the library's deterministic, table-driven log/sincos). */
 void bhip_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void bhip_normals_host(uint64_t seed, uint32_t path, uint32_t iter, int n0, int n, double *z);
 

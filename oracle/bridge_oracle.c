@@ -223,7 +223,7 @@ double bo_logpdfnormal(int d, const double *x, const double *Sigma)
 }
 
 /* ------------------------------------------------------------------------------------------
- * RNG, specification "bhip-philox-v1" (DESIGN.md).  The reference draws from Julia's global
+ * RNG, specification "bhip-philox-v2" (DESIGN.md).  The reference draws from Julia's global
  * randn (src/wiener.jl:31,44,55) which cannot be reproduced outside Julia; this is
  * the counter-based replacement shared, by specification, with the HIP kernels.
  * ------------------------------------------------------------------------------------------ */
@@ -243,68 +243,61 @@ void bo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* deterministic natural log for x in (0,1] built from +,-,*,/,fma only (bit-identical on CPU and
- * GPU): x = 2^e * m, m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(s), s = (m-1)/(m+1). */
-BO_CLONES double bo_log(double x)
+/* Constant tables of the specification (data; generated by scripts/gen_rng_tables.py, every entry correctly rounded):
+ *   BO_LOGTAB[k] = {A_k, B_k}, k = 0..128;  BO_SCTAB[j] = {cos(2 pi j/32), sin(2 pi j/32)}, j = 0..31 */
+#include "bo_rng_tables.h"
+static const double BO_LOGTAB[2 * BO_LOGTAB_N] = BO_LOGTAB_INIT;
+static const double BO_SCTAB[2 * BO_SCTAB_N] = BO_SCTAB_INIT;
+
+/* L(x) = -2 ln x for x in (0,1], from integer operations, +, *, fma and the table only (bit-identical on CPU and
+ * GPU).  x = 2^e m0 with m0 in [1,2); row k = round(128 m0) - 128; rows k > 53 treat m0/2 (exponent e + 1).
+ * s = m0 A_k + 2 (one fma) is -2 (m/c_k - 1), and -2 ln(1 - s/2) = s + s^2/4 + s^3/12 + ... + s^7/448. */
+BO_CLONES double bo_m2log(double x)
 {
     union { double d; uint64_t u; } v; v.d = x;
-    int e = (int)((v.u >> 52) & 0x7ff) - 1023;
+    uint32_t top = (uint32_t)(v.u >> 32);
+    uint32_t k = (((top >> 12) & 255u) + 1u) / 2u;
+    int e = (int)(top >> 20) - 1023;
+    if (k > 53u) e += 1;
     v.u = (v.u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
-    double m = v.d;
-    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
-    double s = (m - 1.0) / (m + 1.0);
-    double z = s * s;
-    double p = 1.0 / 23.0;
-    p = fma(p, z, 1.0 / 21.0);
-    p = fma(p, z, 1.0 / 19.0);
-    p = fma(p, z, 1.0 / 17.0);
-    p = fma(p, z, 1.0 / 15.0);
-    p = fma(p, z, 1.0 / 13.0);
-    p = fma(p, z, 1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0);
-    p = fma(p, z, 1.0 / 7.0);
-    p = fma(p, z, 1.0 / 5.0);
-    p = fma(p, z, 1.0 / 3.0);
-    double t = s * z;                 /* s^3 */
-    double lm = fma(t, p, s);         /* atanh(s) */
-    lm = lm + lm;
+    double s = fma(v.d, BO_LOGTAB[2 * k], 2.0);
+    double q = 1.0 / 448.0;
+    q = fma(q, s, 1.0 / 192.0);
+    q = fma(q, s, 1.0 / 80.0);
+    q = fma(q, s, 1.0 / 32.0);
+    q = fma(q, s, 1.0 / 12.0);
+    q = fma(q, s, 1.0 / 4.0);
+    double series = fma(s * s, q, s);
     double de = (double)e;
-    /* ln2 split: hi has 32 significant bits so de*hi is exact */
-    return fma(de, 6.93147180369123816490e-01, fma(de, 1.90821492927058770002e-10, lm));
+    /* -2 ln2 = hi + lo, hi with 32 significant bits so that de*hi is exact */
+    double hi = -2.0 * 6.93147180369123816490e-01, lo = -2.0 * 1.90821492927058770002e-10;
+    return fma(de, hi, fma(de, lo, BO_LOGTAB[2 * k + 1] + series));
 }
+BO_CLONES double bo_log(double x) { return -0.5 * bo_m2log(x); }
 
-/* deterministic sin/cos(2*pi*u), u in [0,1): quadrant q = round(4u), f = u - q/4 exact,
- * theta = 2pi*f in [-pi/4, pi/4], Taylor polynomials evaluated with fma. */
-BO_CLONES void bo_sincos2pi(double u, double *sn, double *cs)
+/* sin/cos(2 pi u) for u = K 2^-53 in [0,1), `w` = the upper 32 of the 64 source bits: jr = round(32 u) from the
+ * top six bits, f = u - jr/32 exactly, x = 2 pi f, Taylor sine / cosine of x (to x^9 / x^10), then the rotation by
+ * row jr mod 32 of the table. */
+BO_CLONES void bo_sincos2pi(double u, uint32_t w, double *sn, double *cs)
 {
-    double q = floor(fma(u, 4.0, 0.5));
-    double f = fma(q, -0.25, u);
-    double th = f * 6.283185307179586;
-    double z = th * th;
-    double ps = -1.0 / 1307674368000.0;          /* -1/15! */
-    ps = fma(ps, z, 1.0 / 6227020800.0);         /*  1/13! */
-    ps = fma(ps, z, -1.0 / 39916800.0);          /* -1/11! */
-    ps = fma(ps, z, 1.0 / 362880.0);             /*  1/9!  */
+    uint32_t jr = ((w >> 26) + 1u) / 2u;
+    double f = fma((double)jr, -1.0 / 32.0, u);
+    double ck = BO_SCTAB[2 * (jr % 32u)], sk = BO_SCTAB[2 * (jr % 32u) + 1];
+    double x = f * 6.283185307179586;
+    double z = x * x;
+    double ps = 1.0 / 362880.0;                  /*  1/9!  */
     ps = fma(ps, z, -1.0 / 5040.0);              /* -1/7!  */
     ps = fma(ps, z, 1.0 / 120.0);                /*  1/5!  */
     ps = fma(ps, z, -1.0 / 6.0);                 /* -1/3!  */
-    double s0 = fma(th * z, ps, th);
-    double pc = 1.0 / 20922789888000.0;          /*  1/16! */
-    pc = fma(pc, z, -1.0 / 87178291200.0);       /* -1/14! */
-    pc = fma(pc, z, 1.0 / 479001600.0);          /*  1/12! */
-    pc = fma(pc, z, -1.0 / 3628800.0);           /* -1/10! */
+    double sf = fma(x * z, ps, x);
+    double pc = -1.0 / 3628800.0;                /* -1/10! */
     pc = fma(pc, z, 1.0 / 40320.0);              /*  1/8!  */
     pc = fma(pc, z, -1.0 / 720.0);               /* -1/6!  */
     pc = fma(pc, z, 1.0 / 24.0);                 /*  1/4!  */
     pc = fma(pc, z, -0.5);                       /* -1/2!  */
-    double c0 = fma(z, pc, 1.0);
-    int qi = (int)q & 3;
-    double s, c;
-    if (qi == 0) { s = s0; c = c0; }
-    else if (qi == 1) { s = c0; c = -s0; }
-    else if (qi == 2) { s = -s0; c = -c0; }
-    else { s = -c0; c = s0; }
-    *sn = s; *cs = c;
+    double cf = fma(z, pc, 1.0);
+    *cs = fma(-sk, sf, ck * cf);
+    *sn = fma(ck, sf, sk * cf);
 }
 
 /* one Philox block -> two standard normals (Box-Muller).  counter = (path, stream, iter, block),
@@ -316,9 +309,9 @@ BO_CLONES void bo_normal_pair(uint64_t seed, uint32_t path, uint32_t iter, uint3
     uint64_t a = ((uint64_t)r[1] << 32) | r[0], b = ((uint64_t)r[3] << 32) | r[2];
     double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;   /* (0,1] */
     double u2 = (double)(b >> 11) * 0x1.0p-53;         /* [0,1) */
-    double rad = sqrt(-2.0 * bo_log(u1));
+    double rad = sqrt(bo_m2log(u1));
     double s, c;
-    bo_sincos2pi(u2, &s, &c);
+    bo_sincos2pi(u2, r[3], &s, &c);
     z[0] = rad * c;
     z[1] = rad * s;
 }

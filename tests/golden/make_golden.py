@@ -1,10 +1,16 @@
 #!/usr/bin/env python
-"""Writes tests/golden/guided_paths_v1.npz: for every problem of tests/problems.py (N = 101) the Wiener paths of
-the noise specification bhip-philox-v1, the guided paths, the log-likelihoods and a short pCN chain, as computed by
+"""Writes tests/golden/guided_paths_v2.npz: for every problem of tests/problems.py (N = 101) the Wiener paths of
+the noise specification bhip-philox-v2, the guided paths, the log-likelihoods and a short pCN chain, as computed by
 the CPU oracle (oracle/bridge_oracle.c) AFTER it passed its pins (tests/test_oracle.py, K1..K14).
 
+guided_paths_v1.npz (round 1, noise specification v1) stays committed: its Wiener paths are no longer what the
+generator draws, but the guided paths and log-likelihoods GIVEN those stored Wiener paths do not involve the
+generator, and both the oracle and the kernels must still reproduce them bit for bit (the tests do that), so the
+frozen round-1 arithmetic keeps guarding the solver across the change of the noise specification.  This script
+refuses to write v2 unless that holds.
+
 The reference (Julia) stores no guided paths or llikelihood values and cannot run here, so these
-vectors do not come from Bridge.jl: they freeze the oracle + noise specification of round 1, so that a later
+vectors do not come from Bridge.jl: they freeze the oracle + noise specification, so that a later
 change to BOTH the oracle and the kernels cannot drift unnoticed.  Regenerate only with a new version suffix.
 
     python tests/golden/make_golden.py
@@ -40,8 +46,26 @@ def build():
     return out
 
 
+def check_v1_given_W():
+    """the noise-independent part of the round-1 file: X and ll from ITS stored W"""
+    g = np.load(os.path.join(HERE, "guided_paths_v1.npz"))
+    n, npaths = int(g["meta"][0]), int(g["meta"][1])
+    for c in problems.cases(n) + problems.forward_cases(n):
+        W = g[c.name + "/W"]
+        tol = 0.0 if c.exact else 1e-12
+        if c.kind == o.GUIDE_NONE:
+            X = np.stack([o.solve_em(c.model, c.d, c.mp, c.par, c.tt, c.x0, W[p]) for p in range(npaths)])
+        else:
+            ref = c.oracle_proposal()
+            X = np.stack([o.solve_guided(ref, c.x0, W[p]) for p in range(npaths)])
+            ll = np.array([o.llikelihood(ref, X[p]) for p in range(npaths)])
+            assert np.abs(ll - g[c.name + "/ll"]).max() <= tol * (1 + np.abs(ll).max()), c.name
+        assert np.abs(X - g[c.name + "/X"]).max() <= tol * (1 + np.abs(X).max()), c.name
+
+
 if __name__ == "__main__":
+    check_v1_given_W()
     data = build()
-    fn = os.path.join(HERE, "guided_paths_v1.npz")
+    fn = os.path.join(HERE, "guided_paths_v2.npz")
     np.savez_compressed(fn, **data)
     print(fn, os.path.getsize(fn), "bytes,", len(data), "arrays")

@@ -96,7 +96,9 @@ def bo_log(x):
 
 def sincos2pi(u):
     s, c = C.c_double(), C.c_double()
-    lib().bo_sincos2pi(C.c_double(u), C.byref(s), C.byref(c))
+    K = int(u * 2.0 ** 53)          # u = K*2^-53; the generator hands over the top 32 of its 64 source bits (K >> 21)
+    assert K * 2.0 ** -53 == u
+    lib().bo_sincos2pi(C.c_double(u), C.c_uint32(K >> 21), C.byref(s), C.byref(c))
     return s.value, c.value
 
 

@@ -285,9 +285,9 @@ def test_inline_philox_equals_rocrand_device_generator(tmp_path):
 
 
 def test_device_forms_of_the_generator_are_bit_identical(tmp_path):
-    """bhip_rng.h evaluates the uniforms, the division inside det_log and the square root of Box-Muller with
-    shorter device sequences; tests/rng_device_forms.hip compares them with the portable expressions
-    (integer->double conversion, IEEE division, IEEE sqrt) on 2^32 inputs from the ranges used"""
+    """bhip_rng.h evaluates the uniforms and the square root of Box-Muller with shorter device sequences;
+    tests/rng_device_forms.hip compares them with the portable expressions (integer->double conversion, IEEE sqrt)
+    on 2^32 inputs from the ranges used, and the LDS copy of the tables with the constant-memory one"""
     import os
     import shutil
     import subprocess
@@ -304,10 +304,10 @@ def test_device_forms_of_the_generator_are_bit_identical(tmp_path):
 
 @pytest.mark.parametrize("case", problems.cases(101) + problems.forward_cases(101), ids=lambda c: c.name)
 def test_committed_golden_vectors_on_device(ctx, case):
-    """the frozen round-1 vectors (tests/golden/guided_paths_v1.npz) through the C ABI: in-kernel noise, guided
+    """the frozen vectors (tests/golden/guided_paths_v2.npz) through the C ABI: in-kernel noise, guided
     solve, fused log-likelihood and a pCN chain reproduce them without the oracle being involved"""
     import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "guided_paths_v1.npz"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "guided_paths_v2.npz"))
     N, npaths, seed, iters = (int(v) for v in g["meta"])
     rho = float(g["rho"])
     Po = case.bh_proposal(bh, ctx)
@@ -323,6 +323,24 @@ def test_committed_golden_vectors_on_device(ctx, case):
         Xc, Wc = ch.paths(1, 1)
         assert np.array_equal(Wc[0], g[case.name + "/chain_W"]) and np.array_equal(Xc[0], g[case.name + "/chain_X"])
         assert ch.ll()[1] == g[case.name + "/chain_ll_acc"][0] and ch.acc()[1] == g[case.name + "/chain_ll_acc"][1]
+
+
+@pytest.mark.parametrize("case", problems.cases(101) + problems.forward_cases(101), ids=lambda c: c.name)
+def test_round1_golden_paths_given_their_wiener_paths_on_device(ctx, case):
+    """guided_paths_v1.npz (noise specification v1): the guided paths and log-likelihoods GIVEN its stored Wiener paths
+    do not involve the generator; the external-W solve must still reproduce them (frozen round-1 arithmetic)"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "guided_paths_v1.npz"))
+    Po = case.bh_proposal(bh, ctx)
+    W = bh.EnsemblePath.from_paths(case.tt, g[case.name + "/W"], ctx)
+    if case.kind == o.GUIDE_NONE:
+        X = bh.solve(bh.EulerMaruyama(), case.x0, W, Po)
+        check_paths(case, X.paths(), g[case.name + "/X"])
+        return
+    ll = ctx.empty(W.npaths)
+    X = bh.solve(bh.Euler(), case.x0, W, Po, ll=ll)
+    check_paths(case, X.paths(), g[case.name + "/X"])
+    check_ll(case, ll.cpu().numpy(), g[case.name + "/ll"])
 
 
 def test_batched_chain_steps_equal_single_steps(ctx):

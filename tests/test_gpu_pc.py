@@ -1,0 +1,121 @@
+"""GPU tests of the wave-specialised (producer/consumer) kernels, bridge.jl_amd/csrc/bhip_pc_kernel.h.
+
+The producer wave draws the Wiener noise / does the pCN mix and the chain-state traffic, the consumer wave runs the
+Euler recurrence + log-likelihood of src/euler.jl:247-268, src/partialbridge.jl:67-77.  They must give, bit for bit,
+what the one-lane-does-everything kernels give (which the parity tests compare with the oracle): same Wiener paths,
+paths, log-likelihoods, accept decisions -- for every test problem with noise dimension 1 or 2, ragged ensemble sizes
+(tails of the 64-path workgroup), grids that are not multiples of the 16-value chunk, with and without the stores.
+The default context runs the wave-specialised kernels, so the oracle parity tests of test_gpu_parity.py already go
+through them; here both variants are run side by side through the C ABI option BHIP_OPT_WAVE_SPECIALISED.
+"""
+import numpy as np
+import pytest
+import torch
+
+import bridgehip as bh
+import oracle as o
+import problems
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return bh.default_context(0)
+
+
+def both(ctx, fn):
+    out = []
+    for v in (1, 0):
+        ctx.set_option(bh.OPT_WAVE_SPECIALISED, v)
+        try:
+            out.append(fn())
+        finally:
+            ctx.set_option(bh.OPT_WAVE_SPECIALISED, 1)
+    return out
+
+
+CASES = [c for c in problems.cases(143) + problems.forward_cases(143) if c.mp in (1, 2)]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
+@pytest.mark.parametrize("P", [1, 63, 64, 200])
+def test_fresh_proposals_equal_monolithic(ctx, case, P):
+    Po = case.bh_proposal(bh, ctx)
+
+    def run():
+        X, W, ll = bh.sample_solve(case.x0, Po, P, seed=77, iter=5, path0=123, store_W=True)
+        return X.paths(), W.paths(), None if ll is None else ll.cpu().numpy()
+    (Xa, Wa, la), (Xb, Wb, lb) = both(ctx, run)
+    assert np.array_equal(Wa, Wb) and np.array_equal(Xa, Xb)
+    assert (la is None and lb is None) or np.array_equal(la, lb)
+    # and against the oracle directly (chain p of the ensemble = global path id 123 + p)
+    p = P - 1
+    W_ref = o.wiener_sample(case.tt, case.mp, 77, 123 + p, 5)
+    assert np.array_equal(Wa[p], W_ref)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c.kind != o.GUIDE_NONE], ids=lambda c: c.name)
+def test_pcn_chains_equal_monolithic(ctx, case):
+    Po = case.bh_proposal(bh, ctx)
+
+    def run():
+        ch = bh.Chains(Po, case.x0, 150, seed=31, path0=7)
+        ch.step(case.rho, 6)
+        X, W = ch.paths(0, 150)
+        return X, W, ch.ll(), ch.acc(), ch.proposal_X().cpu().numpy(), ch.stats().cpu().numpy()
+    a, b = both(ctx, run)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+    assert 0 < a[3].sum() < 6 * 150
+
+
+@pytest.mark.parametrize("N", [2, 3, 16, 17, 18, 33, 129])
+def test_short_and_ragged_grids(ctx, N):
+    """grids around the chunk size: 16 values per chunk = 16 grid points (m' = 1) / 8 (m' = 2)"""
+    # (FitzHugh-Nagumo is stiff: on grids this coarse its Euler scheme overflows, so the d = 1 bridge stands in below 129 points)
+    for name in (("fhn_partialbridge_extreme" if N >= 129 else "ou_guidedbridge"), "linpro2_guidedbridge"):
+        case = [c for c in problems.cases(N) if c.name == name][0]
+        Po = case.bh_proposal(bh, ctx)
+
+        def run():
+            X, W, ll = bh.sample_solve(case.x0, Po, 70, seed=3, store_W=True)
+            ch = bh.Chains(Po, case.x0, 70, seed=3)
+            ch.step(0.8, 3)
+            Xc, Wc = ch.paths(0, 70)
+            return X.paths(), W.paths(), ll.cpu().numpy(), Xc, Wc, ch.ll(), ch.acc()
+        a, b = both(ctx, run)
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v), (name, N)
+        ref = case.oracle_proposal()
+        r = o.mcmc(ref, case.x0, 0.8, 3, 3, 69)
+        assert np.array_equal(a[3][69], r["X"]) and np.array_equal(a[4][69], r["W"]) and a[5][69] == r["ll"] and a[6][69] == r["acc"]
+
+
+def test_no_store_variants_and_per_path_starts(ctx):
+    """log-likelihood only (no X, no W store) and per-path starting points x0_dev on the wave-specialised kernel"""
+    case = [c for c in problems.cases(201) if c.name == "fhn_partialbridge_first"][0]
+    Po = case.bh_proposal(bh, ctx)
+    P = 130
+    rng = np.random.default_rng(0)
+    x0s = case.x0[None, :] + 0.05 * rng.standard_normal((P, 2))
+    x0_dev = torch.tensor(np.ascontiguousarray(x0s.T), dtype=torch.float64, device=ctx.device)   # [d][P]
+
+    def run():
+        ll = ctx.empty(P)
+        X = bh.EnsemblePath(Po.tt, 2, P, ctx)
+        ll2 = ctx.empty(P)
+        ctx.check(ctx.lib.bhip_sample_solve(ctx.h, Po.h, None, bh.api.vp(x0_dev.data_ptr()), None, P, None, P,
+                                            bh.api.vp(ll.data_ptr()), 0, P, 5, 1, 0))
+        ctx.check(ctx.lib.bhip_sample_solve(ctx.h, Po.h, None, bh.api.vp(x0_dev.data_ptr()), None, P, X.ptr(), P,
+                                            bh.api.vp(ll2.data_ptr()), 0, P, 5, 1, 0))
+        return ll.cpu().numpy(), ll2.cpu().numpy(), X.paths()
+    a, b = both(ctx, run)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+    assert np.array_equal(a[0], a[1])
+    ref = case.oracle_proposal()
+    for p in (0, 64, 129):
+        W = o.wiener_sample(case.tt, 1, 5, p, 1)
+        Xr = o.solve_guided(ref, x0s[p], W)
+        assert np.array_equal(a[2][p], Xr) and a[0][p] == o.llikelihood(ref, Xr)

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in bridgehip.h but not exported"
     assert declared == set(bh._lib.SIGNATURES), declared ^ set(bh._lib.SIGNATURES)
-    assert bh._lib.load().bhip_version() == 100
+    assert bh._lib.load().bhip_version() == 200
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

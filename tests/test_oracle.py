@@ -411,21 +411,17 @@ def test_girsanov_antisymmetry_and_vector_models():
     assert abs(g - ref) <= 1e-12 * max(1.0, abs(ref))
 
 
-# --------------------------------------------------------------------------- frozen vectors of round 1
-def test_oracle_reproduces_committed_golden_vectors():
-    """tests/golden/guided_paths_v1.npz (written by tests/golden/make_golden.py) freezes the oracle and the noise
-    specification: Wiener paths, guided paths, log-likelihoods and a short pCN chain for every test problem."""
+# --------------------------------------------------------------------------- frozen vectors
+def _check_given_W(g, with_noise):
     import problems
-    sys_path = os.path.join(GOLD, "make_golden.py")
-    assert os.path.exists(sys_path)
-    g = np.load(os.path.join(GOLD, "guided_paths_v1.npz"))
     N, npaths, seed, iters = (int(v) for v in g["meta"])
     rho = float(g["rho"])
     names = set()
     for c in problems.cases(N) + problems.forward_cases(N):
         names.add(c.name)
-        W = np.stack([o.wiener_sample(c.tt, c.mp, seed, p, 0) for p in range(npaths)])
-        assert np.array_equal(W, g[c.name + "/W"]), c.name
+        W = g[c.name + "/W"]
+        if with_noise:
+            assert np.array_equal(np.stack([o.wiener_sample(c.tt, c.mp, seed, p, 0) for p in range(npaths)]), W), c.name
         if c.kind == o.GUIDE_NONE:
             X = np.stack([o.solve_em(c.model, c.d, c.mp, c.par, c.tt, c.x0, W[p]) for p in range(npaths)])
             assert np.array_equal(X, g[c.name + "/X"]), c.name
@@ -437,8 +433,22 @@ def test_oracle_reproduces_committed_golden_vectors():
         tol = 0.0 if c.exact else 1e-12
         assert np.abs(X - g[c.name + "/X"]).max() <= tol * (1 + np.abs(X).max()), c.name
         assert np.abs(ll - g[c.name + "/ll"]).max() <= tol * (1 + np.abs(ll).max()), c.name
-        if c.exact:
+        if c.exact and with_noise:
             r = o.mcmc(ref, c.x0, rho, iters, seed, 1)
             assert np.array_equal(r["W"], g[c.name + "/chain_W"]) and np.array_equal(r["X"], g[c.name + "/chain_X"]), c.name
             assert r["ll"] == g[c.name + "/chain_ll_acc"][0] and r["acc"] == g[c.name + "/chain_ll_acc"][1], c.name
     assert {k.split("/")[0] for k in g.files if "/" in k} == names
+
+
+def test_oracle_reproduces_committed_golden_vectors():
+    """tests/golden/guided_paths_v2.npz (written by tests/golden/make_golden.py) freezes the oracle and the noise
+    specification bhip-philox-v2: Wiener paths, guided paths, log-likelihoods and a short pCN chain for every test problem."""
+    assert os.path.exists(os.path.join(GOLD, "make_golden.py"))
+    _check_given_W(np.load(os.path.join(GOLD, "guided_paths_v2.npz")), True)
+
+
+def test_round1_golden_paths_given_their_wiener_paths():
+    """guided_paths_v1.npz was written under noise specification v1.  Its Wiener paths are data; the guided paths and
+    log-likelihoods GIVEN them do not involve the generator and must still be reproduced bit for bit -- the round-1
+    arithmetic keeps guarding the solver across the change of the noise specification."""
+    _check_given_W(np.load(os.path.join(GOLD, "guided_paths_v1.npz")), False)
