@@ -16,9 +16,17 @@ pCN mix -> guided Euler step -> log-likelihood increment (+ the accept at the en
 All inputs are resident in HBM when the timed region starts.  The timed region ends with the
 device-side reduction of the acceptance / log-weight statistics and (N > 1) ONE RCCL all-gather.
 
-`--mode proposals` times independent fresh proposals instead (sample!+solve!+llikelihood, X stored),
-`--mode linpro32` config C5 (d = 32 on the fp64 matrix cores).  At N = 1 the default run appends the
-kernel-level figures of those two modes as `other_modes` (measured after the timed region).
+Other modes (`--mode`), each a named BASELINE / SURVEY 8(d) configuration:
+  proposals   C3 as independent fresh proposals (sample!+solve!+llikelihood, X stored), 262 144 paths
+  c2          C2: 1-d OU GuidedBridge, 65 536 independent paths (mode E, 8 B/path-step)
+  c4shard     SURVEY C4's per-GPU shard: the default workload with 32 768 chains
+  nclar       D1's "3-d": NCLAR partial bridge, 262 144 fresh proposals (24 B/path-step)
+  nclar_mcmc  the same as pCN chains (40 B/path-step)
+  linpro32    C5: LinPro d = 32 on the fp64 matrix cores, 65 536 paths;  linpro32_mcmc: its pCN chains
+At N = 1 the default run appends the kernel-level figures of all of them as `other_modes` (measured after the timed
+region), a `sustained` record (>= 1 s of back-to-back launches) and the CPU baseline.  At N > 1 the SURVEY-C4 shard size
+(32 768 chains per GPU) is timed after the headline region with the same barrier / max-over-ranks protocol and reported
+as `survey_c4` next to the 262 144-chains-per-GPU headline.
 """
 import argparse
 import json
@@ -34,6 +42,8 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np
 import torch
 import torch.distributed as dist
+
+import math
 
 import bridgehip as bh
 from bridgehip import dist as bdist
@@ -68,7 +78,16 @@ def cpu_baseline(seconds_budget=20.0):
     ap = problems.fhn_aux_end(*FHN, V_END)
     Lt, Mt, mut = o.partialbridge_ode(tt, 2, 1, 1, o.AUX_AFFINE, ap, [[1.0, 0.0]], [[1e-10]])
     Po = o.proposal_lmmu(tt, 2, 1, 1, o.MODEL_FHN, list(FHN), o.AUX_AFFINE, ap, Lt, Mt, mut, [V_END])
-    ncpu = os.cpu_count() or 1
+    # the threads this process may actually use: affinity mask and cgroup quota, not os.cpu_count()
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        pass
+    usable = max(1, min(ncpu, int(quota)) if quota else ncpu)
     iters = 9
     per_chain = (iters + 1) * (N_GRID - 1)
 
@@ -81,83 +100,133 @@ def cpu_baseline(seconds_budget=20.0):
     rate1 = timed(16, 1)
     nch1 = max(8, int(rate1 * seconds_budget / 3 / per_chain))
     rate1 = timed(nch1, 1)
-    # OpenMP over chains: the best thread count is not always "all hardware threads" (SMT / NUMA); probe a
-    # few counts with ~0.5 s each, then time the best one for ~seconds_budget/3
+    # OpenMP over chains: the best thread count is not always "all hardware threads" (SMT / NUMA); probe a few
+    # counts with ~2 s of work each (sized from the running best rate), then time the best one for ~seconds_budget/3
     best_t, best_r = 1, rate1
-    for th in sorted({t for t in (8, 16, 32, 64, 96, 128, 192, ncpu) if 1 < t <= ncpu}):
-        r = timed(max(th * 4, int(best_r * 0.5 / per_chain) // th * th), th)
+    probed = {}
+    for th in sorted({t for t in (8, 16, 32, 64, 128, usable // 2, usable) if 1 < t <= usable}):
+        guess = max(best_r, rate1 * min(th, 16))
+        r = timed(max(th * 4, int(guess * 2.0 / per_chain) // th * th), th)
+        probed[th] = r
         if r > best_r:
             best_t, best_r = th, r
     nchc = max(best_t, int(best_r * seconds_budget / 3 / per_chain) // best_t * best_t)
     ratec = timed(nchc, best_t)
     return {"value": ratec, "unit": "path-steps/s", "cores": best_t, "kind": "port",
-            "value_1thread": rate1, "host_cpus": ncpu,
+            "value_1thread": rate1, "host_cpus": os.cpu_count(), "affinity_cpus": ncpu, "cgroup_cpu_quota": quota,
+            "probed_threads": {str(k): v for k, v in probed.items()},
             "sample": f"{nchc} chains x {iters + 1} pCN iterations x {N_GRID - 1} steps of the bench workload "
-                      f"(OpenMP over chains, {best_t} threads = the fastest of the probed counts on {ncpu} hardware threads); "
+                      f"(OpenMP over chains, {best_t} threads = the fastest of the probed counts, {usable} usable hardware threads); "
                       f"1-thread figure on {nch1} chains; "
                       "C restatement of Bridge.jl's four-pass loop (no Julia on this box), not Bridge.jl itself"}
 
 
-def profiled_traffic(kernel_tag, tags=("r1_mcmc",)):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summaries
-    (profiles/<tag>_fetch.txt, <tag>_write.txt; separate --pmc passes).  FETCH_SIZE / WRITE_SIZE are in
-    KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream (MI355X_MICROARCH.md, HBM
-    section), hence the factor 2.  Returns (bytes, source) or (None, None)."""
+PROFILE_TAG = "r2"   # profiles/<PROFILE_TAG>_<mode>_{trace,fetch,write}.txt, written by scripts/gpu_profile.sh this round
+
+
+def profiled_traffic(mode, kernel_name):
+    """HBM bytes per launch of the dominant kernel from this round's committed rocprofv3 PMC summaries
+    (profiles/r2_<mode>_fetch.txt, _write.txt; separate --pmc passes of `bench.py --mode <mode>`, scripts/gpu_profile.sh).
+    FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream
+    (MI355X_MICROARCH.md, HBM section), hence the factor 2.  The kernel is looked up by the exact name the current
+    build launches: a summary that does not contain it (kernel changed, profile stale) gives NO figure -- loudly."""
     import re
-    for tag in tags:
-        vals = {}
-        for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-            fn = os.path.join(ROOT, "profiles", f"{tag}_{kind}.txt")
-            if not os.path.exists(fn):
-                break
-            for line in open(fn):
-                if kernel_tag in line and counter in line:
-                    m = re.search(counter + r"\s+\d+\s+([0-9.]+)", line)
-                    if m:
-                        vals[kind] = float(m.group(1))
-        if len(vals) == 2:
-            return (2.0 * vals["fetch"] + vals["write"]) * 1024.0, f"profiles/{tag}_fetch.txt (x2, gfx950 correction) + profiles/{tag}_write.txt"
-    return None, None
+    vals = {}
+    for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        fn = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{mode}_{kind}.txt")
+        if not os.path.exists(fn):
+            return None, f"MISSING: {os.path.relpath(fn, ROOT)} (run scripts/gpu_profile.sh {PROFILE_TAG}_{mode} --mode {mode})"
+        for line in open(fn):
+            if kernel_name in line and counter in line:
+                m = re.search(counter + r"\s+\d+\s+([0-9.]+)", line)
+                if m:
+                    vals[kind] = float(m.group(1))
+        if kind not in vals:
+            msg = f"STALE: {os.path.relpath(fn, ROOT)} has no {counter} row for '{kernel_name}' -- re-profile"
+            print("bench.py: " + msg, file=sys.stderr)
+            return None, msg
+    return (2.0 * vals["fetch"] + vals["write"]) * 1024.0, (f"profiles/{PROFILE_TAG}_{mode}_fetch.txt (x2, gfx950 correction) + "
+                                                           f"profiles/{PROFILE_TAG}_{mode}_write.txt")
+
+
+def _linpro32(ctx):
+    d = 32
+    rng = np.random.default_rng(5)
+    G, G2 = rng.standard_normal((d, d)) / np.sqrt(d), rng.standard_normal((d, d)) / np.sqrt(d)
+    sig = 0.5 * np.eye(d) + 0.05 * G2
+    return bh.GuidedBridge(np.linspace(0.0, 1.0, N_GRID), bh.LinPro(-np.eye(d) + 0.1 * G, np.zeros(d), sig),
+                           bh.LinPro(-np.eye(d), np.zeros(d), sig), 0.5 * np.ones(d), ctx=ctx)
+
+
+def _ou(ctx):
+    # C2 (SURVEY 8(d)): target LinPro(-0.8, 0, sqrt(.7)), auxiliary LinPro(-0.8, 0.2, sqrt(.7)), T = 2   test/guip.jl:117-120,248
+    return bh.GuidedBridge(tau_grid(2.0, N_GRID), bh.LinPro([[-0.8]], [0.0], [[math.sqrt(0.7)]]),
+                           bh.LinPro([[-0.8]], [0.2], [[math.sqrt(0.7)]]), [0.1], ctx=ctx)
+
+
+def _nclar(ctx):
+    # NCLAR(3) partial bridge (partialbridge_nclar.jl:13,43-45,52-86): alpha=6, omega=2pi, sigma=1, L=[1 0 0], v=5/128, T=0.5
+    P = bh.NclarDiffusion(6.0, 2 * math.pi, 1.0)
+    Pt = bh.AffineAux([[0, 1, 0], [0, 0, 1], [0, 0, 0]], [0, 0, 0], [[0.0], [0.0], [1.0]])
+    return bh.PartialBridge(tau_grid(0.5, N_GRID), P, Pt, [[1.0, 0, 0]], [5 / 128], [[1e-10]], ctx=ctx)
+
+
+def pc_pairs(P):
+    """workgroup shape the wave-specialised kernel is launched with (bhip_pc_kernel.h launch_pc)"""
+    g = (P + 63) // 64
+    return 2 if g <= 512 else 4 if g <= 1024 else 1
+
+
+# mode -> (proposal builder, d, m', x0, default paths, chains?, rho, workload text, kernel-name builder)
+MODES = {
+    "mcmc": (build_proposal, 2, 1, X0, 262144, True, RHO,
+             FHN_WORKLOAD + "pCN-MCMC rho=0.9: one step = one MH iteration of every chain",
+             lambda P: f"k_pc<bhip::MFHN, 2, 1, 7, 1, {pc_pairs(P)}>"),
+    "c4shard": (build_proposal, 2, 1, X0, 32768, True, RHO,
+                FHN_WORKLOAD + "pCN-MCMC rho=0.9, SURVEY-C4 shard size (32 768 chains per GPU)",
+                lambda P: f"k_pc<bhip::MFHN, 2, 1, 7, 1, {pc_pairs(P)}>"),
+    "proposals": (build_proposal, 2, 1, X0, 262144, False, None,
+                  FHN_WORKLOAD + "independent fused proposals (sample!+solve!+llikelihood)",
+                  lambda P: (f"k_pc<bhip::MFHN, 2, 1, 6, 1, {pc_pairs(P)}>" if P <= 98304 else "k_paths<bhip::MFHN, 2, 1, 1, 1>")),
+    "c2": (_ou, 1, 1, (0.5,), 65536, False, None,
+           "C2: 1-d OU target LinPro(-0.8,0,sqrt(.7)), GuidedBridge with auxiliary LinPro(-0.8,0.2,sqrt(.7)), 1001-point tau-grid T=2, "
+           "independent fused proposals",
+           lambda P: (f"k_pc<bhip::MLinPro<1>, 1, 1, 6, 1, {pc_pairs(P)}>" if P <= 98304 else "k_paths<bhip::MLinPro<1>, 1, 1, 1, 1>")),
+    "nclar": (_nclar, 3, 1, (0.0, 0.0, 0.0), 262144, False, None,
+              "NCLAR 3-d PartialBridge (scalar noise, L=[1 0 0], v=5/128), 1001-point tau-grid T=0.5, independent fused proposals",
+              lambda P: (f"k_pc<bhip::MNCLAR, 2, 1, 6, 1, {pc_pairs(P)}>" if P <= 98304 else "k_paths<bhip::MNCLAR, 2, 1, 1, 1>")),
+    "nclar_mcmc": (_nclar, 3, 1, (0.0, 0.0, 0.0), 262144, True, 0.95,
+                   "NCLAR 3-d PartialBridge (scalar noise, L=[1 0 0], v=5/128), 1001-point tau-grid T=0.5, pCN-MCMC rho=0.95",
+                   lambda P: f"k_pc<bhip::MNCLAR, 2, 1, 7, 1, {pc_pairs(P)}>"),
+    "linpro32": (_linpro32, 32, 32, tuple([0.0] * 32), 65536, False, None,
+                 "LinPro d=32 GuidedBridge (dense sigma, pre-inverted Hdiamond), 1001-point grid T=1, independent fused proposals",
+                 lambda P: "k_tile<32, 1, false>"),
+    "linpro32_mcmc": (_linpro32, 32, 32, tuple([0.0] * 32), 65536, True, 0.95,
+                      "LinPro d=32 GuidedBridge (dense sigma, pre-inverted Hdiamond), 1001-point grid T=1, pCN-MCMC rho=0.95",
+                      lambda P: "k_tile<32, 2, false>"),
+}
 
 
 class Workload:
     """one bench mode: owns its device buffers; step() = one launch of the dominant kernel"""
 
     def __init__(self, mode, ctx, chains, rank):
+        build, d, mp, x0, default_P, is_chains, rho, text, kname = MODES[mode]
         self.mode, self.ctx = mode, ctx
-        self.P = chains
-        self.flops_per_pathstep = None
+        self.P = chains if chains else default_P
+        self.path0 = rank * self.P                   # contiguous shard of the global ids; the RNG is keyed by the global id
+        self.Po = build(ctx)
+        self.workload = text
+        self.kernel = kname(self.P)
+        self.flops_per_pathstep = 5 * 2 * d * d if d > 3 else None   # d = 32: five d x d mat-vecs per path-step
         self.chains = None
-        if mode == "linpro32":
-            # config C5 (SURVEY 8(d)): LinPro d=32 GuidedBridge on the fp64 MFMA tile kernel; 65 536 paths by default
-            d = 32
-            if chains == 262144:
-                self.P = 65536
-            rng = np.random.default_rng(5)
-            G, G2 = rng.standard_normal((d, d)) / np.sqrt(d), rng.standard_normal((d, d)) / np.sqrt(d)
-            sig = 0.5 * np.eye(d) + 0.05 * G2
-            self.Po = bh.GuidedBridge(np.linspace(0.0, 1.0, N_GRID), bh.LinPro(-np.eye(d) + 0.1 * G, np.zeros(d), sig),
-                                      bh.LinPro(-np.eye(d), np.zeros(d), sig), 0.5 * np.ones(d), ctx=ctx)
-            self._fresh(d, np.zeros(d), 5)
-            self.bytes_per_pathstep = 8 * d              # write X (8d)
-            self.flops_per_pathstep = 5 * 2 * d * d      # five d x d mat-vecs
-            self.kernel = "k_tile<32>"
-            self.workload = "LinPro d=32 GuidedBridge (dense sigma, pre-inverted Hdiamond), 1001-point grid T=1, independent fused proposals"
-        elif mode == "mcmc":
-            self.Po = build_proposal(ctx)
-            self.path0 = rank * self.P                   # contiguous shard of the global chain ids; RNG keyed by global id
-            self.chains = bh.Chains(self.Po, X0, self.P, seed=4, path0=self.path0, store_X=True)
-            self.step = lambda: self.chains.step(RHO, 1)
-            self.bytes_per_pathstep = 8 * 2 + 16 * 1     # write Xo (8d) + read W, write Wo (16 m')   SURVEY 8(d) mode M
-            self.kernel = "k_chain_lines<MFHN, LMMU, 1, store X>"
-            self.workload = FHN_WORKLOAD + "pCN-MCMC rho=0.9: one step = one MH iteration of every chain"
+        if is_chains:
+            self.chains = bh.Chains(self.Po, np.array(x0), self.P, seed=4, path0=self.path0, store_X=True)
+            self.step = lambda: self.chains.step(rho, 1)
+            self.bytes_per_pathstep = 8 * d + 16 * mp    # write Xo (8d) + read W, write Wo (16 m')   SURVEY 8(d) mode M
         else:
-            self.Po = build_proposal(ctx)
-            self._fresh(2, np.array(X0), 4)
-            self.bytes_per_pathstep = 8 * 2              # write X (8d)                               SURVEY 8(d) mode E
-            self.kernel = "k_paths<MFHN, LMMU, 1, FRESH>"
-            self.workload = FHN_WORKLOAD + "independent fused proposals (sample!+solve!+llikelihood)"
-        self.path0 = rank * self.P
+            self._fresh(d, np.array(x0), 4)
+            self.bytes_per_pathstep = 8 * d              # write X (8d)                               SURVEY 8(d) mode E
 
     def _fresh(self, d, x0, seed):
         ctx, P = self.ctx, self.P
@@ -185,6 +254,10 @@ class Workload:
             tf = per_launch * self.flops_per_pathstep / avg_s / 1e12
             r.update({"bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TF,
                       "algorithmic_flops_per_path_step": self.flops_per_pathstep, "hbm_algorithmic_GBs": gbs})
+        tr, src = profiled_traffic(self.mode, self.kernel)
+        if tr is not None and self.P != MODES[self.mode][4]:
+            tr, src = None, "profiled at the mode's default size only"
+        r["traffic"], r["traffic_source"] = tr, src
         return r
 
 
@@ -201,13 +274,43 @@ def kernel_times(w, steps, warmup):
     return [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
 
 
+def timed_region(w, steps, world, ctx, stats):
+    """the contract's timed region: K steps bracketed by barrier + synchronize on both sides, MAX over ranks; ends with
+    the device-side statistics reduction and (N > 1) the ONE all-gather of the statistics block"""
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        evs[k].record()
+        w.step()
+    evs[steps].record()
+    if w.chains is not None:
+        w.chains.stats(stats)
+    else:
+        stats.zero_()
+    gathered = bdist.allgather_stats(stats, world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    return elapsed, [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)], gathered
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--chains", type=int, default=262144, help="chains (paths) per GPU")
-    ap.add_argument("--mode", choices=["mcmc", "proposals", "linpro32"], default="mcmc")
+    ap.add_argument("--chains", type=int, default=0, help="chains (paths) per GPU; 0 = the mode's named size")
+    ap.add_argument("--mode", choices=sorted(MODES), default="mcmc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true")
     args = ap.parse_args()
@@ -242,34 +345,9 @@ def main():
     if world > 1:   # untimed: the first collective of each kind sets up RCCL's channels over xGMI
         stats.zero_()
         bdist.allgather_stats(stats, world)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    elapsed, kern_ms, gathered = timed_region(w, args.steps, world, ctx, stats)
 
-    evs =[torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        evs[k].record()
-        w.step()
-    evs[args.steps].record()
-    if args.mode == "mcmc":
-        w.chains.stats(stats)
-    else:
-        stats.zero_()
-    gathered = bdist.allgather_stats(stats, world)       # the ONE collective: acceptance / log-weight statistics
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    kern_ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps)]
-
+    out = None
     if rank == 0:
         total_pathsteps = float(world) * P * steps_per_unit * args.steps
         out = {
@@ -290,35 +368,49 @@ def main():
                        "parallelism": f"chains sharded over {world} GPU(s), one RCCL all-gather of the statistics block"},
             "roofline": w.roofline(kern_ms),
         }
-        if args.mode == "mcmc" and P == 262144:
-            # measured once per round with rocprofv3 PMC passes on this exact command (scripts/gpu_profile.sh)
-            tr, src = profiled_traffic("k_chain_lines<bhip::MFHN, 2, 1, 1>")
-            if tr:
-                out["roofline"]["traffic"] = tr
-                out["roofline"]["traffic_source"] = src
-        if args.mode == "mcmc":
+        if w.chains is not None:
             summary = bdist.combine_stats(gathered)
             out["config"]["acceptance_rate"] = summary["acceptance_rate"]
             out["config"]["mean_ll"] = summary["mean_ll"]
             out["config"]["chains_total"] = summary["chains"]
-        if world == 1 and args.mode == "mcmc" and args.chains == 262144 and not args.no_other_modes:
-            # kernel-level figures of the other two workloads (outside the timed region above)
-            others = []
-            del w
+    default_run = args.mode == "mcmc" and args.chains == 0
+    if world == 1 and default_run and not args.no_other_modes:
+        # >= 1 s of back-to-back launches of the headline kernel (the timed region above is K = 20 launches = 30-40 ms)
+        n_sus = max(50, int(1.2e3 / max(float(np.mean(kern_ms)), 1e-3)))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            w.step()
+        torch.cuda.synchronize()
+        t_sus = time.perf_counter() - t0
+        out["sustained"] = {"launches": n_sus, "seconds": t_sus, "ms_per_step": t_sus / n_sus * 1e3,
+                            "path_steps_per_s": P * steps_per_unit * n_sus / t_sus,
+                            "hbm_frac": P * steps_per_unit * n_sus * w.bytes_per_pathstep / t_sus / 1e9 / HBM_PEAK_GBS}
+        # kernel-level figures of the other named configurations (outside the timed region above)
+        others = []
+        del w
+        torch.cuda.empty_cache()
+        for mode in ("c4shard", "c2", "proposals", "nclar", "nclar_mcmc", "linpro32", "linpro32_mcmc"):
+            wo = Workload(mode, ctx, 0, rank)
+            ms = kernel_times(wo, args.steps, args.warmup)
+            others.append({"mode": mode, "workload": wo.workload, "paths": wo.P,
+                           "path_steps_per_s": wo.P * steps_per_unit / (float(np.mean(ms)) * 1e-3), "roofline": wo.roofline(ms)})
+            del wo
             torch.cuda.empty_cache()
-            for mode in ("proposals", "linpro32"):
-                wo = Workload(mode, ctx, args.chains, rank)
-                ms = kernel_times(wo, args.steps, args.warmup)
-                roof = wo.roofline(ms)
-                tr, src = profiled_traffic(*{"proposals": ("k_paths<bhip::MFHN, 2, 1, 1, 1>", ("r1_prop",)),
-                                             "linpro32": ("k_tile<32, 1, false>", ("r1_lin32",))}[mode])
-                if tr and wo.P == (262144 if mode == "proposals" else 65536):
-                    roof["traffic"], roof["traffic_source"] = tr, src
-                others.append({"mode": mode, "workload": wo.workload, "paths": wo.P,
-                               "path_steps_per_s": wo.P * steps_per_unit / (float(np.mean(ms)) * 1e-3), "roofline": roof})
-                del wo
-                torch.cuda.empty_cache()
-            out["other_modes"] = others
+        out["other_modes"] = others
+    elif world > 1 and default_run:
+        # SURVEY 8(d) C4 quotes 32 768 chains per GPU: the same protocol at that shard size, next to the headline
+        del w
+        torch.cuda.empty_cache()
+        wc = Workload("c4shard", ctx, 0, rank)
+        for _ in range(args.warmup):
+            wc.step()
+        el_c, ms_c, _ = timed_region(wc, args.steps, world, ctx, stats)
+        if rank == 0:
+            tp = float(world) * wc.P * steps_per_unit * args.steps
+            out["survey_c4"] = {"chains_per_gpu": wc.P, "value": tp / el_c, "unit": "path-steps/s", "ms_per_step": el_c / args.steps * 1e3,
+                                "scaling": "weak", "roofline": wc.roofline(ms_c)}
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -941,7 +941,9 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
         ch->lines = false;
         ch->nch = 0;
     }
-    const size_t wbytes = ch->lines ? sizeof(double) * 2 * ch->nch * ch->ld * LINE_DOUBLES : sizeof(double) * 2 * N * po->mh.mp * ch->ld;
+    const size_t wbytes = ch->lines ? sizeof(double) * 2 * ch->nch * ch->ld * LINE_DOUBLES
+                        : po->mh.d > 3 ? sizeof(double) * 2 * N * (tile_dim(po->mh.d) / 16) * ch->ld * 16   // tile lines (bhip_tile_kernel.h)
+                                       : sizeof(double) * 2 * N * po->mh.mp * ch->ld;
     const size_t xbytes = sizeof(double) * N * po->mh.d * ch->ld;
     hipError_t e = hipMalloc((void **)&ch->Wc, wbytes);
     if (e == hipSuccess && (flags & BHIP_CHAINS_STORE_X)) e = hipMalloc((void **)&ch->Xo, xbytes);
@@ -977,8 +979,18 @@ int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
     ch->x0.assign(x0, x0 + po->mh.d);
     HIPCHK(ctx, hipMemsetAsync(ch->cur, 0, ch->ld, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ch->acc, 0, sizeof(unsigned int) * ch->ld, ctx->stream));
-    if (po->mh.d > 3) {   // MFMA tile kernel: fresh W into half 0 of every slot, X and ll of the initial state
-        int rct = launch_tile_path(po, x0, nullptr, 0, ch->Wc, ch->ld, ch->Xo, ch->ld, ch->llcur, skip, ch->n, 1, ch->seed, 0, ch->path0, 2);
+    if (po->mh.d > 3) {   // MFMA tile kernel: fresh W into a plain SoA scratch array, re-arranged into half 0 of the tile lines; X and ll of the initial state
+        const int N = (int)po->tt.size(), d = po->mh.d, T = tile_dim(d) / 16;
+        double *tmpW = nullptr;
+        HIPCHK(ctx, hipMalloc((void **)&tmpW, sizeof(double) * N * d * ch->n));
+        int rct = launch_tile_path(po, x0, nullptr, 0, tmpW, ch->n, ch->Xo, ch->ld, ch->llcur, skip, ch->n, 1, ch->seed, 0, ch->path0, 1);
+        if (!rct) {
+            const long tot = (long)N * 16 * T * ch->n;
+            hipLaunchKernelGGL(k_soa_to_tlines, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, tmpW, ch->Wc, N, d, T, ch->ld, ch->n);
+            if (hipGetLastError() != hipSuccess) rct = fail(ctx, BHIP_EHIP, "k_soa_to_tlines launch failed");
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tmpW);
         if (rct) return rct;
         ch->skip0 = skip; ch->iter = 0; ch->inited = true;
         return BHIP_OK;
@@ -1080,6 +1092,13 @@ static int gather_current_W(bhip_chains *ch, long p0, long np, double *W_soa)
     if (ch->lines) {
         const int N = (int)ch->po->tt.size();
         hipLaunchKernelGGL(k_lines_to_soa, dim3((unsigned)((np + 63) / 64), (unsigned)ch->nch), dim3(256), 0, ctx->stream, ch->Wc, ch->cur, N, ch->po->mh.mp, ch->nch, ch->ld, p0, np, W_soa);
+        HIPCHK(ctx, hipGetLastError());
+        return BHIP_OK;
+    }
+    if (ch->po->mh.d > 3) {
+        const int N = (int)ch->po->tt.size(), d = ch->po->mh.d, T = tile_dim(d) / 16;
+        const long tot = (long)N * d * np;
+        hipLaunchKernelGGL(k_tlines_to_soa, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ch->Wc, ch->cur, W_soa, N, d, T, ch->ld, p0, np);
         HIPCHK(ctx, hipGetLastError());
         return BHIP_OK;
     }
@@ -1220,6 +1239,10 @@ int bhip_chains_load(bhip_chains *ch, const void *host_buf)
         if (ch->lines) {
             hipLaunchKernelGGL(k_soa_to_lines, dim3((unsigned)(ch->ld / 64), (unsigned)ch->nch), dim3(256), 0, ctx->stream, tmp, ch->n, (int)N, po->mh.mp, ch->nch,
                                ch->Wc, ch->ld, ch->n);
+        } else if (po->mh.d > 3) {
+            const int T = tile_dim(po->mh.d) / 16;
+            const long tot = (long)N * 16 * T * ch->n;
+            hipLaunchKernelGGL(k_soa_to_tlines, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, tmp, ch->Wc, (int)N, po->mh.d, T, ch->ld, ch->n);
         } else {
             const long E = (long)N * po->mh.mp, tot = E * ch->n;
             hipLaunchKernelGGL(k_soa_to_slots, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, tmp, ch->Wc, E, ch->ld, ch->n);

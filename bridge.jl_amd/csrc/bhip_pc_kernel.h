@@ -304,10 +304,8 @@ void launch_pc_n(const KArgs &a, hipStream_t st, long groups)
 {
     using RL = RowLayout<GK, M::D, MO, is_constdiff<M>::value>;
     const size_t lds = NPAIR == 1 ? PC_LDS : sizeof(double) * (RNG_TAB_DOUBLES + NPAIR * (2 * PC_TILE + 2 * (LINE_DOUBLES / M::MP) * RL::RS));
-    if (lds > 65536) {   // more than the default 64 KB of dynamic LDS: opt in (once per instantiation)
-        static bool raised = false;
-        if (!raised) { (void)hipFuncSetAttribute((const void *)k_pc<M, GK, MO, MODE, FL, NPAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
-    }
+    // more than the default 64 KB of dynamic LDS: opt in -- per device and cheap, so on every launch (a process may drive several devices)
+    if (lds > 65536) (void)hipFuncSetAttribute((const void *)k_pc<M, GK, MO, MODE, FL, NPAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_pc<M, GK, MO, MODE, FL, NPAIR>), dim3((unsigned)((groups + NPAIR - 1) / NPAIR)), dim3(128 * NPAIR), lds, st, a);
 }
 template <class M, int GK, int MO, int MODE, int FL>

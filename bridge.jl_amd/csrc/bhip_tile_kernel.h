@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *cm = lds;                  // 4*DD fragment matrices + 5*D vectors
     double *hb = lds + 4 * DD + 5 * D; // 2 * STEP
+    double *rtab_lds = hb + 2 * STEP;  // the generator's tables (RNG_TAB_DOUBLES), for the noise-drawing instantiations
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, j = lane & 15;
     const long p_raw = (long)blockIdx.x * 64 + wave * 16 + j;
@@ -111,7 +112,9 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 
     for (int c = tid; c < 4 * DD + 5 * D; c += 256) cm[c] = a.cst[c];
     for (int c = tid; c < STEP; c += 256) hb[c] = a.steps[c];
+    if constexpr (NOISE == 1 || NOISE == 2) TabLDS::load(rtab_lds, tid, 256);
     __syncthreads();
+    const TabLDS rtab(rtab_lds);
     const double *Bf = cm, *Btf = cm + DD, *Af = cm + 2 * DD, *Sf = cm + 3 * DD;
     const double *mu = cm + 4 * DD, *mua = mu + D, *beta = mu + 2 * D, *vend = mu + 3 * D;
 
@@ -120,11 +123,19 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     // chain of additions of the wave-uniform stride 4*ld (one VALU each) instead of a 64-bit multiply per access.
     // Lanes beyond the ensemble (p_raw >= P) replicate path P-1 exactly (same path id, same loads), so their
     // stores write identical values to identical addresses and need no execution mask.
-    const size_t rsWin = 4 * (size_t)a.ldWin, rsX = 4 * (size_t)a.ldX, rsWo = 4 * (size_t)a.ldWout * a.wstride, rsC = 4 * (size_t)a.ldC;
+    const size_t rsWin = 4 * (size_t)a.ldWin, rsX = 4 * (size_t)a.ldX, rsWo = 4 * (size_t)a.ldWout * a.wstride;
     const double *winp = (NOISE == 0 || NOISE == 3) ? a.Win + (size_t)kq * a.ldWin + p : nullptr;
     double *xp = a.X ? a.X + (size_t)kq * a.ldX + p : nullptr;
     double *wop = (NOISE == 1 && a.Wout) ? a.Wout + ((size_t)kq * a.ldWout + p) * a.wstride : nullptr;
-    tile_d2v *wsp = NOISE == 2 ? reinterpret_cast<tile_d2v *>(a.Wc) + (size_t)kq * a.ldC + p : nullptr;
+    // pCN chain state, TILE-LINE layout: a 128-byte line per (parity half h, grid point i, row group t, chain p) holding
+    // the 16 components 16t .. 16t+15 of W[i]:   Wl[(((h*N + i)*T + t)*ld + p)*16 + (4r + kq)].
+    // A lane reads its 8 values of the chain's CURRENT half and writes the proposal to the OTHER half (the accept flips the
+    // chain's parity bit); the four lanes kq = 0..3 of a chain and the four accesses r = 0..3 cover each line completely,
+    // back to back, so that whole lines travel: 8 m' B read + 8 m' B written per path-step -- the algorithmic bytes
+    // (the 16-byte slots of round 1 moved the unchanged half too: 1280 instead of 768 B per path-step at d = 32).
+    const size_t tl_grid = (size_t)T * a.ldC * 16, tl_half = (size_t)N * tl_grid;   // doubles per grid point / per half
+    const double *wrd = nullptr;
+    double *wwr = nullptr;
 
     double x[T][4], wprev[T][4];
     {
@@ -149,16 +160,16 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     int cpar = 0;
     if constexpr (NOISE == 2) {
         cpar = a.cur[p];
-        tile_d2v *q = wsp;
+        wrd = a.Wc + (size_t)cpar * tl_half + (size_t)p * 16 + kq;
+        wwr = a.Wc + (size_t)(cpar ^ 1) * tl_half + (size_t)p * 16 + kq;
 #pragma unroll
         for (int t = 0; t < T; t++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 w2prev[t][r] = 0.0;
-                if (ok(t, r)) *q = tile_d2v{0.0, 0.0};   // W[1] = Wo[1] = 0
-                q += rsC;
+                wwr[(size_t)t * a.ldC * 16 + 4 * r] = 0.0;   // Wo[0] = 0 (W[0] = 0 is already in the current half)
             }
-        wsp += (size_t)dtr * a.ldC;          // -> slots of W[1]
+        wrd += tl_grid; wwr += tl_grid;      // -> grid point 1
     }
 
     for (int i = 0; i < nsteps; i++) {
@@ -203,16 +214,12 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 }
             winp += (size_t)dtr * a.ldWin;
         } else {
-            tile_d2v slot[NOISE == 2 ? T : 1][4];
-            if constexpr (NOISE == 2) {   // the chain's slots of step i+1: issued first, consumed after the normals
-                const tile_d2v *q = wsp;
+            double wcur[NOISE == 2 ? T : 1][4];
+            if constexpr (NOISE == 2) {   // the chain's current W[i+1]: issued first, consumed after the normals
 #pragma unroll
                 for (int t = 0; t < T; t++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        slot[t][r] = ok(t, r) ? __builtin_nontemporal_load(q) : tile_d2v{0.0, 0.0};
-                        q += rsC;
-                    }
+                    for (int r = 0; r < 4; r++) wcur[t][r] = wrd[(size_t)t * a.ldC * 16 + 4 * r];
             }
             // normal index n = i*D + row; block n>>1 = i*D/2 + 2*ks + (kq>>1), element kq&1 (ks = 4t+r).
             // lanes kq and kq^1 share blocks: the even lane draws ks = 0..2T-1, the odd one ks = 2T..4T-1.
@@ -223,13 +230,12 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 const int ks = h + (odd ? 2 * T : 0);
                 double z0, z1;
                 if constexpr ((BHIP_TILE_EXP & 2) != 0) { z0 = 1e-3 * (double)(lane + ks); z1 = -z0; }
-                else normal_pair(a.k0, a.k1, path, a.iter, (uint32_t)(i * (dtr / 2) + 2 * ks + (kq >> 1)), z0, z1);
+                else normal_pair(rtab, a.k0, a.k1, path, a.iter, (uint32_t)(i * (dtr / 2) + 2 * ks + (kq >> 1)), z0, z1);
                 const double keep = odd ? z1 : z0, give = odd ? z0 : z1;
                 const double got = __shfl_xor(give, 16, 64);   // partner's block: h (partner even) or h + 2T (partner odd)
                 mine[h] = odd ? got : keep;            // K-slice h       : drawn by the even lane
                 mine[h + 2 * T] = odd ? keep : got;    // K-slice h + 2T  : drawn by the odd lane
             }
-            tile_d2v *qs = wsp;
             double *qo = wop;
 #pragma unroll
             for (int t = 0; t < T; t++)
@@ -237,21 +243,20 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 for (int r = 0; r < 4; r++) {
                     if constexpr (NOISE == 2) {
                         // sample!(W2); Wo = rho*W + sqrt(1-rho^2)*W2   partialbridge_fitzhugh.jl:145-147
-                        const double wc = cpar ? slot[t][r].y : slot[t][r].x;
+                        const double wc = wcur[t][r];
                         const double w2 = w2prev[t][r] + rdt * mine[4 * t + r];
                         const double wo = a.rho * wc + a.srho * w2;
                         dw[t][r] = wo - wprev[t][r];
                         w2prev[t][r] = w2;
                         wprev[t][r] = wo;
-                        if (ok(t, r)) __builtin_nontemporal_store(cpar ? tile_d2v{wo, slot[t][r].y} : tile_d2v{slot[t][r].x, wo}, qs);
-                        qs += rsC;
+                        wwr[(size_t)t * a.ldC * 16 + 4 * r] = wo;   // (zero-padded rows carry exact zeros)
                     } else {
                         const double wn = wprev[t][r] + rdt * mine[4 * t + r];   // sample!: W[i+1] = W[i] + sqrt(dt)*xi
                         dw[t][r] = wn - wprev[t][r];
                         wprev[t][r] = wn;
                     }
                 }
-            if (NOISE == 2) wsp += (size_t)dtr * a.ldC;
+            if (NOISE == 2) { wrd += tl_grid; wwr += tl_grid; }
             if (NOISE == 1 && a.Wout) {   // one wave-uniform test for the whole row group
 #pragma unroll
                 for (int t = 0; t < T; t++)
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
         // if log(rand()) <= llo - ll: W <- Wo (parity flip), ll <- llo, acc += 1     partialbridge_fitzhugh.jl:160-167
         if (live && kq == 0) {
             const double u = accept_uniform(a.k0, a.k1, path, a.iter);
-            if (det_log(u) <= ll - a.llcur[p]) {
+            if (det_log(u, rtab) <= ll - a.llcur[p]) {
                 a.cur[p] = (unsigned char)(cpar ^ 1);
                 a.llcur[p] = ll;
                 a.acc[p] += 1u;
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 template <int D, int NOISE, bool PAD = false>
 hipError_t launch_tile(const TArgs &a, hipStream_t st)
 {
-    const size_t lds = sizeof(double) * (4 * D * D + 5 * D + 2 * (D * D + D));
+    const size_t lds = sizeof(double) * (4 * D * D + 5 * D + 2 * (D * D + D) + RNG_TAB_DOUBLES);
     // per device and cheap: set on every launch (a process may drive several devices)
     hipError_t e = hipFuncSetAttribute((const void *)k_tile<D, NOISE, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
