@@ -274,7 +274,7 @@ def kernel_times(w, steps, warmup):
     return [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
 
 
-def timed_region(w, steps, world, ctx, stats):
+def timed_region(w, steps, world, ctx, stats, comm=None):
     """the contract's timed region: K steps bracketed by barrier + synchronize on both sides, MAX over ranks; ends with
     the device-side statistics reduction and (N > 1) the ONE all-gather of the statistics block"""
     torch.cuda.synchronize()
@@ -291,7 +291,7 @@ def timed_region(w, steps, world, ctx, stats):
         w.chains.stats(stats)
     else:
         stats.zero_()
-    gathered = bdist.allgather_stats(stats, world)
+    gathered = bdist.allgather_stats(stats, world, comm)   # N > 1: bhip_comm_allgather_stats (RCCL inside the library)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -335,6 +335,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     ctx = bh.Context(local)
+    # the data-path collective lives in the product: an RCCL communicator over the ranks (torch.distributed only carries
+    # the id handshake, the barriers and the max-over-ranks of the clock)
+    comm = bdist.Comm.from_torch_dist(ctx) if (world > 1 and not single) else None
     w = Workload(args.mode, ctx, args.chains, rank)
     P = w.P
     steps_per_unit = N_GRID - 1
@@ -344,8 +347,8 @@ def main():
         w.step()
     if world > 1:   # untimed: the first collective of each kind sets up RCCL's channels over xGMI
         stats.zero_()
-        bdist.allgather_stats(stats, world)
-    elapsed, kern_ms, gathered = timed_region(w, args.steps, world, ctx, stats)
+        bdist.allgather_stats(stats, world, comm)
+    elapsed, kern_ms, gathered = timed_region(w, args.steps, world, ctx, stats, comm)
 
     out = None
     if rank == 0:
@@ -365,7 +368,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": w.workload, "mode": args.mode, "paths_per_gpu": P, "grid_points": N_GRID,
                        "path_steps_per_step": P * steps_per_unit * world,
-                       "parallelism": f"chains sharded over {world} GPU(s), one RCCL all-gather of the statistics block"},
+                       "parallelism": f"chains sharded over {world} GPU(s), one RCCL all-gather of the statistics block "
+                                      "(bhip_comm_allgather_stats, inside libbridgehip.so)"},
             "roofline": w.roofline(kern_ms),
         }
         if w.chains is not None:
@@ -405,7 +409,7 @@ def main():
         wc = Workload("c4shard", ctx, 0, rank)
         for _ in range(args.warmup):
             wc.step()
-        el_c, ms_c, _ = timed_region(wc, args.steps, world, ctx, stats)
+        el_c, ms_c, _ = timed_region(wc, args.steps, world, ctx, stats, comm)
         if rank == 0:
             tp = float(world) * wc.P * steps_per_unit * args.steps
             out["survey_c4"] = {"chains_per_gpu": wc.P, "value": tp / el_c, "unit": "path-steps/s", "ms_per_step": el_c / args.steps * 1e3,
@@ -414,6 +418,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.destroy()
     if world > 1:
         dist.destroy_process_group()
 

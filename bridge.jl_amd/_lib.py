@@ -64,6 +64,14 @@ SIGNATURES = {
     "bhip_chains_save": (C.c_int, [vp, vp]),
     "bhip_chains_load": (C.c_int, [vp, vp]),
     "bhip_welford_merge": (C.c_int, [C.c_long, C.c_int, dp, dp, dp, C.c_double, dp, dp]),
+    "bhip_comm_unique_id": (C.c_int, [vp, C.c_size_t]),
+    "bhip_comm_init_rank": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
+    "bhip_comm_init_all": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(vp)]),
+    "bhip_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bhip_comm_allgather": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "bhip_comm_allgather_stats": (C.c_int, [vp, vp, vp]),
+    "bhip_comm_allgather_group": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_size_t]),
+    "bhip_comm_destroy": (None, [vp]),
     "bhip_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "bhip_normals_host": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, dp]),
 }

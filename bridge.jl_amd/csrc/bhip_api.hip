@@ -5,6 +5,7 @@
 #include "bhip_path_kernel.h"
 #include "bhip_chain_kernel.h"
 #include "bhip_pc_kernel.h"
+#include "bhip_comm.hpp"
 #include "bhip_tile_kernel.h"
 #include "bhip_girsanov_kernel.h"
 #include "bhip_rtc.hpp"
@@ -1305,6 +1306,136 @@ int bhip_welford_merge(long entries, int d, double *na, double *mean_a, double *
     *na = n;
     return BHIP_OK;
 }
+
+// ------------------------------------------------------------------ the collective (RCCL over xGMI), SURVEY 8(e)
+struct bhip_comm {
+    bhip_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int nranks = 0, rank = 0;
+};
+
+static int rccl_fail(bhip_ctx *ctx, const char *what, ncclResult_t r)
+{
+    RcclApi &api = rccl();
+    return fail(ctx, BHIP_EHIP, std::string(what) + ": " + (api.GetErrorString ? api.GetErrorString(r) : "RCCL error"));
+}
+#define RCCL_READY(ctx)                                                                           \
+    RcclApi &api = rccl();                                                                        \
+    if (!api.err.empty()) return fail(ctx, BHIP_EHIP, api.err)
+
+int bhip_comm_unique_id(void *id, size_t bytes)
+{
+    if (!id || bytes < sizeof(ncclUniqueId)) return BHIP_EINVAL;
+    RcclApi &api = rccl();
+    if (!api.err.empty()) return BHIP_EHIP;
+    ncclUniqueId u;
+    if (api.GetUniqueId(&u) != ncclSuccess) return BHIP_EHIP;
+    std::memset(id, 0, bytes);
+    std::memcpy(id, &u, sizeof(u));
+    return BHIP_OK;
+}
+
+int bhip_comm_init_rank(bhip_ctx *ctx, int nranks, int rank, const void *id, bhip_comm **out)
+{
+    if (!ctx || !id || !out) return BHIP_EINVAL;
+    *out = nullptr;
+    NEED_DEVICE(ctx);
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, BHIP_EINVAL, "bhip_comm_init_rank: need 0 <= rank < nranks");
+    RCCL_READY(ctx);
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    ncclComm_t c = nullptr;
+    const ncclResult_t r = api.CommInitRank(&c, nranks, u, rank);
+    if (r != ncclSuccess) return rccl_fail(ctx, "ncclCommInitRank", r);
+    bhip_comm *cm = new (std::nothrow) bhip_comm();
+    if (!cm) { api.CommDestroy(c); return fail(ctx, BHIP_EHIP, "out of host memory"); }
+    cm->ctx = ctx; cm->comm = c; cm->nranks = nranks; cm->rank = rank;
+    *out = cm;
+    return BHIP_OK;
+}
+
+int bhip_comm_init_all(int ndev, bhip_ctx *const *ctxs, bhip_comm **comms_out)
+{
+    if (ndev < 1 || !ctxs || !comms_out) return BHIP_EINVAL;
+    for (int k = 0; k < ndev; k++) {
+        comms_out[k] = nullptr;
+        if (!ctxs[k] || ctxs[k]->host_only) return BHIP_EINVAL;
+    }
+    bhip_ctx *ctx = ctxs[0];
+    RCCL_READY(ctx);
+    std::vector<int> devs(ndev);
+    for (int k = 0; k < ndev; k++) {
+        devs[k] = ctxs[k]->device;
+        for (int j = 0; j < k; j++)
+            if (devs[j] == devs[k]) return fail(ctx, BHIP_EINVAL, "bhip_comm_init_all: one context per device (RCCL refuses two ranks on one device)");
+    }
+    std::vector<ncclComm_t> cs(ndev, nullptr);
+    const ncclResult_t r = api.CommInitAll(cs.data(), ndev, devs.data());
+    if (r != ncclSuccess) return rccl_fail(ctx, "ncclCommInitAll", r);
+    for (int k = 0; k < ndev; k++) {
+        bhip_comm *cm = new (std::nothrow) bhip_comm();
+        if (!cm) return fail(ctx, BHIP_EHIP, "out of host memory");
+        cm->ctx = ctxs[k]; cm->comm = cs[k]; cm->nranks = ndev; cm->rank = k;
+        comms_out[k] = cm;
+    }
+    return BHIP_OK;
+}
+
+int bhip_comm_info(const bhip_comm *comm, int *nranks, int *rank)
+{
+    if (!comm) return BHIP_EINVAL;
+    if (nranks) *nranks = comm->nranks;
+    if (rank) *rank = comm->rank;
+    return BHIP_OK;
+}
+
+int bhip_comm_allgather(bhip_comm *comm, const double *send_dev, double *recv_dev, size_t count)
+{
+    if (!comm || !send_dev || !recv_dev || count == 0) return BHIP_EINVAL;
+    bhip_ctx *ctx = comm->ctx;
+    NEED_DEVICE(ctx);
+    RCCL_READY(ctx);
+    const ncclResult_t r = api.AllGather(send_dev, recv_dev, count, ncclDouble, comm->comm, ctx->stream);
+    if (r != ncclSuccess) return rccl_fail(ctx, "ncclAllGather", r);
+    return BHIP_OK;
+}
+
+int bhip_comm_allgather_stats(bhip_comm *comm, const double *stats_dev, double *all_dev)
+{
+    return bhip_comm_allgather(comm, stats_dev, all_dev, BHIP_STATS_LEN);
+}
+
+int bhip_comm_allgather_group(int n, bhip_comm *const *comms, const double *const *send_dev, double *const *recv_dev, size_t count)
+{
+    if (n < 1 || !comms || !send_dev || !recv_dev || count == 0) return BHIP_EINVAL;
+    for (int k = 0; k < n; k++)
+        if (!comms[k] || !send_dev[k] || !recv_dev[k]) return BHIP_EINVAL;
+    bhip_ctx *ctx = comms[0]->ctx;
+    RCCL_READY(ctx);
+    ncclResult_t r = api.GroupStart();
+    if (r != ncclSuccess) return rccl_fail(ctx, "ncclGroupStart", r);
+    for (int k = 0; k < n && r == ncclSuccess; k++) {
+        if (hipSetDevice(comms[k]->ctx->device) != hipSuccess) { r = ncclUnhandledCudaError; break; }
+        r = api.AllGather(send_dev[k], recv_dev[k], count, ncclDouble, comms[k]->comm, comms[k]->ctx->stream);
+    }
+    const ncclResult_t re = api.GroupEnd();
+    if (r != ncclSuccess) return rccl_fail(ctx, "ncclAllGather (group)", r);
+    if (re != ncclSuccess) return rccl_fail(ctx, "ncclGroupEnd", re);
+    return BHIP_OK;
+}
+
+void bhip_comm_destroy(bhip_comm *comm)
+{
+    if (!comm) return;
+    RcclApi &api = rccl();
+    if (api.err.empty() && comm->comm) {
+        (void)hipSetDevice(comm->ctx->device);
+        (void)hipStreamSynchronize(comm->ctx->stream);
+        api.CommDestroy(comm->comm);
+    }
+    delete comm;
+}
+
 
 void bhip_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
 {

@@ -45,8 +45,64 @@ def shard(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allgather_stats(stats, world=None):
-    """ONE all-gather of the per-rank statistics block -> tensor [world, STATS_LEN] on every rank"""
+class Comm:
+    """The product's own communicator (bhip_comm, RCCL over xGMI, include/bridgehip.h): the all-gather of the statistics
+    block runs inside libbridgehip.so on the context's stream.  One process per GPU: rank 0 draws the RCCL unique id and
+    the launcher's rendezvous (here: whatever torch.distributed group is up -- gloo or nccl) hands it to the other ranks."""
+
+    def __init__(self, ctx, nranks, rank, uid):
+        import ctypes as C
+        self.ctx, self.nranks, self.rank = ctx, int(nranks), int(rank)
+        h = C.c_void_p()
+        buf = (C.c_ubyte * len(uid)).from_buffer_copy(bytes(uid))
+        ctx.check(ctx.lib.bhip_comm_init_rank(ctx.h, self.nranks, self.rank, C.cast(buf, C.c_void_p), C.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def unique_id(ctx):
+        import ctypes as C
+        buf = (C.c_ubyte * 128)()
+        rc = ctx.lib.bhip_comm_unique_id(C.cast(buf, C.c_void_p), 128)
+        if rc != 0:
+            raise RuntimeError(f"bhip_comm_unique_id failed ({rc}): RCCL not available")
+        return bytes(buf)
+
+    @classmethod
+    def from_torch_dist(cls, ctx):
+        """every rank of the initialised torch.distributed group calls this"""
+        if not dist.is_initialized():
+            return cls(ctx, 1, 0, cls.unique_id(ctx))
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.unique_id(ctx) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(ctx, world, rank, box[0])
+
+    def allgather(self, send, recv=None):
+        """send: contiguous float64 device tensor [count]; returns [nranks, count] (one RCCL all-gather, in the library)"""
+        send = send.contiguous()
+        if recv is None:
+            recv = torch.empty(self.nranks * send.numel(), dtype=torch.float64, device=send.device)
+        import ctypes as C
+        self.ctx.check(self.ctx.lib.bhip_comm_allgather(self.h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), send.numel()))
+        return recv.reshape(self.nranks, -1)
+
+    def destroy(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.bhip_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def allgather_stats(stats, world=None, comm=None):
+    """ONE all-gather of the per-rank statistics block -> tensor [world, STATS_LEN] on every rank.
+    comm: a Comm (the product's RCCL communicator); without it the torch.distributed group is used (gloo in the CPU tests)"""
+    if comm is not None:
+        return comm.allgather(stats)
     world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
     if world == 1:
         return stats.reshape(1, -1)

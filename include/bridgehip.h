@@ -251,6 +251,29 @@ int bhip_chains_load(bhip_chains *ch, const void *host_buf);
 int bhip_welford_merge(long entries, int d, double *na, double *mean_a, double *m2_a, double nb,
                        const double *mean_b, const double *m2_b);
 
+/* ------------------------------------------------------------------ multi-GPU: the one collective of the path
+ * The reference has no parallelism (single-threaded Julia; the MH loops of partialbridge_fitzhugh.jl:143-176 run one
+ * chain).  Here chains / proposals are sharded over GPUs by contiguous global path id (path0) with the noise keyed by
+ * that id, so results do not depend on the GPU count and no path data ever crosses a link; what is exchanged is the
+ * statistics block of bhip_chains_stats (and, optionally, Welford states: bhip_chains_pathstats + bhip_welford_merge)
+ * with ONE RCCL all-gather over xGMI.  RCCL is loaded at the first bhip_comm_* call (dlopen librccl.so.1).
+ *   one process per GPU : rank 0 calls bhip_comm_unique_id, the launcher hands the BHIP_COMM_ID_BYTES to every rank
+ *                         (MPI, torch.distributed, a file ...), every rank calls bhip_comm_init_rank on its context;
+ *   one process, n GPUs : bhip_comm_init_all over one context per device, collectives through bhip_comm_allgather_group.
+ * The gather runs on the context's stream, after the kernels that produced the statistics; recv_dev is [nranks][count]. */
+typedef struct bhip_comm bhip_comm;
+#define BHIP_COMM_ID_BYTES 128
+int bhip_comm_unique_id(void *id, size_t bytes);
+int bhip_comm_init_rank(bhip_ctx *ctx, int nranks, int rank, const void *id, bhip_comm **out);
+int bhip_comm_init_all(int ndev, bhip_ctx *const *ctxs, bhip_comm **comms_out);
+int bhip_comm_info(const bhip_comm *comm, int *nranks, int *rank);
+int bhip_comm_allgather(bhip_comm *comm, const double *send_dev, double *recv_dev, size_t count);
+/* = bhip_comm_allgather(comm, stats_dev, all_dev, BHIP_STATS_LEN): all_dev [nranks][BHIP_STATS_LEN] */
+int bhip_comm_allgather_stats(bhip_comm *comm, const double *stats_dev, double *all_dev);
+/* single-process form: the n per-device gathers inside one ncclGroupStart/End */
+int bhip_comm_allgather_group(int n, bhip_comm *const *comms, const double *const *send_dev, double *const *recv_dev, size_t count);
+void bhip_comm_destroy(bhip_comm *comm);
+
 /* ------------------------------------------------------------------ RNG specification helpers (host)
  * bhip-philox-v2: Philox4x32-10, key=(seed lo,hi), counter=(path, stream, iter, block); block j of
  * stream 0 yields the normals 2j, 2j+1 (Box-Muller with the library's deterministic, table-driven log/sincos). */

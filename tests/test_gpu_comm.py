@@ -1,0 +1,95 @@
+"""GPU tests of the collective inside the product: bhip_comm_* (RCCL over xGMI, include/bridgehip.h), SURVEY 8(e).
+
+A gpurun box has ONE GPU, and RCCL refuses two ranks on one device, so what can run here is the real RCCL code path with
+a world of one (communicator creation from a unique id, the all-gather on the context's stream, the single-process
+ncclCommInitAll form) plus, where the box has two or more GPUs, the 2-rank equality test through the same entry points.
+The N > 1 arithmetic (sharding by global id, merging the gathered blocks) is covered on CPU by tests/test_dist_gloo.py.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import bridgehip as bh
+import problems
+from bridgehip import dist as bdist
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return bh.default_context(0)
+
+
+def test_rccl_allgather_of_the_statistics_block_world_of_one(ctx):
+    case = [c for c in problems.cases(129) if c.name == "fhn_partialbridge_extreme"][0]
+    Po = case.bh_proposal(bh, ctx)
+    ch = bh.Chains(Po, case.x0, 512, seed=3)
+    ch.step(0.9, 5)
+    stats = ch.stats()
+    comm = bdist.Comm.from_torch_dist(ctx)          # no process group: a world of one, id drawn locally
+    assert (comm.nranks, comm.rank) == (1, 0)
+    n, r = C.c_int(-1), C.c_int(-1)
+    ctx.check(ctx.lib.bhip_comm_info(comm.h, C.byref(n), C.byref(r)))
+    assert (n.value, r.value) == (1, 0)
+    g = bdist.allgather_stats(stats, 1, comm)       # bhip_comm_allgather -> ncclAllGather on the context's stream
+    torch.cuda.synchronize()
+    assert g.shape == (1, bh.STATS_LEN) and torch.equal(g[0], stats)
+    s = bdist.combine_stats(g)
+    assert s["chains"] == 512 and s["iterations"] == 5 and s["acceptance_rate"] == ch.acc().sum() / (5 * 512)
+    # a longer payload (pointwise Welford state) through the generic entry point
+    _, mean, m2 = ch.pathstats()
+    payload = torch.tensor(np.concatenate([np.ravel(mean), np.ravel(m2)]), dtype=torch.float64, device=ctx.device)
+    out = comm.allgather(payload)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], payload)
+    comm.destroy()
+
+
+def test_single_process_init_all_and_group_gather(ctx):
+    """bhip_comm_init_all over the process's devices (here: as many as the box has) + bhip_comm_allgather_group"""
+    ndev = torch.cuda.device_count()
+    ctxs = [ctx] + [bh.Context(k) for k in range(1, ndev)]
+    hs = (C.c_void_p * ndev)(*[c.h for c in ctxs])
+    comms = (C.c_void_p * ndev)()
+    ctx.check(ctx.lib.bhip_comm_init_all(ndev, hs, comms))
+    send = [torch.arange(8, dtype=torch.float64, device=c.device) + 100 * k for k, c in enumerate(ctxs)]
+    recv = [torch.zeros(8 * ndev, dtype=torch.float64, device=c.device) for c in ctxs]
+    sp = (C.c_void_p * ndev)(*[t.data_ptr() for t in send])
+    rp = (C.c_void_p * ndev)(*[t.data_ptr() for t in recv])
+    ctx.check(ctx.lib.bhip_comm_allgather_group(ndev, comms, sp, rp, 8))
+    for c in ctxs:
+        c.sync()
+    want = torch.cat([torch.arange(8, dtype=torch.float64) + 100 * k for k in range(ndev)])
+    for t in recv:
+        assert torch.equal(t.cpu(), want)
+    for k in range(ndev):
+        ctx.lib.bhip_comm_destroy(comms[k])
+    # argument checking
+    assert ctx.lib.bhip_comm_allgather_group(0, comms, sp, rp, 8) == -1
+    two = (C.c_void_p * 2)(ctx.h, ctx.h)
+    out2 = (C.c_void_p * 2)()
+    assert ctx.lib.bhip_comm_init_all(2, two, out2) == -1   # two ranks on one device
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_bench_two_ranks_over_rccl_equal_one_rank(tmp_path):
+    """bench.py --gpus 2 over real RCCL (torch 'nccl' group for the handshake, bhip_comm_allgather_stats for the data):
+    2 ranks x 4096 chains == 1 rank x 8192 chains, exactly"""
+    common = ["--steps", "4", "--warmup", "0", "--no-cpu-baseline", "--no-other-modes"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--chains", "4096"] + common,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--chains", "8192"] + common,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["config"]["acceptance_rate"] == j1["config"]["acceptance_rate"] and j2["config"]["chains_total"] == 8192
