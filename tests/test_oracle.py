@@ -452,3 +452,26 @@ def test_round1_golden_paths_given_their_wiener_paths():
     log-likelihoods GIVEN them do not involve the generator and must still be reproduced bit for bit -- the round-1
     arithmetic keeps guarding the solver across the change of the noise specification."""
     _check_given_W(np.load(os.path.join(GOLD, "guided_paths_v1.npz")), False)
+
+
+def test_bridgejl_fixtures_if_present():
+    """Outputs of Bridge.jl ITSELF (bridge.jl_amd/julia/bridgejl_fixtures.jl, run by someone who has Julia) on the Wiener
+    paths of the golden file: when tests/golden/julia_out/ exists the oracle must reproduce Bridge.jl's paths and
+    log-likelihoods bit for bit -- the test that would pin parity with the reference.  Skipped here: no julia in the image."""
+    import problems
+    out = os.path.join(GOLD, "julia_out")
+    if not os.path.isdir(out):
+        pytest.skip("no Bridge.jl fixture present (tests/golden/julia_out): parity with Bridge.jl itself stays unpinned")
+    g = np.load(os.path.join(GOLD, "guided_paths_v2.npz"))
+    N, npaths = int(g["meta"][0]), int(g["meta"][1])
+    for c in problems.cases(N):
+        fx = os.path.join(out, c.name + "_X.csv")
+        if not os.path.exists(fx):
+            continue
+        X = np.array([[float.fromhex(v) for v in line.split(",")] for line in open(fx).read().split()]).reshape(npaths, N, c.d)
+        ll = np.array([float.fromhex(v) for v in open(os.path.join(out, c.name + "_ll.csv")).read().split()])
+        ref = c.oracle_proposal()
+        for p in range(npaths):
+            Xo = o.solve_guided(ref, c.x0, g[c.name + "/W"][p])
+            assert np.array_equal(Xo, X[p]), c.name
+            assert o.llikelihood(ref, Xo) == ll[p], c.name
