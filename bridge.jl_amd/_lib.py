@@ -64,6 +64,15 @@ SIGNATURES = {
     "bhip_chains_save": (C.c_int, [vp, vp]),
     "bhip_chains_load": (C.c_int, [vp, vp]),
     "bhip_welford_merge": (C.c_int, [C.c_long, C.c_int, dp, dp, dp, C.c_double, dp, dp]),
+    "bhip_segchains_create": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_long, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(vp)]),
+    "bhip_segchains_destroy": (None, [vp]),
+    "bhip_segchains_init": (C.c_int, [vp, dp, dp, C.c_int]),
+    "bhip_segchains_step": (C.c_int, [vp, dp, dp, C.c_int]),
+    "bhip_segchains_get": (C.c_int, [vp, dp, C.POINTER(C.c_int64), dp]),
+    "bhip_segchains_get_paths": (C.c_int, [vp, C.c_int, C.c_long, C.c_long, dp, dp]),
+    "bhip_segchains_current_X": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_long)]),
+    "bhip_segchains_mcstats": (C.c_int, [vp, C.c_int, C.c_long, dp, dp, C.POINTER(C.c_int64)]),
+    "bhip_segchains_pooled_stats": (C.c_int, [vp, C.c_int, dp, dp, dp]),
     "bhip_comm_unique_id": (C.c_int, [vp, C.c_size_t]),
     "bhip_comm_init_rank": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
     "bhip_comm_init_all": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(vp)]),

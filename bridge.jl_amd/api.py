@@ -836,6 +836,63 @@ class Chains:
             pass
 
 
+class SegChains:
+    """An ensemble of chains over m chained guided segments with ONE Metropolis-Hastings decision per chain and iteration,
+    a pCN move of the starting point and (optionally) mcnext! per iteration -- the loop of
+    supplements/smoothing/smoothing.jl:99-213 (bhip_segchains_*).  pos: the m proposals; pi0 = N(mu, C C')."""
+
+    def __init__(self, pos, mu, chol, nchains, seed=0, path0=0, skip=0, mcnext=False, pooled=False):
+        self.pos, self.ctx = list(pos), pos[0].ctx
+        self.m, self.n, self.d, self.mp, self.N = len(self.pos), int(nchains), pos[0].d, pos[0].mp, len(pos[0].tt)
+        hs = (vp * self.m)(*[P.h for P in self.pos])
+        h = vp()
+        self.ctx.check(self.ctx.lib.bhip_segchains_create(self.ctx.h, self.m, hs, self.n, path0, seed, (1 if mcnext else 0) | (2 if pooled else 0), C.byref(h)))
+        self.h = h
+        mu = np.ascontiguousarray(np.atleast_1d(mu), dtype=np.float64)
+        self.ctx.check(self.ctx.lib.bhip_segchains_init(h, _dptr(mu), _dptr(_cm(np.atleast_2d(chol))), skip))
+        self.iterations = 0
+
+    def step(self, w_old, w_new, iters=None):
+        """iterations with the pCN weights Wo = w_new*W2 + w_old*W (scalars: the same for `iters` iterations, or arrays)"""
+        if np.isscalar(w_old):
+            w_old, w_new = np.full(iters or 1, float(w_old)), np.full(iters or 1, float(w_new))
+        w_old, w_new = np.ascontiguousarray(w_old, dtype=np.float64), np.ascontiguousarray(w_new, dtype=np.float64)
+        self.ctx.check(self.ctx.lib.bhip_segchains_step(self.h, _dptr(w_old), _dptr(w_new), len(w_old)))
+        self.iterations += len(w_old)
+
+    def state(self):
+        """(ll [m, n], acc [n], y0 [n, d])"""
+        ll, acc, y0 = np.empty((self.m, self.n)), np.empty(self.n, dtype=np.int64), np.empty((self.n, self.d))
+        self.ctx.check(self.ctx.lib.bhip_segchains_get(self.h, _dptr(ll), acc.ctypes.data_as(C.POINTER(C.c_int64)), _dptr(y0)))
+        return ll, acc, y0
+
+    def paths(self, segment, p0=0, n=None):
+        n = self.n - p0 if n is None else n
+        X, W = np.empty((n, self.N, self.d)), np.empty((n, self.N, self.mp))
+        self.ctx.check(self.ctx.lib.bhip_segchains_get_paths(self.h, segment, p0, n, _dptr(X), _dptr(W)))
+        return X, W
+
+    def pooled_stats(self, segment):
+        """(mean [N, d], m2 [N, d, d], count) pooled over chains x iterations"""
+        mean, m2, cnt = np.empty((self.N, self.d)), np.empty((self.N, self.d * self.d)), C.c_double()
+        self.ctx.check(self.ctx.lib.bhip_segchains_pooled_stats(self.h, segment, _dptr(mean), _dptr(m2), C.byref(cnt)))
+        return mean, _uncm(m2, self.d, self.d), cnt.value
+
+    def mcstats(self, segment, chain):
+        """the mcnext! state of one chain: (mean [N, d], m2 [N, d, d], count)   src/mclog.jl:48-56"""
+        mean, m2, cnt = np.empty((self.N, self.d)), np.empty((self.N, self.d * self.d)), C.c_int64()
+        self.ctx.check(self.ctx.lib.bhip_segchains_mcstats(self.h, segment, chain, _dptr(mean), _dptr(m2), C.byref(cnt)))
+        return mean, _uncm(m2, self.d, self.d), cnt.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.ctx.lib.bhip_segchains_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 def mcmc(Po, x0, iterations, rho, nchains=1, seed=0, path0=0, skip=0, subsamples=None, store_X=True):
     """The MH loop of partialbridge_fitzhugh.jl:125-176 for `nchains` independent chains.
     Returns dict(chains=Chains, acc=per-chain acceptance counts, ll=final ll,

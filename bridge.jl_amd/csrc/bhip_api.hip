@@ -82,6 +82,7 @@ struct bhip_chains {
     double *llcur = nullptr;
     unsigned int *acc = nullptr;
     double *statpart = nullptr;   // [256][6] per-block partial statistics
+    bool shares_state = false;    // segment > 0 of a multi-segment ensemble: cur / acc / llcur belong to the owner (bhip_segchains)
 };
 
 static int fail(bhip_ctx *ctx, int code, const std::string &msg)
@@ -963,23 +964,27 @@ void bhip_chains_destroy(bhip_chains *ch)
     (void)hipStreamSynchronize(ch->ctx->stream);
     if (ch->Wc) (void)hipFree(ch->Wc);
     if (ch->Xo) (void)hipFree(ch->Xo);
-    if (ch->cur) (void)hipFree(ch->cur);
-    if (ch->llcur) (void)hipFree(ch->llcur);
-    if (ch->acc) (void)hipFree(ch->acc);
+    if (ch->cur && !ch->shares_state) (void)hipFree(ch->cur);
+    if (ch->llcur && !ch->shares_state) (void)hipFree(ch->llcur);
+    if (ch->acc && !ch->shares_state) (void)hipFree(ch->acc);
     if (ch->statpart) (void)hipFree(ch->statpart);
     delete ch;
 }
 
-int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
+// x0_dev (optional): per-chain starting points [d][ldx0] (multi-segment ensembles: the end points of the previous segment);
+// blk0: offset of the Philox block index (segment << 24)
+static int chains_init_impl(bhip_chains *ch, const double *x0, const double *x0_dev, long ldx0, int skip, uint32_t blk0)
 {
-    if (!ch || !x0) return BHIP_EINVAL;
     bhip_ctx *ctx = ch->ctx;
     const bhip_proposal *po = ch->po;
     NEED_DEVICE(ctx);
     if (skip < 0) return fail(ctx, BHIP_EINVAL, "skip must be >= 0");
     ch->x0.assign(x0, x0 + po->mh.d);
-    HIPCHK(ctx, hipMemsetAsync(ch->cur, 0, ch->ld, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ch->acc, 0, sizeof(unsigned int) * ch->ld, ctx->stream));
+    if (!ch->shares_state) {
+        HIPCHK(ctx, hipMemsetAsync(ch->cur, 0, ch->ld, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ch->acc, 0, sizeof(unsigned int) * ch->ld, ctx->stream));
+    }
+    if (po->mh.d > 3 && (x0_dev || blk0)) return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: shared starting point, single segment only");
     if (po->mh.d > 3) {   // MFMA tile kernel: fresh W into a plain SoA scratch array, re-arranged into half 0 of the tile lines; X and ll of the initial state
         const int N = (int)po->tt.size(), d = po->mh.d, T = tile_dim(d) / 16;
         double *tmpW = nullptr;
@@ -997,8 +1002,9 @@ int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
         return BHIP_OK;
     }
     KArgs a;
-    int rc = fill_common(po, a, x0, nullptr, ch->n, skip);
+    int rc = fill_common(po, a, x0, x0_dev, ch->n, skip);
     if (rc) return rc;
+    a.x0_dev = x0_dev; a.ldx0 = ldx0; a.blk0 = blk0;
     double *tmpW = nullptr;
     if (ch->lines) {   // the fresh W goes to a plain SoA scratch array and is re-arranged into half 0 of the lines
         HIPCHK(ctx, hipMalloc((void **)&tmpW, sizeof(double) * po->tt.size() * po->mh.mp * ch->ld));
@@ -1019,6 +1025,29 @@ int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
     if (rc) return rc;
     ch->iter = 0; ch->inited = true;
     return BHIP_OK;
+}
+
+int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
+{
+    if (!ch || !x0) return BHIP_EINVAL;
+    return chains_init_impl(ch, x0, nullptr, 0, skip, 0u);
+}
+
+// ONE pCN proposal of every chain of a segment with the decision deferred (multi-segment ensembles): Wo = w_old*W + w_new*W2,
+// starts from x0_dev, proposal paths to Xo, llo to llo_dev; cur / llcur / acc are left alone (bhip_segchains_step decides)
+static int chains_propose_deferred(bhip_chains *ch, double w_old, double w_new, const double *x0_dev, long ldx0, uint32_t iter, uint32_t blk0,
+                                   double *llo_dev, int skip)
+{
+    const bhip_proposal *po = ch->po;
+    KArgs a;
+    int rc = fill_common(po, a, ch->x0.data(), x0_dev, ch->n, skip);
+    if (rc) return rc;
+    a.x0_dev = x0_dev; a.ldx0 = ldx0; a.blk0 = blk0; a.defer_accept = 1; a.ll = llo_dev;
+    a.Wc = ch->Wc; a.Xo = ch->Xo; a.ldC = ch->ld;
+    a.cur = ch->cur; a.llcur = ch->llcur; a.acc = ch->acc;
+    a.rho = w_old; a.srho = w_new;
+    a.k0 = (uint32_t)ch->seed; a.k1 = (uint32_t)(ch->seed >> 32); a.path0 = ch->path0; a.iter = iter;
+    return do_launch(po, ch->lines ? NOISE_PCN_LINES : NOISE_PCN, a);
 }
 
 int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip)
@@ -1306,6 +1335,8 @@ int bhip_welford_merge(long entries, int d, double *na, double *mean_a, double *
     *na = n;
     return BHIP_OK;
 }
+
+#include "bhip_segchains.inc"
 
 // ------------------------------------------------------------------ the collective (RCCL over xGMI), SURVEY 8(e)
 struct bhip_comm {

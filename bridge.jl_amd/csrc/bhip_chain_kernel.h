@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
     const cptr_t rows = (cptr_t)(uintptr_t)a.rows;
     LaneState<D, MP> st;
 #pragma unroll
-    for (int k = 0; k < D; k++) st.y[k] = a.x0[k];
+    for (int k = 0; k < D; k++) st.y[k] = a.x0_dev ? a.x0_dev[k * a.ldx0 + p] : a.x0[k];
     st.ll = 0.0; st.zc = 0.0;
 #pragma unroll
     for (int k = 0; k < MP; k++) { st.wprev[k] = 0.0; st.w2prev[k] = 0.0; }
@@ -146,11 +146,13 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
     }
     // if log(rand()) <= llo - ll: W <- Wo (parity flip), ll <- llo, acc += 1
     if (live) {
-        const double u = accept_uniform(a.k0, a.k1, path, a.iter);
-        if (det_log(u) <= st.ll - a.llcur[p]) {
-            a.cur[p] = (unsigned char)(c ^ 1);
-            a.llcur[p] = st.ll;
-            a.acc[p] += 1u;
+        if (!a.defer_accept) {
+            const double u = accept_uniform(a.k0, a.k1, path, a.iter);
+            if (det_log(u) <= st.ll - a.llcur[p]) {
+                a.cur[p] = (unsigned char)(c ^ 1);
+                a.llcur[p] = st.ll;
+                a.acc[p] += 1u;
+            }
         }
         if (a.ll) a.ll[p] = st.ll;
     }

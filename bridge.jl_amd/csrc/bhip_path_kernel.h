@@ -69,6 +69,8 @@ struct KArgs {
     unsigned int *acc;
     double rho, srho;
     uint32_t k0, k1, iter, path0;
+    uint32_t blk0;        // offset of the Philox block index (multi-segment chains: segment << 24; 0 otherwise)
+    int defer_accept;     // pCN modes: do not decide -- only report llo in `ll` (joint accept over segments, bhip_segchains_*)
     double x0[3];
     double vend[3];
     double mu_aux[3];
@@ -289,7 +291,7 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int n
         for (int k = 0; k < MP; k++) {
             const int n = i * MP + k;
             double z;
-            if ((n & 1) == 0) normal_pair(tab, a.k0, a.k1, path, a.iter, (uint32_t)(n >> 1), z, st.zc);
+            if ((n & 1) == 0) normal_pair(tab, a.k0, a.k1, path, a.iter, (uint32_t)(n >> 1) + a.blk0, z, st.zc);
             else z = st.zc;
             if constexpr (NOISE == NOISE_FRESH) {
                 const double wn = st.wprev[k] + rdt * z;          // yy[i] = yy[i-1] + rootdt*randn
@@ -544,12 +546,14 @@ __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
 
     if constexpr (NOISE == NOISE_PCN) {
         // if log(rand()) <= llo - ll: X<-Xo, W<-Wo (parity flip), ll<-llo, acc+=1
-        const double u = accept_uniform(a.k0, a.k1, path, a.iter);
-        const double llc = a.llcur[p];
-        if (det_log(u, tab) <= st.ll - llc) {
-            a.cur[p] = (unsigned char)(c ^ 1);
-            a.llcur[p] = st.ll;
-            a.acc[p] += 1u;
+        if (!a.defer_accept) {
+            const double u = accept_uniform(a.k0, a.k1, path, a.iter);
+            const double llc = a.llcur[p];
+            if (det_log(u, tab) <= st.ll - llc) {
+                a.cur[p] = (unsigned char)(c ^ 1);
+                a.llcur[p] = st.ll;
+                a.acc[p] += 1u;
+            }
         }
         if (a.ll) a.ll[p] = st.ll;   // llo trace
     } else {

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(cons
 #ifdef PC_KNOCKOUT_NOISE   /* measurement only: what the consumer alone costs */
                     z0 = 0.25; z1 = -0.5;
 #else
-                    normal_pair(rtab, a.k0, a.k1, path, a.iter, b0 + q, z0, z1);
+                    normal_pair(rtab, a.k0, a.k1, path, a.iter, b0 + q + a.blk0, z0, z1);
 #endif
                     if constexpr (MP == 1) { value(2 * q, carry); value(2 * q + 1, z0); carry = z1; }
                     else { value(2 * q, z0); value(2 * q + 1, z1); }
@@ -275,11 +275,13 @@ __global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(cons
     if constexpr (PCN) {
         // if log(rand()) <= llo - ll: W <- Wo (parity flip), ll <- llo, acc += 1      partialbridge_fitzhugh.jl:160-167
         if (live) {
-            const double u = accept_uniform(a.k0, a.k1, path, a.iter);
-            if (det_log(u, TabLDS(tab)) <= st.ll - a.llcur[p]) {
-                a.cur[p] = (unsigned char)(a.cur[p] ^ 1);
-                a.llcur[p] = st.ll;
-                a.acc[p] += 1u;
+            if (!a.defer_accept) {
+                const double u = accept_uniform(a.k0, a.k1, path, a.iter);
+                if (det_log(u, TabLDS(tab)) <= st.ll - a.llcur[p]) {
+                    a.cur[p] = (unsigned char)(a.cur[p] ^ 1);
+                    a.llcur[p] = st.ll;
+                    a.acc[p] += 1u;
+                }
             }
             if (a.ll) a.ll[p] = st.ll;
         }

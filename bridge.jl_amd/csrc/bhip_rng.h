@@ -10,6 +10,8 @@
 //   stream 0: block j -> standard normals 2j (cos branch) and 2j+1 (sin branch) by Box-Muller,
 //             u1 = (bits53(r0,r1)+1)*2^-53 in (0,1],  u2 = bits53(r2,r3)*2^-53 in [0,1)
 //   stream 1: block 0 -> the Metropolis-Hastings uniform U = (bits53(r0,r1)+1)*2^-53
+//   stream 2: normals of the pCN move of the starting point (multi-segment chains, bhip_segchains_*), same construction
+//   Blocks of stream 0 are offset by segment*2^24 in multi-segment chains (KArgs::blk0): one noise stream per segment.
 //
 // -2*log(u1) and sin/cos(2*pi*u2) are built from integer operations, +, -, *, fma and two small constant
 // tables (bhip_rng_tables.h, generated correctly rounded by scripts/gen_rng_tables.py), so that every host and
@@ -207,9 +209,10 @@ BHIP_HD void det_sincos2pi(double u, uint32_t w, const Tab &tab, double &sn, dou
 
 // block `blk` of stream 0 -> normals 2*blk (z0) and 2*blk+1 (z1)
 template <class Tab>
-BHIP_HD void normal_pair(const Tab &tab, uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t blk, double &z0, double &z1)
+BHIP_HD void normal_pair(const Tab &tab, uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t blk, double &z0, double &z1,
+                         uint32_t stream = 0u)
 {
-    const u32x4 r = philox4x32_10(path, 0u, iter, blk, k0, k1);
+    const u32x4 r = philox4x32_10(path, stream, iter, blk, k0, k1);
     const double u1 = u53_open0(r.x, r.y);
     const double u2 = u53_open1(r.z, r.w);
     const double rad = sqrt_fixed_range(det_m2log(u1, tab));

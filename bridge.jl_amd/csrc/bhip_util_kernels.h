@@ -217,4 +217,100 @@ __global__ __launch_bounds__(256) void k_path_stats(const double *__restrict__ X
         }
 }
 
+// merge a batch (nb samples: mean_b, m2_b) into the running pooled Welford state (na, mean_a, m2_a), per grid point:
+// the parallel form of mcnext (src/mclog.jl:31-38), the same formula as bhip_welford_merge on the host
+static __global__ void k_welford_merge(long entries, int d, double na, double *__restrict__ mean_a, double *__restrict__ m2_a, double nb,
+                                       const double *__restrict__ mean_b, const double *__restrict__ m2_b)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= entries) return;
+    const double n = na + nb;
+    double delta[3];
+    for (int k = 0; k < d; k++) delta[k] = mean_b[e * d + k] - mean_a[e * d + k];
+    for (int c = 0; c < d; c++)
+        for (int r = 0; r < d; r++) {
+            const long q = e * d * d + r + d * c;
+            m2_a[q] = m2_a[q] + m2_b[q] + delta[r] * delta[c] * (na * nb / n);
+        }
+    for (int k = 0; k < d; k++) mean_a[e * d + k] = mean_a[e * d + k] + delta[k] * (nb / n);
+}
+
+// ---- joint MH over chained segments (bhip_segchains.inc): start proposal, joint accept, commit + mcnext!
+template <int D>
+__global__ void k_seg_y0(long n, long ld, double w_old, double w_new, const double *__restrict__ y0, double *__restrict__ y0o,
+                         uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0, KArgs geo /* x0 = mu, mpar[0..D*D) = chol (col-major) */)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    double xi[D + 1];
+#pragma unroll
+    for (int k = 0; k < D; k += 2) normal_pair(TabConst(), k0, k1, path0 + (uint32_t)p, iter, (uint32_t)(k >> 1), xi[k], xi[k + 1], 2u);
+#pragma unroll
+    for (int r = 0; r < D; r++) {
+        double cz = geo.mpar[r] * xi[0];
+#pragma unroll
+        for (int c = 1; c < D; c++) cz += geo.mpar[r + D * c] * xi[c];
+        const double z = geo.x0[r] + cz;                                   // rand(pi0) = mu + C*randn   src/gaussian.jl:54
+        y0o[r * ld + p] = geo.x0[r] + w_new * (z - geo.x0[r]) + w_old * (y0[r * ld + p] - geo.x0[r]);
+    }
+}
+
+static __global__ void k_seg_accept(long n, long ld, int m, int d, const double *__restrict__ llo, double *__restrict__ ll,
+                                    unsigned char *__restrict__ cur, unsigned int *__restrict__ acc, unsigned char *__restrict__ accflag,
+                                    double *__restrict__ y0, const double *__restrict__ y0o, uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    double lls = 0.0;
+    for (int i = 0; i < m; i++) lls += llo[i * ld + p] - ll[i * ld + p];   // ll += llikelihood(XXo[i]) - llikelihood(XX[i])
+    const double u = accept_uniform(k0, k1, path0 + (uint32_t)p, iter);
+    const bool ok = det_log(u) <= lls;
+    accflag[p] = ok ? 1 : 0;
+    if (ok) {
+        cur[p] ^= 1;
+        acc[p] += 1u;
+        for (int i = 0; i < m; i++) ll[i * ld + p] = llo[i * ld + p];
+        for (int k = 0; k < d; k++) y0[k * ld + p] = y0o[k * ld + p];
+    }
+}
+
+// accepted chains: Xc <- Xo;  then (optionally) mcnext! of every chain with its current path:
+//   delta = x - m; m += delta/(n+1); m2 += outer(delta, x - m)        src/mclog.jl:48-56
+template <int D>
+__global__ void k_seg_commit(long n, long ld, int N, const double *__restrict__ Xo, double *__restrict__ Xc, const unsigned char *__restrict__ accflag,
+                             double *__restrict__ mean, double *__restrict__ m2, double count)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (p >= n) return;
+    double x[D];
+    const bool a = accflag[p] != 0;
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        const size_t e = ((size_t)i * D + k) * ld + p;
+        x[k] = a ? Xo[e] : Xc[e];
+        if (a) Xc[e] = x[k];
+    }
+    if (mean) {
+        double delta[D], xm[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            const size_t e = ((size_t)i * D + k) * ld + p;
+            const double mk = mean[e];
+            delta[k] = x[k] - mk;
+            const double mn = mk + delta[k] / (count + 1.0);
+            mean[e] = mn;
+            xm[k] = x[k] - mn;
+        }
+#pragma unroll
+        for (int c = 0; c < D; c++)
+#pragma unroll
+            for (int r = 0; r < D; r++) {
+                const size_t e = ((size_t)i * D * D + r + D * c) * ld + p;
+                m2[e] = m2[e] + delta[r] * xm[c];
+            }
+    }
+}
+
+
 }  // namespace bhip

@@ -251,6 +251,41 @@ int bhip_chains_load(bhip_chains *ch, const void *host_buf);
 int bhip_welford_merge(long entries, int d, double *na, double *mean_a, double *m2_a, double nb,
                        const double *mean_b, const double *m2_b);
 
+/* ------------------------------------------------------------------ joint MH over chained segments (smoothing)
+ * The application loop around the hot path: supplements/smoothing/smoothing.jl:99-213, test/smoothing.jl:73-92.
+ * m guided proposals Po[0..m-1] (same target process, same number of grid points), linked backwards by gpupdate
+ * (bhip_gpupdate) and forwards by the end point bridge! returns (src/euler.jl:267).  Per iteration and chain:
+ *     y0o = mu + w_new*(rand(pi0) - mu) + w_old*(y0 - mu),  pi0 = N(mu, C C')            smoothing.jl:172
+ *     y = y0o; for i: sample!(WWo[i]); WWo[i] = w_new*WWo[i] + w_old*WW[i]; y = bridge!(XXo[i], y, WWo[i], Po[i])
+ *     ll = sum_i llikelihood(XXo[i], Po[i]) - llikelihood(XX[i], Po[i]);  ONE accept: log(U) <= ll  (the script's
+ *          rand() < exp(ll) -- the same event; log is the reproducible form, partialbridge_fitzhugh.jl:161)
+ *     accept: y0 = y0o, XX <-> XXo, WW <-> WWo;    mcstate[i] = mcnext!(mcstate[i], XX[i].yy)   (:211-213, on request)
+ * The script draws rho_ = exp(-alpha*randexp()) per iteration and uses (w_new, w_old) = (sqrt(rho_), sqrt(1-rho_)): the
+ * weights are given per iteration.  d <= 3.  Noise: segment i uses the Philox blocks offset by i*2^24 of stream 0,
+ * the start's normals stream 2, U stream 1 (all keyed by the global chain id path0 + p). */
+typedef struct bhip_segchains bhip_segchains;
+#define BHIP_SEGCHAINS_MCNEXT 1   /* keep the per-chain mcnext! state (mean, m2 per grid point) of every segment on the device */
+#define BHIP_SEGCHAINS_POOLED 2   /* keep ONE state per segment pooled over chains x iterations (one extra read of the current paths per iteration) */
+int bhip_segchains_create(bhip_ctx *ctx, int m, const bhip_proposal *const *pos, long nchains, uint32_t path0, uint64_t seed,
+                          int flags, bhip_segchains **out);
+void bhip_segchains_destroy(bhip_segchains *sc);
+/* mu (d), chol = C (d*d, column-major, lower): pi0 = N(mu, C C').  Initial state: y0 = mu; per segment fresh W,
+ * X = bridge!(...) chained, ll (skip applies to every llikelihood).                               smoothing.jl:99-106 */
+int bhip_segchains_init(bhip_segchains *sc, const double *mu, const double *chol, int skip);
+/* `iters` iterations; w_old[it], w_new[it] host arrays of length iters */
+int bhip_segchains_step(bhip_segchains *sc, const double *w_old, const double *w_new, int iters);
+/* host outputs (any may be NULL): ll [m][nchains] (current, per segment), acc [nchains], y0 [nchains][d] */
+int bhip_segchains_get(bhip_segchains *sc, double *ll, int64_t *acc, double *y0);
+/* current paths of chains p0..p0+np of one segment as AoS host arrays: X [np][N][d], W [np][N][mp] */
+int bhip_segchains_get_paths(bhip_segchains *sc, int segment, long p0, long np, double *X_aos, double *W_aos);
+/* the device-resident current paths of one segment, SoA [N][d][*ld] */
+int bhip_segchains_current_X(bhip_segchains *sc, int segment, double **Xc_dev, long *ld);
+/* the mcnext! state of ONE chain of one segment (src/mclog.jl:48-56): mean [N][d], m2 [N][d*d] (column-major), count */
+int bhip_segchains_mcstats(bhip_segchains *sc, int segment, long chain, double *mean, double *m2, int64_t *count);
+/* the pooled state of one segment: every chain's current path of every iteration as one sample (mcnext semantics,
+ * batches merged with the parallel form, cf. bhip_welford_merge): mean [N][d], m2 [N][d*d], count = chains*iterations */
+int bhip_segchains_pooled_stats(bhip_segchains *sc, int segment, double *mean, double *m2, double *count);
+
 /* ------------------------------------------------------------------ multi-GPU: the one collective of the path
  * The reference has no parallelism (single-threaded Julia; the MH loops of partialbridge_fitzhugh.jl:143-176 run one
  * chain).  Here chains / proposals are sharded over GPUs by contiguous global path id (path0) with the noise keyed by

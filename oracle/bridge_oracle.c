@@ -302,9 +302,9 @@ BO_CLONES void bo_sincos2pi(double u, uint32_t w, double *sn, double *cs)
 
 /* one Philox block -> two standard normals (Box-Muller).  counter = (path, stream, iter, block),
  * key = (seed_lo, seed_hi); stream 0 = Wiener normals, 1 = accept uniforms. */
-BO_CLONES void bo_normal_pair(uint64_t seed, uint32_t path, uint32_t iter, uint32_t block, double z[2])
+BO_CLONES void bo_normal_pair_stream(uint64_t seed, uint32_t path, uint32_t stream, uint32_t iter, uint32_t block, double z[2])
 {
-    uint32_t ctr[4] = {path, 0u, iter, block}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, r[4];
+    uint32_t ctr[4] = {path, stream, iter, block}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, r[4];
     bo_philox4x32_10(ctr, key, r);
     uint64_t a = ((uint64_t)r[1] << 32) | r[0], b = ((uint64_t)r[3] << 32) | r[2];
     double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;   /* (0,1] */
@@ -314,6 +314,10 @@ BO_CLONES void bo_normal_pair(uint64_t seed, uint32_t path, uint32_t iter, uint3
     bo_sincos2pi(u2, r[3], &s, &c);
     z[0] = rad * c;
     z[1] = rad * s;
+}
+BO_CLONES void bo_normal_pair(uint64_t seed, uint32_t path, uint32_t iter, uint32_t block, double z[2])
+{
+    bo_normal_pair_stream(seed, path, 0u, iter, block, z);
 }
 
 double bo_uniform_accept(uint64_t seed, uint32_t path, uint32_t iter)
@@ -1124,6 +1128,129 @@ double bo_ensemble_mcmc(int kind, int N, int d, int mp, int m, int model, const 
 }
 
 /* mcnext! src/mclog.jl:48-56 (vector of d-vectors, m2 = outer(delta, x - m)); scalar case :31-38 */
+/* ------------------------------------------------------------------------------------------
+ * Joint Metropolis-Hastings over m chained GuidedBridge segments with a pCN move of the starting point and
+ * mcnext! per iteration: the non-adaptive core of supplements/smoothing/smoothing.jl:99-213
+ * (test/smoothing.jl:73-92 builds the same chain of proposals):
+ *
+ *   init (:101-106)  y = pi0.mu;  for i in 1:m: sample!(WW[i], Wiener); y = bridge!(XX[i], y, WW[i], Po[i])
+ *   iteration (:165-213)
+ *     y0o = pi0.mu + sqrt(rho_)*(rand(pi0) - pi0.mu) + sqrt(1-rho_)*(y0 - pi0.mu)            :172
+ *     y = y0o;  for i in 1:m: sample!(WWo[i]); WWo[i] = sqrt(rho_)*WWo[i] + sqrt(1-rho_)*WW[i];
+ *                             y = bridge!(XXo[i], y, WWo[i], Po[i])                          :177-184
+ *     ll = sum_i llikelihood(XXo[i], Po[i]) - llikelihood(XX[i], Po[i])                      :187-190
+ *     accept: y0 = y0o, XX <-> XXo, WW <-> WWo                                               :194-201
+ *     for i in 1:m: mcstate[i] = mcnext!(mcstate[i], XX[i].yy)                               :211-213
+ * with the weights (w_new, w_old) = (sqrt(rho_), sqrt(1-rho_)) supplied by the caller (the script draws
+ * rho_ = exp(-alpha*randexp()) per iteration) and rand(pi0) = pi0.mu + C*randn (src/gaussian.jl:54, C = cholupper(Sigma)').
+ * The accept test is log(U) <= ll, the form of partialbridge_fitzhugh.jl:161 (the script writes rand() < exp(ll):
+ * the same event up to rounding at equality; exp is not reproducible across libm/ocml, log is the specification's).
+ * Noise: segment i draws the Philox blocks offset by i*2^24 of stream 0; the start's normals are stream 2; U is stream 1.
+ * All segments share d, m', the target model and the number of grid points N (as in the scripts: M + 1 points each).
+ * ------------------------------------------------------------------------------------------ */
+static void wiener_sample_blk(const double *tt, int N, int mp, uint64_t seed, uint32_t path, uint32_t iter, uint32_t blk0, double *W)
+{
+    for (int j = 0; j < mp; j++) W[j] = 0.0;
+    double pr[2]; long have = -1;
+    for (int i = 1; i < N; i++) {
+        double rootdt = sqrt(tt[i] - tt[i - 1]);
+        for (int j = 0; j < mp; j++) {
+            int idx = (i - 1) * mp + j;
+            if ((idx >> 1) != have) { bo_normal_pair(seed, path, iter, blk0 + (uint32_t)(idx >> 1), pr); have = idx >> 1; }
+            W[mp * i + j] = W[mp * (i - 1) + j] + rootdt * pr[idx & 1];
+        }
+    }
+}
+
+/* props: m proposals.  Xall / Wall: [m][N][d] / [m][N][mp] current state out.  y0_out [d].  mean/m2/nstat: per segment
+ * mcnext! states ([m][N][d], [m][N][d*d], one count) or NULL.  w_old/w_new: [iters] weights per iteration. */
+void bo_smooth_mcmc(int m, const bo_proposal *props, const double *mu, const double *chol, const double *w_old, const double *w_new,
+                    int iters, int skip, uint64_t seed, uint32_t path, double *Xall, double *Wall, double *y0_out,
+                    double *ll_out /* [m] */, long *acc_out, double *mean, double *m2, long *nstat)
+{
+    const int N = props[0].N, d = props[0].d, mp = props[0].mp;
+    const size_t nx = (size_t)N * d, nw = (size_t)N * mp;
+    double *Xo = (double *)malloc(sizeof(double) * nx * m), *Wo = (double *)malloc(sizeof(double) * nw * m);
+    double *W2 = (double *)malloc(sizeof(double) * nw);
+    double *ll = ll_out, *llo = (double *)malloc(sizeof(double) * m);
+    double y0[BO_MAXD], y0o[BO_MAXD], y[BO_MAXD];
+    long acc = 0, ns = 0;
+    for (int k = 0; k < d; k++) y0[k] = mu[k];
+    memcpy(y, y0, sizeof(double) * d);
+    for (int i = 0; i < m; i++) {
+        wiener_sample_blk(props[i].tt, N, mp, seed, path, 0, (uint32_t)i << 24, Wall + nw * i);
+        bo_solve_guided(&props[i], y, Wall + nw * i, Xall + nx * i);
+        memcpy(y, Xall + nx * i + (size_t)(N - 1) * d, sizeof(double) * d);      /* bridge! returns yy[N]  src/euler.jl:267 */
+        ll[i] = bo_llikelihood(&props[i], Xall + nx * i, skip);
+    }
+    if (mean) {   /* mcstart(XX[i].yy): zeros, count 0  src/mclog.jl:22 */
+        memset(mean, 0, sizeof(double) * nx * m);
+        memset(m2, 0, sizeof(double) * nx * d * m);
+    }
+    for (int it = 1; it <= iters; it++) {
+        const double wo = w_old[it - 1], wn = w_new[it - 1];
+        /* rand(pi0) = mu + C*xi, xi = the first d normals of stream 2 */
+        double xi[BO_MAXD + 1], pr[2];
+        for (int k = 0; k < d; k += 2) {
+            bo_normal_pair_stream(seed, path, 2u, (uint32_t)it, (uint32_t)(k >> 1), pr);
+            xi[k] = pr[0]; xi[k + 1] = pr[1];
+        }
+        for (int r = 0; r < d; r++) {
+            double cz = chol[r] * xi[0];
+            for (int c = 1; c < d; c++) cz += chol[r + d * c] * xi[c];
+            const double z = mu[r] + cz;
+            y0o[r] = mu[r] + wn * (z - mu[r]) + wo * (y0[r] - mu[r]);
+        }
+        memcpy(y, y0o, sizeof(double) * d);
+        for (int i = 0; i < m; i++) {
+            wiener_sample_blk(props[i].tt, N, mp, seed, path, (uint32_t)it, (uint32_t)i << 24, W2);
+            const double *Wc = Wall + nw * i;
+            double *Wp = Wo + nw * i;
+            for (size_t k = 0; k < nw; k++) Wp[k] = wo * Wc[k] + wn * W2[k];
+            bo_solve_guided(&props[i], y, Wp, Xo + nx * i);
+            memcpy(y, Xo + nx * i + (size_t)(N - 1) * d, sizeof(double) * d);
+            llo[i] = bo_llikelihood(&props[i], Xo + nx * i, skip);
+        }
+        double lls = 0.0;
+        for (int i = 0; i < m; i++) lls += llo[i] - ll[i];
+        if (bo_log(bo_uniform_accept(seed, path, (uint32_t)it)) <= lls) {
+            acc += 1;
+            memcpy(y0, y0o, sizeof(double) * d);
+            memcpy(Xall, Xo, sizeof(double) * nx * m);
+            memcpy(Wall, Wo, sizeof(double) * nw * m);
+            memcpy(ll, llo, sizeof(double) * m);
+        }
+        if (mean) {
+            long n_i = ns;
+            for (int i = 0; i < m; i++) { n_i = ns; bo_mcnext(N, d, mean + nx * i, m2 + nx * d * i, &n_i, Xall + nx * i); }
+            ns = n_i;
+        }
+    }
+    memcpy(y0_out, y0, sizeof(double) * d);
+    *acc_out = acc;
+    if (nstat) *nstat = ns;
+    free(Xo); free(Wo); free(W2); free(llo);
+}
+
+/* ctypes wrapper: the m proposals as flat arrays of equal shapes; A1..A4 hold the m guides back to back, tts the m grids */
+void bo_smooth_mcmc_flat(int m, int kind, int N, int d, int mp, int mo, int model, const double *par, int aux, const double *apars, int napar,
+                         const double *tts, const double *A1, const double *A2, const double *A3, const double *A4,
+                         const double *mu, const double *chol, const double *w_old, const double *w_new, int iters, int skip,
+                         uint64_t seed, uint32_t path, double *Xall, double *Wall, double *y0_out, double *ll_out, long *acc_out,
+                         double *mean, double *m2, long *nstat)
+{
+    bo_proposal *ps = (bo_proposal *)malloc(sizeof(bo_proposal) * m);
+    size_t s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+    if (kind == BO_GUIDE_HV) { s1 = (size_t)N * d * d; s2 = (size_t)N * d; }
+    else if (kind == BO_GUIDE_LMMU) { s1 = (size_t)N * mo * d; s2 = (size_t)N * mo * mo; s3 = (size_t)N * mo; s4 = mo; }
+    else { s1 = (size_t)N * d; s2 = (size_t)N * d * d; }
+    for (int i = 0; i < m; i++)
+        mk_prop(&ps[i], kind, N, d, mp, mo, model, par, aux, apars + (size_t)napar * i, tts + (size_t)N * i,
+                A1 + s1 * i, A2 + s2 * i, A3 ? A3 + s3 * i : NULL, A4 ? A4 + s4 * i : NULL);
+    bo_smooth_mcmc(m, ps, mu, chol, w_old, w_new, iters, skip, seed, path, Xall, Wall, y0_out, ll_out, acc_out, mean, m2, nstat);
+    free(ps);
+}
+
 void bo_mcnext(int n_entries, int d, double *mean, double *m2, long *n, const double *x)
 {
     long nn = *n;

@@ -185,6 +185,17 @@ void bo_innovations_flat(int kind, int N, int d, int mp, int m, int model, const
 double bo_girsanov(int model, int d, int mp, const double *par, const double *par_t,
                    const double *tt, int N, const double *X);
 
+/* ---- joint MH over chained segments, pCN on the start, mcnext! per iteration (supplements/smoothing/smoothing.jl:99-213) ---- */
+void bo_normal_pair_stream(uint64_t seed, uint32_t path, uint32_t stream, uint32_t iter, uint32_t block, double z[2]);
+void bo_smooth_mcmc(int m, const bo_proposal *props, const double *mu, const double *chol, const double *w_old, const double *w_new,
+                    int iters, int skip, uint64_t seed, uint32_t path, double *Xall, double *Wall, double *y0_out,
+                    double *ll_out, long *acc_out, double *mean, double *m2, long *nstat);
+void bo_smooth_mcmc_flat(int m, int kind, int N, int d, int mp, int mo, int model, const double *par, int aux, const double *apars, int napar,
+                         const double *tts, const double *A1, const double *A2, const double *A3, const double *A4,
+                         const double *mu, const double *chol, const double *w_old, const double *w_new, int iters, int skip,
+                         uint64_t seed, uint32_t path, double *Xall, double *Wall, double *y0_out, double *ll_out, long *acc_out,
+                         double *mean, double *m2, long *nstat);
+
 /* ---- online statistics (src/mclog.jl:22-56,89-93) ---- */
 void bo_mcnext(int n_entries, int d, double *mean, double *m2, long *n, const double *x);
 

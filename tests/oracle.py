@@ -429,6 +429,37 @@ def ensemble_mcmc(P, x0, rho, iters, nchains, path0, seed, threads=1):
     return n, ll, acc
 
 
+def smooth_mcmc(props, mu, chol, w_old, w_new, seed, path, skip=0, stats=False):
+    """bo_smooth_mcmc: joint MH over the chained proposals `props` (supplements/smoothing/smoothing.jl:99-213).
+    Returns dict(X [m,N,d], W [m,N,mp], y0 [d], ll [m], acc, and with stats: mean [m,N,d], m2 [m,N,d,d], n)"""
+    m, P0 = len(props), props[0]
+    N, d, mp = P0.N, P0.d, P0.mp
+    cat = lambda k: (None if P0.A[k] is None else np.ascontiguousarray(np.concatenate([np.ravel(P.A[k]) for P in props])))
+    A = [cat(k) for k in range(4)]
+    ptr = [None if a is None else a.ctypes.data_as(dp) for a in A]
+    tts = np.ascontiguousarray(np.concatenate([P.tt for P in props]))
+    apars = np.ascontiguousarray(np.concatenate([P.apar for P in props]))
+    mu = np.ascontiguousarray(np.atleast_1d(mu), dtype=np.float64)
+    ch = np.ascontiguousarray(cm(np.atleast_2d(chol)), dtype=np.float64)
+    w_old, w_new = np.ascontiguousarray(w_old, dtype=np.float64), np.ascontiguousarray(w_new, dtype=np.float64)
+    X, W = np.empty((m, N, d)), np.empty((m, N, mp))
+    y0, ll, acc = np.empty(d), np.empty(m), C.c_long()
+    mean = np.empty((m, N, d)) if stats else None
+    m2 = np.empty((m, N, d * d)) if stats else None
+    ns = C.c_long()
+    lib().bo_smooth_mcmc_flat(C.c_int(m), C.c_int(P0.kind), C.c_int(N), C.c_int(d), C.c_int(mp), C.c_int(P0.m), C.c_int(P0.model),
+                              P0.par.ctypes.data_as(dp), C.c_int(P0.aux), apars.ctypes.data_as(dp), C.c_int(len(P0.apar)),
+                              tts.ctypes.data_as(dp), *ptr, mu.ctypes.data_as(dp), ch.ctypes.data_as(dp),
+                              w_old.ctypes.data_as(dp), w_new.ctypes.data_as(dp), C.c_int(len(w_old)), C.c_int(skip),
+                              C.c_uint64(seed), C.c_uint32(path), X.ctypes.data_as(dp), W.ctypes.data_as(dp), y0.ctypes.data_as(dp),
+                              ll.ctypes.data_as(dp), C.byref(acc), None if mean is None else mean.ctypes.data_as(dp),
+                              None if m2 is None else m2.ctypes.data_as(dp), C.byref(ns))
+    out = dict(X=X, W=W, y0=y0, ll=ll, acc=acc.value)
+    if stats:
+        out.update(mean=mean, m2=np.swapaxes(m2.reshape(m, N, d, d), -1, -2).copy(), n=ns.value)
+    return out
+
+
 def mcnext(mean, m2, n, x):
     """in-place Welford update; mean [E,d], m2 [E,d*d] (column-major per entry), returns n+1"""
     E, d = mean.shape

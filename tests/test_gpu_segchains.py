@@ -1,0 +1,117 @@
+"""GPU tests of the joint Metropolis-Hastings over chained segments (bhip_segchains_*), the loop of
+supplements/smoothing/smoothing.jl:99-213 / test/smoothing.jl:73-92, against its oracle twin bo_smooth_mcmc.
+
+Bit-exact (==) for polynomial drifts: current paths of every segment, Wiener paths, per-segment log-likelihoods, the
+pCN-moved starting point, acceptance counts and the per-chain mcnext! state (mean, m2) after every iteration count.
+"""
+import numpy as np
+import pytest
+
+import bridgehip as bh
+import oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return bh.default_context(0)
+
+
+def build_segments(ctx, kind, m=3, M=40):
+    """m chained GuidedBridge segments, backward recursion of (Hdiamond, v) through gpupdate (test/smoothing.jl:73-85)"""
+    rng = np.random.default_rng(5)
+    if kind == "linpro2":         # d = m' = 2: line layout, wave-specialised kernel
+        d = 2
+        B = np.array([[-1, 0.1], [-0.2, -1]])
+        sig = 2 * np.array([[-0.212887, 0.0687025], [0.193157, 0.388997]])
+        P, Pt = bh.LinPro(B, [0.02, 0.03], sig), bh.LinPro(0.8 * B, [0.0, 0.0], sig)
+        model, par, aux, apar = o.MODEL_LINPRO, o.linpro_par(B, [0.02, 0.03], sig), o.AUX_LINPRO, o.linpro_par(0.8 * B, [0.0, 0.0], sig)
+        L, Sig = np.array([[1.0, 0.0]]), np.array([[0.05]])
+    elif kind == "ou1":           # d = m' = 1
+        d = 1
+        P, Pt = bh.LinPro([[-0.8]], [0.0], [[0.8]]), bh.LinPro([[-0.8]], [0.2], [[0.8]])
+        model, par, aux, apar = o.MODEL_LINPRO, o.linpro_par([[-0.8]], [0.0], [[0.8]]), o.AUX_LINPRO, o.linpro_par([[-0.8]], [0.2], [[0.8]])
+        L, Sig = np.array([[1.0]]), np.array([[0.1]])
+    else:                         # Lorenz, d = m' = 3: slot layout, path-per-lane kernel   (test/smoothing.jl:19-21)
+        d = 3
+        P = bh.Lorenz((10.0, 20.0, 8 / 3), (3.0, 3.0, 3.0))
+        Pt = bh.LinPro(-np.eye(3), [0.0, 0.0, 0.0], 3.0 * np.eye(3))
+        model, par = o.MODEL_LORENZ, [10.0, 20.0, 8 / 3, 3.0, 3.0, 3.0]
+        aux, apar = o.AUX_LINPRO, o.linpro_par(-np.eye(3), [0.0, 0.0, 0.0], 3.0 * np.eye(3))
+        L, Sig = np.eye(3), np.eye(3)
+    mo = L.shape[0]
+    tgrid = np.linspace(0, 0.3 * m, m * M + 1)
+    obs = rng.standard_normal((m + 1, mo))
+    H, v = bh.gpupdate(np.diag([np.inf] * d), np.zeros(d), np.eye(d), 0.5 * np.eye(d), np.concatenate([obs[m], np.zeros(d)])[:d])
+    segs, refs = [None] * m, [None] * m
+    for i in range(m - 1, -1, -1):
+        tt = tgrid[i * M:(i + 1) * M + 1].copy()
+        segs[i] = bh.GuidedBridge(tt, P, Pt, v, H, ctx=ctx)
+        refs[i] = o.proposal_hv(tt, d, d, model, par, aux, apar, segs[i].Hd, segs[i].V)
+        H, v = bh.gpupdate(segs[i], L, Sig, obs[i])
+    # pi0 = Gaussian(v, Hdiamond) after the last update (smoothing.jl:97-99)
+    return segs, refs, v, np.linalg.cholesky((H + H.T) / 2), d
+
+
+@pytest.mark.parametrize("kind", ["linpro2", "ou1", "lorenz"])
+def test_joint_mh_over_segments_equals_oracle(ctx, kind):
+    segs, refs, mu, chol, d = build_segments(ctx, kind)
+    n, iters = 200, 7
+    rng = np.random.default_rng(0)
+    rho_ = np.exp(-0.5 * rng.exponential(size=iters))          # smoothing.jl:171  rho_ = exp(-alpha*randexp())
+    w_new, w_old = np.sqrt(rho_), np.sqrt(1 - rho_)
+    sc = bh.SegChains(segs, mu, chol, n, seed=17, path0=40, mcnext=True)
+    sc.step(w_old[:3], w_new[:3])
+    sc.step(w_old[3:], w_new[3:])                              # iteration counters continue across calls
+    ll, acc, y0 = sc.state()
+    total_acc = 0
+    for p in (0, 63, 64, 199):
+        r = o.smooth_mcmc(refs, mu, chol, w_old, w_new, 17, 40 + p, stats=True)
+        for i in range(len(segs)):
+            X, W = sc.paths(i, p, 1)
+            assert np.array_equal(X[0], r["X"][i]), (kind, p, i, np.abs(X[0] - r["X"][i]).max())
+            assert np.array_equal(W[0], r["W"][i])
+            mean, m2, cnt = sc.mcstats(i, p)
+            assert cnt == iters == r["n"]
+            assert np.array_equal(mean, r["mean"][i]) and np.array_equal(m2, r["m2"][i])
+        assert np.array_equal(ll[:, p], r["ll"]) and acc[p] == r["acc"] and np.array_equal(y0[p], r["y0"])
+        total_acc += r["acc"]
+    assert 0 < acc.sum() < n * iters
+    # joints: every current path is continuous across the segment boundaries and starts at the chain's y0
+    X0, _ = sc.paths(0, 0, n)
+    assert np.array_equal(X0[:, 0, :], y0)
+    for i in range(len(segs) - 1):
+        Xa, _ = sc.paths(i, 0, n)
+        Xb, _ = sc.paths(i + 1, 0, n)
+        assert np.array_equal(Xa[:, -1, :], Xb[:, 0, :])
+
+
+def test_segchains_argument_checks(ctx):
+    segs, refs, mu, chol, d = build_segments(ctx, "ou1", m=2)
+    other = bh.GuidedBridge(np.linspace(0, 1, 11), bh.LinPro([[-0.8]], [0.0], [[0.8]]), bh.LinPro([[-0.8]], [0.2], [[0.8]]), [0.1], ctx=ctx)
+    with pytest.raises(bh.BridgeError, match="number of grid points"):
+        bh.SegChains([segs[0], other], mu, chol, 8)
+    sc = bh.SegChains(segs, mu, chol, 8)              # without mcnext
+    sc.step(0.9, np.sqrt(1 - 0.81), 2)
+    with pytest.raises(bh.BridgeError, match="MCNEXT"):
+        sc.mcstats(0, 0)
+
+
+def test_pooled_statistics_over_chains_and_iterations(ctx):
+    """BHIP_SEGCHAINS_POOLED: the device-resident mcnext over chains x iterations equals mean / scatter of all current paths"""
+    segs, refs, mu, chol, d = build_segments(ctx, "linpro2", m=2)
+    n, iters = 300, 5
+    sc = bh.SegChains(segs, mu, chol, n, seed=5, pooled=True)
+    samples = [[], []]
+    for it in range(iters):
+        sc.step(0.8, 0.6, 1)
+        for i in range(2):
+            samples[i].append(sc.paths(i, 0, n)[0])
+    for i in range(2):
+        S = np.concatenate(samples[i])                       # [iters*n, N, d]
+        mean, m2, cnt = sc.pooled_stats(i)
+        assert cnt == n * iters
+        assert np.allclose(mean, S.mean(0), rtol=1e-12, atol=1e-13)
+        dev = S - S.mean(0)
+        assert np.allclose(m2, np.einsum("sni,snj->nij", dev, dev), rtol=1e-10, atol=1e-11)
