@@ -35,6 +35,8 @@ SIGNATURES = {
     "bhip_proposal_destroy": (None, [vp]),
     "bhip_proposal_set_aux": (C.c_int, [vp, C.c_int, dp, C.c_int]),
     "bhip_proposal_set_aux_callback": (C.c_int, [vp, vp, vp, C.c_int, dp]),
+    "bhip_proposal_set_aux_linearappr": (C.c_int, [vp, dp, dp, dp, dp]),
+    "bhip_linearappr": (C.c_int, [vp, dp, dp, dp, dp]),
     "bhip_proposal_guide_hv": (C.c_int, [vp, dp, dp]),
     "bhip_proposal_guide_lmmu": (C.c_int, [vp, C.c_int, dp, dp, dp]),
     "bhip_proposal_guide_nuh": (C.c_int, [vp, C.c_int, dp, dp, C.c_double, dp, C.c_int]),
@@ -72,6 +74,7 @@ SIGNATURES = {
     "bhip_segchains_get_paths": (C.c_int, [vp, C.c_int, C.c_long, C.c_long, dp, dp]),
     "bhip_segchains_current_X": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_long)]),
     "bhip_segchains_mcstats": (C.c_int, [vp, C.c_int, C.c_long, dp, dp, C.POINTER(C.c_int64)]),
+    "bhip_segchains_set_proposals": (C.c_int, [vp, C.POINTER(vp)]),
     "bhip_segchains_pooled_stats": (C.c_int, [vp, C.c_int, dp, dp, dp]),
     "bhip_comm_unique_id": (C.c_int, [vp, C.c_size_t]),
     "bhip_comm_init_rank": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),

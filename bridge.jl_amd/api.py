@@ -39,6 +39,7 @@ STATS_LEN = 8
 
 
 OPT_WAVE_SPECIALISED = 1   # BHIP_OPT_WAVE_SPECIALISED
+AUX_LINEARAPPR = 4         # BHIP_AUX_LINEARAPPR
 
 
 class BridgeError(RuntimeError):
@@ -321,6 +322,34 @@ def fitzhugh_aux_linearised_end(P, v):
     return AffineAux(B, beta, [[0.0], [P.sigma]])
 
 
+class LinearAppr:
+    """LinearAppr (src/linpro.jl:181-204): the linearisation of a target along a path on the proposal's grid.
+    LinearAppr(xx, B, b, Sigma) with arrays [N, d], [N, d, d], [N, d], [N, d, m'] -- or LinearAppr.along(Y) = linearappr(Y, P):
+    B_i = bderiv(t_i, y_i, P), b_i = b(t_i, y_i, P), Sigma_i = sigma(t_i, y_i, P), filled by the library for the proposal's target."""
+    aux_kind = 4
+
+    def __init__(self, xx, B=None, b=None, Sigma=None):
+        self.xx = np.ascontiguousarray(np.atleast_2d(xx), dtype=np.float64)
+        self.B, self.b, self.Sigma = B, b, Sigma
+
+    @classmethod
+    def along(cls, Y):
+        return cls(Y)
+
+    def _fill(self, po):
+        N, d, mp = len(po.tt), po.d, po.mp
+        B, b, S = np.empty((N, d * d)), np.empty((N, d)), np.empty((N, d * mp))
+        po.ctx.check(po.ctx.lib.bhip_linearappr(po.h, _dptr(self.xx), _dptr(B), _dptr(b), _dptr(S)))
+        self.B = np.swapaxes(B.reshape(N, d, d), -1, -2).copy()
+        self.b = b
+        self.Sigma = np.swapaxes(S.reshape(N, mp, d), -1, -2).copy()
+
+
+def linearappr(Y, P=None):
+    """linearappr(Y, P)  src/linpro.jl:196 -- the target P is the proposal's (filled when the GuidedBridge is built)"""
+    return LinearAppr.along(Y.yy if hasattr(Y, "yy") else Y)
+
+
 class CallbackAux:
     """user-defined auxiliary: fn(t) -> (B, beta, a) evaluated on the host while the guide ODE is
     integrated (the Python twin of a Julia @cfunction)"""
@@ -439,7 +468,13 @@ class _Proposal(ContinuousTimeProcess):
                                                 _dptr(par), len(par), C.byref(h)))
         self.h = h
         if Pt is not None:
-            if Pt.aux_kind == AUX_CALLBACK:
+            if Pt.aux_kind == AUX_LINEARAPPR:
+                if Pt.B is None:      # LinearAppr given as (path Y, target): linearappr(Y, P) on the host  src/linpro.jl:196
+                    Pt._fill(self)
+                cmN = lambda A: np.ascontiguousarray(np.swapaxes(np.asarray(A, dtype=np.float64), -1, -2))   # [N] column-major matrices
+                self.ctx.check(lib.bhip_proposal_set_aux_linearappr(h, _dptr(np.ascontiguousarray(Pt.xx, dtype=np.float64)), _dptr(cmN(Pt.B)),
+                                                                    _dptr(np.ascontiguousarray(Pt.b, dtype=np.float64)), _dptr(cmN(Pt.Sigma))))
+            elif Pt.aux_kind == AUX_CALLBACK:
                 mu = None if Pt.mu is None else _dptr(np.ascontiguousarray(Pt.mu))
                 self.ctx.check(lib.bhip_proposal_set_aux_callback(h, C.cast(Pt._cfn, vp), None, 0 if Pt.mu is None else 1, mu))
             else:
@@ -871,6 +906,27 @@ class SegChains:
         X, W = np.empty((n, self.N, self.d)), np.empty((n, self.N, self.mp))
         self.ctx.check(self.ctx.lib.bhip_segchains_get_paths(self.h, segment, p0, n, _dptr(X), _dptr(W)))
         return X, W
+
+    def set_proposals(self, pos):
+        """hand over re-built proposals (same shapes): the chains keep their state, ll of the current paths is re-evaluated"""
+        pos = list(pos)
+        hs = (vp * self.m)(*[P.h for P in pos])
+        self.ctx.check(self.ctx.lib.bhip_segchains_set_proposals(self.h, hs))
+        self.pos = pos            # keeps the new proposals alive (and lets the old ones go)
+
+    def adapt(self, P, L, Sigma, obs, HT, vT, means=None):
+        """Adaptive smoothing step, supplements/smoothing/smoothing.jl:130-160: re-linearise every segment's LinearAppr
+        around the running mean of its paths (pooled over the ensemble unless `means` gives them), rebuild the chain of
+        GuidedBridge's backwards from (HT, vT) with gpupdate at the observations obs[i] (obs[m] belongs to the right end and
+        is already folded into (HT, vT)), and hand the new proposals over.  Returns (mu, Hd) of the new pi0 = N(mu, Hd)."""
+        H, v = np.array(HT, dtype=np.float64), np.array(vT, dtype=np.float64)
+        new = [None] * self.m
+        for i in range(self.m - 1, -1, -1):
+            Y = means[i] if means is not None else self.pooled_stats(i)[0]
+            new[i] = GuidedBridge(self.pos[i].tt, P, linearappr(Y), v, H, ctx=self.ctx)
+            H, v = gpupdate(new[i], L, Sigma, obs[i])
+        self.set_proposals(new)
+        return v, H
 
     def pooled_stats(self, segment):
         """(mean [N, d], m2 [N, d, d], count) pooled over chains x iterations"""

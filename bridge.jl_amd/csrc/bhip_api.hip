@@ -398,6 +398,61 @@ int bhip_proposal_set_aux(bhip_proposal *po, int kind, const double *apar, int n
     return BHIP_OK;
 }
 
+int bhip_proposal_set_aux_linearappr(bhip_proposal *po, const double *xx, const double *B, const double *b, const double *Sigma)
+{
+    if (!po) return BHIP_EINVAL;
+    bhip_ctx *ctx = po->ctx;
+    if (!xx || !B || !b || !Sigma) return fail(ctx, BHIP_EINVAL, "bhip_proposal_set_aux_linearappr: null array");
+    const int d = po->mh.d, mp = po->mh.mp;
+    const size_t N = po->tt.size();
+    if (d > 3) return fail(ctx, BHIP_EUNSUPPORTED, "LinearAppr auxiliary: d <= 3");
+    if (!po->mh.constdiff) return fail(ctx, BHIP_EUNSUPPORTED, "LinearAppr auxiliary: the target must have a constant sigma");
+    // constant-diffusivity log-likelihood: the linearisation's Sigma_i must be the target's sigma (a~ = a)
+    const double *sg = po->mh.id == BHIP_MODEL_LINPRO ? po->mh.par.data() + d * d + d : nullptr;
+    for (size_t i = 0; i < N; i++) {
+        const Mat Si(d, mp, Sigma + i * d * mp);
+        const Mat ai = outer(Si);
+        for (int k = 0; k < d * d; k++)
+            if (ai.a[k] != po->mh.a.a[k]) return fail(ctx, BHIP_EUNSUPPORTED, "LinearAppr auxiliary: Sigma_i*Sigma_i' differs from the target's a (state-dependent diffusivity is not supported here)");
+        (void)sg;
+    }
+    po->aux = Aux();
+    po->aux.kind = BHIP_AUX_LINEARAPPR; po->aux.d = d; po->aux.mp = mp;
+    po->aux.la_tt = po->tt;
+    po->aux.la_xx.assign(xx, xx + N * d);
+    po->aux.la_B.assign(B, B + N * d * d);
+    po->aux.la_b.assign(b, b + N * d);
+    po->aux.la_S.assign(Sigma, Sigma + N * d * mp);
+    po->has_aux = true;
+    return BHIP_OK;
+}
+
+int bhip_linearappr(const bhip_proposal *po, const double *Y, double *B, double *b, double *Sigma)
+{
+    if (!po || !Y || !B || !b || !Sigma) return BHIP_EINVAL;
+    bhip_ctx *ctx = po->ctx;
+    const int d = po->mh.d, mp = po->mh.mp;
+    const size_t N = po->tt.size();
+    for (size_t i = 0; i < N; i++) {
+        Mat J, bb;
+        if (!host_bderiv(po->mh, Y + i * d, J) || !host_b(po->mh, Y + i * d, bb))
+            return fail(ctx, BHIP_EUNSUPPORTED, "bhip_linearappr: bderiv is defined for Lorenz, Pendulum, LinPro and Wiener (as in the reference)");
+        std::memcpy(B + i * d * d, J.a.data(), sizeof(double) * d * d);
+        std::memcpy(b + i * d, bb.a.data(), sizeof(double) * d);
+        // sigma(t, x, P) of the built-in processes is constant: the matrix whose outer product is the model's a
+        Mat S(d, mp);
+        const double *p = po->mh.par.data();
+        switch (po->mh.id) {
+        case BHIP_MODEL_LORENZ: for (int k = 0; k < 3; k++) S(k, k) = p[3 + k]; break;
+        case BHIP_MODEL_PENDULUM: S(0, 0) = 0.0; S(1, 0) = p[1]; break;
+        case BHIP_MODEL_LINPRO: S = Mat(d, mp, p + d * d + d); break;
+        default: for (int k = 0; k < d; k++) S(k, k) = 1.0;
+        }
+        std::memcpy(Sigma + i * d * mp, S.a.data(), sizeof(double) * d * mp);
+    }
+    return BHIP_OK;
+}
+
 int bhip_proposal_set_aux_callback(bhip_proposal *po, bhip_aux_fn fn, void *user, int drift_form, const double *mu)
 {
     if (!po) return BHIP_EINVAL;
@@ -560,7 +615,8 @@ int bhip_proposal_guide_hv(bhip_proposal *po, const double *v, const double *hT)
     const int d = po->mh.d;
     Mat vv(d, 1, v), h(d, d);
     if (hT) h = Mat(d, d, hT);
-    guide_hv(po->tt, po->aux, vv, h, po->g);
+    if (po->aux.kind == BHIP_AUX_LINEARAPPR) guide_hv_heuni(po->tt, po->aux, vv, h, po->g);   // src/guip.jl:181-189
+    else guide_hv(po->tt, po->aux, vv, h, po->g);
     return finish_guide(po);
 }
 
@@ -637,6 +693,7 @@ int bhip_proposal_lptilde(const bhip_proposal *po, const double *u, double *out)
     const int d = po->mh.d;
     Mat uu(d, 1, u);
     if (g.kind == BHIP_GUIDE_HV) {   // logpdfnormal(V[1]-u, Hd[1]) - traceB(tt, Pt)   src/guip.jl:206
+        if (!g.have_trB) return fail(po->ctx, BHIP_EUNSUPPORTED, "lptilde: traceB is not defined for this auxiliary (LinearAppr: index-based coefficients)");
         *out = logpdfnormal(g.V[0] - uu, g.Hd[0]) - g.trB;
         return BHIP_OK;
     }

@@ -205,6 +205,18 @@ struct Aux {
     void *user = nullptr;
     int cb_linpro = 0;
     std::vector<double> cb_mu;
+    // BHIP_AUX_LINEARAPPR (src/linpro.jl:181-192): coefficients per grid INDEX -- xx_i (d), B_i (d*d), b_i (d), Sigma_i (d*mp).
+    // The time-based accessors below are only ever called with grid times; the index is recovered by exact match.
+    std::vector<double> la_tt, la_xx, la_B, la_b, la_S;
+    int la_index(double t) const
+    {
+        const size_t i = (size_t)(std::lower_bound(la_tt.begin(), la_tt.end(), t) - la_tt.begin());
+        return (int)std::min(i, la_tt.size() - 1);
+    }
+    Mat Bi(int i) const { return Mat(d, d, la_B.data() + (size_t)i * d * d); }
+    Mat xxi(int i) const { return Mat(d, 1, la_xx.data() + (size_t)i * d); }
+    Mat bi(int i) const { return Mat(d, 1, la_b.data() + (size_t)i * d); }
+    Mat Si(int i) const { return Mat(d, mp, la_S.data() + (size_t)i * d * mp); }
 
     bool linpro_form() const { return kind == BHIP_AUX_LINPRO || (kind == BHIP_AUX_CALLBACK && cb_linpro); }
     const double *mu() const { return kind == BHIP_AUX_LINPRO ? par.data() + d * d : cb_mu.data(); }
@@ -223,6 +235,7 @@ struct Aux {
     }
     Mat B(double t) const
     {
+        if (kind == BHIP_AUX_LINEARAPPR) return Bi(la_index(t));                                  // B((i,s), P) = P.B[i]   :188
         if (kind == BHIP_AUX_CALLBACK) { Mat b_; callback(t, &b_, nullptr, nullptr); return b_; }
         if (kind == BHIP_AUX_FHN_STARTEND) {   // :103
             const double u = uv(t);
@@ -235,6 +248,7 @@ struct Aux {
     }
     Mat beta(double t) const
     {
+        if (kind == BHIP_AUX_LINEARAPPR) { const int i = la_index(t); return bi(i) - Bi(i) * xxi(i); }   // P.b[i] - P.B[i]*P.xx[i]   :189
         if (kind == BHIP_AUX_CALLBACK) { Mat b_; callback(t, nullptr, &b_, nullptr); return b_; }
         if (kind == BHIP_AUX_FHN_STARTEND) {   // :104
             const double u = uv(t);
@@ -247,8 +261,9 @@ struct Aux {
         return Mat(d, 1, par.data() + d * d);
     }
     bool has_sigma() const { return kind != BHIP_AUX_CALLBACK; }
-    Mat sigma(double) const
+    Mat sigma(double t) const
     {
+        if (kind == BHIP_AUX_LINEARAPPR) return Si(la_index(t));                                  // a = outer(P.Sigma[i])  :190-191
         if (kind == BHIP_AUX_FHN_STARTEND) { Mat s(2, 1); s.a[0] = 0.0; s.a[1] = par[4]; return s; }
         return Mat(d, mp, par.data() + d * d + d);
     }
@@ -288,6 +303,41 @@ inline void guide_hv(const std::vector<double> &tt, const Aux &Pt, const Mat &v,
     for (int i = 1; i < N; i++) s = kernelr3(trB, tt[i - 1], s, tt[i] - tt[i - 1]);
     g.trB = s.a[0]; g.have_trB = true;
 }
+
+// GuidedBridge(tt, P, Pt::LinearAppr, v, hT)  src/guip.jl:181-189 with solvebackwardi! / kerneli(::Heun)  src/ode.jl:98-113.
+// As committed, kerneli reads an `i` that solvebackwardi! never passes and the V equation hands `b` where only `_b` exists for
+// a LinearAppr: the reference constructor cannot run.  Restated with the evident intention (i = the loop index, b = _b):
+//     k1 = f_i(y);  k2 = f_{i+1}(y + dt*k1);  y <- y + dt/2*(k1 + k2),  dt = tt[i] - tt[i+1]     (1-based i = N-1 .. 1)
+//     f_j(K) = B_j K + K B_j' - outer(Sigma_j),   f_j(x) = B_j (x - xx_j) + b_j                   src/linpro.jl:187-191
+inline void guide_hv_heuni(const std::vector<double> &tt, const Aux &Pt, const Mat &v, const Mat &hT, Guide &g)
+{
+    const int N = (int)tt.size();
+    g.kind = BHIP_GUIDE_HV; g.m = Pt.d;
+    g.Hd.assign(N, Mat()); g.V.assign(N, Mat());
+    auto fH = [&](int j, const Mat &K) { const Mat B = Pt.Bi(j); return B * K + K * tr(B) - outer(Pt.Si(j)); };
+    auto fV = [&](int j, const Mat &x) { return Pt.Bi(j) * (x - Pt.xxi(j)) + Pt.bi(j); };
+    Mat y = hT;
+    g.Hd[N - 1] = y;
+    for (int i = N - 2; i >= 0; i--) {
+        const double dt = tt[i] - tt[i + 1];
+        const Mat k1 = fH(i, y), k2 = fH(i + 1, y + dt * k1);
+        y = y + (dt / 2) * (k1 + k2);
+        g.Hd[i] = y;
+    }
+    Mat w = v;
+    g.V[N - 1] = w;
+    for (int i = N - 2; i >= 0; i--) {
+        const double dt = tt[i] - tt[i + 1];
+        const Mat k1 = fV(i, w), k2 = fV(i + 1, w + dt * k1);
+        w = w + (dt / 2) * (k1 + k2);
+        g.V[i] = w;
+    }
+    g.have_trB = false;   // traceB needs B(t, P) at off-grid times: lptilde is not defined for a LinearAppr auxiliary
+}
+
+// Bridge.bderiv(t, x, P) for the processes the reference defines it for (Lorenz src/Models.jl:49-53, Pendulum :81-84,
+// LinPro src/linpro.jl:82, Wiener src/wiener.jl:147) and linearappr(Y, P)  src/linpro.jl:196-204
+// (host_bderiv / host_b are defined after ModelHost, below)
 
 // partialbridgeode!(::R3, ...)  src/partialbridge.jl:1-22
 inline void guide_lmmu(const std::vector<double> &tt, const Aux &Pt, const Mat &L0, const Mat &v, const Mat &Sigma, Guide &g)
@@ -472,6 +522,42 @@ inline int row_stride(int gk, int d, int mo, bool constdiff = true)
     else glen = d * d + d;
     const int len = 3 + d * d + d + glen;
     return (len + 1) & ~1;
+}
+
+inline bool host_bderiv(const ModelHost &mh, const double *x, Mat &J)
+{
+    const int d = mh.d;
+    const double *p = mh.par.data();
+    J = Mat(d, d);
+    switch (mh.id) {
+    case BHIP_MODEL_LORENZ:
+        J(0, 0) = -p[0];       J(0, 1) = p[0]; J(0, 2) = 0.0;
+        J(1, 0) = p[1] - x[2]; J(1, 1) = -1.0; J(1, 2) = -x[0];
+        J(2, 0) = x[1];        J(2, 1) = x[0]; J(2, 2) = -p[2];
+        return true;
+    case BHIP_MODEL_PENDULUM:
+        J(0, 0) = 0.0;                      J(0, 1) = 1.0;
+        J(1, 0) = -p[0] * std::cos(x[0]);   J(1, 1) = 0.0;
+        return true;
+    case BHIP_MODEL_LINPRO: J = Mat(d, d, p); return true;
+    case BHIP_MODEL_WIENER: return true;
+    }
+    return false;
+}
+inline bool host_b(const ModelHost &mh, const double *x, Mat &o)
+{
+    const int d = mh.d;
+    const double *p = mh.par.data();
+    o = Mat(d, 1);
+    switch (mh.id) {
+    case BHIP_MODEL_LORENZ:   // src/Models.jl:47
+        o.a[0] = p[0] * (x[1] - x[0]); o.a[1] = x[0] * (p[1] - x[2]) - x[1]; o.a[2] = x[0] * x[1] - p[2] * x[2];
+        return true;
+    case BHIP_MODEL_PENDULUM: o.a[0] = x[1]; o.a[1] = -p[0] * std::sin(x[0]); return true;   // :79
+    case BHIP_MODEL_LINPRO: { Mat xm(d, 1); for (int k = 0; k < d; k++) xm.a[k] = x[k] - p[d * d + k]; o = Mat(d, d, p) * xm; return true; }
+    case BHIP_MODEL_WIENER: return true;
+    }
+    return false;
 }
 
 inline void pack_rows(const std::vector<double> &tt, const ModelHost &mh, const Aux *Pt, const Guide &g, std::vector<double> &rows, int &rs)

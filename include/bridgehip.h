@@ -63,6 +63,7 @@ extern "C" {
 #define BHIP_AUX_LINPRO 1        /* B(d*d), mu(d), sigma(d*mp);  drift B*(x-mu), beta = -B*mu        */
 #define BHIP_AUX_FHN_STARTEND 2  /* eps,s,gamma,beta,sigma,t0,u,T,v  partialbridge_fitzhugh.jl:58-73,102-105 */
 #define BHIP_AUX_CALLBACK 3      /* user C callback (Julia @cfunction), see bhip_proposal_set_aux_callback */
+#define BHIP_AUX_LINEARAPPR 4    /* LinearAppr: coefficients per grid index, see bhip_proposal_set_aux_linearappr    src/linpro.jl:181-204 */
 
 /* guide parametrisations */
 #define BHIP_GUIDE_NONE 0         /* plain Euler-Maruyama of the target            src/euler.jl:135-152 */
@@ -134,6 +135,17 @@ void bhip_proposal_destroy(bhip_proposal *po);
 int bhip_proposal_set_aux(bhip_proposal *po, int aux_kind, const double *apar, int napar);
 /* drift_form: 0 -> b~ = B(t)x + beta(t);  1 -> LinPro form B(x - mu) with mu given (d doubles) */
 int bhip_proposal_set_aux_callback(bhip_proposal *po, bhip_aux_fn fn, void *user, int drift_form, const double *mu);
+/* Pt::LinearAppr (src/linpro.jl:181-192): the linearisation of a target along a path Y on the proposal's own grid --
+ * xx[N][d] = Y, B[N][d*d] (column-major) = bderiv(t_i, y_i, P), b[N][d] = b(t_i, y_i, P), Sigma[N][d*mp] = sigma(t_i, y_i, P):
+ *     _b((i,s), x, Pt) = B_i (x - xx_i) + b_i,   B((i,s), Pt) = B_i,   beta((i,s), Pt) = b_i - B_i xx_i,   a = Sigma_i Sigma_i'.
+ * bhip_proposal_guide_hv then integrates (Hdiamond, V) with the index-based Heun scheme of src/guip.jl:181-189 /
+ * src/ode.jl:98-113 (restated with the loop index it evidently means, see DESIGN.md: the reference constructor reads an
+ * undefined variable).  The log-likelihood uses the constant-diffusivity form, i.e. Sigma_i must equal the target's sigma
+ * (checked): the reference's own !constdiff branch for GuidedBridge is not defined. */
+int bhip_proposal_set_aux_linearappr(bhip_proposal *po, const double *xx, const double *B, const double *b, const double *Sigma);
+/* linearappr(Y, P) / linearappr!(Pt, Y, P)  src/linpro.jl:196-204 (host): fills B, b, Sigma (layouts as above) for the
+ * target of `po` along Y [N][d]; for the processes the reference defines bderiv for: Lorenz, Pendulum, LinPro, Wiener. */
+int bhip_linearappr(const bhip_proposal *po, const double *Y, double *B, double *b, double *Sigma);
 /* GuidedBridge(tt, P, Pt, v, hT = 0)                                       src/guip.jl:172-180 */
 int bhip_proposal_guide_hv(bhip_proposal *po, const double *v, const double *hT);
 /* PartialBridge(tt, P, Pt, L, v, Sigma)                                    src/partialbridge.jl:42-50 */
@@ -282,6 +294,11 @@ int bhip_segchains_get_paths(bhip_segchains *sc, int segment, long p0, long np, 
 int bhip_segchains_current_X(bhip_segchains *sc, int segment, double **Xc_dev, long *ld);
 /* the mcnext! state of ONE chain of one segment (src/mclog.jl:48-56): mean [N][d], m2 [N][d*d] (column-major), count */
 int bhip_segchains_mcstats(bhip_segchains *sc, int segment, long chain, double *mean, double *m2, int64_t *count);
+/* Adaptive smoothing (smoothing.jl:130-160): replace the m proposals by new ones of the same shape -- e.g. GuidedBridge's
+ * whose LinearAppr auxiliaries were re-linearised around the running means (bhip_segchains_pooled_stats -> bhip_linearappr
+ * -> bhip_proposal_guide_hv, linked backwards by bhip_gpupdate).  The chains keep W, X and y0; the log-likelihoods of the
+ * current paths are re-evaluated under the new proposals.  The old proposals may be destroyed afterwards. */
+int bhip_segchains_set_proposals(bhip_segchains *sc, const bhip_proposal *const *pos);
 /* the pooled state of one segment: every chain's current path of every iteration as one sample (mcnext semantics,
  * batches merged with the parallel form, cf. bhip_welford_merge): mean [N][d], m2 [N][d*d], count = chains*iterations */
 int bhip_segchains_pooled_stats(bhip_segchains *sc, int segment, double *mean, double *m2, double *count);

@@ -473,8 +473,27 @@ static double fhn_uv(const double *p, double t)
     double lam = (t - p[5]) / (p[7] - p[5]);
     return p[8] * lam + p[6] * (1 - lam);
 }
+/* LinearAppr (src/linpro.jl:181-192): coefficients per grid INDEX.  par = N, tt(N), xx(N*d), B(N*d*d), b(N*d), Sigma(N*d*mp);
+ * the accessors below are called with grid times only, the index is the exact match. */
+static int la_index(const double *p, double t)
+{
+    int N = (int)p[0], lo = 0, hi = N - 1;
+    const double *tt = p + 1;
+    while (lo < hi) { int mid = (lo + hi) / 2; if (tt[mid] < t) lo = mid + 1; else hi = mid; }
+    return lo;   /* tt[lo] == t for grid times */
+}
+static const double *la_xx(const double *p, int d, int i) { return p + 1 + (int)p[0] + (size_t)i * d; }
+static const double *la_B(const double *p, int d, int i) { int N = (int)p[0]; return p + 1 + N + (size_t)N * d + (size_t)i * d * d; }
+static const double *la_b(const double *p, int d, int i) { int N = (int)p[0]; return p + 1 + N + (size_t)N * d + (size_t)N * d * d + (size_t)i * d; }
+static const double *la_S(const double *p, int d, int mp, int i)
+{
+    int N = (int)p[0];
+    return p + 1 + N + (size_t)N * d + (size_t)N * d * d + (size_t)N * d + (size_t)i * d * mp;
+}
+
 void bo_aux_B(int aux, int d, const double *p, double t, double *B)
 {
+    if (aux == BO_AUX_LINEARAPPR) { memcpy(B, la_B(p, d, la_index(p, t)), sizeof(double) * d * d); return; }   /* B((i,s), P) = P.B[i]  :188 */
     if (aux == BO_AUX_FHN_STARTEND) { /* :103  [1/eps-3*uv^2/eps  -1/eps; gamma -1.0] */
         double uv = fhn_uv(p, t);
         B[0] = 1 / p[0] - 3 * (uv * uv) / p[0]; B[2] = -1 / p[0];
@@ -485,6 +504,13 @@ void bo_aux_B(int aux, int d, const double *p, double t, double *B)
 }
 void bo_aux_beta(int aux, int d, const double *p, double t, double *beta)
 {
+    if (aux == BO_AUX_LINEARAPPR) {   /* beta((i,s), P) = P.b[i] - P.B[i]*P.xx[i]   src/linpro.jl:189 */
+        int i = la_index(p, t);
+        double Bx[BO_MAXD];
+        mv(d, d, la_B(p, d, i), la_xx(p, d, i), Bx);
+        for (int k = 0; k < d; k++) beta[k] = la_b(p, d, i)[k] - Bx[k];
+        return;
+    }
     if (aux == BO_AUX_FHN_STARTEND) { /* :104  (s/eps + 2*uv^3/eps, beta) */
         double uv = fhn_uv(p, t);
         beta[0] = p[1] / p[0] + 2 * (uv * uv * uv) / p[0];
@@ -501,7 +527,7 @@ void bo_aux_beta(int aux, int d, const double *p, double t, double *beta)
 }
 void bo_aux_sigma(int aux, int d, int mp, const double *p, double t, double *S)
 {
-    (void)t;
+    if (aux == BO_AUX_LINEARAPPR) { memcpy(S, la_S(p, d, mp, la_index(p, t)), sizeof(double) * d * mp); return; }   /* a = outer(P.Sigma[i])  :190-191 */
     if (aux == BO_AUX_FHN_STARTEND) { S[0] = 0.0; S[1] = p[4]; return; }
     memcpy(S, p + d * d + d, sizeof(double) * d * mp);
 }
@@ -625,6 +651,95 @@ void bo_gp_hv(const double *tt, int N, int d, int mp, int aux, const double *apa
     for (int i = N - 2; i >= 0; i--) {
         kernelr3(rhs_F, tt[i + 1], w, tt[i] - tt[i + 1], d, &c, w);
         memcpy(V + (size_t)i * d, w, sizeof(double) * d);
+    }
+}
+
+/* GuidedBridge(tt, P, Pt::LinearAppr, v, hT)  src/guip.jl:181-189:
+ *     solvebackwardi!(Heun(), ((i,t), K, P) -> B((i,t),P)*K + K*B((i,t),P)' - a((i,t),P), Hd, hT, Pt)
+ *     solvebackwardi!(Heun(), b, V, v, Pt)
+ * with  solvebackwardi!  src/ode.jl:104-113  (for i in N-1:-1:1: y = kerneli(ker, F, tt[i+1], y, tt[i]-tt[i+1], P))  and
+ *     kerneli(::Heun, f, t, y, dt, P):  k1 = f((i,t), y, P);  k2 = f((i+1, t+dt), y + dt*k1, P);  y + dt/2*(k1 + k2)      :98-102
+ * As committed in the reference `kerneli` reads an `i` that solvebackwardi! never passes (an UndefVarError), and the second
+ * call hands `b` where only `_b((i,s), x, P::LinearAppr)` exists (src/linpro.jl:187): the constructor cannot run there.
+ * Restated with the evident intention -- `i` is the loop index of solvebackwardi!, `b` means _b -- i.e. (1-based i)
+ *     k1 = f_i(y),  k2 = f_{i+1}(y + dt*k1),  y <- y + dt/2*(k1 + k2),   dt = tt[i] - tt[i+1] < 0,
+ * f_j(K) = B_j K + K B_j' - outer(Sigma_j),   f_j(x) = B_j (x - xx_j) + b_j.  A documented deviation. */
+static void la_fH(int d, int mp, const double *Bj, const double *Sj, const double *K, double *out)
+{
+    double BK[D2], KBt[D2], a[D2];
+    mm(d, d, d, Bj, K, BK);
+    mmt(d, d, d, K, Bj, KBt);
+    mmt(d, mp, d, Sj, Sj, a);
+    for (int k = 0; k < d * d; k++) out[k] = BK[k] + KBt[k] - a[k];
+}
+static void la_fV(int d, const double *Bj, const double *xxj, const double *bj, const double *x, double *out)
+{
+    double xm[BO_MAXD];
+    for (int k = 0; k < d; k++) xm[k] = x[k] - xxj[k];
+    mv(d, d, Bj, xm, out);
+    for (int k = 0; k < d; k++) out[k] = out[k] + bj[k];
+}
+void bo_gp_hv_heuni(const double *tt, int N, int d, int mp, const double *xx, const double *B, const double *b, const double *Sigma,
+                    const double *v, const double *hT, double *Hd, double *V)
+{
+    const int dd = d * d;
+    double y[D2], k1[D2], k2[D2], yp[D2];
+    for (int k = 0; k < dd; k++) y[k] = hT ? hT[k] : 0.0;
+    memcpy(Hd + (size_t)(N - 1) * dd, y, sizeof(double) * dd);
+    for (int i = N - 2; i >= 0; i--) {   /* 0-based i = Julia's i - 1 */
+        const double dt = tt[i] - tt[i + 1];
+        la_fH(d, mp, B + (size_t)i * dd, Sigma + (size_t)i * d * mp, y, k1);
+        for (int k = 0; k < dd; k++) yp[k] = y[k] + dt * k1[k];
+        la_fH(d, mp, B + (size_t)(i + 1) * dd, Sigma + (size_t)(i + 1) * d * mp, yp, k2);
+        for (int k = 0; k < dd; k++) y[k] = y[k] + dt / 2 * (k1[k] + k2[k]);
+        memcpy(Hd + (size_t)i * dd, y, sizeof(double) * dd);
+    }
+    double w[BO_MAXD], wp[BO_MAXD];
+    memcpy(w, v, sizeof(double) * d);
+    memcpy(V + (size_t)(N - 1) * d, w, sizeof(double) * d);
+    for (int i = N - 2; i >= 0; i--) {
+        const double dt = tt[i] - tt[i + 1];
+        la_fV(d, B + (size_t)i * dd, xx + (size_t)i * d, b + (size_t)i * d, w, k1);
+        for (int k = 0; k < d; k++) wp[k] = w[k] + dt * k1[k];
+        la_fV(d, B + (size_t)(i + 1) * dd, xx + (size_t)(i + 1) * d, b + (size_t)(i + 1) * d, wp, k2);
+        for (int k = 0; k < d; k++) w[k] = w[k] + dt / 2 * (k1[k] + k2[k]);
+        memcpy(V + (size_t)i * d, w, sizeof(double) * d);
+    }
+}
+
+/* Bridge.bderiv(t, x, P): the Jacobian of the drift, for the processes the reference defines it for:
+ * Lorenz src/Models.jl:49-53, Pendulum :81-84, LinPro src/linpro.jl:82, Wiener src/wiener.jl:147.  Column-major d x d. */
+void bo_bderiv(int model, int d, const double *p, double t, const double *x, double *J)
+{
+    (void)t;
+    memset(J, 0, sizeof(double) * d * d);
+    if (model == BO_MODEL_LORENZ) {
+        J[0] = -p[0];        J[3] = p[0];  J[6] = 0.0;
+        J[1] = p[1] - x[2];  J[4] = -1.0;  J[7] = -x[0];
+        J[2] = x[1];         J[5] = x[0];  J[8] = -p[2];
+    } else if (model == BO_MODEL_PENDULUM) {
+        J[0] = 0.0;                  J[2] = 1.0;
+        J[1] = -p[0] * cos(x[0]);    J[3] = 0.0;
+    } else if (model == BO_MODEL_LINPRO) {
+        memcpy(J, p, sizeof(double) * d * d);
+    }
+}
+
+/* linearappr(Y, P) / linearappr!(Pt, Y, P)  src/linpro.jl:196-204: B_i = bderiv(t_i, y_i, P), b_i = b(t_i, y_i, P),
+ * Sigma_i = sigma(t_i, y_i, P) along the path Y (xx_i = y_i). */
+void bo_linearappr(int model, int d, int mp, const double *par, const double *tt, int N, const double *Y,
+                   double *B, double *b, double *Sigma)
+{
+    for (int i = 0; i < N; i++) {
+        bo_bderiv(model, d, par, tt[i], Y + (size_t)i * d, B + (size_t)i * d * d);
+        bo_b(model, d, par, tt[i], Y + (size_t)i * d, b + (size_t)i * d);
+        /* sigma as a matrix: apply it to the unit vectors */
+        for (int c = 0; c < mp; c++) {
+            double e[BO_MAXD] = {0}, col[BO_MAXD];
+            e[c] = 1.0;
+            bo_sigma_apply(model, d, mp, par, tt[i], Y + (size_t)i * d, e, col);
+            for (int r = 0; r < d; r++) Sigma[(size_t)i * d * mp + r + d * c] = col[r];
+        }
     }
 }
 

@@ -59,7 +59,10 @@ int bo_constdiff(int model);
 enum {
     BO_AUX_AFFINE = 0,        /* constant B,beta,sigma; drift evaluated as B*x+beta   par: B(d*d),beta(d),sigma(d*mp) */
     BO_AUX_LINPRO = 1,        /* src/linpro.jl:65-87: drift B*(x-mu), beta=-B*mu      par: B(d*d),mu(d),sigma(d*mp)   */
-    BO_AUX_FHN_STARTEND = 2   /* partialbridge_fitzhugh.jl:58-73,102-105              par: eps,s,gamma,beta,sigma,t0,u,T,v */
+    BO_AUX_FHN_STARTEND = 2,  /* partialbridge_fitzhugh.jl:58-73,102-105              par: eps,s,gamma,beta,sigma,t0,u,T,v */
+    BO_AUX_LINEARAPPR = 4     /* src/linpro.jl:181-204 LinearAppr: per grid INDEX xx_i, B_i, b_i, Sigma_i.
+                                 par: N, tt(N), xx(N*d), B(N*d*d), b(N*d), Sigma(N*d*mp); the time argument of the accessors
+                                 must be a grid time (the index is recovered by exact match)                             */
 };
 
 /* proposal kinds (guide parametrisations) */
@@ -184,6 +187,13 @@ void bo_innovations_flat(int kind, int N, int d, int mp, int m, int model, const
 /* girsanov(X, P, Pt), src/diffusion.jl:109-123; par_t == NULL: Pt = Wiener */
 double bo_girsanov(int model, int d, int mp, const double *par, const double *par_t,
                    const double *tt, int N, const double *X);
+
+/* ---- LinearAppr (src/linpro.jl:181-204) and the index-based Heun guide of src/guip.jl:181-189, src/ode.jl:98-113 ---- */
+void bo_bderiv(int model, int d, const double *par, double t, const double *x, double *J);
+void bo_linearappr(int model, int d, int mp, const double *par, const double *tt, int N, const double *Y,
+                   double *B, double *b, double *Sigma);
+void bo_gp_hv_heuni(const double *tt, int N, int d, int mp, const double *xx, const double *B, const double *b, const double *Sigma,
+                    const double *v, const double *hT, double *Hd, double *V);
 
 /* ---- joint MH over chained segments, pCN on the start, mcnext! per iteration (supplements/smoothing/smoothing.jl:99-213) ---- */
 void bo_normal_pair_stream(uint64_t seed, uint32_t path, uint32_t stream, uint32_t iter, uint32_t block, double z[2]);

@@ -429,6 +429,43 @@ def ensemble_mcmc(P, x0, rho, iters, nchains, path0, seed, threads=1):
     return n, ll, acc
 
 
+AUX_LINEARAPPR = 4
+
+
+def linearappr(model, d, mp, par, tt, Y):
+    """bo_linearappr: (B [N,d,d], b [N,d], Sigma [N,d,mp]) of the target along Y   src/linpro.jl:196-204"""
+    tt = np.ascontiguousarray(tt, dtype=np.float64)
+    N = len(tt)
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    par = np.ascontiguousarray(par, dtype=np.float64)
+    B, b, S = np.empty((N, d * d)), np.empty((N, d)), np.empty((N, d * mp))
+    lib().bo_linearappr(C.c_int(model), C.c_int(d), C.c_int(mp), par.ctypes.data_as(dp), tt.ctypes.data_as(dp), C.c_int(N),
+                        Y.ctypes.data_as(dp), B.ctypes.data_as(dp), b.ctypes.data_as(dp), S.ctypes.data_as(dp))
+    return np.swapaxes(B.reshape(N, d, d), -1, -2).copy(), b, np.swapaxes(S.reshape(N, mp, d), -1, -2).copy()
+
+
+def linearappr_par(tt, xx, B, b, Sigma):
+    """parameter block of BO_AUX_LINEARAPPR: N, tt, xx, B (column-major per index), b, Sigma (column-major per index)"""
+    cmN = lambda A: np.ravel(np.swapaxes(np.asarray(A, dtype=np.float64), -1, -2))
+    return np.concatenate([[float(len(tt))], np.ravel(tt), np.ravel(xx), cmN(B), np.ravel(b), cmN(Sigma)])
+
+
+def gp_hv_heuni(tt, d, mp, xx, B, b, Sigma, v, hT=None):
+    """bo_gp_hv_heuni: (Hd [N,d,d], V [N,d]) of GuidedBridge(tt, P, Pt::LinearAppr, v, hT)   src/guip.jl:181-189"""
+    tt = np.ascontiguousarray(tt, dtype=np.float64)
+    N = len(tt)
+    cmN = lambda A: np.ascontiguousarray(np.swapaxes(np.asarray(A, dtype=np.float64), -1, -2))
+    xx, b_ = np.ascontiguousarray(xx, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64)
+    Bc, Sc = cmN(B), cmN(Sigma)
+    v = np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64)
+    h = None if hT is None else np.ascontiguousarray(cm(np.atleast_2d(hT)), dtype=np.float64)
+    Hd, V = np.empty((N, d * d)), np.empty((N, d))
+    lib().bo_gp_hv_heuni(tt.ctypes.data_as(dp), C.c_int(N), C.c_int(d), C.c_int(mp), xx.ctypes.data_as(dp), Bc.ctypes.data_as(dp),
+                         b_.ctypes.data_as(dp), Sc.ctypes.data_as(dp), v.ctypes.data_as(dp), None if h is None else h.ctypes.data_as(dp),
+                         Hd.ctypes.data_as(dp), V.ctypes.data_as(dp))
+    return np.swapaxes(Hd.reshape(N, d, d), -1, -2).copy(), V
+
+
 def smooth_mcmc(props, mu, chol, w_old, w_new, seed, path, skip=0, stats=False):
     """bo_smooth_mcmc: joint MH over the chained proposals `props` (supplements/smoothing/smoothing.jl:99-213).
     Returns dict(X [m,N,d], W [m,N,mp], y0 [d], ll [m], acc, and with stats: mean [m,N,d], m2 [m,N,d,d], n)"""
