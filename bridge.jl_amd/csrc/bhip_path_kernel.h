@@ -237,7 +237,8 @@ struct LaneState {
 //   Tab   : where the generator's tables are read from (TabConst, or TabLDS when the kernel keeps a copy in LDS)
 template <class M, int GK, int MO, int NOISE, int FL, class RowPtr = cptr_t, class Tab = TabConst>
 BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int nll, uint32_t path, const double *win_k,
-                        double *wout, long ldwo, double *xout, long ldx, LaneState<M::D, M::MP> &st, const Tab &tab = Tab())
+                        double *wout, long ldwo, double *xout, long ldx, LaneState<M::D, M::MP> &st, const Tab &tab = Tab(),
+                        uint32_t xl = 0u /* lane offset when xout is the wave-uniform base: address = scalar base + 32-bit lane offset */)
 {
     constexpr int D = M::D, MP = M::MP;
     using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
@@ -312,7 +313,7 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int n
     // ---- LOOP B: yy[i] = y (stored BEFORE the update, src/euler.jl:263)
     if constexpr (NOISE != NOISE_LLONLY && (FL & 1) != 0) {
 #pragma unroll
-        for (int k = 0; k < D; k++) st_stream(&xout[((size_t)i * D + k) * ldx], st.y[k]);
+        for (int k = 0; k < D; k++) st_stream(xout + ((size_t)i * D + k) * ldx + xl, st.y[k]);
     }
 
     double bT[D];

@@ -222,8 +222,8 @@ __global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(cons
     double *xout = nullptr;
     long ldx = 0;
     if constexpr ((FL & 1) != 0) {
-        if constexpr (PCN) { xout = a.Xo + p; ldx = a.ldC; }
-        else { xout = a.X + p; ldx = a.ldX; }
+        if constexpr (PCN) { xout = a.Xo; ldx = a.ldC; }   // wave-uniform base; the lane's chain index rides as a 32-bit offset
+        else { xout = a.X; ldx = a.ldX; }
     }
     constexpr int CFL = FL & ~2;   // the W store belongs to the producer
     for (int k = 0; k <= nch; k++) {
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(cons
 #ifdef PC_KNOCKOUT_STEP   /* measurement only: what the producer alone costs */
                     st.ll += wn[0];
 #else
-                    if constexpr (RLDS) path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, lrows + s * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st);
-                    else path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st);
+                    if constexpr (RLDS) path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, lrows + s * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p);
+                    else path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p);
 #endif
                 }
             } else {
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(cons
                     double wn[MP];
 #pragma unroll
                     for (int c = 0; c < MP; c++) wn[c] = mine[s * MP + c];
-                    if constexpr (RLDS) path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, lrows + s * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st);
-                    else path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st);
+                    if constexpr (RLDS) path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, lrows + s * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p);
+                    else path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p);
                 }
             }
         }
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(cons
     }
     if constexpr ((FL & 1) != 0) {
 #pragma unroll
-        for (int k = 0; k < D; k++) st_stream(&xout[((size_t)(N - 1) * D + k) * ldx], st.y[k]);
+        for (int k = 0; k < D; k++) st_stream(&xout[((size_t)(N - 1) * D + k) * ldx + p], st.y[k]);
     }
     if constexpr (PCN) {
         // if log(rand()) <= llo - ll: W <- Wo (parity flip), ll <- llo, acc += 1      partialbridge_fitzhugh.jl:160-167
