@@ -776,7 +776,7 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
             std::lock_guard<std::mutex> lk(user_models_mutex());
             UserModel *um = find_user_model(po->mh.id);
             if (!um) return fail(ctx, BHIP_EINVAL, "unknown user model id");
-            const std::vector<int> key = {gk, mo, noise, fl};
+            const std::vector<int> key = {ctx->device, gk, mo, noise, fl};   // a hipFunction_t belongs to the device it was loaded on
             auto it = um->fns.find(key);
             if (it == um->fns.end()) {
                 const std::string log = rtc_build(*um, gk, mo, noise, fl, &fn);
@@ -840,6 +840,7 @@ int bhip_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, const d
         if (rc) return rc;
     }
     if (ldW < npaths || (X_dev && ldX < npaths)) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
+    if (x0_dev && ldX < npaths) return fail(ctx, BHIP_ELENGTH, "per-path starting points x0_dev are laid out [d][ldX]: ldX must be >= npaths");
     if (po->mh.d > 3) {
         if (x0_dev) return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: shared starting point only");
         return launch_tile_path(po, x0, W_dev, ldW, nullptr, 0, X_dev, ldX, ll_dev, skip, npaths, 0, 0, 0, 0);
@@ -863,6 +864,7 @@ int bhip_sample_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, 
         if (rc) return rc;
     }
     if ((W_dev && ldW < npaths) || (X_dev && ldX < npaths)) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
+    if (x0_dev && ldX < npaths) return fail(ctx, BHIP_ELENGTH, "per-path starting points x0_dev are laid out [d][ldX]: ldX must be >= npaths");
     PATH_RANGE(ctx, path0, npaths > 0 ? npaths : 0);
     if (po->mh.d > 3) {
         if (x0_dev) return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: shared starting point only");
@@ -1114,6 +1116,7 @@ int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip)
     if (!ch->inited) return fail(ctx, BHIP_ESTATE, "bhip_chains_step: call bhip_chains_init first");
     if (iters < 0) return fail(ctx, BHIP_EINVAL, "iters must be >= 0");
     if (!(rho >= -1.0 && rho <= 1.0)) return fail(ctx, BHIP_EINVAL, "rho must lie in [-1, 1] (sqrt(1 - rho^2) is the weight of the fresh noise)");
+    if (skip == BHIP_SKIP_OF_INIT) skip = ch->skip0;   // llo and ll then always sum the same terms
     const bhip_proposal *po = ch->po;
     if (po->mh.d > 3) {
         if (skip < 0) return fail(ctx, BHIP_EINVAL, "skip must be >= 0");
@@ -1134,6 +1137,8 @@ int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip)
     a.k0 = (uint32_t)ch->seed; a.k1 = (uint32_t)(ch->seed >> 32); a.path0 = ch->path0;
     // The proposal buffer Xo is overwritten by every iteration, so within one call only the LAST iteration's
     // store can ever be observed: the earlier iterations run the instantiation without the store.
+    // the line kernels read cur[] and the W lines of whole 64-chain groups: ld is padded to 64 and those arrays are sized by ld
+    if (ch->lines && (ch->ld % 64 != 0 || ch->ld < ch->n)) return fail(ctx, BHIP_ESTATE, "chain storage: leading dimension must be a multiple of 64 covering all chains");
     for (int it = 0; it < iters; it++) {
         a.iter = ++ch->iter;
         a.Xo = it == iters - 1 ? ch->Xo : nullptr;

@@ -30,7 +30,7 @@ struct UserModel {
     int id = 0, d = 0, mp = 0, npar = 0;
     std::string drift;
     std::string sigma;   // empty: constant sigma passed as data; else the body of sigma(t,x,P)
-    std::map<std::vector<int>, hipFunction_t> fns;   // (gk, mo, noise, fl) -> kernel
+    std::map<std::vector<int>, hipFunction_t> fns;   // (device, gk, mo, noise, fl) -> kernel
     std::vector<hipModule_t> modules;
 };
 

@@ -8,9 +8,9 @@
 #     X  = solve(HIPEuler(), x0, W, Po)
 #     ll = llikelihood(LeftRule(), X, Po)
 #
-# NOTE: there is no `julia` binary in the build image, so this file has never been executed; it is
-# the declarative ccall layer a maintainer would add (see INTEGRATION.md).  The same ABI is exercised
-# by the Python ctypes mirror (bridge.jl_amd/api.py) in the test-suite.
+# NOTE: there is no `julia` binary in the build image, so this file has never been parsed or executed -- it is UNTESTED;
+# it is the declarative ccall layer a maintainer would add (see INTEGRATION.md) and is kept thin on purpose.  The same ABI
+# is exercised by the Python ctypes mirror (bridge.jl_amd/api.py) and from plain C (examples/fhn_chains.c) in the test-suite.
 module BridgeHIP
 
 using Bridge, StaticArrays, LinearAlgebra
@@ -44,14 +44,17 @@ ctx() = something(default_ctx[], (default_ctx[] = Context(); default_ctx[]))
 # ---------------------------------------------------------------- process type -> device functor
 # trait: hipmodel(P) -> (model id, d, parameter vector).  Users with their own process types add a
 # method for one of the registry ids, e.g. for the script's FitzhughDiffusion
-#     BridgeHIP.hipmodel(P::FitzhughDiffusion) = (3, 2, [P.ϵ, P.s, P.γ, P.β, P.σ])
+#     BridgeHIP.hipmodel(P::FitzhughDiffusion) = (BridgeHIP.MODEL_FHN, 2, [P.ϵ, P.s, P.γ, P.β, P.σ])
+# the BHIP_MODEL_* ids of include/bridgehip.h
+const MODEL_WIENER, MODEL_OU, MODEL_LINPRO, MODEL_FHN, MODEL_NCLAR = 0, 1, 2, 3, 4
+const MODEL_INTDIFF, MODEL_LORENZ, MODEL_FHN2, MODEL_PENDULUM = 5, 6, 7, 8
 hipmodel(P) = error("no device functor registered for $(typeof(P)); define BridgeHIP.hipmodel")
-hipmodel(P::Bridge.LinPro) = (2, length(P.μ), vcat(vec(collect(P.B)), collect(P.μ), vec(collect(P.σ))))
-hipmodel(P::Bridge.Models.FitzHughNagumo) = (7, 2, [P.ϵ, P.s, P.γ, P.β, P.σ1, P.σ2])
-hipmodel(P::Bridge.Models.Lorenz) = (6, 3, vcat(collect(P.θ), diag(P.σ)))
-hipmodel(P::Bridge.Models.Pendulum) = (8, 2, [P.θ², P.γ])
-hipmodel(::Wiener{SVector{d,Float64}}) where {d} = (0, d, Float64[])
-hipmodel(::Wiener{Float64}) = (0, 1, Float64[])
+hipmodel(P::Bridge.LinPro) = (MODEL_LINPRO, length(P.μ), vcat(vec(collect(P.B)), collect(P.μ), vec(collect(P.σ))))
+hipmodel(P::Bridge.Models.FitzHughNagumo) = (MODEL_FHN2, 2, [P.ϵ, P.s, P.γ, P.β, P.σ1, P.σ2])
+hipmodel(P::Bridge.Models.Lorenz) = (MODEL_LORENZ, 3, vcat(collect(P.θ), diag(P.σ)))
+hipmodel(P::Bridge.Models.Pendulum) = (MODEL_PENDULUM, 2, [P.θ², P.γ])
+hipmodel(::Wiener{SVector{d,Float64}}) where {d} = (MODEL_WIENER, d, Float64[])
+hipmodel(::Wiener{Float64}) = (MODEL_WIENER, 1, Float64[])
 
 # A process WITHOUT a registry functor: give the body of its Bridge.b method as HIP C++ text; the
 # library compiles it for gfx950 with hipRTC (bhip_model_define).  sigma must be constant (d x m').
@@ -257,23 +260,63 @@ function Bridge.girsanov(X::EnsemblePath, Po::HIPProposal, Pt)
 end
 
 # ---------------------------------------------------------------- the MCMC loop of the scripts
+"An ensemble of pCN chains (bhip_chains); the device state (GBs of W / Xo) is released by the finalizer."
+mutable struct Chains
+    h::Ptr{Cvoid}
+    ctx::Context
+    n::Int
+    function Chains(c::Context, h::Ptr{Cvoid}, n)
+        ch = new(h, c, n)
+        finalizer(x -> ccall((:bhip_chains_destroy, lib), Cvoid, (Ptr{Cvoid},), x.h), ch)
+    end
+end
+
+"RCCL communicator of the library (bhip_comm): one process per GPU; `id` = the 128 bytes rank 0 drew with `comm_unique_id()`"
+mutable struct Comm
+    h::Ptr{Cvoid}
+    ctx::Context
+    nranks::Int
+    function Comm(c::Context, nranks::Integer, rank::Integer, id::Vector{UInt8})
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(c, ccall((:bhip_comm_init_rank, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}, Ref{Ptr{Cvoid}}), c.h, nranks, rank, id, r))
+        cm = new(r[], c, nranks)
+        finalizer(x -> ccall((:bhip_comm_destroy, lib), Cvoid, (Ptr{Cvoid},), x.h), cm)
+    end
+end
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    ccall((:bhip_comm_unique_id, lib), Cint, (Ptr{UInt8}, Csize_t), id, 128) == 0 || error("RCCL not available")
+    id
+end
+
 """
-    mcmc(Po, x0, iterations; ρ, nchains, seed) -> (acc, ll, chains)
+    mcmc(Po, x0, iterations; ρ, nchains, seed, path0, comm) -> (acc, ll, chains[, stats])
 
 `nchains` independent copies of the loop in project_partialbridge/partialbridge_fitzhugh.jl:125-176
-(one chain per GPU lane; sample!, pCN mix, solve!, llikelihood and the accept fused in one kernel).
+(one chain per GPU lane; sample!, pCN mix, solve!, llikelihood and the accept fused in one kernel launch per iteration).
+Multi-GPU: one process per GPU, `path0 = rank*nchains`, `comm = Comm(ctx, nranks, rank, id)`: the acceptance / log-weight
+statistics block of every rank is all-gathered over RCCL (`stats[:, r]` = {n, iterations, Σacc, Σll, Σll², min ll, max ll, Σacc²}).
 """
-function mcmc(Po::HIPProposal, x0, iterations; ρ = 0.9, nchains = 1, seed = 0, path0 = 0, skip = 0, store_X = true)
+function mcmc(Po::HIPProposal, x0, iterations; ρ = 0.9, nchains = 1, seed = 0, path0 = 0, skip = 0, store_X = true, comm = nothing)
     r = Ref{Ptr{Cvoid}}(C_NULL)
     c = Po.ctx
     check(c, ccall((:bhip_chains_create, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Clong, UInt32, UInt64, Cint, Ref{Ptr{Cvoid}}),
         c.h, Po.h, nchains, path0, seed, store_X ? 1 : 0, r))
-    ch = r[]
-    check(c, ccall((:bhip_chains_init, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), ch, collect(Float64, x0), skip))
-    check(c, ccall((:bhip_chains_step, lib), Cint, (Ptr{Cvoid}, Cdouble, Cint, Cint), ch, ρ, iterations, skip))
+    ch = Chains(c, r[], nchains)
+    check(c, ccall((:bhip_chains_init, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), ch.h, collect(Float64, x0), skip))
+    check(c, ccall((:bhip_chains_step, lib), Cint, (Ptr{Cvoid}, Cdouble, Cint, Cint), ch.h, ρ, iterations, skip))
     ll = Vector{Float64}(undef, nchains); acc = Vector{Int64}(undef, nchains)
-    check(c, ccall((:bhip_chains_get, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Int64}), ch, ll, acc))
-    acc, ll, ch
+    check(c, ccall((:bhip_chains_get, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Int64}), ch.h, ll, acc))
+    comm === nothing && return acc, ll, ch
+    sd = Ref{Ptr{Cvoid}}(C_NULL); ad = Ref{Ptr{Cvoid}}(C_NULL)
+    check(c, ccall((:bhip_malloc, lib), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), c.h, 64, sd))
+    check(c, ccall((:bhip_malloc, lib), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), c.h, 64 * comm.nranks, ad))
+    check(c, ccall((:bhip_chains_stats, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ch.h, sd[]))
+    check(c, ccall((:bhip_comm_allgather_stats, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), comm.h, sd[], ad[]))
+    stats = Matrix{Float64}(undef, 8, comm.nranks)
+    check(c, ccall((:bhip_memcpy_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), c.h, stats, ad[], 64 * comm.nranks))
+    ccall((:bhip_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), c.h, sd[]); ccall((:bhip_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), c.h, ad[])
+    acc, ll, ch, stats
 end
 
 end # module

@@ -233,7 +233,10 @@ void bhip_chains_destroy(bhip_chains *ch);
 /* iteration 0: W = sample(tt, Wiener()); solve!(X, x0, W, Po); ll = llikelihood(X, Po; skip) */
 int bhip_chains_init(bhip_chains *ch, const double *x0, int skip);
 /* `iters` pCN iterations: sample!(W2); Wo = rho*W + sqrt(1-rho^2)*W2; solve!; llo; accept iff
- * log(U) <= llo - ll  (skip applies to llo like partialbridge_nclar.jl:121) */
+ * log(U) <= llo - ll.  skip applies to llo like partialbridge_nclar.jl:121; pass BHIP_SKIP_OF_INIT to use the skip the
+ * ensemble was initialised with, so that llo and ll sum the same terms (partialbridge_fitzhugh.jl:131,155 passes its
+ * skip to the initial ll only -- with sk = 0 there; any other combination is the caller's explicit choice). */
+#define BHIP_SKIP_OF_INIT (-1)
 int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip);
 /* device-side reduction of the ensemble statistics into stats_dev[8] =
  *   {nchains, iterations done, sum acc, sum ll, sum ll^2, min ll, max ll, sum acc^2}

@@ -343,6 +343,25 @@ def test_round1_golden_paths_given_their_wiener_paths_on_device(ctx, case):
     check_ll(case, ll.cpu().numpy(), g[case.name + "/ll"])
 
 
+def test_chains_with_skip_match_oracle(ctx):
+    """llikelihood(...; skip): the ensemble's skip applies to the initial ll AND (by default) to every llo, as in
+    partialbridge_nclar.jl:121; compared with the oracle chain run with the same skip"""
+    c = [k for k in problems.cases(161) if k.name == "fhn_partialbridge_extreme"][0]
+    Po, ref = c.bh_proposal(bh, ctx), c.oracle_proposal()
+    for skip in (1, 7):
+        ch = bh.Chains(Po, c.x0, 130, seed=5, skip=skip)
+        ch.step(0.9, 6)                       # default: the ensemble's skip
+        out = bh.mcmc(Po, c.x0, 6, 0.9, nchains=130, seed=5, skip=skip)
+        assert np.array_equal(out["ll"], ch.ll()) and np.array_equal(out["acc"], ch.acc())
+        for p in (0, 129):
+            r = o.mcmc(ref, c.x0, 0.9, 6, 5, p, skip=skip)
+            assert ch.ll()[p] == r["ll"] and ch.acc()[p] == r["acc"]
+        lib = ctx.lib
+        ch2 = bh.Chains(Po, c.x0, 130, seed=5, skip=skip)
+        ctx.check(lib.bhip_chains_step(ch2.h, 0.9, 6, -1))     # BHIP_SKIP_OF_INIT through the C ABI
+        assert np.array_equal(ch2.ll(), ch.ll())
+
+
 def test_batched_chain_steps_equal_single_steps(ctx):
     """bhip_chains_step(iters = k) skips the proposal-path store of all but its last iteration (the buffer would be
     overwritten unseen): the chain state, the statistics and the final Xo must equal k calls with iters = 1"""
