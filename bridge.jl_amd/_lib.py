@@ -30,6 +30,7 @@ SIGNATURES = {
     "bhip_upload_aos": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, dp]),
     "bhip_download_aos": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, dp]),
     "bhip_model_define": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int)]),
+    "bhip_model_define_components": (C.c_int, [vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int)]),
     "bhip_model_define_sigma": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]),
     "bhip_proposal_create": (C.c_int, [vp, dp, C.c_int, C.c_int, C.c_int, dp, C.c_int, C.POINTER(vp)]),
     "bhip_proposal_destroy": (None, [vp]),

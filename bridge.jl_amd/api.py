@@ -287,6 +287,27 @@ class UserProcess(ContinuousTimeProcess):
         return self.par if self.sigma is None else np.concatenate([self.par, _cm(self.sigma)])
 
 
+class UserProcessComponents(ContinuousTimeProcess):
+    """A user-defined target at LARGE state dimension (even 4 <= d <= 32, dense constant sigma [d, d]): the body of
+    `Bridge.b(t, x, P)` given COMPONENT-WISE as HIP C++ text -- it sees `int k` (component), `int d`, `double t`,
+    `const double* x`, `const double* par` and writes `double o` -- compiled into the fp64-MFMA tile kernel with hipRTC:
+
+        P = UserProcessComponents(16, "o = (x[(k+1)%d] - x[(k+d-2)%d])*x[(k+d-1)%d] - x[k] + par[0];", par=[8.0], sigma=0.5*np.eye(16))"""
+
+    def __init__(self, d, component_src, par, sigma, ctx=None):
+        self.ctx = ctx or default_context()
+        self.d = self.mp = int(d)
+        self.par = np.atleast_1d(np.asarray(par, dtype=np.float64)).ravel()
+        self.sigma = np.asarray(sigma, dtype=np.float64).reshape(self.d, self.d)
+        self.component_src = component_src
+        mid = C.c_int()
+        self.ctx.check(self.ctx.lib.bhip_model_define_components(self.ctx.h, self.d, len(self.par), component_src.encode(), C.byref(mid)))
+        self.model_id = mid.value
+
+    def params(self):
+        return np.concatenate([self.par, _cm(self.sigma)])
+
+
 # ---- auxiliary processes (Bridge.B / Bridge.beta / Bridge.sigma / Bridge.a 2-arg methods)
 class AffineAux:
     """constant B, beta, sigma;  b~(t,x) = B*x + beta  (e.g. FitzhughDiffusionAux "linearised_end",

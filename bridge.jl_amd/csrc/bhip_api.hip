@@ -60,7 +60,7 @@ struct bhip_proposal {
     bool use_vend = false;
     double vend[3] = {0, 0, 0};
     // large-d (tile kernel) data: per-step fragment matrices, step header, constants
-    double *d_steps = nullptr, *d_hdr = nullptr, *d_cst = nullptr;
+    double *d_steps = nullptr, *d_hdr = nullptr, *d_cst = nullptr, *d_tt = nullptr;
 };
 
 struct bhip_chains {
@@ -303,6 +303,24 @@ static int model_define(bhip_ctx *ctx, int d, int mp, int npar, const char *drif
     return BHIP_OK;
 }
 
+int bhip_model_define_components(bhip_ctx *ctx, int d, int npar, const char *component_src, int *model_id)
+{
+    if (!ctx || !component_src || !model_id) return BHIP_EINVAL;
+    if (d < 4 || d > 32 || (d & 1)) return fail(ctx, BHIP_EUNSUPPORTED, "bhip_model_define_components: even state dimension 4 <= d <= 32 (the MFMA tile kernel); d <= 3: bhip_model_define");
+    if (npar < 0 || npar > 16) return fail(ctx, BHIP_EINVAL, "bhip_model_define_components: at most 16 drift parameters");
+    std::unique_ptr<UserModel> um(new UserModel());
+    um->d = d; um->mp = d; um->npar = npar; um->drift = component_src; um->components = true;
+    std::vector<char> code;
+    std::string low;
+    const std::string log = rtc_tile_compile(*um, d <= 16 ? 16 : 32, 0, d != 16 && d != 32, code, low);   // validate the text now (needs no GPU)
+    if (!log.empty()) return fail(ctx, BHIP_EINVAL, log);
+    std::lock_guard<std::mutex> lk(user_models_mutex());
+    um->id = USER_MODEL_BASE + (int)user_models().size();
+    *model_id = um->id;
+    user_models().push_back(std::move(um));
+    return BHIP_OK;
+}
+
 int bhip_model_define(bhip_ctx *ctx, int d, int mp, int npar, const char *drift_src, int *model_id)
 {
     return model_define(ctx, d, mp, npar, drift_src, nullptr, model_id);
@@ -334,6 +352,16 @@ int bhip_proposal_create(bhip_ctx *ctx, const double *tt, int N, int model, int 
         const UserModel *um = find_user_model(model);
         if (!um) { rc = BHIP_EINVAL; err = "unknown user model id"; }
         else if (d > 0 && d != um->d) { rc = BHIP_EINVAL; err = "dimension does not match the user model"; }
+        else if (um->components) {   // d > 3: par = drift parameters, then the constant sigma (d x d, column-major)
+            if (npar != um->npar + um->d * um->d) { rc = BHIP_EINVAL; err = "component-wise user model expects npar + d*d parameters (drift parameters, then sigma)"; }
+            else {
+                ModelHost &mh = po->mh;
+                mh.id = model; mh.d = um->d; mh.mp = um->d;
+                mh.par.assign(par, par + npar);
+                mh.a = outer(Mat(um->d, um->d, par + um->npar));
+                mh.dpar.assign(par, par + um->npar);
+            }
+        }
         else if (!um->sigma.empty()) {   // state-dependent sigma(t,x,P): nothing to derive on the host
             if (npar != um->npar) { rc = BHIP_EINVAL; err = "user model with a sigma text expects exactly its npar parameters"; }
             else {
@@ -373,6 +401,7 @@ void bhip_proposal_destroy(bhip_proposal *po)
     if (!po->ctx->host_only) {
         (void)hipStreamSynchronize(po->ctx->stream);
         if (po->d_rows) (void)hipFree(po->d_rows);
+        if (po->d_tt) (void)hipFree(po->d_tt);
         if (po->d_rdtp) (void)hipFree(po->d_rdtp);
         if (po->d_steps) (void)hipFree(po->d_steps);
         if (po->d_hdr) (void)hipFree(po->d_hdr);
@@ -494,8 +523,9 @@ static int build_tile_data(bhip_proposal *po)
     const bool plain = po->g.kind == BHIP_GUIDE_NONE;   // forward Euler-Maruyama: the guide matrices are zero
     // The tile kernel is instantiated for 16 and 32 components; other EVEN dimensions 4..30 run zero padded (an even
     // dimension keeps a Philox block inside one grid point, which the lane-pair exchange of the normals relies on).
-    if (po->mh.id != BHIP_MODEL_LINPRO || d > 32 || (d & 1))
-        return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: LinPro target with an even dimension 4 <= d <= 32");
+    const bool user = po->mh.id >= USER_MODEL_BASE;   // component-wise hipRTC drift (bhip_model_define_components): no B, mu
+    if ((po->mh.id != BHIP_MODEL_LINPRO && !user) || d > 32 || (d & 1))
+        return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: LinPro target or a component-wise user drift, even dimension 4 <= d <= 32");
     if (!plain && (!po->has_aux || (po->aux.kind != BHIP_AUX_AFFINE && po->aux.kind != BHIP_AUX_LINPRO)))
         return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: time-constant auxiliary process");
     const int Dp = tile_dim(d);
@@ -521,18 +551,23 @@ static int build_tile_data(bhip_proposal *po)
     }
     std::vector<double> cst(4 * DD + 5 * Dp, 0.0);
     const double *par = po->mh.par.data();
-    to_fragments(pad_mat(Mat(d, d, par), Dp), &cst[0]);                          // B
+    const double *sig = user ? par + po->mh.dpar.size() : par + dd + d;          // user: [drift parameters, sigma]; LinPro: [B, mu, sigma]
+    if (!user) to_fragments(pad_mat(Mat(d, d, par), Dp), &cst[0]);               // B (user drift: evaluated component-wise, no matrix)
     if (!plain) to_fragments(pad_mat(po->aux.B(po->tt[0]), Dp), &cst[DD]);       // B~
     to_fragments(pad_mat(po->mh.a, Dp), &cst[2 * DD]);                           // a = sigma*sigma'
-    to_fragments(pad_mat(Mat(d, d, par + dd + d), Dp), &cst[3 * DD]);            // sigma
-    std::memcpy(&cst[4 * DD], par + dd, sizeof(double) * d);                     // mu
+    to_fragments(pad_mat(Mat(d, d, sig), Dp), &cst[3 * DD]);                     // sigma
+    if (!user) std::memcpy(&cst[4 * DD], par + dd, sizeof(double) * d);          // mu
     if (!plain) {
         if (po->aux.linpro_form()) std::memcpy(&cst[4 * DD + Dp], po->aux.mu(), sizeof(double) * d);                        // mu~ (else 0)
         else { const Mat be = po->aux.beta(po->tt[0]); std::memcpy(&cst[4 * DD + 2 * Dp], be.a.data(), sizeof(double) * d); }   // beta~ (else 0)
     }
     if (po->g.kind == BHIP_GUIDE_HV) std::memcpy(&cst[4 * DD + 3 * Dp], po->g.V[N - 1].a.data(), sizeof(double) * d);       // vend
-    for (double **q : {&po->d_steps, &po->d_hdr, &po->d_cst})
+    for (double **q : {&po->d_steps, &po->d_hdr, &po->d_cst, &po->d_tt})
         if (*q) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(*q)); *q = nullptr; }
+    if (user) {   // b_k(t, x, P) may depend on t
+        HIPCHK(ctx, hipMalloc((void **)&po->d_tt, sizeof(double) * N));
+        HIPCHK(ctx, hipMemcpy(po->d_tt, po->tt.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    }
     HIPCHK(ctx, hipMalloc((void **)&po->d_steps, sizeof(double) * steps.size()));
     HIPCHK(ctx, hipMalloc((void **)&po->d_hdr, sizeof(double) * hdr.size()));
     HIPCHK(ctx, hipMalloc((void **)&po->d_cst, sizeof(double) * cst.size()));
@@ -544,18 +579,19 @@ static int build_tile_data(bhip_proposal *po)
 
 static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const double *W_in, long ldWin, double *W_out, long ldWout,
                             double *X, long ldX, double *ll, int skip, long npaths, int noise, uint64_t seed, uint32_t iter, uint32_t path0,
-                            int wstride = 1, const bhip_chains *ch = nullptr, double rho = 0.0)
+                            int wstride = 1, const bhip_chains *ch = nullptr, double rho = 0.0, const double *x0_dev = nullptr, long ldx0 = 0)
 {
     const bhip_proposal *po = po_c;
     bhip_ctx *ctx = po->ctx;
     NEED_DEVICE(ctx);
     const int d = po->mh.d;
     if (!po->d_steps) return fail(ctx, BHIP_ESTATE, "proposal has no large-d guide data (compute a guide first)");
-    if (!x0) return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: shared starting point only");
+    if (!x0 && !x0_dev) return fail(ctx, BHIP_EINVAL, "need a starting point");
     if (npaths < 1 || skip < 0) return fail(ctx, BHIP_EINVAL, "bad npaths/skip");
     TArgs a;
     std::memset(&a, 0, sizeof(a));
-    std::memcpy(a.x0, x0, sizeof(double) * d);   // by value in the kernel arguments (rows d..Dp-1 stay zero)
+    if (x0) std::memcpy(a.x0, x0, sizeof(double) * d);   // by value in the kernel arguments (rows d..Dp-1 stay zero)
+    a.x0_dev = x0_dev; a.ldx0 = ldx0;
     a.steps = po->d_steps; a.hdr = po->d_hdr; a.cst = po->d_cst;
     a.dtrue = d;
     a.N = (int)po->tt.size(); a.skip = skip; a.use_vend = po->use_vend; a.noise = noise; a.P = npaths;
@@ -565,6 +601,29 @@ static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const d
     if (noise == 2) {   // pCN chain step
         a.Wc = ch->Wc; a.ldC = ch->ld; a.cur = ch->cur; a.llcur = ch->llcur; a.acc = ch->acc;
         a.rho = rho; a.srho = std::sqrt(1 - rho * rho);
+    }
+    if (po->mh.id >= USER_MODEL_BASE) {   // component-wise user drift: the hipRTC instantiation k_tile<D, noise, PAD, MUserBig>
+        const int D = tile_dim(d);
+        const bool pad = d != D;
+        for (size_t k = 0; k < po->mh.dpar.size() && k < 16; k++) a.upar[k] = po->mh.dpar[k];
+        a.tt = po->d_tt;
+        hipFunction_t fn = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(user_models_mutex());
+            UserModel *um = find_user_model(po->mh.id);
+            if (!um || !um->components) return fail(ctx, BHIP_EINVAL, "unknown component-wise user model id");
+            const std::vector<int> key = {ctx->device, -1, D, noise, pad ? 1 : 0};
+            auto it = um->fns.find(key);
+            if (it == um->fns.end()) {
+                const std::string log = rtc_tile_build(*um, D, noise, pad, &fn);
+                if (!log.empty()) return fail(ctx, BHIP_EHIP, log);
+                um->fns[key] = fn;
+            } else fn = it->second;
+        }
+        TArgs args = a;
+        void *params[] = {&args};
+        HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)((npaths + 63) / 64), 1, 1, 256, 1, 1, (unsigned)tile_lds_bytes(D, true), ctx->stream, params, nullptr));
+        return BHIP_OK;
     }
     hipError_t le = hipSuccess;
     if (d == 32) le = launch_tile_noise<32, false>(a, noise, ctx->stream);
@@ -771,21 +830,36 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
     const int mo = gk == BHIP_GUIDE_LMMU ? po->g.m : 1;
     if (po->mh.id >= USER_MODEL_BASE) {   // hipRTC-compiled user drift: compile this instantiation on first use
         if (gk_dispatch == BHIP_GUIDE_NUH_INPLACE) fl |= 4;
+        // the wave-specialised kernels where they apply, with the workgroup shapes of launch_pc (module kernels take up to the
+        // full 160 KB of dynamic LDS on gfx950 without an opt-in: probed, 48 ... 160 KB)
+        int npair = 0, knoise = noise;
+        const long groups = (a.P + 63) / 64;
+        if (ctx->wave_specialised && a.rdtp && (po->mh.mp == 1 || po->mh.mp == 2) && a.wstride == 1) {
+            if (noise == NOISE_FRESH && a.P <= PC_FRESH_MAX_PATHS) knoise = NOISE_FRESH_PC;
+            else if (noise == NOISE_PCN_LINES) knoise = NOISE_PCN_LINES_PC;
+            if (knoise != noise) npair = groups <= PC_MAX_GROUPS_2PAIR ? 2 : groups <= PC_MAX_GROUPS_4PAIR ? 4 : 1;
+        }
         hipFunction_t fn = nullptr;
         {
             std::lock_guard<std::mutex> lk(user_models_mutex());
             UserModel *um = find_user_model(po->mh.id);
             if (!um) return fail(ctx, BHIP_EINVAL, "unknown user model id");
-            const std::vector<int> key = {ctx->device, gk, mo, noise, fl};   // a hipFunction_t belongs to the device it was loaded on
+            const std::vector<int> key = {ctx->device, gk, mo, knoise, fl, npair};   // a hipFunction_t belongs to the device it was loaded on
             auto it = um->fns.find(key);
             if (it == um->fns.end()) {
-                const std::string log = rtc_build(*um, gk, mo, noise, fl, &fn);
+                const std::string log = rtc_build(*um, gk, mo, knoise, fl, &fn, npair);
                 if (!log.empty()) return fail(ctx, BHIP_EHIP, log);
                 um->fns[key] = fn;
             } else fn = it->second;
         }
         KArgs args = a;
         void *params[] = {&args};
+        if (npair > 0) {
+            const int spc = LINE_DOUBLES / po->mh.mp;
+            const unsigned lds = npair == 1 ? (unsigned)PC_LDS : (unsigned)(sizeof(double) * (RNG_TAB_DOUBLES + npair * (2 * PC_TILE + 2 * spc * a.rs)));
+            HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)((groups + npair - 1) / npair), 1, 1, 128 * npair, 1, 1, lds, ctx->stream, params, nullptr));
+            return BHIP_OK;
+        }
         const long grid = (a.P + 255) / 256;
         const unsigned lds = noise == NOISE_PCN_LINES ? (unsigned)CHAIN_LINES_LDS : 0u;
         HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, lds, ctx->stream, params, nullptr));
@@ -841,10 +915,8 @@ int bhip_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, const d
     }
     if (ldW < npaths || (X_dev && ldX < npaths)) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
     if (x0_dev && ldX < npaths) return fail(ctx, BHIP_ELENGTH, "per-path starting points x0_dev are laid out [d][ldX]: ldX must be >= npaths");
-    if (po->mh.d > 3) {
-        if (x0_dev) return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: shared starting point only");
-        return launch_tile_path(po, x0, W_dev, ldW, nullptr, 0, X_dev, ldX, ll_dev, skip, npaths, 0, 0, 0, 0);
-    }
+    if (po->mh.d > 3)
+        return launch_tile_path(po, x0, W_dev, ldW, nullptr, 0, X_dev, ldX, ll_dev, skip, npaths, 0, 0, 0, 0, 1, nullptr, 0.0, x0_dev, ldX);
     KArgs a;
     int rc = fill_common(po, a, x0, x0_dev, npaths, skip);
     if (rc) return rc;
@@ -866,10 +938,8 @@ int bhip_sample_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, 
     if ((W_dev && ldW < npaths) || (X_dev && ldX < npaths)) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
     if (x0_dev && ldX < npaths) return fail(ctx, BHIP_ELENGTH, "per-path starting points x0_dev are laid out [d][ldX]: ldX must be >= npaths");
     PATH_RANGE(ctx, path0, npaths > 0 ? npaths : 0);
-    if (po->mh.d > 3) {
-        if (x0_dev) return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: shared starting point only");
-        return launch_tile_path(po, x0, nullptr, 0, W_dev, ldW, X_dev, ldX, ll_dev, skip, npaths, 1, seed, iter, path0);
-    }
+    if (po->mh.d > 3)
+        return launch_tile_path(po, x0, nullptr, 0, W_dev, ldW, X_dev, ldX, ll_dev, skip, npaths, 1, seed, iter, path0, 1, nullptr, 0.0, x0_dev, ldX);
     KArgs a;
     int rc = fill_common(po, a, x0, x0_dev, npaths, skip);
     if (rc) return rc;

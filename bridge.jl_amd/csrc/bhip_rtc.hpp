@@ -26,8 +26,13 @@ static const char *const RTC_PREFIX =
 #include "bhip_rtc_src.inc"
     ;
 
+static const char *const RTC_PREFIX_TILE =
+#include "bhip_rtc_tile_src.inc"
+    ;
+
 struct UserModel {
     int id = 0, d = 0, mp = 0, npar = 0;
+    bool components = false;   // d > 3: the drift is given component-wise and runs on the MFMA tile kernel (bhip_model_define_components)
     std::string drift;
     std::string sigma;   // empty: constant sigma passed as data; else the body of sigma(t,x,P)
     std::map<std::vector<int>, hipFunction_t> fns;   // (device, gk, mo, noise, fl) -> kernel
@@ -53,7 +58,18 @@ inline UserModel *find_user_model(int id)
     return (k >= 0 && k < (int)v.size()) ? v[k].get() : nullptr;
 }
 
-inline std::string rtc_source(const UserModel &um, int gk, int mo, int noise, int fl)
+// the instantiation behind (noise, npair): npair > 0 selects the wave-specialised kernel k_pc (noise 6 / 7 = NOISE_FRESH_PC /
+// NOISE_PCN_LINES_PC of bhip_pc_kernel.h) with that many producer/consumer pairs per workgroup
+inline std::string rtc_kernel_name(int gk, int mo, int noise, int fl, int npair, bool qualified)
+{
+    const std::string ns = qualified ? "bhip::" : "";
+    const std::string args = std::to_string(gk) + ", " + std::to_string(mo) + ", ";
+    if (npair > 0) return ns + "k_pc<" + ns + "MUser, " + args + std::to_string(noise) + ", " + std::to_string(fl) + ", " + std::to_string(npair) + ">";
+    if (noise == NOISE_PCN_LINES) return ns + "k_chain_lines<" + ns + "MUser, " + args + std::to_string(fl) + ">";
+    return ns + "k_paths<" + ns + "MUser, " + args + std::to_string(noise) + ", " + std::to_string(fl) + ">";
+}
+
+inline std::string rtc_source(const UserModel &um, int gk, int mo, int noise, int fl, int npair = 0)
 {
     std::string s = RTC_PREFIX;
     s += "\nnamespace bhip {\nstruct MUser {\n";
@@ -146,22 +162,15 @@ inline std::string rtc_source(const UserModel &um, int gk, int mo, int noise, in
 )";
     }
     s += "};\n";
-    if (noise == NOISE_PCN_LINES)
-        s += "template __global__ void k_chain_lines<MUser, " + std::to_string(gk) + ", " + std::to_string(mo) + ", " + std::to_string(fl) + ">(const KArgs);\n}\n";
-    else
-        s += "template __global__ void k_paths<MUser, " + std::to_string(gk) + ", " + std::to_string(mo) + ", " + std::to_string(noise) + ", " +
-             std::to_string(fl) + ">(const KArgs);\n}\n";
+    s += "template __global__ void " + rtc_kernel_name(gk, mo, noise, fl, npair, false) + "(const KArgs);\n}\n";
     return s;
 }
 
 // compile one instantiation (no GPU needed); returns "" on success, else the hipRTC log
-inline std::string rtc_compile(const UserModel &um, int gk, int mo, int noise, int fl, std::vector<char> &code, std::string &low)
+inline std::string rtc_compile(const UserModel &um, int gk, int mo, int noise, int fl, std::vector<char> &code, std::string &low, int npair = 0)
 {
-    const std::string src = rtc_source(um, gk, mo, noise, fl);
-    const std::string name = noise == NOISE_PCN_LINES
-                                 ? "bhip::k_chain_lines<bhip::MUser, " + std::to_string(gk) + ", " + std::to_string(mo) + ", " + std::to_string(fl) + ">"
-                                 : "bhip::k_paths<bhip::MUser, " + std::to_string(gk) + ", " + std::to_string(mo) + ", " + std::to_string(noise) + ", " +
-                                       std::to_string(fl) + ">";
+    const std::string src = rtc_source(um, gk, mo, noise, fl, npair);
+    const std::string name = rtc_kernel_name(gk, mo, noise, fl, npair, true);
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "bhip_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return "hiprtcCreateProgram failed";
     hiprtcAddNameExpression(prog, name.c_str());
@@ -186,12 +195,60 @@ inline std::string rtc_compile(const UserModel &um, int gk, int mo, int noise, i
     return "";
 }
 
-// compile + load one instantiation
-inline std::string rtc_build(UserModel &um, int gk, int mo, int noise, int fl, hipFunction_t *out)
+// ---- d > 3: k_tile<D, NOISE, PAD, MUserBig>, the target drift evaluated component-wise by the user's text
+inline std::string rtc_tile_compile(const UserModel &um, int D, int noise, bool pad, std::vector<char> &code, std::string &low)
+{
+    std::string s = RTC_PREFIX_TILE;
+    s += "\nnamespace bhip {\nstruct MUserBig {\n    static constexpr bool ON = true;\n";
+    s += "    static __device__ __forceinline__ double bk(int k, double t, const double *x, const double *par)\n    {\n";
+    s += "        const int d = " + std::to_string(um.d) + "; (void)d; (void)t; (void)par; (void)k;\n        double o = 0.0;\n        " + um.drift + "\n        return o;\n    }\n};\n";
+    const std::string inst = "k_tile<" + std::to_string(D) + ", " + std::to_string(noise) + ", " + (pad ? "true" : "false") + ", MUserBig>";
+    s += "template __global__ void " + inst + "(const TArgs);\n}\n";
+    const std::string name = "bhip::k_tile<" + std::to_string(D) + ", " + std::to_string(noise) + ", " + (pad ? "true" : "false") + ", bhip::MUserBig>";
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, s.c_str(), "bhip_user_model_tile.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return "hiprtcCreateProgram failed";
+    hiprtcAddNameExpression(prog, name.c_str());
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+    const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, ' ');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return "hipRTC compilation of the user process failed:\n" + log;
+    }
+    const char *lowered = nullptr;
+    hiprtcGetLoweredName(prog, name.c_str(), &lowered);
+    low = lowered ? lowered : "";
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    code.resize(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    return "";
+}
+inline std::string rtc_tile_build(UserModel &um, int D, int noise, bool pad, hipFunction_t *out)
 {
     std::vector<char> code;
     std::string low;
-    const std::string log = rtc_compile(um, gk, mo, noise, fl, code, low);
+    const std::string log = rtc_tile_compile(um, D, noise, pad, code, low);
+    if (!log.empty()) return log;
+    hipModule_t mod;
+    if (hipModuleLoadData(&mod, code.data()) != hipSuccess) return "hipModuleLoadData failed for the compiled user model";
+    hipFunction_t f;
+    if (hipModuleGetFunction(&f, mod, low.c_str()) != hipSuccess) return "kernel symbol not found in the compiled user model: " + low;
+    um.modules.push_back(mod);
+    *out = f;
+    return "";
+}
+
+// compile + load one instantiation
+inline std::string rtc_build(UserModel &um, int gk, int mo, int noise, int fl, hipFunction_t *out, int npair = 0)
+{
+    std::vector<char> code;
+    std::string low;
+    const std::string log = rtc_compile(um, gk, mo, noise, fl, code, low, npair);
     if (!log.empty()) return log;
     hipModule_t mod;
     if (hipModuleLoadData(&mod, code.data()) != hipSuccess) return "hipModuleLoadData failed for the compiled user model";

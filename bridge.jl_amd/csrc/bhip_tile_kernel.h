@@ -61,7 +61,16 @@ struct TArgs {
     double *llcur;
     unsigned int *acc;
     double rho, srho;
+    // user-defined target drift at large d (bhip_model_define_components, hipRTC): parameters by value, grid times
+    double upar[16];
+    const double *tt;
+    const double *x0_dev;   // optional per-path starting points [d][ldx0] (segment chaining: src/euler.jl:267 returns the end point)
+    long ldx0;
 };
+// The target drift of the built-in instantiations is LinPro's B(x - mu), one of the five MFMA products.  A hipRTC user process
+// supplies its drift COMPONENT-WISE instead: UD::bk(k, t, x, par) = b_k(t, x, P), where x points to the path's whole state
+// vector (gathered per wave in LDS -- a lane holds only 8 of a path's 32 components).
+struct NoUserDrift { static constexpr bool ON = false; };
 typedef double tile_d2v __attribute__((ext_vector_type(2)));
 
 template <int T>
@@ -89,7 +98,7 @@ __device__ __forceinline__ void tile_mv(const double *__restrict__ Mf, const dou
     }
 }
 
-template <int D, int NOISE, bool PAD = false>
+template <int D, int NOISE, bool PAD = false, class UD = NoUserDrift>
 __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per SIMD: <= 256 VGPR+AGPR
 {
     constexpr int T = D / 16;
@@ -99,6 +108,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     double *cm = lds;                  // 4*DD fragment matrices + 5*D vectors
     double *hb = lds + 4 * DD + 5 * D; // 2 * STEP
     double *rtab_lds = hb + 2 * STEP;  // the generator's tables (RNG_TAB_DOUBLES), for the noise-drawing instantiations
+    double *xs_lds = rtab_lds + RNG_TAB_DOUBLES;   // UD::ON: the state vectors of the block's 64 paths, [4 waves][16 paths][D]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, j = lane & 15;
     const long p_raw = (long)blockIdx.x * 64 + wave * 16 + j;
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
         for (int t = 0; t < T; t++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                x[t][r] = a.x0[16 * t + 4 * r + kq];
+                x[t][r] = (a.x0_dev && ok(t, r)) ? a.x0_dev[(size_t)(16 * t + 4 * r + kq) * a.ldx0 + p] : a.x0[16 * t + 4 * r + kq];
                 wprev[t][r] = (NOISE == 0 && ok(t, r)) ? *q : 0.0;
                 if (NOISE == 0) q += rsWin;
                 if (NOISE == 1 && a.Wout) { if (ok(t, r)) *qo = 0.0; qo += rsWo; }
@@ -288,7 +298,24 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
             }
         double rr[T][4], bT[T][4], bA[T][4], g[T][4], s[T][4];
         tile_mv<T>(hm, w, rr, lane);
-        tile_mv<T>(Bf, xm, bT, lane);
+        if constexpr (UD::ON) {
+            // gather the path's state (its components sit in 4 lanes x 8 registers) and evaluate b_k for this lane's rows
+            double *xv = xs_lds + (size_t)(wave * 16 + j) * D;
+            __builtin_amdgcn_wave_barrier();   // the previous step's reads of xv are done
+#pragma unroll
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) xv[16 * t + 4 * r + kq] = x[t][r];
+            __builtin_amdgcn_wave_barrier();   // one wave's LDS operations execute in order: the writes above precede the reads below
+            const double ti = a.tt[i];
+#pragma unroll
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = 16 * t + 4 * r + kq;
+                    bT[t][r] = (!PAD || row < dtr) ? UD::bk(row, ti, xv, a.upar) : 0.0;
+                }
+        } else tile_mv<T>(Bf, xm, bT, lane);
         tile_mv<T>(Btf, xa, bA, lane);
         if constexpr (NOISE != 3) {
             tile_mv<T>(Af, rr, g, lane);
@@ -349,10 +376,15 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     if (a.ll && live && kq == 0) a.ll[p] = ll;
 }
 
+// ---- BHIP_RTC_END  (above: device code, also embedded for hipRTC user drifts at large d; below: host launch)
+
+// dynamic LDS of k_tile<D, ., ., UD>: constants, two step buffers, generator tables (+ the gathered states for a user drift)
+constexpr size_t tile_lds_bytes(int D, bool user) { return sizeof(double) * (4 * D * D + 5 * D + 2 * (D * D + D) + RNG_TAB_DOUBLES + (user ? 64 * D : 0)); }
+
 template <int D, int NOISE, bool PAD = false>
 hipError_t launch_tile(const TArgs &a, hipStream_t st)
 {
-    const size_t lds = sizeof(double) * (4 * D * D + 5 * D + 2 * (D * D + D) + RNG_TAB_DOUBLES);
+    const size_t lds = tile_lds_bytes(D, false);
     // per device and cheap: set on every launch (a process may drive several devices)
     hipError_t e = hipFuncSetAttribute((const void *)k_tile<D, NOISE, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -347,6 +347,7 @@ int bo_model_dims(int model, int d_hint, int *d, int *mp)
     case BO_MODEL_WIENER: *d = d_hint; *mp = d_hint; return 0;
     case BO_MODEL_OU: *d = 1; *mp = 1; return 0;
     case BO_MODEL_LINPRO: *d = d_hint; *mp = d_hint; return 0;
+    case BO_MODEL_LORENZ96: *d = d_hint; *mp = d_hint; return 0;
     case BO_MODEL_FHN: *d = 2; *mp = 1; return 0;
     case BO_MODEL_NCLAR: *d = 3; *mp = 1; return 0;
     case BO_MODEL_INTDIFF: *d = 2; *mp = 1; return 0;
@@ -378,6 +379,9 @@ void bo_b(int model, int d, const double *p, double t, const double *x, double *
         for (int k = 0; k < d; k++) xm[k] = x[k] - mu[k];
         mv(d, d, B, xm, o);
         break; }
+    case BO_MODEL_LORENZ96: /* stand-in user drift at d > 3: b_k = (x_{k+1} - x_{k-2})*x_{k-1} - x_k + F, indices mod d */
+        for (int k = 0; k < d; k++) o[k] = (x[(k + 1) % d] - x[(k + d - 2) % d]) * x[(k + d - 1) % d] - x[k] + p[0];
+        break;
     case BO_MODEL_FHN: /* partialbridge_fitzhugh.jl:44  ((x1-x2-x1^3+s)/eps, gamma*x1-x2+beta) */
         o[0] = (x[0] - x[1] - x[0] * x[0] * x[0] + p[1]) / p[0];
         o[1] = p[2] * x[0] - x[1] + p[3];
@@ -427,6 +431,7 @@ void bo_sigma_apply(int model, int d, int mp, const double *p, double t, const d
     case BO_MODEL_WIENER: for (int k = 0; k < d; k++) o[k] = dw[k]; break;  /* sigma = I */
     case BO_MODEL_OU: o[0] = p[1] * dw[0]; break;
     case BO_MODEL_LINPRO: mv(d, d, p + d * d + d, dw, o); break;            /* P.sigma*dw */
+    case BO_MODEL_LORENZ96: mv(d, d, p + 1, dw, o); break;
     case BO_MODEL_FHN: o[0] = 0.0 * dw[0]; o[1] = p[4] * dw[0]; break;      /* R2(0, sigma)*dw */
     case BO_MODEL_NCLAR: o[0] = 0.0 * dw[0]; o[1] = 0.0 * dw[0]; o[2] = p[2] * dw[0]; break;
     case BO_MODEL_INTDIFF: o[0] = 0.0 * dw[0]; o[1] = p[0] * dw[0]; break;
@@ -447,6 +452,7 @@ static void model_sigma_mat(int model, int d, int mp, const double *p, double t,
     case BO_MODEL_WIENER: for (int k = 0; k < d; k++) S[k + d * k] = 1.0; break;
     case BO_MODEL_OU: S[0] = p[1]; break;
     case BO_MODEL_LINPRO: memcpy(S, p + d * d + d, sizeof(double) * d * d); break;
+    case BO_MODEL_LORENZ96: memcpy(S, p + 1, sizeof(double) * d * d); break;
     case BO_MODEL_FHN: S[1] = p[4]; break;
     case BO_MODEL_NCLAR: S[2] = p[2]; break;
     case BO_MODEL_INTDIFF: S[1] = p[0]; break;

@@ -50,6 +50,9 @@ enum {
     /* two processes with a STATE-DEPENDENT sigma(t,x) (constdiff = false), the shape of a user-defined
      * Bridge.b / Bridge.sigma pair (README.md:69-77); used to check the hipRTC user-process path */
     BO_MODEL_SDIFF1 = 9,      /* b = kappa*(theta - x), sigma = s*sqrt(1 + x^2)            par: kappa,theta,s */
+    BO_MODEL_LORENZ96 = 11,   /* stand-in for a user-defined drift at d > 3 (no such process in the reference; the extension point
+                                 is README.md:69-77):  b_k = (x_{k+1} - x_{k-2})*x_{k-1} - x_k + F, cyclic; dense constant sigma.
+                                 par: F, sigma(d*d)  */
     BO_MODEL_SDIFF2 = 10      /* b = (th1*(m1-x1) + c*x2, th2*(m2-x2)),
                                  sigma = [s1*sqrt(1+x1^2)  s3*x2; 0  s2]                   par: th1,m1,c,th2,m2,s1,s2,s3 */
 };

@@ -15,6 +15,7 @@ _SO = os.path.join(_ODIR, "libbridge_oracle.so")
 
 MODEL_WIENER, MODEL_OU, MODEL_LINPRO, MODEL_FHN, MODEL_NCLAR, MODEL_INTDIFF, MODEL_LORENZ, MODEL_FHN2, MODEL_PENDULUM = range(9)
 MODEL_SDIFF1, MODEL_SDIFF2 = 9, 10        # state-dependent sigma (oracle-side stand-ins for hipRTC user processes)
+MODEL_LORENZ96 = 11                       # Lorenz-96 with a dense constant sigma: stand-in for a component-wise user drift at d > 3
 AUX_AFFINE, AUX_LINPRO, AUX_FHN_STARTEND = range(3)
 GUIDE_NONE, GUIDE_HV, GUIDE_LMMU, GUIDE_NUH, GUIDE_NUH_INPLACE = range(5)
 

@@ -199,3 +199,19 @@ def test_tile_kernel_refuses_odd_and_too_large_dimensions(ctx):
         B, sig = -np.eye(d), 0.5 * np.eye(d)
         with pytest.raises(bh.BridgeError, match="even dimension"):
             bh.GuidedBridge(np.linspace(0, 1, 11), bh.LinPro(B, np.zeros(d), sig), bh.LinPro(B, np.zeros(d), sig), np.zeros(d), ctx=ctx)
+
+
+def test_tile_kernel_per_path_starting_points(ctx):
+    """x0_dev at large d (segment chaining: solve! returns the end point, src/euler.jl:267): every path from its own start"""
+    d, P = 16, 50
+    c = problems.linpro_big_case(d, 81)
+    Po, ref = c.bh_proposal(bh, ctx), c.oracle_proposal()
+    rng = np.random.default_rng(3)
+    starts = c.x0[None, :] + 0.2 * rng.standard_normal((P, d))
+    u = torch.tensor(np.ascontiguousarray(starts.T), dtype=torch.float64, device=ctx.device)      # [d][P]
+    X, W, ll = bh.sample_solve(u, Po, P, seed=6, store_W=True)
+    Xh, Wh, llh = X.paths(), W.paths(), ll.cpu().numpy()
+    for p in (0, 17, 49):
+        Xr = o.solve_guided(ref, starts[p], Wh[p])
+        _close(Xh[p], Xr, llh[p:p + 1], np.array([o.llikelihood(ref, Xr)]))
+        assert np.array_equal(Xh[p, 0], starts[p])
