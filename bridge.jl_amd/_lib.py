@@ -77,6 +77,9 @@ SIGNATURES = {
     "bhip_segchains_mcstats": (C.c_int, [vp, C.c_int, C.c_long, dp, dp, C.POINTER(C.c_int64)]),
     "bhip_segchains_set_proposals": (C.c_int, [vp, C.POINTER(vp)]),
     "bhip_segchains_pooled_stats": (C.c_int, [vp, C.c_int, dp, dp, dp]),
+    "bhip_segchains_set_pi0": (C.c_int, [vp, dp, dp, C.c_int]),
+    "bhip_segchains_adapt_device": (C.c_int, [vp, C.c_int, dp, dp, dp, dp, dp, C.c_int, C.c_int]),
+    "bhip_segchains_chain_guide": (C.c_int, [vp, C.c_int, C.c_long, dp, dp, dp]),
     "bhip_comm_unique_id": (C.c_int, [vp, C.c_size_t]),
     "bhip_comm_init_rank": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
     "bhip_comm_init_all": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(vp)]),

@@ -892,6 +892,15 @@ class Chains:
             pass
 
 
+SEG_NEWBLOCK, SEG_DOACCEPT = 1, 2
+
+
+def cholupper_t(H):
+    """cholupper(Hermitian(H))': the lower Cholesky factor read from H's UPPER triangle (src/gaussian.jl:54 needs it for rand(pi0))"""
+    H = np.atleast_2d(np.asarray(H, dtype=np.float64))
+    return np.linalg.cholesky(np.triu(H) + np.triu(H, 1).T)
+
+
 class SegChains:
     """An ensemble of chains over m chained guided segments with ONE Metropolis-Hastings decision per chain and iteration,
     a pCN move of the starting point and (optionally) mcnext! per iteration -- the loop of
@@ -935,11 +944,12 @@ class SegChains:
         self.ctx.check(self.ctx.lib.bhip_segchains_set_proposals(self.h, hs))
         self.pos = pos            # keeps the new proposals alive (and lets the old ones go)
 
-    def adapt(self, P, L, Sigma, obs, HT, vT, means=None):
+    def adapt(self, P, L, Sigma, obs, HT, vT, means=None, set_pi0=True, newblock=True, doaccept=False):
         """Adaptive smoothing step, supplements/smoothing/smoothing.jl:130-160: re-linearise every segment's LinearAppr
         around the running mean of its paths (pooled over the ensemble unless `means` gives them), rebuild the chain of
         GuidedBridge's backwards from (HT, vT) with gpupdate at the observations obs[i] (obs[m] belongs to the right end and
-        is already folded into (HT, vT)), and hand the new proposals over.  Returns (mu, Hd) of the new pi0 = N(mu, Hd)."""
+        is already folded into (HT, vT)), hand the new proposals over and install pi0 = Gaussian(mu, Hermitian(Hd)) (:153) with
+        the script's newblock / doaccept switches.  Returns (mu, Hd)."""
         H, v = np.array(HT, dtype=np.float64), np.array(vT, dtype=np.float64)
         new = [None] * self.m
         for i in range(self.m - 1, -1, -1):
@@ -947,7 +957,41 @@ class SegChains:
             new[i] = GuidedBridge(self.pos[i].tt, P, linearappr(Y), v, H, ctx=self.ctx)
             H, v = gpupdate(new[i], L, Sigma, obs[i])
         self.set_proposals(new)
+        if set_pi0:
+            self.set_pi0(v, cholupper_t(H), newblock=newblock, doaccept=doaccept)
         return v, H
+
+    def set_pi0(self, mu=None, chol=None, newblock=True, doaccept=False):
+        """pi0 <- Gaussian(mu, chol chol') (smoothing.jl:153); newblock: the start stays put until the first accept (:154,166-167);
+        doaccept: the next iteration accepts unconditionally (:156-158,193)"""
+        fl = (SEG_NEWBLOCK if newblock else 0) | (SEG_DOACCEPT if doaccept else 0)
+        if mu is None:
+            self.ctx.check(self.ctx.lib.bhip_segchains_set_pi0(self.h, None, None, fl))
+        else:
+            mu = np.ascontiguousarray(np.atleast_1d(mu), dtype=np.float64)
+            self.ctx.check(self.ctx.lib.bhip_segchains_set_pi0(self.h, _dptr(mu), _dptr(_cm(np.atleast_2d(chol))), fl))
+
+    def adapt_device(self, L, Sigma, obs, HT, vT, hwindow=0, newblock=True, doaccept=False):
+        """The adaptation block of smoothing.jl:130-160 for every chain at once, on the device: every chain re-linearises its
+        LinearAppr auxiliaries around ITS OWN running means (needs mcnext=True), rebuilds its GuidedBridge's backwards from
+        (HT, vT) with gpupdate at obs[i] (the observation at the left end of segment i) and gets its own pi0."""
+        L = np.atleast_2d(np.asarray(L, dtype=np.float64))
+        mo = L.shape[0]
+        obs = np.ascontiguousarray(np.asarray(obs, dtype=np.float64)[:self.m].reshape(self.m, mo))
+        vT = np.ascontiguousarray(np.atleast_1d(vT), dtype=np.float64)
+        fl = (SEG_NEWBLOCK if newblock else 0) | (SEG_DOACCEPT if doaccept else 0)
+        self.ctx.check(self.ctx.lib.bhip_segchains_adapt_device(self.h, mo, _dptr(_cm(L)), _dptr(_cm(np.atleast_2d(Sigma))), _dptr(obs),
+                                                                _dptr(_cm(np.atleast_2d(HT))), _dptr(vT), int(hwindow), fl))
+
+    def chain_guide(self, segment, chain):
+        """one chain's device-built guide of one segment: dict(B [N-1,d,d], beta [N-1,d], G [N-1,g] (the kernels' guide
+        entries: d = 3 -> cofactors of Hd (row-wise 3x3), det, V), mu [d], chol [d,d])"""
+        d = self.d
+        g = 2 if d == 1 else 7 if d == 2 else 13
+        rows, mu, ch = np.empty((self.N - 1, d * d + d + g)), np.empty(d), np.empty(d * d)
+        self.ctx.check(self.ctx.lib.bhip_segchains_chain_guide(self.h, segment, chain, _dptr(rows), _dptr(mu), _dptr(ch)))
+        return dict(B=_uncm(rows[:, :d * d].copy(), d, d), beta=rows[:, d * d:d * d + d].copy(), G=rows[:, d * d + d:].copy(),
+                    mu=mu, chol=ch.reshape(d, d).T.copy())
 
     def pooled_stats(self, segment):
         """(mean [N, d], m2 [N, d, d], count) pooled over chains x iterations"""

@@ -7,6 +7,7 @@
 #include "bhip_pc_kernel.h"
 #include "bhip_comm.hpp"
 #include "bhip_tile_kernel.h"
+#include "bhip_guide_kernel.h"
 #include "bhip_girsanov_kernel.h"
 #include "bhip_rtc.hpp"
 #include "bhip_util_kernels.h"
@@ -31,6 +32,10 @@ launch_fn get_launch_pendulum(int, int, int, int);
 launch_fn get_launch_wiener1(int, int, int, int);
 launch_fn get_launch_wiener2(int, int, int, int);
 launch_fn get_launch_wiener3(int, int, int, int);
+launch_fn get_launch_ppr_lorenz(int, int);
+launch_fn get_launch_ppr_pendulum(int, int);
+guide_launch_fn get_guide_launch_lorenz(int);
+guide_launch_fn get_guide_launch_pendulum(int);
 }  // namespace bhip
 
 #ifndef PC_FRESH_MAX_PATHS
@@ -83,6 +88,9 @@ struct bhip_chains {
     unsigned int *acc = nullptr;
     double *statpart = nullptr;   // [256][6] per-block partial statistics
     bool shares_state = false;    // segment > 0 of a multi-segment ensemble: cur / acc / llcur belong to the owner (bhip_segchains)
+    // per-chain coefficient rows / endpoint rule (owned by bhip_segchains after bhip_segchains_adapt_device), else null
+    const double *prows = nullptr, *vend_pc = nullptr;
+    const unsigned char *uv_pc = nullptr;
 };
 
 static int fail(bhip_ctx *ctx, int code, const std::string &msg)
@@ -1164,6 +1172,19 @@ int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
 
 // ONE pCN proposal of every chain of a segment with the decision deferred (multi-segment ensembles): Wo = w_old*W + w_new*W2,
 // starts from x0_dev, proposal paths to Xo, llo to llo_dev; cur / llcur / acc are left alone (bhip_segchains_step decides)
+// launches on per-chain coefficient rows (device-built guides): the monolithic kernels, PerPathRow instantiations
+static int launch_ppr(bhip_chains *ch, int noise, KArgs &a)
+{
+    bhip_ctx *ctx = ch->ctx;
+    const bhip_proposal *po = ch->po;
+    a.prows = ch->prows; a.ldr = ch->ld; a.vend_pc = ch->vend_pc; a.uv_pc = ch->uv_pc;
+    const int fl = (noise == NOISE_PCN || noise == NOISE_PCN_LINES) ? (a.Xo ? 1 : 0) : 0;
+    launch_fn f = po->mh.id == BHIP_MODEL_LORENZ ? get_launch_ppr_lorenz(noise, fl) : po->mh.id == BHIP_MODEL_PENDULUM ? get_launch_ppr_pendulum(noise, fl) : nullptr;
+    if (!f) return fail(ctx, BHIP_EUNSUPPORTED, "no per-chain-guide kernel for this model");
+    HIPCHK(ctx, f(a, ctx->stream));
+    return BHIP_OK;
+}
+
 static int chains_propose_deferred(bhip_chains *ch, double w_old, double w_new, const double *x0_dev, long ldx0, uint32_t iter, uint32_t blk0,
                                    double *llo_dev, int skip)
 {
@@ -1176,7 +1197,18 @@ static int chains_propose_deferred(bhip_chains *ch, double w_old, double w_new, 
     a.cur = ch->cur; a.llcur = ch->llcur; a.acc = ch->acc;
     a.rho = w_old; a.srho = w_new;
     a.k0 = (uint32_t)ch->seed; a.k1 = (uint32_t)(ch->seed >> 32); a.path0 = ch->path0; a.iter = iter;
+    if (ch->prows) return launch_ppr(ch, ch->lines ? NOISE_PCN_LINES : NOISE_PCN, a);
     return do_launch(po, ch->lines ? NOISE_PCN_LINES : NOISE_PCN, a);
+}
+
+// llikelihood(LeftRule(), X, Po) of every chain's path under the chain's OWN guide
+static int chains_llikelihood_ppr(bhip_chains *ch, const double *X_dev, long ldX, double *ll_dev, int skip)
+{
+    KArgs a;
+    int rc = fill_common(ch->po, a, ch->x0.data(), nullptr, ch->n, skip);
+    if (rc) return rc;
+    a.Win = X_dev; a.ldWin = ldX; a.ll = ll_dev;
+    return launch_ppr(ch, NOISE_LLONLY, a);
 }
 
 int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip)

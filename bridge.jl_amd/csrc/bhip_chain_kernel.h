@@ -37,7 +37,7 @@ BHIP_DEV size_t line_index(int h, int k, long chain, int nch, long ld)
 #define BHIP_LINES_STAGE 1
 #endif
 
-template <class M, int GK, int MO, int FL>
+template <class M, int GK, int MO, int FL, bool PPR = false /* per-chain coefficient rows */>
 __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(const KArgs a)
 {
     constexpr int D = M::D, MP = M::MP;
@@ -90,7 +90,11 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
         double wc[MP];
 #pragma unroll
         for (int cc = 0; cc < MP; cc++) wc[cc] = mine[s * MP + cc];
-        path_step<M, GK, MO, NOISE_PCN, FL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wc, nullptr, 0, xout, ldx, st);
+        if constexpr (PPR)
+            path_step<M, GK, MO, NOISE_PCN, FL, PerPathRow>(model, a, PerPathRow{rows + (size_t)i * RL::RS, a.prows + (size_t)i * (RL::LEN - 3) * a.ldr + p, a.ldr},
+                                                            i, nll, path, wc, nullptr, 0, xout, ldx, st);
+        else
+            path_step<M, GK, MO, NOISE_PCN, FL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wc, nullptr, 0, xout, ldx, st);
 #pragma unroll
         for (int cc = 0; cc < MP; cc++) mine[s * MP + cc] = st.wprev[cc];
     };
@@ -136,7 +140,12 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
         __builtin_amdgcn_wave_barrier();   // the tile is overwritten by the next chunk only after these reads
     }
 
-    if (a.use_vend) {   // endpoint(y, P::GuidedBridge) src/euler.jl:241-242
+    if constexpr (PPR) {
+        if (a.uv_pc[p]) {
+#pragma unroll
+            for (int k = 0; k < D; k++) st.y[k] = a.vend_pc[(size_t)k * a.ldr + p];
+        }
+    } else if (a.use_vend) {   // endpoint(y, P::GuidedBridge) src/euler.jl:241-242
 #pragma unroll
         for (int k = 0; k < D; k++) st.y[k] = a.vend[k];
     }
@@ -162,11 +171,11 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
 
 constexpr size_t CHAIN_LINES_LDS = sizeof(double) * 4 * 64 * LINE_ROW;   // one tile per wave, 4 waves per block: 34 KiB
 
-template <class M, int GK, int MO, int FL>
+template <class M, int GK, int MO, int FL, bool PPR>
 hipError_t launch_chain_lines(const KArgs &a, hipStream_t st)
 {
     const long grid = (a.P + 255) / 256;
-    hipLaunchKernelGGL((k_chain_lines<M, GK, MO, FL>), dim3((unsigned)grid), dim3(256), CHAIN_LINES_LDS, st, a);
+    hipLaunchKernelGGL((k_chain_lines<M, GK, MO, FL, PPR>), dim3((unsigned)grid), dim3(256), CHAIN_LINES_LDS, st, a);
     return hipGetLastError();
 }
 

@@ -1,0 +1,318 @@
+// bhip_guide_kernel.h -- guide pre-computation ON THE DEVICE, one guide per chain.
+//
+// Adaptive smoothing (supplements/smoothing/smoothing.jl:130-160) re-linearises every segment's auxiliary process around
+// the running mean of THE CHAIN'S OWN paths (xx = mcstate[i][1]) and rebuilds the chain of GuidedBridge's backwards:
+//
+//     H, v = gpupdate(prior, last observation)                                    (host, once: shared by all chains)
+//     for i = m .. 1:  linearappr!(Pt[i], Y_i, P)        B_j = bderiv(t_j, Y_j), b_j = b(t_j, Y_j), xx_j = Y_j   src/linpro.jl:196-204
+//                      Po[i] = GuidedBridge(tt_i, P, Pt[i], v, H)     index-based Heun, src/guip.jl:181-189 (bhip_host.hpp: guide_hv_heuni)
+//                      H, v = gpupdate(Po[i], L, Sigma, obs_i)        src/guip.jl:221-231
+//     pi0 = Gaussian(v, Hermitian(H))
+//
+// With an ensemble every chain has its own means, hence its own guides: O(m N d^3) work and m N (d^2 + d + ...) doubles
+// PER CHAIN -- the case where the host cannot keep up.  Here a lane owns a chain and walks a segment's grid backwards with
+// (K, V) in registers; per grid point it evaluates the linearisation, does the two Heun steps and writes the chain's
+// coefficient row in the layout the path kernels read (RowLayout minus the three shared time entries), SoA over chains:
+//     prow[(i*PRL + q)*ld + p],   q: B~_i (d*d), beta~_i = b_i - B_i xx_i (d), guide part of pack_rows (cofactors, det, V)
+// The operations and their order are those of bhip_host.hpp (Mat products accumulate left to right, StaticArrays closed
+// forms for inv/det), so a chain's rows are bit-identical to what the host would compute for that chain's means.
+#pragma once
+#include "bhip_path_kernel.h"
+
+namespace bhip {
+
+// ---- small static matrices, column-major; the operation order of bhip_host.hpp's Mat operators
+template <int R, int K, int C>
+BHIP_DEV void sm_mul(const double *A, const double *B, double *O)   // O(RxC) = A(RxK) * B(KxC)
+{
+#pragma unroll
+    for (int j = 0; j < C; j++)
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            double s = A[i] * B[K * j];
+#pragma unroll
+            for (int l = 1; l < K; l++) s += A[i + R * l] * B[l + K * j];
+            O[i + R * j] = s;
+        }
+}
+template <int R, int K, int C>
+BHIP_DEV void sm_mul_t(const double *A, const double *B, double *O)   // O(RxC) = A(RxK) * B'(KxC), B stored CxK
+{
+#pragma unroll
+    for (int j = 0; j < C; j++)
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            double s = A[i] * B[j];
+#pragma unroll
+            for (int l = 1; l < K; l++) s += A[i + R * l] * B[j + C * l];
+            O[i + R * j] = s;
+        }
+}
+template <int N>
+BHIP_DEV double sm_det(const double *a)   // StaticArrays det.jl
+{
+    if constexpr (N == 1) return a[0];
+    else if constexpr (N == 2) return a[0] * a[3] - a[2] * a[1];
+    else {
+        const double c0 = a[4] * a[8] - a[5] * a[7], c1 = a[5] * a[6] - a[3] * a[8], c2 = a[3] * a[7] - a[4] * a[6];
+        return a[0] * c0 + a[1] * c1 + a[2] * c2;
+    }
+}
+template <int N>
+BHIP_DEV void sm_inv(const double *a, double *R)   // StaticArrays inv.jl
+{
+    if constexpr (N == 1) R[0] = 1.0 / a[0];
+    else if constexpr (N == 2) {
+        const double d = sm_det<2>(a);
+        R[0] = a[3] / d; R[1] = -(a[1] / d); R[2] = -(a[2] / d); R[3] = a[0] / d;
+    } else {
+        double x0[3] = {a[0], a[1], a[2]};
+        const double x1[3] = {a[3], a[4], a[5]}, x2[3] = {a[6], a[7], a[8]};
+        double y0[3] = {x1[1] * x2[2] - x1[2] * x2[1], x1[2] * x2[0] - x1[0] * x2[2], x1[0] * x2[1] - x1[1] * x2[0]};
+        const double d = x0[0] * y0[0] + x0[1] * y0[1] + x0[2] * y0[2];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { x0[k] = x0[k] / d; y0[k] = y0[k] / d; }
+        const double y1[3] = {x2[1] * x0[2] - x2[2] * x0[1], x2[2] * x0[0] - x2[0] * x0[2], x2[0] * x0[1] - x2[1] * x0[0]};
+        const double y2[3] = {x0[1] * x1[2] - x0[2] * x1[1], x0[2] * x1[0] - x0[0] * x1[2], x0[0] * x1[1] - x0[1] * x1[0]};
+        R[0] = y0[0]; R[1] = y1[0]; R[2] = y2[0]; R[3] = y0[1]; R[4] = y1[1]; R[5] = y2[1];
+        R[6] = y0[2]; R[7] = y1[2]; R[8] = y2[2];
+    }
+}
+
+// the guide part of a coefficient row for the (Hdiamond, V) guide: bhip_host.hpp pack_rows
+template <int D>
+BHIP_DEV void hv_row_part(const double *A, const double *V, double *q)
+{
+    if constexpr (D == 1) { q[0] = A[0]; q[1] = V[0]; }
+    else if constexpr (D == 2) { q[0] = A[0]; q[1] = A[1]; q[2] = A[2]; q[3] = A[3]; q[4] = sm_det<2>(A); q[5] = V[0]; q[6] = V[1]; }
+    else {
+        auto a = [&](int i, int j) { return A[(i - 1) + 3 * (j - 1)]; };
+        q[0] = a(2, 2) * a(3, 3) - a(2, 3) * a(3, 2); q[1] = a(1, 3) * a(3, 2) - a(1, 2) * a(3, 3); q[2] = a(1, 2) * a(2, 3) - a(1, 3) * a(2, 2);
+        q[3] = a(2, 3) * a(3, 1) - a(2, 1) * a(3, 3); q[4] = a(1, 1) * a(3, 3) - a(1, 3) * a(3, 1); q[5] = a(1, 3) * a(2, 1) - a(1, 1) * a(2, 3);
+        q[6] = a(2, 1) * a(3, 2) - a(2, 2) * a(3, 1); q[7] = a(1, 2) * a(3, 1) - a(1, 1) * a(3, 2); q[8] = a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1);
+        q[9] = sm_det<3>(A); q[10] = V[0]; q[11] = V[1]; q[12] = V[2];
+    }
+}
+
+// gpupdate(Hd, V, L, Sigma, v), finite branch  src/guip.jl:221-231 (bhip_host.hpp gpupdate).  Si = inv(Sigma) from the host.
+template <int D, int MO>
+BHIP_DEV void sm_gpupdate(const double *Hd, const double *V, const double *L, const double *Sigma, const double *Si, const double *v,
+                          double *Hd_out, double *V_out)
+{
+    double LH[MO * D], S[MO * MO], Sinv[MO * MO], T1[D * MO], T2[D * MO], T3[D * D], Z[D * D], w1[D], w2[D];
+    sm_mul<MO, D, D>(L, Hd, LH);            // L*Hd
+    sm_mul_t<MO, D, MO>(LH, L, S);          // (L*Hd)*L'
+#pragma unroll
+    for (int k = 0; k < MO * MO; k++) S[k] = Sigma[k] + S[k];
+    sm_inv<MO>(S, Sinv);
+    sm_mul_t<D, D, MO>(Hd, L, T1);          // Hd*L'
+    sm_mul<D, MO, MO>(T1, Sinv, T2);        // (Hd*L')*inv(S)
+    sm_mul<D, MO, D>(T2, L, T3);            // (...)*L
+#pragma unroll
+    for (int j = 0; j < D; j++)
+#pragma unroll
+        for (int i = 0; i < D; i++) Z[i + D * j] = (i == j ? 1.0 : 0.0) - T3[i + D * j];
+    sm_mul<D, D, D>(Z, Hd, Hd_out);         // Z*Hd
+    sm_mul_t<D, D, MO>(Hd_out, L, T1);      // (Z*Hd)*L'
+    sm_mul<D, MO, MO>(T1, Si, T2);          // (...)*inv(Sigma)
+    sm_mul<D, MO, 1>(T2, v, w1);
+    sm_mul<D, D, 1>(Z, V, w2);
+#pragma unroll
+    for (int k = 0; k < D; k++) V_out[k] = w1[k] + w2[k];
+}
+
+// cholupper(Hermitian(A))': the lower factor from the UPPER triangle (StaticArrays cholesky closed forms; oracle bo_chol_lower)
+template <int D>
+BHIP_DEV void sm_chol_lower(const double *A, double *C)
+{
+#pragma unroll
+    for (int k = 0; k < D * D; k++) C[k] = 0.0;
+    if constexpr (D == 1) C[0] = sqrt(A[0]);
+    else if constexpr (D == 2) {
+        const double a = sqrt(A[0]), b = A[2] / a;
+        C[0] = a; C[1] = b; C[3] = sqrt(A[3] - b * b);
+    } else {
+        const double a11 = sqrt(A[0]), a12 = A[3] / a11, a22 = sqrt(A[4] - a12 * a12);
+        const double a13 = A[6] / a11, a23 = (A[7] - a12 * a13) / a22, a33 = sqrt(A[8] - a13 * a13 - a23 * a23);
+        C[0] = a11; C[1] = a12; C[2] = a13; C[4] = a22; C[5] = a23; C[8] = a33;
+    }
+}
+
+struct GArgs {
+    long n, ld;
+    int N, rs, hwindow;
+    const double *srows;   // the segment's shared rows: t_i, dt_i at [i*rs + 0], [i*rs + 1]
+    const double *mean;    // [N][D][ld]: the chains' linearisation paths (running means, mcnext!)
+    double *prow;          // out [N-1][PRL][ld]
+    double *carry;         // [D*D + D][ld]: (Hdiamond, v) at the segment's right end in; after gpupdate at its left end out
+    double *vend;          // out [D][ld]: V[N-1] of the chain (endpoint rule, src/euler.jl:241-242)
+    unsigned char *uv;     // out [ld]: norm(Hd[N-1], 1) < eps()
+    double L[9], Sigma[9], Si[9], obs[3];
+    double mpar[40];
+};
+
+// per-chain rows: everything of RowLayout except (t, dt, sqrt(dt))
+template <int D> constexpr int pp_row_len() { return D * D + D + (D == 1 ? 2 : D == 2 ? 7 : 13); }
+
+template <class M, int MO>
+__global__ __launch_bounds__(64) void k_seg_guide(const GArgs g)
+{
+    constexpr int D = M::D, MP = M::MP, DD = D * D, PRL = pp_row_len<D>();
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.n) return;
+    const M model(g.mpar);
+    const int N = g.N;
+    const cptr_t srows = (cptr_t)(uintptr_t)g.srows;
+
+    // outer(Sigma_j): sigma is constant for the processes with a bderiv; S*S' through the model's own sigma*dw
+    double aS[DD];
+    {
+        double Sg[D * MP];
+#pragma unroll
+        for (int c = 0; c < MP; c++) {
+            double e[MP], col[D], zero[D];
+#pragma unroll
+            for (int k = 0; k < MP; k++) e[k] = k == c ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < D; k++) zero[k] = 0.0;
+            model.sdw(0.0, zero, e, col);
+#pragma unroll
+            for (int r = 0; r < D; r++) Sg[r + D * c] = col[r];
+        }
+        sm_mul_t<D, MP, D>(Sg, Sg, aS);
+    }
+
+    // the linearisation point at grid index j: the chain's mean, or its moving average (smoothing.jl:136,142)
+    auto loadY = [&](int j, double *y) {
+        if (g.hwindow <= 0) {
+#pragma unroll
+            for (int k = 0; k < D; k++) y[k] = g.mean[((size_t)j * D + k) * g.ld + p];
+        } else {
+            const int lo = max(0, j - g.hwindow), hi = min(N - 1, j + g.hwindow);
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+                double s = g.mean[((size_t)lo * D + k) * g.ld + p];
+                for (int l = lo + 1; l <= hi; l++) s += g.mean[((size_t)l * D + k) * g.ld + p];
+                y[k] = s / (double)(hi - lo + 1);
+            }
+        }
+    };
+    auto fH = [&](const double *B, const double *K, double *out) {   // B K + K B' - outer(Sigma)
+        double BK[DD], KBt[DD];
+        sm_mul<D, D, D>(B, K, BK);
+        sm_mul_t<D, D, D>(K, B, KBt);
+#pragma unroll
+        for (int k = 0; k < DD; k++) out[k] = (BK[k] + KBt[k]) - aS[k];
+    };
+    auto fV = [&](const double *B, const double *xx, const double *b, const double *x, double *out) {   // B (x - xx) + b
+        double xm[D], Bx[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) xm[k] = x[k] - xx[k];
+        sm_mul<D, D, 1>(B, xm, Bx);
+#pragma unroll
+        for (int k = 0; k < D; k++) out[k] = Bx[k] + b[k];
+    };
+
+    double K[DD], w[D];
+#pragma unroll
+    for (int k = 0; k < DD; k++) K[k] = g.carry[(size_t)k * g.ld + p];
+#pragma unroll
+    for (int k = 0; k < D; k++) w[k] = g.carry[(size_t)(DD + k) * g.ld + p];
+    {   // endpoint(y, P::GuidedBridge): norm(Hd[end], 1) < eps() ? V[end] : y
+        double n1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < DD; k++) n1 += fabs(K[k]);
+        g.uv[p] = n1 < 2.220446049250313e-16 ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < D; k++) g.vend[(size_t)k * g.ld + p] = w[k];
+    }
+    double B1[DD], b1[D], x1[D];
+    loadY(N - 1, x1);
+    model.bderiv(0.0, x1, B1);   // (bderiv and b of these processes do not depend on t)
+    model.b(0.0, x1, b1);
+    for (int i = N - 2; i >= 0; i--) {
+        double B0[DD], b0[D], x0[D];
+        loadY(i, x0);
+        const double t = srows[(size_t)i * g.rs];
+        const double dt = -srows[(size_t)i * g.rs + 1];   // tt[i] - tt[i+1] = -(tt[i+1] - tt[i]) exactly
+        model.bderiv(t, x0, B0);
+        model.b(t, x0, b0);
+        {
+            double k1[DD], k2[DD], yp[DD];
+            fH(B0, K, k1);
+#pragma unroll
+            for (int k = 0; k < DD; k++) yp[k] = K[k] + dt * k1[k];
+            fH(B1, yp, k2);
+#pragma unroll
+            for (int k = 0; k < DD; k++) K[k] = K[k] + (dt / 2) * (k1[k] + k2[k]);
+        }
+        {
+            double k1[D], k2[D], wp[D];
+            fV(B0, x0, b0, w, k1);
+#pragma unroll
+            for (int k = 0; k < D; k++) wp[k] = w[k] + dt * k1[k];
+            fV(B1, x1, b1, wp, k2);
+#pragma unroll
+            for (int k = 0; k < D; k++) w[k] = w[k] + (dt / 2) * (k1[k] + k2[k]);
+        }
+        // the chain's coefficient row of step i
+        double row[PRL];
+#pragma unroll
+        for (int k = 0; k < DD; k++) row[k] = B0[k];
+        {
+            double Bx[D];
+            sm_mul<D, D, 1>(B0, x0, Bx);
+#pragma unroll
+            for (int k = 0; k < D; k++) row[DD + k] = b0[k] - Bx[k];   // beta((i,s), P) = P.b[i] - P.B[i]*P.xx[i]   src/linpro.jl:189
+        }
+        hv_row_part<D>(K, w, row + DD + D);
+        double *o = g.prow + (size_t)i * PRL * g.ld + p;
+#pragma unroll
+        for (int q = 0; q < PRL; q++) o[(size_t)q * g.ld] = row[q];
+#pragma unroll
+        for (int k = 0; k < DD; k++) B1[k] = B0[k];
+#pragma unroll
+        for (int k = 0; k < D; k++) { b1[k] = b0[k]; x1[k] = x0[k]; }
+    }
+    // fold the observation at the segment's left end: the right-end condition of the previous segment (or pi0)
+    double Hn[DD], vn[D];
+    sm_gpupdate<D, MO>(K, w, g.L, g.Sigma, g.Si, g.obs, Hn, vn);
+#pragma unroll
+    for (int k = 0; k < DD; k++) g.carry[(size_t)k * g.ld + p] = Hn[k];
+#pragma unroll
+    for (int k = 0; k < D; k++) g.carry[(size_t)(DD + k) * g.ld + p] = vn[k];
+}
+
+// pi0 = Gaussian(v, Hermitian(H)) per chain from the carry: mu = v, C = cholupper(Hermitian(H))'
+template <int D>
+__global__ void k_seg_pi0(long n, long ld, const double *__restrict__ carry, double *__restrict__ mu, double *__restrict__ chol)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    double H[D * D], C[D * D];
+#pragma unroll
+    for (int k = 0; k < D * D; k++) H[k] = carry[(size_t)k * ld + p];
+    sm_chol_lower<D>(H, C);
+#pragma unroll
+    for (int k = 0; k < D * D; k++) chol[(size_t)k * ld + p] = C[k];
+#pragma unroll
+    for (int k = 0; k < D; k++) mu[(size_t)k * ld + p] = carry[(size_t)(D * D + k) * ld + p];
+}
+
+typedef hipError_t (*guide_launch_fn)(const GArgs &, hipStream_t);
+template <class M, int MO>
+hipError_t launch_seg_guide(const GArgs &g, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_seg_guide<M, MO>), dim3((unsigned)((g.n + 63) / 64)), dim3(64), 0, st, g);
+    return hipGetLastError();
+}
+template <class M>
+guide_launch_fn get_guide_launch(int mo)
+{
+    if (mo == 1) return launch_seg_guide<M, 1>;
+    if constexpr (M::D >= 2) { if (mo == 2) return launch_seg_guide<M, 2>; }
+    if constexpr (M::D >= 3) { if (mo == 3) return launch_seg_guide<M, 3>; }
+    return nullptr;
+}
+
+}  // namespace bhip

@@ -3,6 +3,7 @@
 #include "bhip_path_kernel.h"
 #include "bhip_chain_kernel.h"
 #include "bhip_pc_kernel.h"
+#include "bhip_guide_kernel.h"
 
 namespace bhip {
 #if BHIP_INST == 0
@@ -21,10 +22,14 @@ launch_fn get_launch_nclar(int gk, int mo, int noise, int fl) { return get_launc
 launch_fn get_launch_intdiff(int gk, int mo, int noise, int fl) { return get_launch<MIntDiff>(gk, mo, noise, fl); }
 #elif BHIP_INST == 7
 launch_fn get_launch_lorenz(int gk, int mo, int noise, int fl) { return get_launch<MLorenz>(gk, mo, noise, fl); }
+launch_fn get_launch_ppr_lorenz(int noise, int fl) { return get_launch_ppr<MLorenz>(noise, fl); }
+guide_launch_fn get_guide_launch_lorenz(int mo) { return get_guide_launch<MLorenz>(mo); }
 #elif BHIP_INST == 8
 launch_fn get_launch_fhn2(int gk, int mo, int noise, int fl) { return get_launch<MFHN2>(gk, mo, noise, fl); }
 #elif BHIP_INST == 9
 launch_fn get_launch_pendulum(int gk, int mo, int noise, int fl) { return get_launch<MPendulum>(gk, mo, noise, fl); }
+launch_fn get_launch_ppr_pendulum(int noise, int fl) { return get_launch_ppr<MPendulum>(noise, fl); }
+guide_launch_fn get_guide_launch_pendulum(int mo) { return get_guide_launch<MPendulum>(mo); }
 #elif BHIP_INST == 10
 launch_fn get_launch_wiener1(int gk, int mo, int noise, int fl) { return get_launch<MWiener<1>>(gk, mo, noise, fl); }
 launch_fn get_launch_wiener2(int gk, int mo, int noise, int fl) { return get_launch<MWiener<2>>(gk, mo, noise, fl); }

@@ -172,7 +172,13 @@ struct MLorenz {
         o[2] = x[0] * x[1] - t3 * x[2];
     }
     BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const { o[0] = s1 * dw[0]; o[1] = s2 * dw[1]; o[2] = s3 * dw[2]; }
-    BHIP_DEV void amul(double, const double *, const double *r, double *o) const { o[0] = a1 * r[0]; o[1] = a2 * r[1]; o[2] = a3 * r[2]; }
+    BHIP_DEV void amul(double, const double *, const double *r, double *o) const { o[0] = a1 * r[0]; o[1] = a2 * r[1]; o[2] = a3 * r[2]; }    // Bridge.bderiv(t, x, P::Lorenz)  src/Models.jl:49-53 (column-major 3 x 3): the linearisation of LinearAppr guides
+    BHIP_DEV void bderiv(double, const double *x, double *J) const
+    {
+        J[0] = -t1;       J[3] = t1;   J[6] = 0.0;
+        J[1] = t2 - x[2]; J[4] = -1.0; J[7] = -x[0];
+        J[2] = x[1];      J[5] = x[0]; J[8] = -t3;
+    }
 };
 
 // ---- Models.FitzHughNagumo            src/Models.jl:9-20  (diagonal 2-d noise)
@@ -204,6 +210,8 @@ struct MPendulum {
     BHIP_DEV void b(double, const double *x, double *o) const { o[0] = x[1]; o[1] = -th2 * sin(x[0]); }
     BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const { o[0] = 0.0; o[1] = gam * dw[0]; }
     BHIP_DEV void amul(double, const double *, const double *r, double *o) const { o[0] = 0.0; o[1] = a22 * r[1]; }
+    // Bridge.bderiv(t, x, P::Pendulum)  src/Models.jl:81-84
+    BHIP_DEV void bderiv(double, const double *x, double *J) const { J[0] = 0.0; J[1] = -th2 * cos(x[0]); J[2] = 1.0; J[3] = 0.0; }
 };
 
 // ---- Wiener{SVector{D}}: b = 0, sigma = a = I            src/wiener.jl:143-167

@@ -75,9 +75,23 @@ struct KArgs {
     double vend[3];
     double mu_aux[3];
     double mpar[40];
+    // per-chain coefficient rows (device-built guides, bhip_guide_kernel.h): prows[(i*PRL + q)*ldr + p] holds entry 3 + q of
+    // chain p's row of step i (the three time entries stay in the shared rows); per-chain endpoint rule
+    const double *prows;
+    long ldr;
+    const double *vend_pc;        // [D][ldr]
+    const unsigned char *uv_pc;   // [ldr]
 };
 
 typedef const __attribute__((address_space(4))) double *cptr_t;
+
+// a coefficient row whose time entries are shared (scalar loads) and whose other entries belong to the lane's chain
+struct PerPathRow {
+    cptr_t sh;
+    const double *pp;
+    long ld;
+    BHIP_DEV double operator[](int q) const { return q < 3 ? sh[q] : pp[(size_t)(q - 3) * ld]; }
+};
 typedef double d2v __attribute__((ext_vector_type(2)));   // one 16-byte chain slot
 
 // Streaming accesses of the ensemble: every byte is written once / read once per launch and never
@@ -391,7 +405,7 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int n
 #define BHIP_WPE 4
 #endif
 
-template <class M, int GK, int MO, int NOISE, int FL>
+template <class M, int GK, int MO, int NOISE, int FL, bool PPR = false /* per-chain coefficient rows */>
 __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
 {
     constexpr int D = M::D, MP = M::MP;
@@ -411,6 +425,11 @@ __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
     const int N = a.N;
     const int nll = N - 1 - a.skip;
     const cptr_t rows = (cptr_t)(uintptr_t)a.rows;
+    using RowT = typename bhip_cond<PPR, PerPathRow, cptr_t>::type;
+    auto rowat = [&](int i) {
+        if constexpr (PPR) return PerPathRow{rows + (size_t)i * RL::RS, a.prows + (size_t)i * (RL::LEN - 3) * a.ldr + p, a.ldr};
+        else return rows + (size_t)i * RL::RS;
+    };
 
     LaneState<D, MP> st;
 #pragma unroll
@@ -517,16 +536,16 @@ __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
     for (; i + 1 < nsteps; i += 2) {
         double cur[NIN];
         advance(i, cur);
-        path_step<M, GK, MO, NOISE, FL, cptr_t, TabT>(model, a, rows + (size_t)i * RL::RS, i, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
+        path_step<M, GK, MO, NOISE, FL, RowT, TabT>(model, a, rowat(i), i, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
         commit(i);
         advance(i + 1, cur);
-        path_step<M, GK, MO, NOISE, FL, cptr_t, TabT>(model, a, rows + (size_t)(i + 1) * RL::RS, i + 1, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
+        path_step<M, GK, MO, NOISE, FL, RowT, TabT>(model, a, rowat(i + 1), i + 1, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
         commit(i + 1);
     }
     if (i < nsteps) {
         double cur[NIN];
         advance(i, cur);
-        path_step<M, GK, MO, NOISE, FL, cptr_t, TabT>(model, a, rows + (size_t)i * RL::RS, i, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
+        path_step<M, GK, MO, NOISE, FL, RowT, TabT>(model, a, rowat(i), i, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
         commit(i);
     }
 
@@ -535,7 +554,12 @@ __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
         for (int k = 0; k < D; k++) st_stream(&wout[((size_t)(N - 1) * D + k) * ldwo], st.wprev[k]);   // ww[N] = w
     }
     if constexpr (NOISE != NOISE_LLONLY && NOISE != NOISE_INNOV) {
-        if (a.use_vend) {   // endpoint(y, P::GuidedBridge) src/euler.jl:241-242
+        if constexpr (PPR) {
+            if (a.uv_pc[p]) {
+#pragma unroll
+                for (int k = 0; k < D; k++) st.y[k] = a.vend_pc[(size_t)k * a.ldr + p];
+            }
+        } else if (a.use_vend) {   // endpoint(y, P::GuidedBridge) src/euler.jl:241-242
 #pragma unroll
             for (int k = 0; k < D; k++) st.y[k] = a.vend[k];
         }
@@ -567,18 +591,34 @@ __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
 
 typedef hipError_t (*launch_fn)(const KArgs &, hipStream_t);
 
-template <class M, int GK, int MO, int FL>
+template <class M, int GK, int MO, int FL, bool PPR = false>
 hipError_t launch_chain_lines(const KArgs &a, hipStream_t st);   // bhip_chain_kernel.h
 template <class M, int GK, int MO, int MODE, int FL>
 hipError_t launch_pc(const KArgs &a, hipStream_t st);            // bhip_pc_kernel.h
 
-template <class M, int GK, int MO, int NOISE, int FL>
+template <class M, int GK, int MO, int NOISE, int FL, bool PPR = false>
 hipError_t launch_paths(const KArgs &a, hipStream_t st)
 {
     const int block = 256;
     const long grid = (a.P + block - 1) / block;
-    hipLaunchKernelGGL((k_paths<M, GK, MO, NOISE, FL>), dim3((unsigned)grid), dim3(block), 0, st, a);
+    hipLaunchKernelGGL((k_paths<M, GK, MO, NOISE, FL, PPR>), dim3((unsigned)grid), dim3(block), 0, st, a);
     return hipGetLastError();
+}
+
+// per-chain coefficient rows (GuidedBridge's with LinearAppr auxiliaries re-linearised per chain, bhip_guide_kernel.h):
+// the pCN proposal on either chain layout and the stand-alone log-likelihood
+template <class M>
+launch_fn get_launch_ppr(int noise, int fl)
+{
+    switch (noise) {
+    case NOISE_PCN: return (fl & 1) ? launch_paths<M, BHIP_GUIDE_HV, 1, NOISE_PCN, 1, true> : launch_paths<M, BHIP_GUIDE_HV, 1, NOISE_PCN, 0, true>;
+    case NOISE_PCN_LINES:
+        if constexpr (M::MP == 1 || M::MP == 2)
+            return (fl & 1) ? launch_chain_lines<M, BHIP_GUIDE_HV, 1, 1, true> : launch_chain_lines<M, BHIP_GUIDE_HV, 1, 0, true>;
+        return nullptr;
+    case NOISE_LLONLY: return launch_paths<M, BHIP_GUIDE_HV, 1, NOISE_LLONLY, 0, true>;
+    }
+    return nullptr;
 }
 
 // all (guide, obs-dim, noise, flags) instantiations of one model.

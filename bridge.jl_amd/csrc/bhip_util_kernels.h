@@ -238,35 +238,48 @@ static __global__ void k_welford_merge(long entries, int d, double na, double *_
 // ---- joint MH over chained segments (bhip_segchains.inc): start proposal, joint accept, commit + mcnext!
 template <int D>
 __global__ void k_seg_y0(long n, long ld, double w_old, double w_new, const double *__restrict__ y0, double *__restrict__ y0o,
-                         uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0, KArgs geo /* x0 = mu, mpar[0..D*D) = chol (col-major) */)
+                         uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0, KArgs geo /* x0 = mu, mpar[0..D*D) = chol (col-major) */,
+                         const double *__restrict__ mu_pc, const double *__restrict__ chol_pc /* per-chain pi0 ([D][ld], [D*D][ld]) or null */,
+                         const unsigned char *__restrict__ newblock /* smoothing.jl:166-167: after an adaptation y0o = y0 until the first accept */)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    double xi[D + 1];
+    if (newblock && newblock[p]) {
+#pragma unroll
+        for (int r = 0; r < D; r++) y0o[r * ld + p] = y0[r * ld + p];
+        return;
+    }
+    double xi[D + 1], mu[D], ch[D * D];
+#pragma unroll
+    for (int k = 0; k < D; k++) mu[k] = mu_pc ? mu_pc[(size_t)k * ld + p] : geo.x0[k];
+#pragma unroll
+    for (int k = 0; k < D * D; k++) ch[k] = chol_pc ? chol_pc[(size_t)k * ld + p] : geo.mpar[k];
 #pragma unroll
     for (int k = 0; k < D; k += 2) normal_pair(TabConst(), k0, k1, path0 + (uint32_t)p, iter, (uint32_t)(k >> 1), xi[k], xi[k + 1], 2u);
 #pragma unroll
     for (int r = 0; r < D; r++) {
-        double cz = geo.mpar[r] * xi[0];
+        double cz = ch[r] * xi[0];
 #pragma unroll
-        for (int c = 1; c < D; c++) cz += geo.mpar[r + D * c] * xi[c];
-        const double z = geo.x0[r] + cz;                                   // rand(pi0) = mu + C*randn   src/gaussian.jl:54
-        y0o[r * ld + p] = geo.x0[r] + w_new * (z - geo.x0[r]) + w_old * (y0[r * ld + p] - geo.x0[r]);
+        for (int c = 1; c < D; c++) cz += ch[r + D * c] * xi[c];
+        const double z = mu[r] + cz;                                       // rand(pi0) = mu + C*randn   src/gaussian.jl:54
+        y0o[r * ld + p] = mu[r] + w_new * (z - mu[r]) + w_old * (y0[r * ld + p] - mu[r]);
     }
 }
 
 static __global__ void k_seg_accept(long n, long ld, int m, int d, const double *__restrict__ llo, double *__restrict__ ll,
                                     unsigned char *__restrict__ cur, unsigned int *__restrict__ acc, unsigned char *__restrict__ accflag,
-                                    double *__restrict__ y0, const double *__restrict__ y0o, uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0)
+                                    double *__restrict__ y0, const double *__restrict__ y0o, uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0,
+                                    unsigned char *__restrict__ newblock, int doaccept /* smoothing.jl:156-158,193: the first adaptive proposal is accepted */)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     double lls = 0.0;
     for (int i = 0; i < m; i++) lls += llo[i * ld + p] - ll[i * ld + p];   // ll += llikelihood(XXo[i]) - llikelihood(XX[i])
     const double u = accept_uniform(k0, k1, path0 + (uint32_t)p, iter);
-    const bool ok = det_log(u) <= lls;
+    const bool ok = doaccept || det_log(u) <= lls;
     accflag[p] = ok ? 1 : 0;
     if (ok) {
+        if (newblock) newblock[p] = 0;
         cur[p] ^= 1;
         acc[p] += 1u;
         for (int i = 0; i < m; i++) ll[i * ld + p] = llo[i * ld + p];

@@ -314,6 +314,30 @@ int bhip_segchains_set_proposals(bhip_segchains *sc, const bhip_proposal *const 
 /* the pooled state of one segment: every chain's current path of every iteration as one sample (mcnext semantics,
  * batches merged with the parallel form, cf. bhip_welford_merge): mean [N][d], m2 [N][d*d], count = chains*iterations */
 int bhip_segchains_pooled_stats(bhip_segchains *sc, int segment, double *mean, double *m2, double *count);
+/* pi0 <- Gaussian(mu, chol*chol') after an adaptation (supplements/smoothing/smoothing.jl:153; mu, chol both NULL: unchanged),
+ * with the script's two switches:
+ *   BHIP_SEG_NEWBLOCK  the start is not moved (y0o = y0) until a proposal has been accepted          (:154,166-167,201)
+ *   BHIP_SEG_DOACCEPT  the next iteration accepts unconditionally (the first adaptive proposal)       (:156-158,193) */
+#define BHIP_SEG_NEWBLOCK 1
+#define BHIP_SEG_DOACCEPT 2
+int bhip_segchains_set_pi0(bhip_segchains *sc, const double *mu, const double *chol, int flags);
+/* Guide pre-computation ON THE DEVICE, one guide per chain -- the adaptation block of supplements/smoothing/smoothing.jl:130-160
+ * for every chain at once: linearappr!(Pt[i], Y, P) around the chain's OWN running mean Y = mcstate[i][1] (src/linpro.jl:196-204;
+ * hwindow > 0: its moving average over j-hwindow..j+hwindow, smoothmean :136,142), GuidedBridge(tt_i, P, Pt[i], v, H) by the
+ * index-based Heun solver (src/guip.jl:181-189, src/ode.jl:98-113), H, v = gpupdate(Po[i], L, Sigma, obs[i]) backwards
+ * through the segments (src/guip.jl:221-231), pi0 = Gaussian(v, Hermitian(H)).
+ *   requires BHIP_SEGCHAINS_MCNEXT, GuidedBridge segments with LinearAppr auxiliaries, a target whose bderiv exists on the
+ *   device (Lorenz src/Models.jl:49-53, Pendulum :81-84)
+ *   L [mo x d], Sigma [mo x mo] column-major; obs [m][mo]: obs[i] = the observation at the LEFT end of segment i (V.yy[i]);
+ *   (HT [d x d], vT [d]) = gpupdate(prior, last observation): the right-end condition of segment m-1 (bhip_gpupdate)
+ *   flags: BHIP_SEG_NEWBLOCK | BHIP_SEG_DOACCEPT as above
+ * Afterwards every chain proposes with its own coefficient rows and pi0; the log-likelihoods of the current paths are
+ * re-evaluated under them.  bhip_segchains_set_proposals returns the ensemble to shared proposals. */
+int bhip_segchains_adapt_device(bhip_segchains *sc, int mo, const double *L, const double *Sigma, const double *obs,
+                                const double *HT, const double *vT, int hwindow, int flags);
+/* one chain's device-built guide: rows [N-1][d*d + d + g] = (B~_i, beta~_i, guide part: Hd and V as the kernels read them --
+ * d = 1: Hd, V; d = 2: Hd (4), det, V; d = 3: cofactors of Hd (9), det, V), and its pi0: mu [d], chol [d*d] (lower, column-major) */
+int bhip_segchains_chain_guide(bhip_segchains *sc, int segment, long chain, double *rows, double *mu, double *chol);
 
 /* ------------------------------------------------------------------ multi-GPU: the one collective of the path
  * The reference has no parallelism (single-threaded Julia; the MH loops of partialbridge_fitzhugh.jl:143-176 run one

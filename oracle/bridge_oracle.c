@@ -1372,6 +1372,168 @@ void bo_smooth_mcmc_flat(int m, int kind, int N, int d, int mp, int mo, int mode
     free(ps);
 }
 
+/* cholupper(Hermitian(A))' for n <= 3: the LOWER factor C (C*C' = A) computed from A's UPPER triangle, as
+ * rand(P::Gaussian) = P.mu + cholupper(P.Sigma)'*randn (src/gaussian.jl:54) needs it for pi0 = Gaussian(v, Hermitian(Hd))
+ * (supplements/smoothing/smoothing.jl:96,153).  cholesky of a static matrix lives in StaticArrays (a dependency of
+ * Bridge.jl that is not part of /root/reference; REQUIRE names it without a pin); its published closed forms are
+ *   2x2: a = sqrt(A11); b = A12/a; c = sqrt(A22 - b^2)
+ *   3x3: a11 = sqrt(A11); a12 = A12/a11; a22 = sqrt(A22 - a12^2); a13 = A13/a11; a23 = (A23 - a12*a13)/a22;
+ *        a33 = sqrt(A33 - a13^2 - a23^2)                                  (U = [a11 a12 a13; 0 a22 a23; 0 0 a33]) */
+void bo_chol_lower(int n, const double *A, double *C)
+{
+    memset(C, 0, sizeof(double) * n * n);
+    if (n == 1) { C[0] = sqrt(A[0]); return; }
+    if (n == 2) {
+        double a = sqrt(A[0]), b = A[2] / a;
+        C[0] = a; C[1] = b; C[3] = sqrt(A[3] - b * b);
+        return;
+    }
+    double a11 = sqrt(A[0]), a12 = A[3] / a11, a22 = sqrt(A[4] - a12 * a12);
+    double a13 = A[6] / a11, a23 = (A[7] - a12 * a13) / a22, a33 = sqrt(A[8] - a13 * a13 - a23 * a23);
+    C[0] = a11; C[1] = a12; C[2] = a13; C[4] = a22; C[5] = a23; C[8] = a33;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The smoothing loop WITH adaptation: supplements/smoothing/smoothing.jl:75-213 for ONE chain.
+ *   set-up (:75-109): H,v <- (HT, vT) [= gpupdate of the prior with the last observation, done by the caller];
+ *     for i = m..1: Pt[i] = linearappr(Y0[i], P); Po[i] = GuidedBridge(tt_i, P, Pt[i], v, H); H,v = gpupdate(Po[i], L, Sigma, obs[i])
+ *     pi0 = Gaussian(v, Hermitian(H)); y = pi0.mu; first paths.
+ *   iteration `it` (:126-213):
+ *     if adaptive && it < adaptmax && it % adaptit == 0 (:130-160):  the same backward pass with
+ *        Y = mcstate[i] mean (or its moving average over j-hwindow..j+hwindow, :136,142), linearappr!(Pt, Y, P);
+ *        pi0 <- Gaussian(v, Hermitian(H)); newblock = true; doaccept = (it == adaptit)
+ *     y0o = newblock ? y0 : pi0.mu + w_new*(rand(pi0) - pi0.mu) + w_old*(y0 - pi0.mu)                 (:165-172)
+ *     proposals, ll = sum_i llikelihood(XXo[i], Po[i]) - llikelihood(XX[i], Po[i])  -- both under the CURRENT Po (:187-190)
+ *     accept if doaccept || log(U) <= ll; on accept newblock = false                                  (:193-202)
+ *     mcnext! of every segment                                                                        (:211-213)
+ * LinearAppr guides: the index-based Heun solver as restated in bo_gp_hv_heuni (the reference's kerneli cannot run as
+ * committed, see there).  The moving average sums left to right and divides by the count (Statistics.mean of a short
+ * vector of SVectors).  Noise streams as in bo_smooth_mcmc.
+ * tts [m][N]; Y0 [m][N][d]; obs [m][mo]: obs[i] is the observation at the LEFT end of segment i (V.yy[i]).
+ * Outputs as bo_smooth_mcmc, plus the final pi0 (mu_out [d], H_out [d*d]) and, if rows_out != NULL, the final guides
+ * Hd [m][N][d*d], V [m][N][d] of the chain. */
+static void la_pack(double *ap, int N, int d, int mp, int model, const double *par, const double *tt, const double *Y)
+{
+    ap[0] = (double)N;
+    memcpy(ap + 1, tt, sizeof(double) * N);
+    double *xx = ap + 1 + N, *B = xx + (size_t)N * d, *b = B + (size_t)N * d * d, *S = b + (size_t)N * d;
+    memcpy(xx, Y, sizeof(double) * N * d);
+    bo_linearappr(model, d, mp, par, tt, N, Y, B, b, S);
+}
+static void smooth_build(int m, int N, int d, int mp, int mo, int model, const double *par, const double *tts, const double *Yall,
+                         const double *L, const double *Sigma, const double *obs, const double *HT, const double *vT,
+                         double *apars, size_t napar, double *Hd, double *V, bo_proposal *props, double *mu, double *H0)
+{
+    double H[D2], v[BO_MAXD], Hn[D2], vn[BO_MAXD];
+    memcpy(H, HT, sizeof(double) * d * d); memcpy(v, vT, sizeof(double) * d);
+    for (int i = m - 1; i >= 0; i--) {
+        const double *tt = tts + (size_t)N * i;
+        double *ap = apars + napar * i, *Hi = Hd + (size_t)N * d * d * i, *Vi = V + (size_t)N * d * i;
+        la_pack(ap, N, d, mp, model, par, tt, Yall + (size_t)N * d * i);
+        const double *xx = ap + 1 + N, *B = xx + (size_t)N * d, *b = B + (size_t)N * d * d, *S = b + (size_t)N * d;
+        bo_gp_hv_heuni(tt, N, d, mp, xx, B, b, S, v, H, Hi, Vi);
+        mk_prop(&props[i], BO_GUIDE_HV, N, d, mp, d, model, par, BO_AUX_LINEARAPPR, ap, tt, Hi, Vi, NULL, NULL);
+        bo_gpupdate(d, mo, Hi, Vi, L, Sigma, obs + (size_t)mo * i, Hn, vn);
+        memcpy(H, Hn, sizeof(double) * d * d); memcpy(v, vn, sizeof(double) * d);
+    }
+    memcpy(mu, v, sizeof(double) * d); memcpy(H0, H, sizeof(double) * d * d);
+}
+
+void bo_smooth_adaptive(int m, int N, int d, int mp, int mo, int model, const double *par, const double *tts, const double *Y0,
+                        const double *L, const double *Sigma, const double *obs, const double *HT, const double *vT,
+                        const double *w_old, const double *w_new, int iters, int adaptit, int adaptmax, int hwindow, int skip,
+                        uint64_t seed, uint32_t path, double *Xall, double *Wall, double *y0_out, double *ll_out, long *acc_out,
+                        double *mean, double *m2, double *mu_out, double *H_out, double *Hd_out, double *V_out)
+{
+    const size_t nx = (size_t)N * d, nw = (size_t)N * mp;
+    const size_t napar = 1 + (size_t)N + nx + nx * d + nx + (size_t)N * d * mp;
+    bo_proposal *props = (bo_proposal *)malloc(sizeof(bo_proposal) * m);
+    double *apars = (double *)malloc(sizeof(double) * napar * m);
+    double *Hd = (double *)malloc(sizeof(double) * nx * d * m), *V = (double *)malloc(sizeof(double) * nx * m);
+    double *Ysm = (double *)malloc(sizeof(double) * nx * m);
+    double *Xo = (double *)malloc(sizeof(double) * nx * m), *Wo = (double *)malloc(sizeof(double) * nw * m), *W2 = (double *)malloc(sizeof(double) * nw);
+    double *llo = (double *)malloc(sizeof(double) * m), *ll = ll_out;
+    double mu[BO_MAXD], H0[D2], chol[D2], y0[BO_MAXD], y0o[BO_MAXD], y[BO_MAXD];
+    long acc = 0, ns = 0;
+    int newblock = 0;
+    smooth_build(m, N, d, mp, mo, model, par, tts, Y0, L, Sigma, obs, HT, vT, apars, napar, Hd, V, props, mu, H0);
+    bo_chol_lower(d, H0, chol);
+    for (int k = 0; k < d; k++) y0[k] = mu[k];
+    memcpy(y, y0, sizeof(double) * d);
+    for (int i = 0; i < m; i++) {
+        wiener_sample_blk(props[i].tt, N, mp, seed, path, 0, (uint32_t)i << 24, Wall + nw * i);
+        bo_solve_guided(&props[i], y, Wall + nw * i, Xall + nx * i);
+        memcpy(y, Xall + nx * i + (size_t)(N - 1) * d, sizeof(double) * d);
+    }
+    memset(mean, 0, sizeof(double) * nx * m);
+    memset(m2, 0, sizeof(double) * nx * d * m);
+    for (int it = 1; it <= iters; it++) {
+        int doaccept = 0;
+        if (adaptit > 0 && it < adaptmax && it % adaptit == 0) {
+            for (int i = 0; i < m; i++)
+                for (int j = 0; j < N; j++) {
+                    double *dst = Ysm + nx * i + (size_t)j * d;
+                    const double *xx = mean + nx * i;
+                    if (hwindow <= 0) { memcpy(dst, xx + (size_t)j * d, sizeof(double) * d); continue; }
+                    int lo = j - hwindow < 0 ? 0 : j - hwindow, hi = j + hwindow > N - 1 ? N - 1 : j + hwindow;
+                    for (int k = 0; k < d; k++) {
+                        double sacc = xx[(size_t)lo * d + k];
+                        for (int l = lo + 1; l <= hi; l++) sacc += xx[(size_t)l * d + k];
+                        dst[k] = sacc / (double)(hi - lo + 1);
+                    }
+                }
+            smooth_build(m, N, d, mp, mo, model, par, tts, Ysm, L, Sigma, obs, HT, vT, apars, napar, Hd, V, props, mu, H0);
+            bo_chol_lower(d, H0, chol);
+            newblock = 1;
+            if (it == adaptit) doaccept = 1;
+        }
+        const double wo = w_old[it - 1], wn = w_new[it - 1];
+        if (newblock) memcpy(y0o, y0, sizeof(double) * d);
+        else {
+            double xi[BO_MAXD + 1], pr[2];
+            for (int k = 0; k < d; k += 2) {
+                bo_normal_pair_stream(seed, path, 2u, (uint32_t)it, (uint32_t)(k >> 1), pr);
+                xi[k] = pr[0]; xi[k + 1] = pr[1];
+            }
+            for (int r = 0; r < d; r++) {
+                double cz = chol[r] * xi[0];
+                for (int c = 1; c < d; c++) cz += chol[r + d * c] * xi[c];
+                const double z = mu[r] + cz;
+                y0o[r] = mu[r] + wn * (z - mu[r]) + wo * (y0[r] - mu[r]);
+            }
+        }
+        memcpy(y, y0o, sizeof(double) * d);
+        double lls = 0.0;
+        for (int i = 0; i < m; i++) {
+            wiener_sample_blk(props[i].tt, N, mp, seed, path, (uint32_t)it, (uint32_t)i << 24, W2);
+            const double *Wc = Wall + nw * i;
+            double *Wp = Wo + nw * i;
+            for (size_t k = 0; k < nw; k++) Wp[k] = wo * Wc[k] + wn * W2[k];
+            bo_solve_guided(&props[i], y, Wp, Xo + nx * i);
+            memcpy(y, Xo + nx * i + (size_t)(N - 1) * d, sizeof(double) * d);
+            llo[i] = bo_llikelihood(&props[i], Xo + nx * i, skip);
+            ll[i] = bo_llikelihood(&props[i], Xall + nx * i, skip);     /* the current path under the CURRENT proposal (:189) */
+        }
+        for (int i = 0; i < m; i++) lls += llo[i] - ll[i];
+        if (doaccept || bo_log(bo_uniform_accept(seed, path, (uint32_t)it)) <= lls) {
+            acc += 1;
+            memcpy(y0, y0o, sizeof(double) * d);
+            memcpy(Xall, Xo, sizeof(double) * nx * m);
+            memcpy(Wall, Wo, sizeof(double) * nw * m);
+            memcpy(ll, llo, sizeof(double) * m);
+            newblock = 0;
+        }
+        for (int i = 0; i < m; i++) { long n_i = ns; bo_mcnext(N, d, mean + nx * i, m2 + nx * d * i, &n_i, Xall + nx * i); }
+        ns += 1;
+    }
+    memcpy(y0_out, y0, sizeof(double) * d);
+    *acc_out = acc;
+    memcpy(mu_out, mu, sizeof(double) * d); memcpy(H_out, H0, sizeof(double) * d * d);
+    if (Hd_out) memcpy(Hd_out, Hd, sizeof(double) * nx * d * m);
+    if (V_out) memcpy(V_out, V, sizeof(double) * nx * m);
+    free(props); free(apars); free(Hd); free(V); free(Ysm); free(Xo); free(Wo); free(W2); free(llo);
+}
+
 void bo_mcnext(int n_entries, int d, double *mean, double *m2, long *n, const double *x)
 {
     long nn = *n;

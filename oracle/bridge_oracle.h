@@ -209,6 +209,14 @@ void bo_smooth_mcmc_flat(int m, int kind, int N, int d, int mp, int mo, int mode
                          uint64_t seed, uint32_t path, double *Xall, double *Wall, double *y0_out, double *ll_out, long *acc_out,
                          double *mean, double *m2, long *nstat);
 
+/* the smoothing loop with adaptive re-linearisation for one chain (supplements/smoothing/smoothing.jl:75-213) */
+void bo_chol_lower(int n, const double *A, double *C);
+void bo_smooth_adaptive(int m, int N, int d, int mp, int mo, int model, const double *par, const double *tts, const double *Y0,
+                        const double *L, const double *Sigma, const double *obs, const double *HT, const double *vT,
+                        const double *w_old, const double *w_new, int iters, int adaptit, int adaptmax, int hwindow, int skip,
+                        uint64_t seed, uint32_t path, double *Xall, double *Wall, double *y0_out, double *ll_out, long *acc_out,
+                        double *mean, double *m2, double *mu_out, double *H_out, double *Hd_out, double *V_out);
+
 /* ---- online statistics (src/mclog.jl:22-56,89-93) ---- */
 void bo_mcnext(int n_entries, int d, double *mean, double *m2, long *n, const double *x);
 

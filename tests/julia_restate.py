@@ -171,7 +171,7 @@ class GuidedBridge:
         return self.P.b(t, x) + a_of(self.P.sig(t, x)) @ np.linalg.solve(self.Hd[i], self.V[i] - x)
 
     def endpoint(self, y):
-        return self.V[-1] if np.abs(self.Hd[-1]).sum(axis=0).max() < np.finfo(float).eps else y   # norm(., 1) = max column sum
+        return self.V[-1] if np.abs(self.Hd[-1]).sum() < np.finfo(float).eps else y   # norm(A, 1) of a matrix = the entrywise 1-norm (LinearAlgebra / StaticArrays; opnorm is the induced one)
 
 
 class PartialBridgeNuH:

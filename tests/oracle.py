@@ -498,6 +498,44 @@ def smooth_mcmc(props, mu, chol, w_old, w_new, seed, path, skip=0, stats=False):
     return out
 
 
+def chol_lower(A):
+    """cholupper(Hermitian(A))' -- the lower factor from A's upper triangle (StaticArrays closed forms, n <= 3)"""
+    A = np.atleast_2d(np.asarray(A, dtype=np.float64))
+    n = A.shape[0]
+    a = np.ascontiguousarray(cm(A))
+    out = np.empty(n * n)
+    lib().bo_chol_lower(C.c_int(n), a.ctypes.data_as(dp), out.ctypes.data_as(dp))
+    return out.reshape(n, n).T.copy()
+
+
+def smooth_adaptive(model, d, mp, par, tts, Y0, L, Sigma, obs, HT, vT, w_old, w_new, adaptit, adaptmax, seed, path, hwindow=0, skip=0):
+    """bo_smooth_adaptive: the smoothing loop of supplements/smoothing/smoothing.jl:75-213 for one chain, adaptation included.
+    tts [m,N]; Y0 [m,N,d] first linearisation paths; obs [m,mo] (obs[i] at the left end of segment i); (HT, vT) at the right end.
+    Returns dict(X, W, y0, ll, acc, mean, m2, mu, H, Hd [m,N,d,d], V [m,N,d])"""
+    tts = np.ascontiguousarray(tts, dtype=np.float64)
+    m, N = tts.shape
+    Y0 = np.ascontiguousarray(Y0, dtype=np.float64)
+    L = np.atleast_2d(np.asarray(L, dtype=np.float64)); mo = L.shape[0]
+    Lc, Sc = np.ascontiguousarray(cm(L)), np.ascontiguousarray(cm(np.atleast_2d(np.asarray(Sigma, dtype=np.float64))))
+    obs = np.ascontiguousarray(np.asarray(obs, dtype=np.float64).reshape(m, mo))
+    HTc = np.ascontiguousarray(cm(np.atleast_2d(np.asarray(HT, dtype=np.float64))))
+    vT = np.ascontiguousarray(np.atleast_1d(vT), dtype=np.float64)
+    par = np.ascontiguousarray(par, dtype=np.float64)
+    w_old, w_new = np.ascontiguousarray(w_old, dtype=np.float64), np.ascontiguousarray(w_new, dtype=np.float64)
+    X, W = np.empty((m, N, d)), np.empty((m, N, mp))
+    y0, ll, acc = np.empty(d), np.empty(m), C.c_long()
+    mean, m2 = np.empty((m, N, d)), np.empty((m, N, d * d))
+    mu, H = np.empty(d), np.empty(d * d)
+    Hd, V = np.empty((m, N, d * d)), np.empty((m, N, d))
+    P = lambda a: a.ctypes.data_as(dp)
+    lib().bo_smooth_adaptive(C.c_int(m), C.c_int(N), C.c_int(d), C.c_int(mp), C.c_int(mo), C.c_int(model), P(par), P(tts), P(Y0),
+                             P(Lc), P(Sc), P(obs), P(HTc), P(vT), P(w_old), P(w_new), C.c_int(len(w_old)), C.c_int(adaptit),
+                             C.c_int(adaptmax), C.c_int(hwindow), C.c_int(skip), C.c_uint64(seed), C.c_uint32(path),
+                             P(X), P(W), P(y0), P(ll), C.byref(acc), P(mean), P(m2), P(mu), P(H), P(Hd), P(V))
+    return dict(X=X, W=W, y0=y0, ll=ll, acc=acc.value, mean=mean, m2=np.swapaxes(m2.reshape(m, N, d, d), -1, -2).copy(),
+                mu=mu, H=H.reshape(d, d).T.copy(), Hd=np.swapaxes(Hd.reshape(m, N, d, d), -1, -2).copy(), V=V)
+
+
 def mcnext(mean, m2, n, x):
     """in-place Welford update; mean [E,d], m2 [E,d*d] (column-major per entry), returns n+1"""
     E, d = mean.shape

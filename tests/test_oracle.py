@@ -475,3 +475,43 @@ def test_bridgejl_fixtures_if_present():
             Xo = o.solve_guided(ref, c.x0, g[c.name + "/W"][p])
             assert np.array_equal(Xo, X[p]), c.name
             assert o.llikelihood(ref, Xo) == ll[p], c.name
+
+
+def test_adaptive_smoother_without_adaptation_equals_the_plain_smoother_and_chol():
+    """bo_smooth_adaptive (smoothing.jl:75-213) with adaptation switched off must be bo_smooth_mcmc over the proposals it
+    builds itself from the first linearisation paths; bo_chol_lower is a Cholesky factor of the Hermitian(upper) matrix."""
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3):
+        A = rng.standard_normal((n, n)); A = A @ A.T + n * np.eye(n)
+        Au = np.triu(A) + 0.1 * np.tril(rng.standard_normal((n, n)), -1)       # garbage below the diagonal must be ignored
+        C = o.chol_lower(Au)
+        assert np.allclose(C @ C.T, A, rtol=1e-14) and np.array_equal(np.triu(C, 1), np.zeros((n, n)))
+        assert np.allclose(C, np.linalg.cholesky(A), rtol=1e-14)
+    m, M = 2, 30
+    par = [10.0, 20.0, 8 / 3, 3.0, 3.0, 3.0]
+    tgrid = np.linspace(0.0, 0.12, m * M + 1)
+    Yall = np.stack([1.5 + tgrid, -1.5 + 2 * tgrid, 25.0 - tgrid], 1)
+    tts = np.stack([tgrid[i * M:(i + 1) * M + 1] for i in range(m)])
+    Y0 = np.stack([Yall[i * M:(i + 1) * M + 1] for i in range(m)])
+    L, Sig = np.eye(3), 0.5 * np.eye(3)
+    obs = Yall[::M] + 0.3
+    HT, vT = o.gpupdate(1e3 * np.eye(3), np.zeros(3), L, Sig, obs[m])
+    iters = 5
+    w_new = np.sqrt(np.full(iters, 0.2)); w_old = np.sqrt(1 - w_new ** 2)
+    ra = o.smooth_adaptive(o.MODEL_LORENZ, 3, 3, par, tts, Y0, L, Sig, obs[:m], HT, vT, w_old, w_new, 0, 0, 7, 3)
+    # the same proposals, built here
+    H, v, props = HT, vT, [None] * m
+    for i in range(m - 1, -1, -1):
+        B, b, S = o.linearappr(o.MODEL_LORENZ, 3, 3, par, tts[i], Y0[i])
+        Hd, V = o.gp_hv_heuni(tts[i], 3, 3, Y0[i], B, b, S, v, H)
+        assert np.array_equal(Hd, ra["Hd"][i]) and np.array_equal(V, ra["V"][i])
+        props[i] = o.proposal_hv(tts[i], 3, 3, o.MODEL_LORENZ, par, o.AUX_LINEARAPPR, o.linearappr_par(tts[i], Y0[i], B, b, S), Hd, V)
+        H, v = o.gpupdate(Hd[0], V[0], L, Sig, obs[i])
+    assert np.array_equal(ra["mu"], v) and np.array_equal(ra["H"], H)
+    rp = o.smooth_mcmc(props, v, o.chol_lower(H), w_old, w_new, 7, 3, stats=True)
+    for k in ("X", "W", "y0", "ll", "mean", "m2"):
+        assert np.array_equal(ra[k], rp[k]), k
+    assert ra["acc"] == rp["acc"]
+    # with adaptation the guides change and doaccept forces the first adaptive proposal through
+    rb = o.smooth_adaptive(o.MODEL_LORENZ, 3, 3, par, tts, Y0, L, Sig, obs[:m], HT, vT, w_old, w_new, 3, 10 ** 6, 7, 3)
+    assert not np.array_equal(rb["Hd"], ra["Hd"]) and rb["acc"] >= 1 and np.isfinite(rb["ll"]).all()
