@@ -92,6 +92,13 @@ struct PerPathRow {
     long ld;
     BHIP_DEV double operator[](int q) const { return q < 3 ? sh[q] : pp[(size_t)(q - 3) * ld]; }
 };
+// the same row with the chain's entries already in registers (fetched one step ahead by k_paths)
+template <int NPP>
+struct RegRow {
+    cptr_t sh;
+    double v[NPP];
+    BHIP_DEV double operator[](int q) const { return q < 3 ? sh[q] : v[q - 3]; }
+};
 typedef double d2v __attribute__((ext_vector_type(2)));   // one 16-byte chain slot
 
 // Streaming accesses of the ensemble: every byte is written once / read once per launch and never
@@ -406,7 +413,7 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int n
 #endif
 
 template <class M, int GK, int MO, int NOISE, int FL, bool PPR = false /* per-chain coefficient rows */>
-__global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
+__global__ __launch_bounds__(256, PPR ? 2 : BHIP_WPE) void k_paths(const KArgs a)
 {
     constexpr int D = M::D, MP = M::MP;
     using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
@@ -425,11 +432,23 @@ __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
     const int N = a.N;
     const int nll = N - 1 - a.skip;
     const cptr_t rows = (cptr_t)(uintptr_t)a.rows;
-    using RowT = typename bhip_cond<PPR, PerPathRow, cptr_t>::type;
+    // per-chain rows: the chain's RL::LEN - 3 entries of step i+1 are fetched while step i is computed (two register
+    // rows in rotation; the loop is unrolled by two) -- per-lane loads, unlike the shared rows' scalar loads
+    constexpr int NPP = PPR ? RL::LEN - 3 : 1;
+    using RowT = typename bhip_cond<PPR, RegRow<NPP>, cptr_t>::type;
+    RegRow<NPP> rr[2];
+    auto fetch_row = [&](int i, RegRow<NPP> &r) {
+        if constexpr (PPR) {
+            const double *src = a.prows + (size_t)min(i, N - 2) * NPP * a.ldr + p;
+#pragma unroll
+            for (int q = 0; q < NPP; q++) r.v[q] = src[(size_t)q * a.ldr];
+        }
+    };
     auto rowat = [&](int i) {
-        if constexpr (PPR) return PerPathRow{rows + (size_t)i * RL::RS, a.prows + (size_t)i * (RL::LEN - 3) * a.ldr + p, a.ldr};
+        if constexpr (PPR) { rr[i & 1].sh = rows + (size_t)i * RL::RS; return rr[i & 1]; }
         else return rows + (size_t)i * RL::RS;
     };
+    fetch_row(0, rr[0]);
 
     LaneState<D, MP> st;
 #pragma unroll
@@ -536,9 +555,11 @@ __global__ __launch_bounds__(256, BHIP_WPE) void k_paths(const KArgs a)
     for (; i + 1 < nsteps; i += 2) {
         double cur[NIN];
         advance(i, cur);
+        fetch_row(i + 1, rr[1]);
         path_step<M, GK, MO, NOISE, FL, RowT, TabT>(model, a, rowat(i), i, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
         commit(i);
         advance(i + 1, cur);
+        fetch_row(i + 2, rr[0]);
         path_step<M, GK, MO, NOISE, FL, RowT, TabT>(model, a, rowat(i + 1), i + 1, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
         commit(i + 1);
     }
