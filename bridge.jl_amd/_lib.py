@@ -38,6 +38,8 @@ SIGNATURES = {
     "bhip_proposal_set_aux_callback": (C.c_int, [vp, vp, vp, C.c_int, dp]),
     "bhip_proposal_set_aux_linearappr": (C.c_int, [vp, dp, dp, dp, dp]),
     "bhip_linearappr": (C.c_int, [vp, dp, dp, dp, dp]),
+    "bhip_linearnoiseappr_path": (C.c_int, [vp, dp, C.c_int, dp]),
+    "bhip_proposal_set_aux_linearnoiseappr": (C.c_int, [vp, dp]),
     "bhip_proposal_guide_hv": (C.c_int, [vp, dp, dp]),
     "bhip_proposal_guide_lmmu": (C.c_int, [vp, C.c_int, dp, dp, dp]),
     "bhip_proposal_guide_nuh": (C.c_int, [vp, C.c_int, dp, dp, C.c_double, dp, C.c_int]),

@@ -366,6 +366,30 @@ class LinearAppr:
         self.Sigma = np.swapaxes(S.reshape(N, mp, d), -1, -2).copy()
 
 
+class LinearNoiseAppr:
+    """LinearNoiseAppr(tt, P, x, a, direction)  src/guip.jl:114-146: B = 0, beta_i = the slope of the deterministic path Y
+    (R3 of the target's drift, direction "forward" from x at tt[1], "backward" from x at tt[end], "nothing": Y = 0), a = the
+    target's a.  LinearNoiseAppr.with_path(Y) takes Y as given (the adaptation's Pt.Y.yy[:] = xx, smoothing.jl:136-139).
+    The grid and the target are the proposal's; `a` must be the target's a (checked by the library)."""
+    aux_kind = 4
+    noise = True
+
+    def __init__(self, tt=None, P=None, x=None, a=None, direction="forward", Y=None):
+        self.x = None if x is None else np.ascontiguousarray(np.atleast_1d(x), dtype=np.float64)
+        self.direction = {"forward": 1, "backward": -1, "nothing": 0, 1: 1, -1: -1, 0: 0}[direction]
+        self.Y = None if Y is None else np.ascontiguousarray(Y, dtype=np.float64)
+
+    @classmethod
+    def with_path(cls, Y):
+        return cls(Y=Y)
+
+    def _install(self, po):
+        if self.Y is None:
+            self.Y = np.empty((len(po.tt), po.d))
+            po.ctx.check(po.ctx.lib.bhip_linearnoiseappr_path(po.h, None if self.x is None else _dptr(self.x), self.direction, _dptr(self.Y)))
+        po.ctx.check(po.ctx.lib.bhip_proposal_set_aux_linearnoiseappr(po.h, _dptr(self.Y)))
+
+
 def linearappr(Y, P=None):
     """linearappr(Y, P)  src/linpro.jl:196 -- the target P is the proposal's (filled when the GuidedBridge is built)"""
     return LinearAppr.along(Y.yy if hasattr(Y, "yy") else Y)
@@ -489,7 +513,9 @@ class _Proposal(ContinuousTimeProcess):
                                                 _dptr(par), len(par), C.byref(h)))
         self.h = h
         if Pt is not None:
-            if Pt.aux_kind == AUX_LINEARAPPR:
+            if getattr(Pt, "noise", False):
+                Pt._install(self)
+            elif Pt.aux_kind == AUX_LINEARAPPR:
                 if Pt.B is None:      # LinearAppr given as (path Y, target): linearappr(Y, P) on the host  src/linpro.jl:196
                     Pt._fill(self)
                 cmN = lambda A: np.ascontiguousarray(np.swapaxes(np.asarray(A, dtype=np.float64), -1, -2))   # [N] column-major matrices

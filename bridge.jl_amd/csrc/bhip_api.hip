@@ -464,6 +464,8 @@ int bhip_proposal_set_aux_linearappr(bhip_proposal *po, const double *xx, const 
     return BHIP_OK;
 }
 
+static Mat host_sigma(const ModelHost &mh);
+static Mat host_sigma_fwd(const ModelHost &mh) { return host_sigma(mh); }
 int bhip_linearappr(const bhip_proposal *po, const double *Y, double *B, double *b, double *Sigma)
 {
     if (!po || !Y || !B || !b || !Sigma) return BHIP_EINVAL;
@@ -476,17 +478,74 @@ int bhip_linearappr(const bhip_proposal *po, const double *Y, double *B, double 
             return fail(ctx, BHIP_EUNSUPPORTED, "bhip_linearappr: bderiv is defined for Lorenz, Pendulum, LinPro and Wiener (as in the reference)");
         std::memcpy(B + i * d * d, J.a.data(), sizeof(double) * d * d);
         std::memcpy(b + i * d, bb.a.data(), sizeof(double) * d);
-        // sigma(t, x, P) of the built-in processes is constant: the matrix whose outer product is the model's a
-        Mat S(d, mp);
-        const double *p = po->mh.par.data();
-        switch (po->mh.id) {
-        case BHIP_MODEL_LORENZ: for (int k = 0; k < 3; k++) S(k, k) = p[3 + k]; break;
-        case BHIP_MODEL_PENDULUM: S(0, 0) = 0.0; S(1, 0) = p[1]; break;
-        case BHIP_MODEL_LINPRO: S = Mat(d, mp, p + d * d + d); break;
-        default: for (int k = 0; k < d; k++) S(k, k) = 1.0;
-        }
+        const Mat S = host_sigma_fwd(po->mh);
         std::memcpy(Sigma + i * d * mp, S.a.data(), sizeof(double) * d * mp);
     }
+    return BHIP_OK;
+}
+
+// sigma(t, x, P) of the built-in processes with a host drift (constant): the matrix whose outer product is the model's a
+static Mat host_sigma(const ModelHost &mh)
+{
+    const int d = mh.d, mp = mh.mp;
+    Mat S(d, mp);
+    const double *p = mh.par.data();
+    switch (mh.id) {
+    case BHIP_MODEL_LORENZ: for (int k = 0; k < 3; k++) S(k, k) = p[3 + k]; break;
+    case BHIP_MODEL_PENDULUM: S(0, 0) = 0.0; S(1, 0) = p[1]; break;
+    case BHIP_MODEL_LINPRO: S = Mat(d, mp, p + d * d + d); break;
+    default: for (int k = 0; k < d; k++) S(k, k) = 1.0;
+    }
+    return S;
+}
+
+// LinearNoiseAppr(tt, P, x, a, direction)  src/guip.jl:114-146: the deterministic path y' = b(t, y, P) by Ralston-3 --
+// solve!(R3(), b, Y, x, P) forward from x at tt[1] (direction 1, src/ode.jl:178-184), solvebackward!(R3(), b, Y, x, P)
+// backward from x at tt[N] (-1, src/ode.jl:88-97), zeros (0, :nothing)
+int bhip_linearnoiseappr_path(const bhip_proposal *po, const double *x, int direction, double *Y)
+{
+    if (!po || !Y || (direction != 0 && !x)) return BHIP_EINVAL;
+    bhip_ctx *ctx = po->ctx;
+    const int d = po->mh.d, N = (int)po->tt.size();
+    std::memset(Y, 0, sizeof(double) * N * d);
+    if (direction == 0) return BHIP_OK;
+    Mat probe;
+    if (!host_b(po->mh, x, probe)) return fail(ctx, BHIP_EUNSUPPORTED, "bhip_linearnoiseappr_path: no host drift for this target (Lorenz, Pendulum, LinPro, Wiener have one)");
+    auto F = [&](double, const Mat &y) { Mat o; host_b(po->mh, y.a.data(), o); return o; };
+    Mat y(d, 1, x);
+    const std::vector<double> &tt = po->tt;
+    if (direction > 0) {
+        std::memcpy(Y, y.a.data(), sizeof(double) * d);
+        for (int i = 1; i < N; i++) { y = kernelr3(F, tt[i - 1], y, tt[i] - tt[i - 1]); std::memcpy(Y + (size_t)i * d, y.a.data(), sizeof(double) * d); }
+    } else {
+        std::memcpy(Y + (size_t)(N - 1) * d, y.a.data(), sizeof(double) * d);
+        for (int i = N - 2; i >= 0; i--) { y = kernelr3(F, tt[i + 1], y, tt[i] - tt[i + 1]); std::memcpy(Y + (size_t)i * d, y.a.data(), sizeof(double) * d); }
+    }
+    return BHIP_OK;
+}
+
+// The auxiliary itself: B(t, P) = 0I, beta((i,t)) = (Y[i] - Y[i-1])/(tt[i] - tt[i-1]), _b = beta at max(i, 2), a = the target's a.
+// (As committed `_b` calls an undefined `beta_` and `a((i,t), P)` has no method: restated with the evident intention)
+// In the index-based Heun solver this is a LinearAppr with B_i = 0, xx_i = 0, b_i = that slope: carried as one.
+int bhip_proposal_set_aux_linearnoiseappr(bhip_proposal *po, const double *Y)
+{
+    if (!po || !Y) return BHIP_EINVAL;
+    bhip_ctx *ctx = po->ctx;
+    const int d = po->mh.d, mp = po->mh.mp, N = (int)po->tt.size();
+    if (d > 3) return fail(ctx, BHIP_EUNSUPPORTED, "LinearNoiseAppr auxiliary: d <= 3");
+    if (!po->mh.constdiff) return fail(ctx, BHIP_EUNSUPPORTED, "LinearNoiseAppr auxiliary: the target must have a constant sigma");
+    if (po->mh.id >= USER_MODEL_BASE || (po->mh.id != BHIP_MODEL_LORENZ && po->mh.id != BHIP_MODEL_PENDULUM && po->mh.id != BHIP_MODEL_LINPRO && po->mh.id != BHIP_MODEL_WIENER))
+        return fail(ctx, BHIP_EUNSUPPORTED, "LinearNoiseAppr auxiliary: targets Lorenz, Pendulum, LinPro, Wiener");
+    std::vector<double> xx((size_t)N * d, 0.0), B((size_t)N * d * d, 0.0), b((size_t)N * d), S((size_t)N * d * mp);
+    const Mat Sg = host_sigma(po->mh);
+    for (int j = 0; j < N; j++) {
+        const int jj = j < 1 ? 1 : j;
+        for (int k = 0; k < d; k++) b[(size_t)j * d + k] = (Y[(size_t)jj * d + k] - Y[(size_t)(jj - 1) * d + k]) / (po->tt[jj] - po->tt[jj - 1]);
+        std::memcpy(S.data() + (size_t)j * d * mp, Sg.a.data(), sizeof(double) * d * mp);
+    }
+    int rc = bhip_proposal_set_aux_linearappr(po, xx.data(), B.data(), b.data(), S.data());
+    if (rc) return rc;
+    po->aux.la_noise = true;
     return BHIP_OK;
 }
 

@@ -141,6 +141,7 @@ BHIP_DEV void sm_chol_lower(const double *A, double *C)
 struct GArgs {
     long n, ld;
     int N, rs, hwindow;
+    int lna;               // LinearNoiseAppr auxiliaries (src/guip.jl:114-146): B_j = 0, xx_j = 0, b_j = slope of the mean path at max(j, 1)
     const double *srows;   // the segment's shared rows: t_i, dt_i at [i*rs + 0], [i*rs + 1]
     const double *mean;    // [N][D][ld]: the chains' linearisation paths (running means, mcnext!)
     double *prow;          // out [N-1][PRL][ld]
@@ -226,17 +227,29 @@ __global__ __launch_bounds__(64) void k_seg_guide(const GArgs g)
 #pragma unroll
         for (int k = 0; k < D; k++) g.vend[(size_t)k * g.ld + p] = w[k];
     }
+    // the linearisation at grid index j: LinearAppr (linearappr!, src/linpro.jl:196-204) or LinearNoiseAppr (Pt.Y.yy[:] = xx)
+    auto linearise = [&](int j, double *B, double *b, double *xx) {
+        if (g.lna) {
+            const int jj = max(j, 1);
+            double ya[D], yb[D];
+            loadY(jj, ya); loadY(jj - 1, yb);
+            const double h = srows[(size_t)(jj - 1) * g.rs + 1];   // tt[jj] - tt[jj-1]
+#pragma unroll
+            for (int k = 0; k < D; k++) { b[k] = (ya[k] - yb[k]) / h; xx[k] = 0.0; }
+#pragma unroll
+            for (int k = 0; k < DD; k++) B[k] = 0.0;
+        } else {
+            loadY(j, xx);
+            model.bderiv(0.0, xx, B);   // (bderiv and b of these processes do not depend on t)
+            model.b(0.0, xx, b);
+        }
+    };
     double B1[DD], b1[D], x1[D];
-    loadY(N - 1, x1);
-    model.bderiv(0.0, x1, B1);   // (bderiv and b of these processes do not depend on t)
-    model.b(0.0, x1, b1);
+    linearise(N - 1, B1, b1, x1);
     for (int i = N - 2; i >= 0; i--) {
         double B0[DD], b0[D], x0[D];
-        loadY(i, x0);
-        const double t = srows[(size_t)i * g.rs];
+        linearise(i, B0, b0, x0);
         const double dt = -srows[(size_t)i * g.rs + 1];   // tt[i] - tt[i+1] = -(tt[i+1] - tt[i]) exactly
-        model.bderiv(t, x0, B0);
-        model.b(t, x0, b0);
         {
             double k1[DD], k2[DD], yp[DD];
             fH(B0, K, k1);

@@ -208,6 +208,7 @@ struct Aux {
     // BHIP_AUX_LINEARAPPR (src/linpro.jl:181-192): coefficients per grid INDEX -- xx_i (d), B_i (d*d), b_i (d), Sigma_i (d*mp).
     // The time-based accessors below are only ever called with grid times; the index is recovered by exact match.
     std::vector<double> la_tt, la_xx, la_B, la_b, la_S;
+    bool la_noise = false;   // the coefficients carry a LinearNoiseAppr (src/guip.jl:114-146): B_i = 0, b_i = slope of its deterministic path
     int la_index(double t) const
     {
         const size_t i = (size_t)(std::lower_bound(la_tt.begin(), la_tt.end(), t) - la_tt.begin());

@@ -155,6 +155,17 @@ int bhip_proposal_set_aux_linearappr(bhip_proposal *po, const double *xx, const 
 /* linearappr(Y, P) / linearappr!(Pt, Y, P)  src/linpro.jl:196-204 (host): fills B, b, Sigma (layouts as above) for the
  * target of `po` along Y [N][d]; for the processes the reference defines bderiv for: Lorenz, Pendulum, LinPro, Wiener. */
 int bhip_linearappr(const bhip_proposal *po, const double *Y, double *B, double *b, double *Sigma);
+/* LinearNoiseAppr(tt, P, x, a, direction)  src/guip.jl:114-146, the auxiliary supplements/smoothing/smoothing.jl:85 uses with
+ * direction = :backward:   Y = the deterministic path y' = b(t,y,P) by Ralston-3 (forward from x at tt[1]: direction 1,
+ * src/ode.jl:178-184; backward from x at tt[N]: -1, src/ode.jl:88-97; zeros: 0), B(t,P) = 0I,
+ * beta((i,t)) = (Y[i] - Y[i-1])/(tt[i] - tt[i-1]), _b((i,t),x,P) = beta at max(i,2), a = the target's a.
+ * bhip_linearnoiseappr_path computes Y [N][d]; bhip_proposal_set_aux_linearnoiseappr installs the auxiliary for a given Y
+ * (the adaptation replaces Y by the running mean, smoothing.jl:136-139).  Targets with a host drift: Lorenz, Pendulum,
+ * LinPro, Wiener.  As committed the reference type cannot reach a GuidedBridge (`_b` calls an undefined `beta_`, the
+ * two-argument `a((i,t), P)` has no method): restated with the evident intention -- in the index-based Heun solver it is a
+ * LinearAppr with B_i = 0, xx_i = 0, b_i = that slope, and is carried as one. */
+int bhip_linearnoiseappr_path(const bhip_proposal *po, const double *x, int direction, double *Y);
+int bhip_proposal_set_aux_linearnoiseappr(bhip_proposal *po, const double *Y);
 /* GuidedBridge(tt, P, Pt, v, hT = 0)                                       src/guip.jl:172-180 */
 int bhip_proposal_guide_hv(bhip_proposal *po, const double *v, const double *hT);
 /* PartialBridge(tt, P, Pt, L, v, Sigma)                                    src/partialbridge.jl:42-50 */

@@ -749,6 +749,54 @@ void bo_linearappr(int model, int d, int mp, const double *par, const double *tt
     }
 }
 
+/* LinearNoiseAppr(tt, P, x, a, direction)  src/guip.jl:114-146 ("precursor of the linear noise approximation"):
+ *   Y = the deterministic path y' = b(t, y, P) by Ralston-3: solve!(R3(), b, Y, x, P) forward from x at tt[1]
+ *       (direction 1, src/ode.jl:178-184), solvebackward!(R3(), b, Y, x, P) backward from x at tt[N] (direction -1,
+ *       src/ode.jl:88-97), zeros for :nothing (0);
+ *   B(t, P) = 0I;  beta((i,t), P) = (Y[i] - Y[i-1])/(tt[i] - tt[i-1]);  _b((i,t), x, P) = beta((max(i,2), t), P);  a = P.a.
+ * As committed the type cannot be used in a GuidedBridge either: `_b` calls an undefined `beta_`, `a((i,t), P)` (two
+ * arguments) has no method, and the constructor hands `b` where only `_b` exists (same defects as LinearAppr, see
+ * bo_gp_hv_heuni).  Restated with the evident intention; in the index-based Heun solver it is then exactly a LinearAppr
+ * with B_i = 0, xx_i = 0, b_i = beta at max(i,2) and Sigma_i*Sigma_i' = a -- which is how oracle and product carry it.
+ * The target's sigma supplies Sigma_i (the scripts pass a = a(t, v, P) of the target, supplements/smoothing/smoothing.jl:80,85). */
+static void rhs_target_b(double t, const double *x, double *out, void *vc)
+{
+    ode_ctx *c = (ode_ctx *)vc;   /* aux field carries the MODEL id here, apar its parameters */
+    bo_b(c->aux, c->d, c->apar, t, x, out);
+}
+void bo_lna_path(int model, int d, const double *par, const double *tt, int N, const double *x, int direction, double *Y)
+{
+    ode_ctx c = {model, d, 0, 0, par, 0};
+    double y[BO_MAXD];
+    memset(Y, 0, sizeof(double) * N * d);
+    if (direction == 0) return;
+    memcpy(y, x, sizeof(double) * d);
+    if (direction > 0) {
+        memcpy(Y, y, sizeof(double) * d);
+        for (int i = 1; i < N; i++) { kernelr3(rhs_target_b, tt[i - 1], y, tt[i] - tt[i - 1], d, &c, y); memcpy(Y + (size_t)i * d, y, sizeof(double) * d); }
+    } else {
+        memcpy(Y + (size_t)(N - 1) * d, y, sizeof(double) * d);
+        for (int i = N - 2; i >= 0; i--) { kernelr3(rhs_target_b, tt[i + 1], y, tt[i] - tt[i + 1], d, &c, y); memcpy(Y + (size_t)i * d, y, sizeof(double) * d); }
+    }
+}
+/* the LinearAppr coefficients that carry a LinearNoiseAppr with deterministic path Y */
+void bo_lna_coeffs(int model, int d, int mp, const double *par, const double *tt, int N, const double *Y,
+                   double *xx, double *B, double *b, double *Sigma)
+{
+    memset(xx, 0, sizeof(double) * N * d);
+    memset(B, 0, sizeof(double) * N * d * d);
+    for (int j = 0; j < N; j++) {
+        int jj = j < 1 ? 1 : j;                                    /* max(i, 2), 1-based */
+        for (int k = 0; k < d; k++) b[(size_t)j * d + k] = (Y[(size_t)jj * d + k] - Y[(size_t)(jj - 1) * d + k]) / (tt[jj] - tt[jj - 1]);
+        for (int c = 0; c < mp; c++) {
+            double e[BO_MAXD] = {0}, col[BO_MAXD];
+            e[c] = 1.0;
+            bo_sigma_apply(model, d, mp, par, tt[j], Y + (size_t)j * d, e, col);
+            for (int r = 0; r < d; r++) Sigma[(size_t)j * d * mp + r + d * c] = col[r];
+        }
+    }
+}
+
 /* gpupdate(Hd, V, L, Sigma, v)  src/guip.jl:221-231: fold an observation v = L x + N(0,Sigma) at the left
  * end of a segment into (Hdiamond, V) -- the backward link between chained GuidedBridge segments
  * (test/smoothing.jl:73-83).  Z = I - Hd*L'*inv(Sigma + L*Hd*L')*L ; (Z*Hd, Z*Hd*L'*inv(Sigma)*v + Z*V);
@@ -1409,27 +1457,36 @@ void bo_chol_lower(int n, const double *A, double *C)
  * LinearAppr guides: the index-based Heun solver as restated in bo_gp_hv_heuni (the reference's kerneli cannot run as
  * committed, see there).  The moving average sums left to right and divides by the count (Statistics.mean of a short
  * vector of SVectors).  Noise streams as in bo_smooth_mcmc.
+ * lna = 0: LinearAppr auxiliaries (initnu = :foci / :brown style, Y0 given); lna = 1: LinearNoiseAppr auxiliaries whose
+ * deterministic paths are Y0; lna = 2: LinearNoiseAppr(tt_i, P, v, a, :backward) as the script builds them (:85), Y0 unused.
  * tts [m][N]; Y0 [m][N][d]; obs [m][mo]: obs[i] is the observation at the LEFT end of segment i (V.yy[i]).
  * Outputs as bo_smooth_mcmc, plus the final pi0 (mu_out [d], H_out [d*d]) and, if rows_out != NULL, the final guides
  * Hd [m][N][d*d], V [m][N][d] of the chain. */
-static void la_pack(double *ap, int N, int d, int mp, int model, const double *par, const double *tt, const double *Y)
+static void la_pack(double *ap, int N, int d, int mp, int model, const double *par, const double *tt, const double *Y, int lna)
 {
     ap[0] = (double)N;
     memcpy(ap + 1, tt, sizeof(double) * N);
     double *xx = ap + 1 + N, *B = xx + (size_t)N * d, *b = B + (size_t)N * d * d, *S = b + (size_t)N * d;
+    if (lna) { bo_lna_coeffs(model, d, mp, par, tt, N, Y, xx, B, b, S); return; }
     memcpy(xx, Y, sizeof(double) * N * d);
     bo_linearappr(model, d, mp, par, tt, N, Y, B, b, S);
 }
 static void smooth_build(int m, int N, int d, int mp, int mo, int model, const double *par, const double *tts, const double *Yall,
                          const double *L, const double *Sigma, const double *obs, const double *HT, const double *vT,
-                         double *apars, size_t napar, double *Hd, double *V, bo_proposal *props, double *mu, double *H0)
+                         double *apars, size_t napar, double *Hd, double *V, bo_proposal *props, double *mu, double *H0,
+                         int lna /* 0: LinearAppr along Yall; 1: LinearNoiseAppr with Y = Yall; 2: LinearNoiseAppr(tt, P, v, a, :backward), smoothing.jl:85 */)
 {
     double H[D2], v[BO_MAXD], Hn[D2], vn[BO_MAXD];
     memcpy(H, HT, sizeof(double) * d * d); memcpy(v, vT, sizeof(double) * d);
     for (int i = m - 1; i >= 0; i--) {
         const double *tt = tts + (size_t)N * i;
         double *ap = apars + napar * i, *Hi = Hd + (size_t)N * d * d * i, *Vi = V + (size_t)N * d * i;
-        la_pack(ap, N, d, mp, model, par, tt, Yall + (size_t)N * d * i);
+        if (lna == 2) {
+            double *Yb = (double *)malloc(sizeof(double) * N * d);
+            bo_lna_path(model, d, par, tt, N, v, -1, Yb);
+            la_pack(ap, N, d, mp, model, par, tt, Yb, 1);
+            free(Yb);
+        } else la_pack(ap, N, d, mp, model, par, tt, Yall + (size_t)N * d * i, lna);
         const double *xx = ap + 1 + N, *B = xx + (size_t)N * d, *b = B + (size_t)N * d * d, *S = b + (size_t)N * d;
         bo_gp_hv_heuni(tt, N, d, mp, xx, B, b, S, v, H, Hi, Vi);
         mk_prop(&props[i], BO_GUIDE_HV, N, d, mp, d, model, par, BO_AUX_LINEARAPPR, ap, tt, Hi, Vi, NULL, NULL);
@@ -1443,7 +1500,7 @@ void bo_smooth_adaptive(int m, int N, int d, int mp, int mo, int model, const do
                         const double *L, const double *Sigma, const double *obs, const double *HT, const double *vT,
                         const double *w_old, const double *w_new, int iters, int adaptit, int adaptmax, int hwindow, int skip,
                         uint64_t seed, uint32_t path, double *Xall, double *Wall, double *y0_out, double *ll_out, long *acc_out,
-                        double *mean, double *m2, double *mu_out, double *H_out, double *Hd_out, double *V_out)
+                        double *mean, double *m2, double *mu_out, double *H_out, double *Hd_out, double *V_out, int lna)
 {
     const size_t nx = (size_t)N * d, nw = (size_t)N * mp;
     const size_t napar = 1 + (size_t)N + nx + nx * d + nx + (size_t)N * d * mp;
@@ -1456,7 +1513,7 @@ void bo_smooth_adaptive(int m, int N, int d, int mp, int mo, int model, const do
     double mu[BO_MAXD], H0[D2], chol[D2], y0[BO_MAXD], y0o[BO_MAXD], y[BO_MAXD];
     long acc = 0, ns = 0;
     int newblock = 0;
-    smooth_build(m, N, d, mp, mo, model, par, tts, Y0, L, Sigma, obs, HT, vT, apars, napar, Hd, V, props, mu, H0);
+    smooth_build(m, N, d, mp, mo, model, par, tts, Y0, L, Sigma, obs, HT, vT, apars, napar, Hd, V, props, mu, H0, lna);
     bo_chol_lower(d, H0, chol);
     for (int k = 0; k < d; k++) y0[k] = mu[k];
     memcpy(y, y0, sizeof(double) * d);
@@ -1482,7 +1539,7 @@ void bo_smooth_adaptive(int m, int N, int d, int mp, int mo, int model, const do
                         dst[k] = sacc / (double)(hi - lo + 1);
                     }
                 }
-            smooth_build(m, N, d, mp, mo, model, par, tts, Ysm, L, Sigma, obs, HT, vT, apars, napar, Hd, V, props, mu, H0);
+            smooth_build(m, N, d, mp, mo, model, par, tts, Ysm, L, Sigma, obs, HT, vT, apars, napar, Hd, V, props, mu, H0, lna ? 1 : 0);   /* Pt.Y.yy[:] = xx (:136-139) */
             bo_chol_lower(d, H0, chol);
             newblock = 1;
             if (it == adaptit) doaccept = 1;

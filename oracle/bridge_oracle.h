@@ -215,7 +215,11 @@ void bo_smooth_adaptive(int m, int N, int d, int mp, int mo, int model, const do
                         const double *L, const double *Sigma, const double *obs, const double *HT, const double *vT,
                         const double *w_old, const double *w_new, int iters, int adaptit, int adaptmax, int hwindow, int skip,
                         uint64_t seed, uint32_t path, double *Xall, double *Wall, double *y0_out, double *ll_out, long *acc_out,
-                        double *mean, double *m2, double *mu_out, double *H_out, double *Hd_out, double *V_out);
+                        double *mean, double *m2, double *mu_out, double *H_out, double *Hd_out, double *V_out, int lna);
+/* LinearNoiseAppr (src/guip.jl:114-146) carried as LinearAppr coefficients */
+void bo_lna_path(int model, int d, const double *par, const double *tt, int N, const double *x, int direction, double *Y);
+void bo_lna_coeffs(int model, int d, int mp, const double *par, const double *tt, int N, const double *Y,
+                   double *xx, double *B, double *b, double *Sigma);
 
 /* ---- online statistics (src/mclog.jl:22-56,89-93) ---- */
 void bo_mcnext(int n_entries, int d, double *mean, double *m2, long *n, const double *x);

@@ -508,7 +508,28 @@ def chol_lower(A):
     return out.reshape(n, n).T.copy()
 
 
-def smooth_adaptive(model, d, mp, par, tts, Y0, L, Sigma, obs, HT, vT, w_old, w_new, adaptit, adaptmax, seed, path, hwindow=0, skip=0):
+def lna_path(model, d, par, tt, x, direction):
+    """LinearNoiseAppr's deterministic path: R3 of the target drift forward (1) / backward (-1) from x, zeros (0)"""
+    tt = np.ascontiguousarray(tt, dtype=np.float64); par = np.ascontiguousarray(par, dtype=np.float64)
+    x = np.ascontiguousarray(np.atleast_1d(x), dtype=np.float64)
+    Y = np.empty((len(tt), d))
+    lib().bo_lna_path(C.c_int(model), C.c_int(d), par.ctypes.data_as(dp), tt.ctypes.data_as(dp), C.c_int(len(tt)), x.ctypes.data_as(dp),
+                      C.c_int(direction), Y.ctypes.data_as(dp))
+    return Y
+
+
+def lna_coeffs(model, d, mp, par, tt, Y):
+    """(xx, B, b, Sigma) of the LinearAppr that carries LinearNoiseAppr with deterministic path Y"""
+    tt = np.ascontiguousarray(tt, dtype=np.float64); par = np.ascontiguousarray(par, dtype=np.float64)
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    N = len(tt)
+    xx, B, b, S = np.empty((N, d)), np.empty((N, d * d)), np.empty((N, d)), np.empty((N, d * mp))
+    lib().bo_lna_coeffs(C.c_int(model), C.c_int(d), C.c_int(mp), par.ctypes.data_as(dp), tt.ctypes.data_as(dp), C.c_int(N), Y.ctypes.data_as(dp),
+                        xx.ctypes.data_as(dp), B.ctypes.data_as(dp), b.ctypes.data_as(dp), S.ctypes.data_as(dp))
+    return xx, np.swapaxes(B.reshape(N, d, d), -1, -2).copy(), b, np.swapaxes(S.reshape(N, mp, d), -1, -2).copy()
+
+
+def smooth_adaptive(model, d, mp, par, tts, Y0, L, Sigma, obs, HT, vT, w_old, w_new, adaptit, adaptmax, seed, path, hwindow=0, skip=0, lna=0):
     """bo_smooth_adaptive: the smoothing loop of supplements/smoothing/smoothing.jl:75-213 for one chain, adaptation included.
     tts [m,N]; Y0 [m,N,d] first linearisation paths; obs [m,mo] (obs[i] at the left end of segment i); (HT, vT) at the right end.
     Returns dict(X, W, y0, ll, acc, mean, m2, mu, H, Hd [m,N,d,d], V [m,N,d])"""
@@ -531,7 +552,7 @@ def smooth_adaptive(model, d, mp, par, tts, Y0, L, Sigma, obs, HT, vT, w_old, w_
     lib().bo_smooth_adaptive(C.c_int(m), C.c_int(N), C.c_int(d), C.c_int(mp), C.c_int(mo), C.c_int(model), P(par), P(tts), P(Y0),
                              P(Lc), P(Sc), P(obs), P(HTc), P(vT), P(w_old), P(w_new), C.c_int(len(w_old)), C.c_int(adaptit),
                              C.c_int(adaptmax), C.c_int(hwindow), C.c_int(skip), C.c_uint64(seed), C.c_uint32(path),
-                             P(X), P(W), P(y0), P(ll), C.byref(acc), P(mean), P(m2), P(mu), P(H), P(Hd), P(V))
+                             P(X), P(W), P(y0), P(ll), C.byref(acc), P(mean), P(m2), P(mu), P(H), P(Hd), P(V), C.c_int(lna))
     return dict(X=X, W=W, y0=y0, ll=ll, acc=acc.value, mean=mean, m2=np.swapaxes(m2.reshape(m, N, d, d), -1, -2).copy(),
                 mu=mu, H=H.reshape(d, d).T.copy(), Hd=np.swapaxes(Hd.reshape(m, N, d, d), -1, -2).copy(), V=V)
 

@@ -203,3 +203,43 @@ def test_adapt_device_argument_checks():
         sc2.adapt_device(S["L"], S["Sig"], S["obs"][:2], S["HT"], S["vT"])
     with pytest.raises(bh.BridgeError, match="per-chain"):
         sc2.chain_guide(0, 0)
+
+
+def test_linearnoiseappr_segments_and_their_per_chain_adaptation():
+    """supplements/smoothing/smoothing.jl with initnu = :backward (:28,85): every segment's auxiliary is
+    LinearNoiseAppr(tt_i, P, v, a, :backward); the adaptation replaces its deterministic path by the chain's running mean
+    (:136-139).  Device ensemble == the oracle's single-chain loop, bit for bit, through two adaptations."""
+    ctx = bh.default_context(0)
+    m, M, n = 3, 40, 128
+    tgrid = np.linspace(0.0, 0.24, m * M + 1)
+    truth = lorenz_drift_path(tgrid, (1.5, -1.5, 25.0))
+    rng = np.random.default_rng(7)
+    L, Sig = np.eye(3), 0.25 * np.eye(3)
+    obs = truth[::M] + 0.5 * rng.standard_normal((m + 1, 3))
+    P = bh.Lorenz(LOR["theta"], LOR["sigma"])
+    HT, vT = bh.gpupdate(1e3 * np.eye(3), np.zeros(3), L, Sig, obs[m])
+    tts = np.stack([tgrid[i * M:(i + 1) * M + 1] for i in range(m)])
+    H, v, segs = HT, vT, [None] * m
+    for i in range(m - 1, -1, -1):
+        segs[i] = bh.GuidedBridge(tts[i].copy(), P, bh.LinearNoiseAppr(tts[i], P, v, None, "backward"), v, H, ctx=ctx)
+        H, v = bh.gpupdate(segs[i], L, Sig, obs[i])
+    adaptit, iters = 4, 10
+    w_new = np.sqrt(np.full(iters, 0.1)); w_old = np.sqrt(1 - w_new ** 2)
+    sc = bh.SegChains(segs, v, o.chol_lower(H), n, seed=13, mcnext=True)
+    sc.step(w_old[:adaptit - 1], w_new[:adaptit - 1])
+    sc.adapt_device(L, Sig, obs[:m], HT, vT, newblock=True, doaccept=True)
+    sc.step(w_old[adaptit - 1:2 * adaptit - 1], w_new[adaptit - 1:2 * adaptit - 1])
+    sc.adapt_device(L, Sig, obs[:m], HT, vT, newblock=True, doaccept=False)
+    sc.step(w_old[2 * adaptit - 1:], w_new[2 * adaptit - 1:])
+    ll, acc, y0 = sc.state()
+    Y0 = np.zeros((m, M + 1, 3))
+    for p in (0, 63, n - 1):
+        r = o.smooth_adaptive(o.MODEL_LORENZ, 3, 3, LOR_PAR, tts, Y0, L, Sig, obs[:m], HT, vT, w_old, w_new, adaptit, 10 ** 6, 13, p, lna=2)
+        for i in range(m):
+            X, W = sc.paths(i, p, 1)
+            assert np.array_equal(X[0], r["X"][i]) and np.array_equal(W[0], r["W"][i])
+            g = sc.chain_guide(i, p)
+            assert np.array_equal(g["G"][:, 10:13], r["V"][i][:-1]) and np.array_equal(g["B"], np.zeros((M, 3, 3)))
+        assert np.array_equal(ll[:, p], r["ll"]) and acc[p] == r["acc"] and np.array_equal(y0[p], r["y0"])
+        assert np.array_equal(sc.chain_guide(0, p)["mu"], r["mu"])
+    assert np.isfinite(ll).all() and (acc >= 1).all()

@@ -180,3 +180,31 @@ def test_adaptive_relinearisation_of_the_smoothing_segments():
     a.step(0.95, math.sqrt(1 - 0.95 ** 2), 6)
     _, acc1, _ = a.state()
     assert (acc1 - acc0).sum() > 0 and np.isfinite(a.state()[0]).all()
+
+
+def test_linearnoiseappr_host_equals_oracle():
+    """LinearNoiseAppr (src/guip.jl:114-146): deterministic path by R3 (forward / backward / nothing), slope coefficients, and the
+    GuidedBridge built on it (index-based Heun) -- host C++ == oracle bit for bit; properties: B = 0 makes Hd(t) = hT + a (T - t)
+    and V the trapezoidal integral of the slopes."""
+    hctx = bh.Context(-1)
+    tt = np.linspace(0.0, 0.3, 61) ** 1.0
+    P = bh.Lorenz(LOR["theta"], LOR["sigma"])
+    v, hT = np.array([2.0, -1.0, 24.0]), 0.3 * np.eye(3)
+    for direction, dnum in (("backward", -1), ("forward", 1), ("nothing", 0)):
+        Po = bh.GuidedBridge(tt, P, bh.LinearNoiseAppr(tt, P, v, None, direction), v, hT, ctx=hctx)
+        Y = o.lna_path(o.MODEL_LORENZ, 3, LOR_PAR, tt, v, dnum)
+        assert np.array_equal(Po.Pt.Y, Y)
+        xx, B, b, S = o.lna_coeffs(o.MODEL_LORENZ, 3, 3, LOR_PAR, tt, Y)
+        Hd, V = o.gp_hv_heuni(tt, 3, 3, xx, B, b, S, v, hT)
+        assert np.array_equal(Po.Hd, Hd) and np.array_equal(Po.V, V)
+        if dnum == -1:
+            assert np.array_equal(Y[-1], v)
+            assert np.array_equal(b[0], b[1]) and np.array_equal(b[5], (Y[5] - Y[4]) / (tt[5] - tt[4]))    # max(i, 2)
+        if dnum == 1:
+            assert np.array_equal(Y[0], v)
+        a = np.diag(np.array(LOR["sigma"]) ** 2)
+        assert np.allclose(Hd[0], hT + a * (tt[-1] - tt[0]), rtol=1e-13)
+        assert np.allclose(V[0], v - sum(0.5 * (b[i] + b[i + 1]) * (tt[i + 1] - tt[i]) for i in range(len(tt) - 1)), rtol=1e-12, atol=1e-12)
+    with pytest.raises(bh.BridgeError, match="Lorenz, Pendulum, LinPro, Wiener"):
+        bh.GuidedBridge(np.linspace(0, 1, 11), bh.FitzhughDiffusion(0.1, 0.0, 1.5, 0.8, 0.3), bh.LinearNoiseAppr(x=[0.0, 0.0], direction="backward"),
+                        [0.0, 0.0], np.eye(2), ctx=hctx)
