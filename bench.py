@@ -24,7 +24,8 @@ Other modes (`--mode`), each a named BASELINE / SURVEY 8(d) configuration:
   nclar_mcmc  the same as pCN chains (40 B/path-step)
   linpro32    C5: LinPro d = 32 on the fp64 matrix cores, 65 536 paths;  linpro32_mcmc: its pCN chains
 At N = 1 the default run appends the kernel-level figures of all of them as `other_modes` (measured after the timed
-region), a `sustained` record (>= 1 s of back-to-back launches) and the CPU baseline.  At N > 1 the SURVEY-C4 shard size
+region), a `smoothing` record (the application loop of SURVEY 8(f) 1-2: joint MH over chained Lorenz segments with shared
+and with per-chain device-built guides), a `sustained` record (>= 1 s of back-to-back launches) and the CPU baseline.  At N > 1 the SURVEY-C4 shard size
 (32 768 chains per GPU) is timed after the headline region with the same barrier / max-over-ranks protocol and reported
 as `survey_c4` next to the 262 144-chains-per-GPU headline.
 """
@@ -274,6 +275,52 @@ def kernel_times(w, steps, warmup):
     return [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
 
 
+def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
+    """The application loop around the hot path (supplements/smoothing/smoothing.jl:99-213): Lorenz d = 3,
+    m GuidedBridge segments of M steps with LinearAppr auxiliaries, n chains, joint MH + pCN on the start + mcnext! per chain
+    and iteration.  Times one iteration with guides shared by the ensemble, the per-chain adaptation on the device
+    (bhip_segchains_adapt_device) and one iteration with per-chain guides; algorithmic bytes per path-step as DESIGN 10 states."""
+    P = bh.Lorenz((10.0, 20.0, 8 / 3), (3.0, 3.0, 3.0))
+    tgrid = np.linspace(0.0, 0.002 * m * M, m * M + 1)
+    Y = np.zeros((m * M + 1, 3)); y = np.array([1.5, -1.5, 25.0])
+    for i in range(m * M + 1):
+        Y[i] = y
+        if i < m * M:
+            y = y + np.array([10 * (y[1] - y[0]), y[0] * (20 - y[2]) - y[1], y[0] * y[1] - 8 / 3 * y[2]]) * (tgrid[i + 1] - tgrid[i])
+    L, Sig = np.eye(3), 0.25 * np.eye(3)
+    obs = Y[::M] + 0.5 * np.random.default_rng(0).standard_normal((m + 1, 3))
+    HT, vT = bh.gpupdate(1e3 * np.eye(3), np.zeros(3), L, Sig, obs[m])
+    H, v, segs = HT, vT, [None] * m
+    for i in range(m - 1, -1, -1):
+        segs[i] = bh.GuidedBridge(tgrid[i * M:(i + 1) * M + 1].copy(), P, bh.linearappr(Y[i * M:(i + 1) * M + 1]), v, H, ctx=ctx)
+        H, v = bh.gpupdate(segs[i], L, Sig, obs[i])
+    sc = bh.SegChains(segs, v, bh.cholupper_t(H), n, seed=1, mcnext=True)
+    wo, wn = 0.9, math.sqrt(1 - 0.81)
+
+    def t(fn, k):
+        fn(); torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+        for j in range(k):
+            ev[j].record(); fn()
+        ev[k].record(); torch.cuda.synchronize()
+        return float(np.mean([ev[j].elapsed_time(ev[j + 1]) for j in range(k)]))
+    ps = n * m * M
+    ms_sh = t(lambda: sc.step(wo, wn, 1), reps)
+    ms_ad = t(lambda: sc.adapt_device(L, Sig, obs[:m], HT, vT), max(2, reps // 2))
+    ms_pc = t(lambda: sc.step(wo, wn, 1), reps)
+    ok = bool(np.isfinite(sc.state()[0]).all())
+    b_sh = 96 + 24 + 48 + 192      # W slots r+w (m' = 3), Xo store, commit Xo -> Xc, mcnext! state r+w
+    b_pc = b_sh + 200              # + the chain's 25 coefficient doubles per step
+    return {"workload": f"Lorenz smoothing: {m} GuidedBridge(LinearAppr) segments x {M} steps, {n} chains, joint MH + pCN start + mcnext! per iteration",
+            "path_steps_per_iteration": ps, "finite": ok,
+            "iteration_shared_guides": {"ms": ms_sh, "path_steps_per_s": ps / ms_sh * 1e3, "algorithmic_bytes_per_path_step": b_sh,
+                                        "hbm_frac": ps * b_sh / ms_sh / 1e6 / HBM_PEAK_GBS},
+            "adapt_device": {"ms": ms_ad, "guide_segments_per_s": n * m / ms_ad * 1e3,
+                             "algorithmic_bytes": n * m * (M + 1) * 224, "hbm_frac": n * m * (M + 1) * 224 / ms_ad / 1e6 / HBM_PEAK_GBS},
+            "iteration_per_chain_guides": {"ms": ms_pc, "path_steps_per_s": ps / ms_pc * 1e3, "algorithmic_bytes_per_path_step": b_pc,
+                                           "hbm_frac": ps * b_pc / ms_pc / 1e6 / HBM_PEAK_GBS}}
+
+
 def timed_region(w, steps, world, ctx, stats, comm=None):
     """the contract's timed region: K steps bracketed by barrier + synchronize on both sides, MAX over ranks; ends with
     the device-side statistics reduction and (N > 1) the ONE all-gather of the statistics block"""
@@ -402,6 +449,7 @@ def main():
             del wo
             torch.cuda.empty_cache()
         out["other_modes"] = others
+        out["smoothing"] = smoothing_record(ctx)
     elif world > 1 and default_run:
         # SURVEY 8(d) C4 quotes 32 768 chains per GPU: the same protocol at that shard size, next to the headline
         del w
