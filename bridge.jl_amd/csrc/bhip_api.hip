@@ -596,7 +596,7 @@ static int build_tile_data(bhip_proposal *po)
     if (!plain && (!po->has_aux || (po->aux.kind != BHIP_AUX_AFFINE && po->aux.kind != BHIP_AUX_LINPRO)))
         return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: time-constant auxiliary process");
     const int Dp = tile_dim(d);
-    const size_t DD = (size_t)Dp * Dp, STEP = DD + Dp, dd = (size_t)d * d;
+    const size_t DD = (size_t)Dp * Dp, STEP = DD + Dp + 2, dd = (size_t)d * d;   // Hm_i fragments, nu_i, then (dt_i, sqrt(dt_i))
     std::vector<double> steps((size_t)(N - 1) * STEP, 0.0), hdr((size_t)(N - 1) * 2);
     for (int i = 0; i < N - 1; i++) {
         // Every guide is brought to the form r = Hm_i (nu_i - x) the tile kernel evaluates:
@@ -615,6 +615,8 @@ static int build_tile_data(bhip_proposal *po)
         std::memcpy(&steps[(size_t)i * STEP + DD], nu.a.data(), sizeof(double) * d);
         hdr[2 * i] = po->tt[i + 1] - po->tt[i];
         hdr[2 * i + 1] = std::sqrt(po->tt[i + 1] - po->tt[i]);
+        steps[(size_t)i * STEP + DD + Dp] = hdr[2 * i];           // travel to LDS with the step's matrix (no separate load in the time loop)
+        steps[(size_t)i * STEP + DD + Dp + 1] = hdr[2 * i + 1];
     }
     std::vector<double> cst(4 * DD + 5 * Dp, 0.0);
     const double *par = po->mh.par.data();

@@ -35,14 +35,14 @@ namespace bhip {
 typedef double double4v __attribute__((ext_vector_type(4)));
 
 // Timing experiments only (results become WRONG): bit0 no per-step barrier / matrix staging, bit1 no normal
-// generation, bit2 no MFMA products.  scripts/gpu_tile_probe.py runs the variants (profiles/r1_tile_breakdown.txt).
+// generation, bit2 no MFMA products, bit3 no chain-state loads, bit4 no chain-state stores (pCN instantiation).  scripts/gpu_tile_probe.py runs the variants (profiles/r1_tile_breakdown.txt).
 #ifndef BHIP_TILE_EXP
 #define BHIP_TILE_EXP 0
 #endif
 
 struct TArgs {
-    const double *steps;   // [N-1][D*D + D]: Hm_i in fragment order, then nu_i (natural order)
-    const double *hdr;     // [N-1][2]: dt_i, sqrt(dt_i)
+    const double *steps;   // [N-1][D*D + D + 2]: Hm_i in fragment order, nu_i (natural order), dt_i, sqrt(dt_i)
+    const double *hdr;     // [N-1][2]: dt_i, sqrt(dt_i) (the same values, for the instantiations that load them directly)
     const double *cst;     // 4 fragment matrices (B, B~, a, sigma), then mu, mu~, beta~, vend (D each; a fifth D-slot is unused)
     double x0[32];         // shared starting point (zero padded), passed by value: launches on one proposal do not interfere
     int dtrue;             // state dimension of the process (<= the kernel's D; the rest is zero padding, template PAD)
@@ -72,6 +72,18 @@ struct TArgs {
 // vector (gathered per wave in LDS -- a lane holds only 8 of a path's 32 components).
 struct NoUserDrift { static constexpr bool ON = false; };
 typedef double tile_d2v __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) double *tile_cptr_t;   // constant address space: wave-uniform reads go through the scalar unit
+// the ensembles and the chain state are streamed: written / read once per launch (same hint as the d <= 3 kernels)
+#ifndef BHIP_TILE_NT
+#define BHIP_TILE_NT 0
+#endif
+// pCN chains: the chain's current W[i+2] is fetched global -> LDS directly (global_load_lds_dwordx4, no staging registers)
+// while step i is computed -- a full step of latency cover; 0: plain loads at the top of the step that consumes them
+#ifndef BHIP_TILE_LDSDMA
+#define BHIP_TILE_LDSDMA 1
+#endif
+template <class V> __device__ __forceinline__ void tile_st(V *p, V v) { if constexpr (BHIP_TILE_NT) __builtin_nontemporal_store(v, p); else *p = v; }
+template <class V> __device__ __forceinline__ V tile_ld(const V *p) { if constexpr (BHIP_TILE_NT) return __builtin_nontemporal_load(p); else return *p; }
 
 template <int T>
 __device__ __forceinline__ void tile_mv(const double *__restrict__ Mf, const double (&v)[T][4], double (&out)[T][4], int lane)
@@ -103,12 +115,13 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 {
     constexpr int T = D / 16;
     constexpr int DD = D * D;
-    constexpr int STEP = DD + D;
+    constexpr int STEP = DD + D + 2;   // Hm_i (fragment order), nu_i, dt_i, sqrt(dt_i)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *cm = lds;                  // 4*DD fragment matrices + 5*D vectors
     double *hb = lds + 4 * DD + 5 * D; // 2 * STEP
     double *rtab_lds = hb + 2 * STEP;  // the generator's tables (RNG_TAB_DOUBLES), for the noise-drawing instantiations
     double *xs_lds = rtab_lds + RNG_TAB_DOUBLES;   // UD::ON: the state vectors of the block's 64 paths, [4 waves][16 paths][D]
+    double *wb_lds = xs_lds + (UD::ON ? 64 * D : 0);   // NOISE == 2: per wave 2T x 64 16-byte pieces of the chain's current W (LDS-DMA target)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, j = lane & 15;
     const long p_raw = (long)blockIdx.x * 64 + wave * 16 + j;
@@ -138,10 +151,11 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     double *xp = a.X ? a.X + (size_t)kq * a.ldX + p : nullptr;
     double *wop = (NOISE == 1 && a.Wout) ? a.Wout + ((size_t)kq * a.ldWout + p) * a.wstride : nullptr;
     // pCN chain state, TILE-LINE layout: a 128-byte line per (parity half h, grid point i, row group t, chain p) holding
-    // the 16 components 16t .. 16t+15 of W[i]:   Wl[(((h*N + i)*T + t)*ld + p)*16 + (4r + kq)].
+    // the 16 components 16t .. 16t+15 of W[i]:   Wl[(((h*N + i)*T + t)*ld + p)*16 + tl_pos(4r + kq)],
+    // tl_pos(4r + kq) = 8(r>>1) + 2kq + (r&1): a lane's values r = 2j, 2j+1 are neighbours (one 16-byte access) and the four
+    // lanes kq = 0..3 of a chain cover a contiguous 64-byte half line per instruction, the line in two.
     // A lane reads its 8 values of the chain's CURRENT half and writes the proposal to the OTHER half (the accept flips the
-    // chain's parity bit); the four lanes kq = 0..3 of a chain and the four accesses r = 0..3 cover each line completely,
-    // back to back, so that whole lines travel: 8 m' B read + 8 m' B written per path-step -- the algorithmic bytes
+    // chain's parity bit), so that whole lines travel: 8 m' B read + 8 m' B written per path-step -- the algorithmic bytes
     // (the 16-byte slots of round 1 moved the unchanged half too: 1280 instead of 768 B per path-step at d = 32).
     const size_t tl_grid = (size_t)T * a.ldC * 16, tl_half = (size_t)N * tl_grid;   // doubles per grid point / per half
     const double *wrd = nullptr;
@@ -170,17 +184,30 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     int cpar = 0;
     if constexpr (NOISE == 2) {
         cpar = a.cur[p];
-        wrd = a.Wc + (size_t)cpar * tl_half + (size_t)p * 16 + kq;
-        wwr = a.Wc + (size_t)(cpar ^ 1) * tl_half + (size_t)p * 16 + kq;
+        wrd = a.Wc + (size_t)cpar * tl_half + (size_t)p * 16 + 2 * kq;
+        wwr = a.Wc + (size_t)(cpar ^ 1) * tl_half + (size_t)p * 16 + 2 * kq;
 #pragma unroll
-        for (int t = 0; t < T; t++)
+        for (int t = 0; t < T; t++) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                w2prev[t][r] = 0.0;
-                wwr[(size_t)t * a.ldC * 16 + 4 * r] = 0.0;   // Wo[0] = 0 (W[0] = 0 is already in the current half)
-            }
+            for (int r = 0; r < 4; r++) w2prev[t][r] = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) *(tile_d2v *)(wwr + (size_t)t * a.ldC * 16 + 8 * jj) = tile_d2v{0.0, 0.0};   // Wo[0] = 0 (W[0] = 0 is already in the current half)
+        }
         wrd += tl_grid; wwr += tl_grid;      // -> grid point 1
     }
+    double *wb = wb_lds + (size_t)wave * (2 * T * 128);
+    auto dma_w = [&]() {   // the chain's current W at the grid point wrd stands on -> wb (lane L's piece q at wb + (q*64 + L)*2)
+        if constexpr (NOISE == 2 && BHIP_TILE_LDSDMA) {
+#pragma unroll
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wrd + (size_t)t * a.ldC * 16 + 8 * jj),
+                                                     (__attribute__((address_space(3))) void *)(wb + (t * 2 + jj) * 128), 16, 0, 0);
+        }
+    };
+    dma_w();              // grid point 1 ...
+    if constexpr (NOISE == 2 && BHIP_TILE_LDSDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... landed before step 0 reads it
 
     for (int i = 0; i < nsteps; i++) {
         const int cur = (BHIP_TILE_EXP & 1) ? 0 : i & 1;
@@ -195,7 +222,11 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 stage[c] = idx < STEP ? a.steps[(size_t)(i + 1) * STEP + idx] : 0.0;
             }
         }
-        const double dt = a.hdr[2 * i], rdt = a.hdr[2 * i + 1];
+        // (dt, sqrt(dt)) ride along with the staged matrix: a vector load here would be waited for with vmcnt(0) -- the
+        // compiler's rule while an LDS-DMA is in flight -- i.e. for the chain-state DMA issued just above, a full memory
+        // latency per step; a scalar load would turn every lgkmcnt(N) of the LDS -> MFMA pipeline into lgkmcnt(0)
+        // (the instantiations without a DMA keep the plain load: measured 2 % faster there than the LDS read)
+        const double dt = (NOISE == 2 && BHIP_TILE_LDSDMA) ? hm[DD + D] : a.hdr[2 * i], rdt = (NOISE == 2 && BHIP_TILE_LDSDMA) ? hm[DD + D + 1] : a.hdr[2 * i + 1];
 
         // ---- the Wiener increment tile
         double dw[T][4];
@@ -225,11 +256,26 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
             winp += (size_t)dtr * a.ldWin;
         } else {
             double wcur[NOISE == 2 ? T : 1][4];
-            if constexpr (NOISE == 2) {   // the chain's current W[i+1]: issued first, consumed after the normals
+            if constexpr (NOISE == 2 && BHIP_TILE_LDSDMA) {
+                // the chain's current W[i+1] landed in LDS during the previous step; read it, then start the DMA of W[i+2]
 #pragma unroll
                 for (int t = 0; t < T; t++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) wcur[t][r] = wrd[(size_t)t * a.ldC * 16 + 4 * r];
+                    for (int jj = 0; jj < 2; jj++) {
+                        const tile_d2v v = *(const tile_d2v *)(wb + ((t * 2 + jj) * 64 + lane) * 2);
+                        wcur[t][2 * jj] = v.x; wcur[t][2 * jj + 1] = v.y;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the DMA may overwrite the pieces
+                wrd += tl_grid;
+                if (i + 1 < nsteps) dma_w();
+            } else if constexpr (NOISE == 2) {   // the chain's current W[i+1]: issued first, consumed after the normals
+#pragma unroll
+                for (int t = 0; t < T; t++)
+#pragma unroll
+                    for (int jj = 0; jj < 2; jj++) {
+                        const tile_d2v v = (BHIP_TILE_EXP & 8) ? tile_d2v{1e-3 * (double)lane, 2e-3} : tile_ld((const tile_d2v *)(wrd + (size_t)t * a.ldC * 16 + 8 * jj));
+                        wcur[t][2 * jj] = v.x; wcur[t][2 * jj + 1] = v.y;
+                    }
             }
             // normal index n = i*D + row; block n>>1 = i*D/2 + 2*ks + (kq>>1), element kq&1 (ks = 4t+r).
             // lanes kq and kq^1 share blocks: the even lane draws ks = 0..2T-1, the odd one ks = 2T..4T-1.
@@ -259,14 +305,16 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                         dw[t][r] = wo - wprev[t][r];
                         w2prev[t][r] = w2;
                         wprev[t][r] = wo;
-                        wwr[(size_t)t * a.ldC * 16 + 4 * r] = wo;   // (zero-padded rows carry exact zeros)
+                        if constexpr ((BHIP_TILE_EXP & 16) == 0) {   // (zero-padded rows carry exact zeros)
+                            if ((r & 1) == 1) tile_st((tile_d2v *)(wwr + (size_t)t * a.ldC * 16 + 8 * (r >> 1)), tile_d2v{wprev[t][r - 1], wo});
+                        }
                     } else {
                         const double wn = wprev[t][r] + rdt * mine[4 * t + r];   // sample!: W[i+1] = W[i] + sqrt(dt)*xi
                         dw[t][r] = wn - wprev[t][r];
                         wprev[t][r] = wn;
                     }
                 }
-            if (NOISE == 2) { wrd += tl_grid; wwr += tl_grid; }
+            if constexpr (NOISE == 2) { if (!BHIP_TILE_LDSDMA) wrd += tl_grid; wwr += tl_grid; }
             if (NOISE == 1 && a.Wout) {   // one wave-uniform test for the whole row group
 #pragma unroll
                 for (int t = 0; t < T; t++)
@@ -282,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 #pragma unroll
             for (int t = 0; t < T; t++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) { if (ok(t, r)) *q = x[t][r]; q += rsX; }
+                for (int r = 0; r < 4; r++) { if (ok(t, r)) tile_st(q, x[t][r]); q += rsX; }
             xp += (size_t)dtr * a.ldX;
         }
 
@@ -346,6 +394,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 if (idx < STEP) hb[(cur ^ 1) * STEP + idx] = stage[c];
             }
         }
+        if constexpr (NOISE == 2 && BHIP_TILE_LDSDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of W[i+2] has landed (issued a step ago)
         if constexpr ((BHIP_TILE_EXP & 1) == 0) __syncthreads();
     }
 
@@ -379,12 +428,15 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 // ---- BHIP_RTC_END  (above: device code, also embedded for hipRTC user drifts at large d; below: host launch)
 
 // dynamic LDS of k_tile<D, ., ., UD>: constants, two step buffers, generator tables (+ the gathered states for a user drift)
-constexpr size_t tile_lds_bytes(int D, bool user) { return sizeof(double) * (4 * D * D + 5 * D + 2 * (D * D + D) + RNG_TAB_DOUBLES + (user ? 64 * D : 0)); }
+constexpr size_t tile_lds_bytes(int D, bool user, bool chains = true)
+{
+    return sizeof(double) * (4 * D * D + 5 * D + 2 * (D * D + D + 2) + RNG_TAB_DOUBLES + (user ? 64 * D : 0) + (chains ? 4 * 2 * (D / 16) * 128 : 0));
+}
 
 template <int D, int NOISE, bool PAD = false>
 hipError_t launch_tile(const TArgs &a, hipStream_t st)
 {
-    const size_t lds = tile_lds_bytes(D, false);
+    const size_t lds = tile_lds_bytes(D, false, NOISE == 2);
     // per device and cheap: set on every launch (a process may drive several devices)
     hipError_t e = hipFuncSetAttribute((const void *)k_tile<D, NOISE, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
