@@ -188,23 +188,23 @@ MODES = {
                 lambda P: f"k_pc<bhip::MFHN, 2, 1, 7, 1, {pc_pairs(P)}>"),
     "proposals": (build_proposal, 2, 1, X0, 262144, False, None,
                   FHN_WORKLOAD + "independent fused proposals (sample!+solve!+llikelihood)",
-                  lambda P: (f"k_pc<bhip::MFHN, 2, 1, 6, 1, {pc_pairs(P)}>" if P <= 98304 else "k_paths<bhip::MFHN, 2, 1, 1, 1>")),
+                  lambda P: (f"k_pc<bhip::MFHN, 2, 1, 6, 1, {pc_pairs(P)}>" if P <= 98304 else "k_paths<bhip::MFHN, 2, 1, 1, 1, false>")),
     "c2": (_ou, 1, 1, (0.5,), 65536, False, None,
            "C2: 1-d OU target LinPro(-0.8,0,sqrt(.7)), GuidedBridge with auxiliary LinPro(-0.8,0.2,sqrt(.7)), 1001-point tau-grid T=2, "
            "independent fused proposals",
-           lambda P: (f"k_pc<bhip::MLinPro<1>, 1, 1, 6, 1, {pc_pairs(P)}>" if P <= 98304 else "k_paths<bhip::MLinPro<1>, 1, 1, 1, 1>")),
+           lambda P: (f"k_pc<bhip::MLinPro<1>, 1, 1, 6, 1, {pc_pairs(P)}>" if P <= 98304 else "k_paths<bhip::MLinPro<1>, 1, 1, 1, 1, false>")),
     "nclar": (_nclar, 3, 1, (0.0, 0.0, 0.0), 262144, False, None,
               "NCLAR 3-d PartialBridge (scalar noise, L=[1 0 0], v=5/128), 1001-point tau-grid T=0.5, independent fused proposals",
-              lambda P: (f"k_pc<bhip::MNCLAR, 2, 1, 6, 1, {pc_pairs(P)}>" if P <= 98304 else "k_paths<bhip::MNCLAR, 2, 1, 1, 1>")),
+              lambda P: (f"k_pc<bhip::MNCLAR, 2, 1, 6, 1, {pc_pairs(P)}>" if P <= 98304 else "k_paths<bhip::MNCLAR, 2, 1, 1, 1, false>")),
     "nclar_mcmc": (_nclar, 3, 1, (0.0, 0.0, 0.0), 262144, True, 0.95,
                    "NCLAR 3-d PartialBridge (scalar noise, L=[1 0 0], v=5/128), 1001-point tau-grid T=0.5, pCN-MCMC rho=0.95",
                    lambda P: f"k_pc<bhip::MNCLAR, 2, 1, 7, 1, {pc_pairs(P)}>"),
     "linpro32": (_linpro32, 32, 32, tuple([0.0] * 32), 65536, False, None,
                  "LinPro d=32 GuidedBridge (dense sigma, pre-inverted Hdiamond), 1001-point grid T=1, independent fused proposals",
-                 lambda P: "k_tile<32, 1, false>"),
+                 lambda P: "k_tile<32, 1, false, bhip::NoUserDrift>"),
     "linpro32_mcmc": (_linpro32, 32, 32, tuple([0.0] * 32), 65536, True, 0.95,
                       "LinPro d=32 GuidedBridge (dense sigma, pre-inverted Hdiamond), 1001-point grid T=1, pCN-MCMC rho=0.95",
-                      lambda P: "k_tile<32, 2, false>"),
+                      lambda P: "k_tile<32, 2, false, bhip::NoUserDrift>"),
 }
 
 

@@ -50,7 +50,29 @@ struct bhip_ctx {
     double *scratch = nullptr;
     size_t scratch_bytes = 0;
     bool wave_specialised = true;   // BHIP_OPT_WAVE_SPECIALISED: producer/consumer kernels (bhip_pc_kernel.h) where they exist
+    // lifetime: every proposal / chain ensemble / communicator holds a reference.  bhip_ctx_destroy with live children only
+    // closes the context (garbage collectors -- Python at interpreter exit, Julia finalizers -- destroy handles in any order);
+    // the last child releases it.  A closed context's stream is no longer synchronised (it was borrowed and may be gone).
+    int refs = 0;
+    bool closed = false;
 };
+static void ctx_free(bhip_ctx *ctx)
+{
+    if (ctx->scratch) { if (!ctx->closed) (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->scratch); }
+    delete ctx;
+}
+static void ctx_retain(bhip_ctx *ctx) { __atomic_add_fetch(&ctx->refs, 1, __ATOMIC_SEQ_CST); }
+static void ctx_release(bhip_ctx *ctx)
+{
+    if (__atomic_sub_fetch(&ctx->refs, 1, __ATOMIC_SEQ_CST) == 0 && ctx->closed) ctx_free(ctx);
+}
+// before a child releases device memory: wait for the context's stream unless the context was already closed
+static void ctx_quiesce(bhip_ctx *ctx)
+{
+    if (ctx->host_only) return;
+    if (!ctx->closed) (void)hipStreamSynchronize(ctx->stream);
+    else (void)hipDeviceSynchronize();
+}
 
 struct bhip_proposal {
     bhip_ctx *ctx = nullptr;
@@ -192,8 +214,12 @@ int bhip_ctx_create(int device, void *stream, bhip_ctx **out)
 void bhip_ctx_destroy(bhip_ctx *ctx)
 {
     if (!ctx) return;
-    if (ctx->scratch) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->scratch); }
-    delete ctx;
+    if (__atomic_load_n(&ctx->refs, __ATOMIC_SEQ_CST) > 0) {   // children alive: they keep using (and finally free) the context
+        if (!ctx->host_only) (void)hipStreamSynchronize(ctx->stream);
+        ctx->closed = true;
+        return;
+    }
+    ctx_free(ctx);
 }
 
 int bhip_ctx_sync(bhip_ctx *ctx)
@@ -352,6 +378,7 @@ int bhip_proposal_create(bhip_ctx *ctx, const double *tt, int N, int model, int 
     bhip_proposal *po = new (std::nothrow) bhip_proposal();
     if (!po) return fail(ctx, BHIP_EHIP, "out of host memory");
     po->ctx = ctx;
+    ctx_retain(ctx);
     po->tt.assign(tt, tt + N);
     std::string err;
     int rc = BHIP_OK;
@@ -397,7 +424,7 @@ int bhip_proposal_create(bhip_ctx *ctx, const double *tt, int N, int model, int 
     } else {
         rc = model_setup(model, d, par, npar, po->mh, err);
     }
-    if (rc) { delete po; return fail(ctx, rc, "bhip_proposal_create: " + err); }
+    if (rc) { delete po; ctx_release(ctx); return fail(ctx, rc, "bhip_proposal_create: " + err); }
     po->g.kind = BHIP_GUIDE_NONE;
     *out = po;
     return BHIP_OK;
@@ -406,8 +433,9 @@ int bhip_proposal_create(bhip_ctx *ctx, const double *tt, int N, int model, int 
 void bhip_proposal_destroy(bhip_proposal *po)
 {
     if (!po) return;
-    if (!po->ctx->host_only) {
-        (void)hipStreamSynchronize(po->ctx->stream);
+    bhip_ctx *ctx = po->ctx;
+    if (!ctx->host_only) {
+        ctx_quiesce(ctx);
         if (po->d_rows) (void)hipFree(po->d_rows);
         if (po->d_tt) (void)hipFree(po->d_tt);
         if (po->d_rdtp) (void)hipFree(po->d_rdtp);
@@ -416,6 +444,7 @@ void bhip_proposal_destroy(bhip_proposal *po)
         if (po->d_cst) (void)hipFree(po->d_cst);
     }
     delete po;
+    ctx_release(ctx);
 }
 
 int bhip_proposal_set_aux(bhip_proposal *po, int kind, const double *apar, int napar)
@@ -1132,6 +1161,7 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     bhip_chains *ch = new (std::nothrow) bhip_chains();
     if (!ch) return fail(ctx, BHIP_EHIP, "out of host memory");
     ch->ctx = ctx; ch->po = po; ch->n = nchains; ch->ld = (nchains + 63) / 64 * 64;
+    ctx_retain(ctx);
     ch->path0 = path0; ch->seed = seed; ch->flags = flags;
     const size_t N = po->tt.size();
     ch->lines = po->mh.d <= 3 && (po->mh.mp == 1 || po->mh.mp == 2);
@@ -1159,7 +1189,8 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
 void bhip_chains_destroy(bhip_chains *ch)
 {
     if (!ch) return;
-    (void)hipStreamSynchronize(ch->ctx->stream);
+    bhip_ctx *ctx = ch->ctx;
+    ctx_quiesce(ctx);
     if (ch->Wc) (void)hipFree(ch->Wc);
     if (ch->Xo) (void)hipFree(ch->Xo);
     if (ch->cur && !ch->shares_state) (void)hipFree(ch->cur);
@@ -1167,6 +1198,7 @@ void bhip_chains_destroy(bhip_chains *ch)
     if (ch->acc && !ch->shares_state) (void)hipFree(ch->acc);
     if (ch->statpart) (void)hipFree(ch->statpart);
     delete ch;
+    ctx_release(ctx);
 }
 
 // x0_dev (optional): per-chain starting points [d][ldx0] (multi-segment ensembles: the end points of the previous segment);
@@ -1606,6 +1638,7 @@ int bhip_comm_init_rank(bhip_ctx *ctx, int nranks, int rank, const void *id, bhi
     bhip_comm *cm = new (std::nothrow) bhip_comm();
     if (!cm) { api.CommDestroy(c); return fail(ctx, BHIP_EHIP, "out of host memory"); }
     cm->ctx = ctx; cm->comm = c; cm->nranks = nranks; cm->rank = rank;
+    ctx_retain(ctx);
     *out = cm;
     return BHIP_OK;
 }
@@ -1632,6 +1665,7 @@ int bhip_comm_init_all(int ndev, bhip_ctx *const *ctxs, bhip_comm **comms_out)
         bhip_comm *cm = new (std::nothrow) bhip_comm();
         if (!cm) return fail(ctx, BHIP_EHIP, "out of host memory");
         cm->ctx = ctxs[k]; cm->comm = cs[k]; cm->nranks = ndev; cm->rank = k;
+        ctx_retain(ctxs[k]);
         comms_out[k] = cm;
     }
     return BHIP_OK;
@@ -1684,12 +1718,14 @@ void bhip_comm_destroy(bhip_comm *comm)
 {
     if (!comm) return;
     RcclApi &api = rccl();
+    bhip_ctx *ctx = comm->ctx;
     if (api.err.empty() && comm->comm) {
-        (void)hipSetDevice(comm->ctx->device);
-        (void)hipStreamSynchronize(comm->ctx->stream);
+        (void)hipSetDevice(ctx->device);
+        ctx_quiesce(ctx);
         api.CommDestroy(comm->comm);
     }
     delete comm;
+    ctx_release(ctx);
 }
 
 

@@ -87,6 +87,9 @@ int bhip_device_count(void);
  * device = -1 creates a HOST-ONLY context: proposals and their guide coefficients can be computed
  * and read back (bhip_proposal_guide_get), every call that needs the GPU returns BHIP_EHIP. */
 int bhip_ctx_create(int device, void *stream, bhip_ctx **out);
+/* Handles may be destroyed in ANY order (finalizers of a garbage collector run in no particular one): proposals, chain
+ * ensembles and communicators hold a reference to their context; destroying a context that still has such children only
+ * closes it -- no new work may be issued through it, the children remain destroyable -- and the last child frees it. */
 void bhip_ctx_destroy(bhip_ctx *ctx);
 int bhip_ctx_sync(bhip_ctx *ctx);
 /* Options.  BHIP_OPT_WAVE_SPECIALISED (default 1): run fresh proposals and pCN iterations (noise dimension 1 or 2) on
