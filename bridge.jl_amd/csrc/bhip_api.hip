@@ -36,6 +36,39 @@ launch_fn get_launch_ppr_lorenz(int, int);
 launch_fn get_launch_ppr_pendulum(int, int);
 guide_launch_fn get_guide_launch_lorenz(int);
 guide_launch_fn get_guide_launch_pendulum(int);
+launch_fn get_launch_ppr_linpro1(int, int);
+launch_fn get_launch_ppr_linpro2(int, int);
+launch_fn get_launch_ppr_linpro3(int, int);
+launch_fn get_launch_ppr_wiener1(int, int);
+launch_fn get_launch_ppr_wiener2(int, int);
+launch_fn get_launch_ppr_wiener3(int, int);
+guide_launch_fn get_guide_launch_linpro1(int);
+guide_launch_fn get_guide_launch_linpro2(int);
+guide_launch_fn get_guide_launch_linpro3(int);
+guide_launch_fn get_guide_launch_wiener1(int);
+guide_launch_fn get_guide_launch_wiener2(int);
+guide_launch_fn get_guide_launch_wiener3(int);
+// the targets with a bderiv (the reference defines it for Lorenz, Pendulum, LinPro, Wiener): per-chain guide kernels
+static launch_fn find_launch_ppr(const ModelHost &mh, int noise, int fl)
+{
+    switch (mh.id) {
+    case BHIP_MODEL_LORENZ: return get_launch_ppr_lorenz(noise, fl);
+    case BHIP_MODEL_PENDULUM: return get_launch_ppr_pendulum(noise, fl);
+    case BHIP_MODEL_LINPRO: return mh.d == 1 ? get_launch_ppr_linpro1(noise, fl) : mh.d == 2 ? get_launch_ppr_linpro2(noise, fl) : mh.d == 3 ? get_launch_ppr_linpro3(noise, fl) : nullptr;
+    case BHIP_MODEL_WIENER: return mh.d == 1 ? get_launch_ppr_wiener1(noise, fl) : mh.d == 2 ? get_launch_ppr_wiener2(noise, fl) : mh.d == 3 ? get_launch_ppr_wiener3(noise, fl) : nullptr;
+    }
+    return nullptr;
+}
+static guide_launch_fn find_guide_launch(const ModelHost &mh, int mo)
+{
+    switch (mh.id) {
+    case BHIP_MODEL_LORENZ: return get_guide_launch_lorenz(mo);
+    case BHIP_MODEL_PENDULUM: return get_guide_launch_pendulum(mo);
+    case BHIP_MODEL_LINPRO: return mh.d == 1 ? get_guide_launch_linpro1(mo) : mh.d == 2 ? get_guide_launch_linpro2(mo) : mh.d == 3 ? get_guide_launch_linpro3(mo) : nullptr;
+    case BHIP_MODEL_WIENER: return mh.d == 1 ? get_guide_launch_wiener1(mo) : mh.d == 2 ? get_guide_launch_wiener2(mo) : mh.d == 3 ? get_guide_launch_wiener3(mo) : nullptr;
+    }
+    return nullptr;
+}
 }  // namespace bhip
 
 #ifndef PC_FRESH_MAX_PATHS
@@ -1272,7 +1305,7 @@ static int launch_ppr(bhip_chains *ch, int noise, KArgs &a)
     const bhip_proposal *po = ch->po;
     a.prows = ch->prows; a.ldr = ch->ld; a.vend_pc = ch->vend_pc; a.uv_pc = ch->uv_pc;
     const int fl = (noise == NOISE_PCN || noise == NOISE_PCN_LINES) ? (a.Xo ? 1 : 0) : 0;
-    launch_fn f = po->mh.id == BHIP_MODEL_LORENZ ? get_launch_ppr_lorenz(noise, fl) : po->mh.id == BHIP_MODEL_PENDULUM ? get_launch_ppr_pendulum(noise, fl) : nullptr;
+    launch_fn f = find_launch_ppr(po->mh, noise, fl);
     if (!f) return fail(ctx, BHIP_EUNSUPPORTED, "no per-chain-guide kernel for this model");
     HIPCHK(ctx, f(a, ctx->stream));
     return BHIP_OK;

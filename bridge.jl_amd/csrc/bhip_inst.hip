@@ -10,10 +10,16 @@ namespace bhip {
 launch_fn get_launch_ou(int gk, int mo, int noise, int fl) { return get_launch<MOU>(gk, mo, noise, fl); }
 #elif BHIP_INST == 1
 launch_fn get_launch_linpro1(int gk, int mo, int noise, int fl) { return get_launch<MLinPro<1>>(gk, mo, noise, fl); }
+launch_fn get_launch_ppr_linpro1(int noise, int fl) { return get_launch_ppr<MLinPro<1>>(noise, fl); }
+guide_launch_fn get_guide_launch_linpro1(int mo) { return get_guide_launch<MLinPro<1>>(mo); }
 #elif BHIP_INST == 2
 launch_fn get_launch_linpro2(int gk, int mo, int noise, int fl) { return get_launch<MLinPro<2>>(gk, mo, noise, fl); }
+launch_fn get_launch_ppr_linpro2(int noise, int fl) { return get_launch_ppr<MLinPro<2>>(noise, fl); }
+guide_launch_fn get_guide_launch_linpro2(int mo) { return get_guide_launch<MLinPro<2>>(mo); }
 #elif BHIP_INST == 3
 launch_fn get_launch_linpro3(int gk, int mo, int noise, int fl) { return get_launch<MLinPro<3>>(gk, mo, noise, fl); }
+launch_fn get_launch_ppr_linpro3(int noise, int fl) { return get_launch_ppr<MLinPro<3>>(noise, fl); }
+guide_launch_fn get_guide_launch_linpro3(int mo) { return get_guide_launch<MLinPro<3>>(mo); }
 #elif BHIP_INST == 4
 launch_fn get_launch_fhn(int gk, int mo, int noise, int fl) { return get_launch<MFHN>(gk, mo, noise, fl); }
 #elif BHIP_INST == 5
@@ -32,8 +38,14 @@ launch_fn get_launch_ppr_pendulum(int noise, int fl) { return get_launch_ppr<MPe
 guide_launch_fn get_guide_launch_pendulum(int mo) { return get_guide_launch<MPendulum>(mo); }
 #elif BHIP_INST == 10
 launch_fn get_launch_wiener1(int gk, int mo, int noise, int fl) { return get_launch<MWiener<1>>(gk, mo, noise, fl); }
+launch_fn get_launch_ppr_wiener1(int noise, int fl) { return get_launch_ppr<MWiener<1>>(noise, fl); }
+guide_launch_fn get_guide_launch_wiener1(int mo) { return get_guide_launch<MWiener<1>>(mo); }
 launch_fn get_launch_wiener2(int gk, int mo, int noise, int fl) { return get_launch<MWiener<2>>(gk, mo, noise, fl); }
+launch_fn get_launch_ppr_wiener2(int noise, int fl) { return get_launch_ppr<MWiener<2>>(noise, fl); }
+guide_launch_fn get_guide_launch_wiener2(int mo) { return get_guide_launch<MWiener<2>>(mo); }
 launch_fn get_launch_wiener3(int gk, int mo, int noise, int fl) { return get_launch<MWiener<3>>(gk, mo, noise, fl); }
+launch_fn get_launch_ppr_wiener3(int noise, int fl) { return get_launch_ppr<MWiener<3>>(noise, fl); }
+guide_launch_fn get_guide_launch_wiener3(int mo) { return get_guide_launch<MWiener<3>>(mo); }
 #else
 #error "BHIP_INST must be 0..10"
 #endif

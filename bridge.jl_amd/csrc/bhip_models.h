@@ -73,6 +73,12 @@ struct MLinPro {
             o[i] = s;
         }
     }
+    // Bridge.bderiv(t, x, P::LinPro) = P.B   src/linpro.jl:82
+    BHIP_DEV void bderiv(double, const double *, double *J) const
+    {
+#pragma unroll
+        for (int k = 0; k < D * D; k++) J[k] = p[k];
+    }
     BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const
     {
         const double *S = p + D * D + D;
@@ -220,6 +226,12 @@ struct MWiener {
     static constexpr int D = D_, MP = D_, ID = BHIP_MODEL_WIENER;
     static constexpr bool noisy(int) { return true; }
     BHIP_DEV explicit MWiener(const double *) {}
+    // Bridge.bderiv(t, x, P::Wiener) = 0   src/wiener.jl:147
+    BHIP_DEV void bderiv(double, const double *, double *J) const
+    {
+#pragma unroll
+        for (int k = 0; k < D * D; k++) J[k] = 0.0;
+    }
     BHIP_DEV void b(double, const double *, double *o) const
     {
 #pragma unroll

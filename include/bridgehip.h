@@ -341,7 +341,7 @@ int bhip_segchains_set_pi0(bhip_segchains *sc, const double *mu, const double *c
  * index-based Heun solver (src/guip.jl:181-189, src/ode.jl:98-113), H, v = gpupdate(Po[i], L, Sigma, obs[i]) backwards
  * through the segments (src/guip.jl:221-231), pi0 = Gaussian(v, Hermitian(H)).
  *   requires BHIP_SEGCHAINS_MCNEXT, GuidedBridge segments with LinearAppr auxiliaries, a target whose bderiv exists on the
- *   device (Lorenz src/Models.jl:49-53, Pendulum :81-84)
+ *   device (Lorenz src/Models.jl:49-53, Pendulum :81-84, LinPro src/linpro.jl:82, Wiener src/wiener.jl:147; d <= 3)
  *   L [mo x d], Sigma [mo x mo] column-major; obs [m][mo]: obs[i] = the observation at the LEFT end of segment i (V.yy[i]);
  *   (HT [d x d], vT [d]) = gpupdate(prior, last observation): the right-end condition of segment m-1 (bhip_gpupdate)
  *   flags: BHIP_SEG_NEWBLOCK | BHIP_SEG_DOACCEPT as above

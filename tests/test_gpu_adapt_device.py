@@ -243,3 +243,39 @@ def test_linearnoiseappr_segments_and_their_per_chain_adaptation():
         assert np.array_equal(ll[:, p], r["ll"]) and acc[p] == r["acc"] and np.array_equal(y0[p], r["y0"])
         assert np.array_equal(sc.chain_guide(0, p)["mu"], r["mu"])
     assert np.isfinite(ll).all() and (acc >= 1).all()
+
+
+def test_linear_target_per_chain_guides_are_the_targets_own_guide():
+    """bderiv of a LinPro is its B (src/linpro.jl:82): the linearisation along ANY path is the target itself, so every chain's
+    device-built guide must agree with every other chain's and with the host guide of the same LinPro used as its own auxiliary
+    (Ralston-3) up to the second-order Heun error; the log-likelihood ratio then vanishes and every proposal is accepted."""
+    ctx = bh.default_context(0)
+    m, M, n = 2, 200, 4096
+    Bm = np.array([[-1.0, 0.3], [-0.2, -0.8]])
+    sg = np.array([[0.8, 0.1], [-0.3, 0.6]])
+    mu_ = np.array([0.1, -0.2])
+    P = bh.LinPro(Bm, mu_, sg)
+    tgrid = np.linspace(0.0, 1.0, m * M + 1)
+    L, Sig = np.eye(2), 0.1 * np.eye(2)
+    obs = np.array([[0.3, -0.1], [0.5, 0.2], [0.2, 0.4]])
+    HT, vT = bh.gpupdate(1e3 * np.eye(2), np.zeros(2), L, Sig, obs[m])
+    H, v, segs, r3 = HT, vT, [None] * m, [None] * m
+    for i in range(m - 1, -1, -1):
+        tt = tgrid[i * M:(i + 1) * M + 1].copy()
+        Y = np.stack([np.sin(3 * tt), np.cos(2 * tt)], 1)                      # an arbitrary first linearisation path
+        segs[i] = bh.GuidedBridge(tt, P, bh.linearappr(Y), v, H, ctx=ctx)
+        r3[i] = bh.GuidedBridge(tt, P, P, v, H, ctx=bh.Context(-1))
+        H, v = bh.gpupdate(segs[i], L, Sig, obs[i])
+    sc = bh.SegChains(segs, v, o.chol_lower(H), n, seed=17, mcnext=True)
+    sc.step(0.8, 0.6, 3)
+    sc.adapt_device(L, Sig, obs[:m], HT, vT, newblock=False)
+    g = {p: sc.chain_guide(m - 1, p) for p in (0, 1000, n - 1)}
+    for p in (1000, n - 1):
+        assert np.allclose(g[p]["G"], g[0]["G"], rtol=1e-11, atol=1e-13) and np.array_equal(g[p]["B"], g[0]["B"])
+    assert np.array_equal(g[0]["B"][7], Bm)
+    assert np.abs(g[0]["G"][:, 5:7] - r3[m - 1].V[:-1]).max() < 1e-4          # Heun vs Ralston-3 on the same ODE
+    assert np.abs(g[0]["G"][:, :4] - np.stack([h.T.ravel() for h in r3[m - 1].Hd[:-1]])).max() < 1e-4
+    acc0 = sc.state()[1].copy()
+    sc.step(0.8, 0.6, 10)
+    ll, acc, _ = sc.state()
+    assert np.array_equal(acc - acc0, np.full(n, 10)) and np.abs(ll).max() < 1e-9
