@@ -350,3 +350,61 @@ def test_mcmc_reaches_the_exact_linear_bridge_law_d32(ctx):
     assert np.all(np.abs(xi.mean(1) - mean) < 6 * se + 5e-3), np.abs(xi.mean(1) - mean).max()
     assert np.abs(xi.var(1) / np.diag(cov) - 1).max() < 0.08
     assert 0.05 < ch.acc().sum() / (n * 150) < 0.99
+
+
+def test_smoothing_loop_reaches_the_exact_linear_gaussian_smoothing_law(ctx):
+    """The application loop end to end, distribution level: an Ornstein-Uhlenbeck target (beta = 0.8, a = 0.7)
+    observed with noise at the four knots of three chained GuidedBridge segments whose auxiliary is a DIFFERENT linear
+    process -- every proposal is wrong by its Girsanov weight, the start is drawn from the auxiliary's pi0, and only the joint
+    Metropolis-Hastings decision on the summed log-likelihoods (bhip_segchains_*: pCN on y0 and on every segment's W, one
+    accept) makes the chains sample the true smoothing law.  That law is Gaussian: flat prior on X(0), exact OU transitions,
+    observations N(y_k; x_k, Sigma), and the N(0, piH) pseudo-prior at T the backward recursion starts from
+    (supplements/smoothing/smoothing.jl:75).  32 768 chains after 300 iterations must match its mean and variance at the knots
+    up to Monte-Carlo error and the O(dt) bias of the Euler scheme; the first proposals must not."""
+    beta, a = 0.8, 0.7
+    m, M, n, iters = 3, 400, 32768, 300
+    tgrid = np.linspace(0.0, 1.5, m * M + 1)
+    knots = tgrid[::M]
+    y = np.array([0.9, 0.2, -0.4, 0.5])
+    Sig, piH = 0.05, 1e3
+    P = bh.LinPro([[-beta]], [0.0], [[math.sqrt(a)]])
+    Pt = bh.LinPro([[-0.3]], [0.2], [[math.sqrt(a)]])               # a deliberately different auxiliary
+    L, S = np.array([[1.0]]), np.array([[Sig]])
+    HT, vT = bh.gpupdate(np.array([[piH]]), np.zeros(1), L, S, y[m:m + 1])
+    H, v, segs = HT, vT, [None] * m
+    for i in range(m - 1, -1, -1):
+        segs[i] = bh.GuidedBridge(tgrid[i * M:(i + 1) * M + 1].copy(), P, Pt, v, H, ctx=ctx)
+        H, v = bh.gpupdate(segs[i], L, S, y[i:i + 1])
+    # exact law of (X(t_0), .., X(t_3))
+    Lam, eta = np.zeros((m + 1, m + 1)), np.zeros(m + 1)
+    for k in range(m + 1):
+        Lam[k, k] += 1 / Sig; eta[k] += y[k] / Sig
+    Lam[m, m] += 1 / piH
+    for k in range(m):
+        dl = knots[k + 1] - knots[k]
+        phi, q = math.exp(-beta * dl), a * (1 - math.exp(-2 * beta * dl)) / (2 * beta)
+        Lam[k, k] += phi * phi / q; Lam[k + 1, k + 1] += 1 / q
+        Lam[k, k + 1] -= phi / q; Lam[k + 1, k] -= phi / q
+    cov = np.linalg.inv(Lam)
+    mean = cov @ eta
+    sc = bh.SegChains(segs, v, np.sqrt(H), n, seed=23)
+
+    def knot_values():
+        cols = [sc.paths(i, 0, n)[0][:, 0, 0] for i in range(m)] + [sc.paths(m - 1, 0, n)[0][:, -1, 0]]
+        return np.stack(cols, 1)
+    X0 = knot_values()
+    w_new = math.sqrt(0.5)
+    sc.step(math.sqrt(1 - w_new ** 2), w_new, iters)
+    X = knot_values()
+    se = np.sqrt(np.diag(cov) / n)
+    err = np.abs(X.mean(0) - mean)
+    assert (err < 6 * se + 5e-3).all(), (X.mean(0), mean)
+    # the Euler scheme inflates the variance at the right end of a guided segment by ~ a*dt/(2*Hd) (stiff guiding term
+    # a/Hd ~ 15 near a noisy observation): 3.9 % at M = 100 steps per segment (measured 3-5 %), ~1 % here; MC error 0.8 %
+    assert (np.abs(X.var(0) / np.diag(cov) - 1) < 0.035).all(), (X.var(0), np.diag(cov))
+    emp = np.cov(X.T)
+    assert np.abs(emp[0, 1] - cov[0, 1]) < 0.05 * math.sqrt(cov[0, 0] * cov[1, 1]) + 2e-3          # the knots are correlated as they should be
+    # the first proposals (start at pi0's mean, wrong drift) are visibly off: the test has power
+    assert np.abs(X0.mean(0) - mean).max() > 10 * err.max() or np.abs(X0.var(0) / np.diag(cov) - 1).max() > 0.3
+    acc = sc.state()[1]
+    assert 0.1 < acc.mean() / iters < 0.95
