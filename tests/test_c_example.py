@@ -12,19 +12,20 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp_path):
+def _build(tmp_path, name="fhn_chains"):
     gcc = shutil.which("gcc")
     if gcc is None:
         pytest.skip("gcc not available")
-    exe = str(tmp_path / "fhn_chains")
+    exe = str(tmp_path / name)
     lib = os.path.join(ROOT, "bridge.jl_amd")
-    subprocess.check_call([gcc, "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "fhn_chains.c"),
+    subprocess.check_call([gcc, "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".c"),
                            "-L", lib, "-lbridgehip", "-Wl,-rpath," + lib, "-lm", "-o", exe])
     return exe
 
 
-def test_c_example_compiles_against_the_header(tmp_path):
-    exe = _build(tmp_path)
+@pytest.mark.parametrize("name", ["fhn_chains", "lorenz_smoothing"])
+def test_c_example_compiles_against_the_header(tmp_path, name):
+    exe = _build(tmp_path, name)
     assert os.path.exists(exe)
 
 
@@ -50,3 +51,50 @@ def test_c_example_matches_the_python_mirror(tmp_path):
     m = re.search(r"acceptance ([0-9.]+) mean ll (\S+)", out.stdout)
     assert abs(float(m.group(1)) - acc.sum() / (nchains * iters)) < 1e-4 and abs(float(m.group(2)) - ll.mean()) < 1e-5
     assert abs(float(re.search(r"endpoint x1 (\S+)", out.stdout).group(1)) - 1.1) < 1e-3
+
+
+@pytest.mark.gpu
+def test_c_smoothing_example_matches_the_python_mirror(tmp_path):
+    """examples/lorenz_smoothing.c: the adaptive smoothing loop (chained LinearAppr segments, joint MH, mcnext!, per-chain
+    adaptation on the device) driven through the C ABI from plain C == the same loop through the Python mirror, bit for bit"""
+    import math
+    import bridgehip as bh
+    exe = _build(tmp_path, "lorenz_smoothing")
+    n, iters, adaptit = 200, 12, 5
+    out = subprocess.run([exe, str(n), str(iters), str(adaptit)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = {int(m.group(1)): (int(m.group(2)), float.fromhex(m.group(3))) for m in re.finditer(r"chain (\d+) acc (\d+) ll (\S+)", out.stdout)}
+    assert len(got) == 4
+    ctx = bh.default_context(0)
+    m, M = 3, 40
+    par = ((10.0, 20.0, 8.0 / 3), (3.0, 3.0, 3.0))
+    tgrid = np.array([0.24 * i / (m * M) for i in range(m * M + 1)])
+    ref = np.zeros((m * M + 1, 3)); y = np.array([1.5, -1.5, 25.0])
+    for i in range(m * M + 1):
+        ref[i] = y
+        if i < m * M:
+            b = np.array([10.0 * (y[1] - y[0]), y[0] * (20.0 - y[2]) - y[1], y[0] * y[1] - 8.0 / 3 * y[2]])
+            y = y + b * (tgrid[i + 1] - tgrid[i])
+    obs = np.array([[ref[j * M, k] + 0.3 * ((j + k) % 3 - 1) for k in range(3)] for j in range(m + 1)])
+    L, Sig = np.eye(3), 0.25 * np.eye(3)
+    P = bh.Lorenz(*par)
+    HT, vT = bh.gpupdate(1e3 * np.eye(3), np.zeros(3), L, Sig, obs[m])
+    H, v, segs = HT, vT, [None] * m
+    for i in range(m - 1, -1, -1):
+        segs[i] = bh.GuidedBridge(tgrid[i * M:(i + 1) * M + 1].copy(), P, bh.linearappr(ref[i * M:(i + 1) * M + 1]), v, H, ctx=ctx)
+        H, v = bh.gpupdate(segs[i], L, Sig, obs[i])
+    C = np.zeros((3, 3))
+    C[0, 0] = math.sqrt(H[0, 0]); C[1, 0] = H[0, 1] / C[0, 0]; C[1, 1] = math.sqrt(H[1, 1] - C[1, 0] * C[1, 0])
+    C[2, 0] = H[0, 2] / C[0, 0]; C[2, 1] = (H[1, 2] - C[1, 0] * C[2, 0]) / C[1, 1]; C[2, 2] = math.sqrt(H[2, 2] - C[2, 0] * C[2, 0] - C[2, 1] * C[2, 1])
+    sc = bh.SegChains(segs, v, C, n, seed=7, mcnext=True)
+    w_new, w_old = math.sqrt(0.1), math.sqrt(0.9)
+    for it in range(1, iters + 1):
+        if it % adaptit == 0:
+            sc.adapt_device(L, Sig, obs[:m], HT, vT, newblock=True, doaccept=(it == adaptit))
+        sc.step(w_old, w_new, 1)
+    ll, acc, _ = sc.state()
+    for p, (a, l) in got.items():
+        s = 0.0
+        for i in range(m):
+            s += ll[i, p]
+        assert a == acc[p] and l == s, (p, a, acc[p], l, s)
