@@ -321,6 +321,39 @@ def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
                                            "hbm_frac": ps * b_pc / ms_pc / 1e6 / HBM_PEAK_GBS}}
 
 
+def box_calibration(device):
+    """What THIS box's memory system does on the plainest streams (boxes of the pool differ: the headline kernel moves exactly
+    its algorithmic bytes and ran at 1.53-1.62 ms on some, 1.80-1.84 ms on others): device-to-device copy (1 read : 1 write)
+    and fill (write only) of 1 GiB, GB/s of bytes moved; plus the partition modes and clocks rocm-smi reports."""
+    import subprocess
+    n = 1 << 27
+    a = torch.empty(n, dtype=torch.float64, device=device)
+    b = torch.empty(n, dtype=torch.float64, device=device)
+    a.fill_(1.0); b.copy_(a); torch.cuda.synchronize()
+
+    def t(fn, k=10):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(k):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / k * 1e-3
+    tc, tf = t(lambda: b.copy_(a)), t(lambda: a.fill_(2.0))
+    out = {"copy_1r1w_GBs": 2 * 8 * n / tc / 1e9, "fill_write_GBs": 8 * n / tf / 1e9}
+    del a, b
+    torch.cuda.empty_cache()
+    try:
+        r = subprocess.run(["rocm-smi", "--showmemorypartition", "--showcomputepartition", "--showclocks"], capture_output=True, text=True, timeout=20)
+        for key, pat in (("compute_partition", "Compute Partition:"), ("memory_partition", "Memory Partition:"), ("mclk", "mclk clock level"), ("fclk", "fclk clock level")):
+            for line in r.stdout.splitlines():
+                if pat in line:
+                    out[key] = line.split(":", 2)[-1].strip() if "clock" not in pat else line.split(":")[-1].strip(" ()")
+                    break
+    except Exception as e:   # the record is context, never a reason to fail the bench
+        out["rocm_smi"] = f"unavailable: {e}"
+    return out
+
+
 def timed_region(w, steps, world, ctx, stats, comm=None):
     """the contract's timed region: K steps bracketed by barrier + synchronize on both sides, MAX over ranks; ends with
     the device-side statistics reduction and (N > 1) the ONE all-gather of the statistics block"""
@@ -450,6 +483,7 @@ def main():
             torch.cuda.empty_cache()
         out["other_modes"] = others
         out["smoothing"] = smoothing_record(ctx)
+        out["box"] = box_calibration(ctx.device)
     elif world > 1 and default_run:
         # SURVEY 8(d) C4 quotes 32 768 chains per GPU: the same protocol at that shard size, next to the headline
         del w

@@ -113,8 +113,14 @@ def load():
         raise ImportError(f"{SO_PATH} is missing: build it with `python __graft_entry__.py` "
                           f"(or make -C bridge.jl_amd/csrc); there is no CPU fallback")
     lib = C.CDLL(SO_PATH)
+    old_build = os.environ.get("BRIDGEHIP_SO_OLD_BUILD") == "1"   # scripts/gpu_ab_*.sh: an OLDER library build for same-box A/B timing
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)   # AttributeError here = header/library mismatch
+        try:
+            fn = getattr(lib, name)   # AttributeError here = header/library mismatch
+        except AttributeError:
+            if old_build:
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     _lib = lib

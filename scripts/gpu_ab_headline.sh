@@ -1,0 +1,13 @@
+#!/bin/bash
+# same-box A/B of the headline / shard / proposals kernels: the current build against an older library build
+# (bridge.jl_amd/variants/<name>.so, default a50f5cd = the commit profiles/r2_bench_default.json was taken at), alternating.
+# The old library lacks newer entry points: the Python mirror only binds what it finds?  -> run the raw modes only.
+OLD=${1:-a50f5cd}
+for rep in 1 2; do
+  for v in old cur; do
+    so=""; ob=0; [ $v = old ] && so=$PWD/bridge.jl_amd/variants/$OLD.so && ob=1
+    for m in mcmc c4shard proposals; do
+      BRIDGEHIP_SO_OLD_BUILD=$ob BRIDGEHIP_SO=$so python bench.py --mode $m --steps 10 --warmup 3 --no-cpu-baseline --no-other-modes 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['config']['mode'], round(d['roofline']['kernel_avg_ms'],4), round(d['roofline']['frac'],4))"
+    done
+  done
+done
