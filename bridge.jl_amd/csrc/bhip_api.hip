@@ -163,6 +163,7 @@ static int fail(bhip_ctx *ctx, int code, const std::string &msg)
 // current for the calling thread (a process may drive several devices through several contexts)
 #define NEED_DEVICE(ctx)                                                                          \
     do {                                                                                          \
+        if ((ctx)->closed) return fail(ctx, BHIP_ESTATE, "the context was destroyed (its remaining children can only be destroyed)"); \
         if ((ctx)->host_only) return fail(ctx, BHIP_EHIP, "host-only context (device -1): no device work possible"); \
         if (hipSetDevice((ctx)->device) != hipSuccess) return fail(ctx, BHIP_EHIP, "hipSetDevice failed for the context's device"); \
     } while (0)

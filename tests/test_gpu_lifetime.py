@@ -24,7 +24,8 @@ def test_context_destroyed_before_its_children():
     L = ctx.lib
     # the context first, then the chains, then the proposal: each call must be safe
     L.bhip_ctx_destroy(h_ctx); ctx.h = None
-    L.bhip_chains_destroy(h_ch); ch.h = None
+    assert L.bhip_chains_step(h_ch, 0.9, 1, 0) == -4                    # BHIP_ESTATE: no new work through a destroyed context ...
+    L.bhip_chains_destroy(h_ch); ch.h = None                             # ... but its children remain destroyable
     L.bhip_proposal_destroy(h_po); Po.h = None
 
 
