@@ -13,6 +13,7 @@
 // partial pivoting; everything is column-major, products accumulate left to right.
 #pragma once
 #include "../../include/bridgehip.h"
+#include "bhip_trig.h"
 #include <cmath>
 #include <cstring>
 #include <functional>
@@ -538,7 +539,7 @@ inline bool host_bderiv(const ModelHost &mh, const double *x, Mat &J)
         return true;
     case BHIP_MODEL_PENDULUM:
         J(0, 0) = 0.0;                      J(0, 1) = 1.0;
-        J(1, 0) = -p[0] * std::cos(x[0]);   J(1, 1) = 0.0;
+        J(1, 0) = -p[0] * det_cos(x[0]);   J(1, 1) = 0.0;
         return true;
     case BHIP_MODEL_LINPRO: J = Mat(d, d, p); return true;
     case BHIP_MODEL_WIENER: return true;
@@ -554,7 +555,7 @@ inline bool host_b(const ModelHost &mh, const double *x, Mat &o)
     case BHIP_MODEL_LORENZ:   // src/Models.jl:47
         o.a[0] = p[0] * (x[1] - x[0]); o.a[1] = x[0] * (p[1] - x[2]) - x[1]; o.a[2] = x[0] * x[1] - p[2] * x[2];
         return true;
-    case BHIP_MODEL_PENDULUM: o.a[0] = x[1]; o.a[1] = -p[0] * std::sin(x[0]); return true;   // :79
+    case BHIP_MODEL_PENDULUM: o.a[0] = x[1]; o.a[1] = -p[0] * det_sin(x[0]); return true;   // :79
     case BHIP_MODEL_LINPRO: { Mat xm(d, 1); for (int k = 0; k < d; k++) xm.a[k] = x[k] - p[d * d + k]; o = Mat(d, d, p) * xm; return true; }
     case BHIP_MODEL_WIENER: return true;
     }

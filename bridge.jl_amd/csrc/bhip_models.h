@@ -11,6 +11,7 @@
 #pragma once
 #include "../../include/bridgehip.h"
 #include <hip/hip_runtime.h>
+#include "bhip_trig.h"
 
 namespace bhip {
 
@@ -141,7 +142,7 @@ struct MNCLAR {
     BHIP_DEV explicit MNCLAR(const double *p) : al(p[0]), om(p[1]), sig(p[2]), a33(p[3]) {}
     BHIP_DEV void b(double, const double *x, double *o) const
     {
-        o[0] = x[1]; o[1] = x[2]; o[2] = -al * sin(om * x[2]);
+        o[0] = x[1]; o[1] = x[2]; o[2] = -al * det_sin(om * x[2]);
     }
     BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const { o[0] = 0.0; o[1] = 0.0; o[2] = sig * dw[0]; }
     BHIP_DEV void amul(double, const double *, const double *r, double *o) const { o[0] = 0.0; o[1] = 0.0; o[2] = a33 * r[2]; }
@@ -156,7 +157,7 @@ struct MIntDiff {
     BHIP_DEV explicit MIntDiff(const double *p) : gam(p[0]), a22(p[1]) {}
     BHIP_DEV void b(double, const double *x, double *o) const
     {
-        o[0] = x[1]; o[1] = -(x[1] + sin(x[1])) + 0.5;
+        o[0] = x[1]; o[1] = -(x[1] + det_sin(x[1])) + 0.5;
     }
     BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const { o[0] = 0.0; o[1] = gam * dw[0]; }
     BHIP_DEV void amul(double, const double *, const double *r, double *o) const { o[0] = 0.0; o[1] = a22 * r[1]; }
@@ -213,11 +214,11 @@ struct MPendulum {
     static constexpr bool noisy(int k) { return k == 1; }
     double th2, gam, a22;
     BHIP_DEV explicit MPendulum(const double *p) : th2(p[0]), gam(p[1]), a22(p[2]) {}
-    BHIP_DEV void b(double, const double *x, double *o) const { o[0] = x[1]; o[1] = -th2 * sin(x[0]); }
+    BHIP_DEV void b(double, const double *x, double *o) const { o[0] = x[1]; o[1] = -th2 * det_sin(x[0]); }
     BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const { o[0] = 0.0; o[1] = gam * dw[0]; }
     BHIP_DEV void amul(double, const double *, const double *r, double *o) const { o[0] = 0.0; o[1] = a22 * r[1]; }
     // Bridge.bderiv(t, x, P::Pendulum)  src/Models.jl:81-84
-    BHIP_DEV void bderiv(double, const double *x, double *J) const { J[0] = 0.0; J[1] = -th2 * cos(x[0]); J[2] = 1.0; J[3] = 0.0; }
+    BHIP_DEV void bderiv(double, const double *x, double *J) const { J[0] = 0.0; J[1] = -th2 * det_cos(x[0]); J[2] = 1.0; J[3] = 0.0; }
 };
 
 // ---- Wiener{SVector{D}}: b = 0, sigma = a = I            src/wiener.jl:143-167

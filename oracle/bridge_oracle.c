@@ -341,6 +341,68 @@ void bo_normals(uint64_t seed, uint32_t path, uint32_t iter, int n0, int n, doub
 /* ------------------------------------------------------------------------------------------
  * target models: b(t,x,P), _scale(dw, sigma(t,x,P)), a(t,x,P)
  * ------------------------------------------------------------------------------------------ */
+/* ------------------------------------------------------------------------------------------
+ * sin / cos of the drift functions (NclarDiffusion, IntegratedDiffusion-with-sin, Pendulum).
+ * Julia's sin(::Float64) / cos(::Float64) (base/special/trig.jl -- Julia Base, not part of /root/reference) are ports of
+ * fdlibm: argument reduction by pi/2 (Cody-Waite with a 33+33+53-bit split of pi/2 for |x| < 2^20*pi/2, Payne-Hanek
+ * beyond), then the kernels __kernel_sin / __kernel_cos on the reduced double-double argument.  Restated here in that form
+ * so that oracle, host C++ and the HIP kernels (bhip_trig.h) share ONE definition and agree bit for bit -- glibc's sin and
+ * the device library's differ from each other and from Julia's in the last place.  Not bit-identical to Julia either:
+ * its kernels evaluate the polynomials with muladd, which fuses or not depending on the CPU; the restatement never fuses.
+ * Always two reduction steps (118 bits of pi/2: the closest approach of a double below 2^20*pi/2 to a multiple of pi/2
+ * leaves > 53 significant bits), no early exit, round-to-nearest-even for the quadrant count.
+ * Domain: |x| < 2^20*pi/2 ~ 1.647e6; outside (and for NaN/Inf) the result is NaN -- the Payne-Hanek range is not
+ * restated; a drift argument of that size means the path has already blown up.  Error <= 1 ulp (tests/test_oracle.py). */
+static const double TRIG_INVPIO2 = 6.36619772367581382433e-01, TRIG_PIO2_1 = 1.57079632673412561417e+00,
+                    TRIG_PIO2_1T = 6.07710050650619224932e-11, TRIG_PIO2_2 = 6.07710050630396597660e-11,
+                    TRIG_PIO2_2T = 2.02226624879595063154e-21, TRIG_MAX = 1647099.3291652855;
+static int trig_reduce(double x, double *y0, double *y1)
+{
+    const double fn = rint(x * TRIG_INVPIO2);
+    double r = x - fn * TRIG_PIO2_1, w, t;          /* fn*pio2_1 is exact: 33 + 20 bits */
+    t = r; w = fn * TRIG_PIO2_2; r = t - w;
+    w = fn * TRIG_PIO2_2T - ((t - r) - w);
+    (void)TRIG_PIO2_1T;
+    *y0 = r - w;
+    *y1 = (r - *y0) - w;
+    return (int)fn;
+}
+static double trig_ksin(double x, double y)
+{
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = x * x, v = z * x;
+    const double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+static double trig_kcos(double x, double y)
+{
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = x * x;
+    const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + (z * r - x * y));
+}
+double bo_sin(double x)
+{
+    if (!(fabs(x) < TRIG_MAX)) return NAN;
+    double y0, y1;
+    const int q = trig_reduce(x, &y0, &y1) & 3;
+    const double s = trig_ksin(y0, y1), c = trig_kcos(y0, y1);
+    const double r = (q & 1) ? c : s;
+    return (q & 2) ? -r : r;
+}
+double bo_cos(double x)
+{
+    if (!(fabs(x) < TRIG_MAX)) return NAN;
+    double y0, y1;
+    const int q = trig_reduce(x, &y0, &y1) & 3;
+    const double s = trig_ksin(y0, y1), c = trig_kcos(y0, y1);
+    const double r = (q & 1) ? s : c;
+    return ((q + 1) & 2) ? -r : r;
+}
+
 int bo_model_dims(int model, int d_hint, int *d, int *mp)
 {
     switch (model) {
@@ -387,10 +449,10 @@ void bo_b(int model, int d, const double *p, double t, const double *x, double *
         o[1] = p[2] * x[0] - x[1] + p[3];
         break;
     case BO_MODEL_NCLAR: /* partialbridge_nclar.jl:58  (x2, x3, -alpha*sin(omega*x3)) */
-        o[0] = x[1]; o[1] = x[2]; o[2] = -p[0] * sin(p[1] * x[2]);
+        o[0] = x[1]; o[1] = x[2]; o[2] = -p[0] * bo_sin(p[1] * x[2]);
         break;
     case BO_MODEL_INTDIFF: /* test/partialbridge.jl:11-12  (x2, -(x2+sin(x2)) + 1/2) */
-        o[0] = x[1]; o[1] = -(x[1] + sin(x[1])) + 0.5;
+        o[0] = x[1]; o[1] = -(x[1] + bo_sin(x[1])) + 0.5;
         break;
     case BO_MODEL_LORENZ: /* src/Models.jl:47 */
         o[0] = p[0] * (x[1] - x[0]);
@@ -402,7 +464,7 @@ void bo_b(int model, int d, const double *p, double t, const double *x, double *
         o[1] = p[2] * x[0] - x[1] + p[3];
         break;
     case BO_MODEL_PENDULUM: /* src/Models.jl:79  (x2, -theta2*sin(x1)) */
-        o[0] = x[1]; o[1] = -p[0] * sin(x[0]);
+        o[0] = x[1]; o[1] = -p[0] * bo_sin(x[0]);
         break;
     case BO_MODEL_SDIFF1:
         o[0] = p[0] * (p[1] - x[0]);
@@ -725,7 +787,7 @@ void bo_bderiv(int model, int d, const double *p, double t, const double *x, dou
         J[2] = x[1];         J[5] = x[0];  J[8] = -p[2];
     } else if (model == BO_MODEL_PENDULUM) {
         J[0] = 0.0;                  J[2] = 1.0;
-        J[1] = -p[0] * cos(x[0]);    J[3] = 0.0;
+        J[1] = -p[0] * bo_cos(x[0]); J[3] = 0.0;
     } else if (model == BO_MODEL_LINPRO) {
         memcpy(J, p, sizeof(double) * d * d);
     }

@@ -210,6 +210,9 @@ void bo_smooth_mcmc_flat(int m, int kind, int N, int d, int mp, int mo, int mode
                          double *mean, double *m2, long *nstat);
 
 /* the smoothing loop with adaptive re-linearisation for one chain (supplements/smoothing/smoothing.jl:75-213) */
+/* sin / cos as the drift functions evaluate them: fdlibm form (what Julia's Base ports), shared with the product */
+double bo_sin(double x);
+double bo_cos(double x);
 void bo_chol_lower(int n, const double *A, double *C);
 void bo_smooth_adaptive(int m, int N, int d, int mp, int mo, int model, const double *par, const double *tts, const double *Y0,
                         const double *L, const double *Sigma, const double *obs, const double *HT, const double *vT,

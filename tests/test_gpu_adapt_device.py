@@ -3,8 +3,8 @@ supplements/smoothing/smoothing.jl:130-160 run for every chain of the ensemble a
 bhip_guide_kernel.h) against the oracle's single-chain restatement of the whole loop (bo_smooth_adaptive).
 
 Lorenz (polynomial drift and Jacobian): every chain's guide, pi0, paths, Wiener paths, log-likelihoods, acceptance counts
-and mcnext! states are compared bit for bit.  Pendulum (sin / cos in drift and Jacobian): device ocml vs host libm differ
-in the last place, tolerance 1e-9 as for the other trigonometric drifts.
+and mcnext! states are compared bit for bit.  Pendulum (sin / cos in drift and Jacobian): bit for bit as well since oracle,
+host and kernels share one fdlibm-form sin / cos (bhip_trig.h, bo_sin / bo_cos).
 """
 import math
 
@@ -155,7 +155,7 @@ def test_adaptation_improves_the_proposals_and_host_route_agrees_for_identical_m
     assert np.isfinite(b.state()[0]).all()
 
 
-def test_pendulum_per_chain_guides_within_trigonometric_tolerance():
+def test_pendulum_per_chain_guides_bit_exact_with_the_shared_sin_cos():
     ctx = bh.default_context(0)
     m, M, n = 2, 50, 128
     tgrid = np.linspace(0.0, 1.0, m * M + 1)
@@ -182,12 +182,18 @@ def test_pendulum_per_chain_guides_within_trigonometric_tolerance():
         r1 = o.smooth_adaptive(o.MODEL_PENDULUM, 2, 1, par, tts, Y0, L, Sig, obs[:m], HT, vT, w_old[:adaptit], w_new[:adaptit], adaptit, 10 ** 6, 5, p)
         for i in range(m):
             g = sc.chain_guide(i, p)
-            assert np.allclose(g["G"][:, 5:7], r1["V"][i][:-1], rtol=1e-9, atol=1e-12)
-            assert np.allclose(g["G"][:, :4], r1["Hd"][i][:-1].transpose(0, 2, 1).reshape(-1, 4), rtol=1e-9, atol=1e-12)
-        assert np.allclose(sc.chain_guide(0, p)["mu"], r1["mu"], rtol=1e-9) and np.allclose(sc.chain_guide(0, p)["chol"], o.chol_lower(r1["H"]), rtol=1e-9)
+            assert np.array_equal(g["G"][:, 5:7], r1["V"][i][:-1])
+            assert np.array_equal(g["G"][:, :4], r1["Hd"][i][:-1].transpose(0, 2, 1).reshape(-1, 4))
+        assert np.array_equal(sc.chain_guide(0, p)["mu"], r1["mu"]) and np.array_equal(sc.chain_guide(0, p)["chol"], o.chol_lower(r1["H"]))
     sc.step(w_old[adaptit - 1:], w_new[adaptit - 1:])
     ll, acc, y0 = sc.state()
     assert np.isfinite(ll).all() and (acc >= 1).all()
+    for p in (0, 127):     # the whole run, chain by chain
+        r = o.smooth_adaptive(o.MODEL_PENDULUM, 2, 1, par, tts, Y0, L, Sig, obs[:m], HT, vT, w_old, w_new, adaptit, adaptit + 1, 5, p)   # adaptmax: one adaptation
+        for i in range(m):
+            X, W = sc.paths(i, p, 1)
+            assert np.array_equal(X[0], r["X"][i]) and np.array_equal(W[0], r["W"][i])
+        assert np.array_equal(ll[:, p], r["ll"]) and acc[p] == r["acc"] and np.array_equal(y0[p], r["y0"])
 
 
 def test_adapt_device_argument_checks():

@@ -33,16 +33,17 @@ def ctx():
     return c
 
 
-def check_paths(case, X_gpu, X_ref, what="X"):
-    if case.exact:
+def check_paths(case, X_gpu, X_ref, what="X", libm_trig=False):
+    # libm_trig: the reference values were frozen before the shared fdlibm-form sin / cos (goldens v1, v2)
+    if case.exact and not (libm_trig and case.trig):
         assert np.array_equal(X_gpu, X_ref), f"{case.name}: {what} not bit-exact, max diff {np.abs(X_gpu - X_ref).max():.3e}"
     else:
         tol = 1e-9 * (1 + np.abs(X_ref).max())
         assert np.abs(X_gpu - X_ref).max() <= tol, f"{case.name}: {what} diff {np.abs(X_gpu - X_ref).max():.3e} > {tol:.1e}"
 
 
-def check_ll(case, ll_gpu, ll_ref):
-    if case.exact:
+def check_ll(case, ll_gpu, ll_ref, libm_trig=False):
+    if case.exact and not (libm_trig and case.trig):
         assert np.array_equal(ll_gpu, ll_ref), f"{case.name}: ll not bit-exact, max diff {np.abs(ll_gpu - ll_ref).max():.3e}"
     else:
         assert np.all(np.abs(ll_gpu - ll_ref) <= 1e-8 * (1 + np.abs(ll_ref))), f"{case.name}: ll diff {np.abs(ll_gpu - ll_ref).max():.3e}"
@@ -302,22 +303,25 @@ def test_device_forms_of_the_generator_are_bit_identical(tmp_path):
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("version", ["v2", "v3"])
 @pytest.mark.parametrize("case", problems.cases(101) + problems.forward_cases(101), ids=lambda c: c.name)
-def test_committed_golden_vectors_on_device(ctx, case):
-    """the frozen vectors (tests/golden/guided_paths_v2.npz) through the C ABI: in-kernel noise, guided
-    solve, fused log-likelihood and a pCN chain reproduce them without the oracle being involved"""
+def test_committed_golden_vectors_on_device(ctx, case, version):
+    """the frozen vectors (tests/golden/guided_paths_v2.npz, _v3.npz) through the C ABI: in-kernel noise, guided
+    solve, fused log-likelihood and a pCN chain reproduce them without the oracle being involved (v2 was written before the
+    shared sin / cos restatement: its sin-drift problems compare to 1e-9, everything in v3 bit for bit)"""
     import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "guided_paths_v2.npz"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"guided_paths_{version}.npz"))
+    lt = version == "v2"
     N, npaths, seed, iters = (int(v) for v in g["meta"])
     rho = float(g["rho"])
     Po = case.bh_proposal(bh, ctx)
     X, W, ll = bh.sample_solve(case.x0, Po, npaths, seed=seed, store_W=True)
     assert np.array_equal(W.paths(), g[case.name + "/W"])
-    check_paths(case, X.paths(), g[case.name + "/X"])
+    check_paths(case, X.paths(), g[case.name + "/X"], libm_trig=lt)
     if case.kind == o.GUIDE_NONE:
         return
-    check_ll(case, ll.cpu().numpy(), g[case.name + "/ll"])
-    if case.exact:
+    check_ll(case, ll.cpu().numpy(), g[case.name + "/ll"], libm_trig=lt)
+    if case.exact and not (lt and case.trig) and (case.name + "/chain_W") in g.files:
         ch = bh.Chains(Po, case.x0, 2, seed=seed)
         ch.step(rho, iters)
         Xc, Wc = ch.paths(1, 1)
@@ -335,12 +339,12 @@ def test_round1_golden_paths_given_their_wiener_paths_on_device(ctx, case):
     W = bh.EnsemblePath.from_paths(case.tt, g[case.name + "/W"], ctx)
     if case.kind == o.GUIDE_NONE:
         X = bh.solve(bh.EulerMaruyama(), case.x0, W, Po)
-        check_paths(case, X.paths(), g[case.name + "/X"])
+        check_paths(case, X.paths(), g[case.name + "/X"], libm_trig=True)
         return
     ll = ctx.empty(W.npaths)
     X = bh.solve(bh.Euler(), case.x0, W, Po, ll=ll)
-    check_paths(case, X.paths(), g[case.name + "/X"])
-    check_ll(case, ll.cpu().numpy(), g[case.name + "/ll"])
+    check_paths(case, X.paths(), g[case.name + "/X"], libm_trig=True)
+    check_ll(case, ll.cpu().numpy(), g[case.name + "/ll"], libm_trig=True)
 
 
 def test_chains_with_skip_match_oracle(ctx):
