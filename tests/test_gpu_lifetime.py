@@ -36,3 +36,9 @@ def test_interpreter_exit_with_live_handles_is_clean(mode):
                         "--no-cpu-baseline", "--no-other-modes"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "terminate called" not in r.stderr and '"metric"' in r.stdout
+
+
+def test_readme_quickstart_runs():
+    env = dict(os.environ, QUICKSTART_PATHS="2048")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "quickstart.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "acceptance" in r.stdout, r.stdout + r.stderr[-2000:]
