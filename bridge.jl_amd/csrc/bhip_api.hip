@@ -279,16 +279,19 @@ int bhip_malloc(bhip_ctx *ctx, size_t bytes, void **dev)
     NEED_DEVICE(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMalloc(dev, bytes ? bytes : 8));
+    ctx_retain(ctx);   // a buffer is a child of its context too (a finalizer may free it after the context was destroyed)
     return BHIP_OK;
 }
 int bhip_free(bhip_ctx *ctx, void *dev)
 {
     if (!ctx) return BHIP_EINVAL;
     if (!dev) return BHIP_OK;
-    NEED_DEVICE(ctx);
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipFree(dev));
-    return BHIP_OK;
+    if (ctx->host_only) return fail(ctx, BHIP_EHIP, "host-only context (device -1): no device memory");
+    (void)hipSetDevice(ctx->device);
+    ctx_quiesce(ctx);
+    const hipError_t e = hipFree(dev);
+    ctx_release(ctx);
+    return e == hipSuccess ? BHIP_OK : BHIP_EHIP;
 }
 int bhip_memcpy_h2d(bhip_ctx *ctx, void *dev, const void *host, size_t bytes)
 {

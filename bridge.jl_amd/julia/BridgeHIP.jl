@@ -39,7 +39,10 @@ check(ctx::Context, rc) = rc == 0 ? nothing :
     throw(BHIPError(rc, unsafe_string(ccall((:bhip_last_error, lib), Cstring, (Ptr{Cvoid},), ctx.h))))
 
 const default_ctx = Ref{Union{Nothing,Context}}(nothing)
-ctx() = something(default_ctx[], (default_ctx[] = Context(); default_ctx[]))
+function default_context()          # (not named `ctx`: a keyword default `ctx = ctx()` would refer to the keyword itself)
+    default_ctx[] === nothing && (default_ctx[] = Context())
+    default_ctx[]
+end
 
 # ---------------------------------------------------------------- process type -> device functor
 # trait: hipmodel(P) -> (model id, d, parameter vector).  Users with their own process types add a
@@ -61,7 +64,7 @@ hipmodel(::Wiener{Float64}) = (MODEL_WIENER, 1, Float64[])
 #     struct DoubleWell <: ContinuousTimeProcess{Float64}; θ::Float64; σ::Float64; end
 #     BridgeHIP.hipmodel(P::DoubleWell) = BridgeHIP.userdrift(1, "o[0] = par[0]*(x[0] - x[0]*x[0]*x[0]);", [P.θ], fill(P.σ, 1, 1))
 const _user_ids = Dict{Tuple{Int,Int,Int,String},Cint}()
-function userdrift(d::Integer, src::String, par::Vector{Float64}, sigma::AbstractMatrix; c::Context = ctx())
+function userdrift(d::Integer, src::String, par::Vector{Float64}, sigma::AbstractMatrix; c::Context = default_context())
     key = (Int(d), size(sigma, 2), length(par), src)
     id = get!(_user_ids, key) do
         r = Ref{Cint}(0)
@@ -75,7 +78,7 @@ end
 # The same with a state-dependent Bridge.σ(t, x, P): `sigsrc` fills s (d x m', column-major, zero-initialised)
 #     BridgeHIP.hipmodel(P::MyDiff) = BridgeHIP.userprocess(1, 1, "o[0] = par[0]*(par[1] - x[0]);",
 #                                                           "s[0] = par[2]*sqrt(1.0 + x[0]*x[0]);", [P.κ, P.θ, P.s])
-function userprocess(d::Integer, mp::Integer, bsrc::String, sigsrc::String, par::Vector{Float64}; c::Context = ctx())
+function userprocess(d::Integer, mp::Integer, bsrc::String, sigsrc::String, par::Vector{Float64}; c::Context = default_context())
     key = (Int(d), Int(mp), length(par), bsrc * "\0" * sigsrc)
     id = get!(_user_ids, key) do
         r = Ref{Cint}(0)
@@ -119,7 +122,7 @@ mutable struct EnsemblePath{T} <: Bridge.AbstractPath{T}
     ctx::Context
 end
 Base.length(X::EnsemblePath) = length(X.tt)
-function EnsemblePath{T}(tt, dim, npaths, c::Context = ctx()) where {T}
+function EnsemblePath{T}(tt, dim, npaths, c::Context = default_context()) where {T}
     r = Ref{Ptr{Cvoid}}(C_NULL)
     check(c, ccall((:bhip_malloc, lib), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), c.h, 8 * length(tt) * dim * npaths, r))
     X = EnsemblePath{T}(collect(Float64, tt), Ptr{Cdouble}(r[]), dim, npaths, c)
@@ -157,27 +160,27 @@ function _proposal(tt, P, Pt, c::Context)
     check(c, ccall((:bhip_proposal_set_aux_callback, lib), Cint,
         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cdouble}),
         r[], cb, pointer_from_objref(keep), Pt isa Bridge.LinPro ? 1 : 0, Pt isa Bridge.LinPro ? collect(Pt.μ) : C_NULL))
-    mp = P isa Bridge.LinPro ? d : size(Bridge.σ(ttv[1], zero(Bridge.valtype(P)), P), 2)
-    Po = HIPProposal{Bridge.valtype(P)}(r[], ttv, d, mp, c, keep)
+    mp = P isa Bridge.LinPro ? d : size(Bridge.σ(ttv[1], zero(valtype(P)), P), 2)
+    Po = HIPProposal{valtype(P)}(r[], ttv, d, mp, c, keep)
     finalizer(p -> ccall((:bhip_proposal_destroy, lib), Cvoid, (Ptr{Cvoid},), p.h), Po)
 end
 
 "GuidedBridge(tt, P, Pt, v, h♢)  src/guip.jl:172-180"
-function HIPGuidedBridge(tt, P, Pt, v, h = nothing; ctx = ctx())
+function HIPGuidedBridge(tt, P, Pt, v, h = nothing; ctx = default_context())
     Po = _proposal(tt, P, Pt, ctx)
     check(ctx, ccall((:bhip_proposal_guide_hv, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}),
         Po.h, collect(Float64, v), h === nothing ? C_NULL : vec(collect(Float64, h))))
     Po
 end
 "PartialBridge(tt, P, Pt, L, v, Σ)  src/partialbridge.jl:42-50"
-function HIPPartialBridge(tt, P, Pt, L, v, Σ = nothing; ctx = ctx())
+function HIPPartialBridge(tt, P, Pt, L, v, Σ = nothing; ctx = default_context())
     Po = _proposal(tt, P, Pt, ctx)
     check(ctx, ccall((:bhip_proposal_guide_lmmu, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
         Po.h, size(L, 1), vec(collect(Float64, L)), collect(Float64, v), Σ === nothing ? C_NULL : vec(collect(Float64, Σ))))
     Po
 end
 "PartialBridgeνH(tt, P, Pt, L, v, ϵ, Σ)  src/partialbridgenuH.jl:134-145  (inplace=true: PartialBridge!)"
-function HIPPartialBridgeνH(tt, P, Pt, L, v, ϵ, Σ = nothing; inplace = false, ctx = ctx())
+function HIPPartialBridgeνH(tt, P, Pt, L, v, ϵ, Σ = nothing; inplace = false, ctx = default_context())
     Po = _proposal(tt, P, Pt, ctx)
     check(ctx, ccall((:bhip_proposal_guide_nuh, lib), Cint,
         (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Cint),
@@ -185,7 +188,7 @@ function HIPPartialBridgeνH(tt, P, Pt, L, v, ϵ, Σ = nothing; inplace = false,
     Po
 end
 "wrap guide arrays computed by Bridge.jl's own constructors (bhip_proposal_guide_arrays)"
-function HIPProposal(Po::Bridge.PartialBridge; ctx = ctx())
+function HIPProposal(Po::Bridge.PartialBridge; ctx = default_context())
     Q = _proposal(Po.tt, Po.Target, Po.Pt, ctx)
     m = length(Po.v)
     check(ctx, ccall((:bhip_proposal_guide_arrays, lib), Cint,
@@ -204,7 +207,7 @@ end
 struct HIPEuler <: Bridge.SDESolver end
 
 "sample(tt, Wiener{T}(), HIPEnsemble(n)): n Wiener paths in HBM  (src/wiener.jl:11-15)"
-function sample(tt, P::Wiener{T}, E::HIPEnsemble; ctx = ctx()) where {T}
+function sample(tt, P::Wiener{T}, E::HIPEnsemble; ctx = default_context()) where {T}
     W = EnsemblePath{T}(tt, length(zero(T)), E.npaths, ctx)
     sample!(W, P; seed = E.seed, iter = E.iter, path0 = E.path0)
 end
