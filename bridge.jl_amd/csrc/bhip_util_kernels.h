@@ -291,13 +291,18 @@ static __global__ void k_seg_accept(long n, long ld, int m, int d, const double 
 
 // accepted chains: Xc <- Xo;  then (optionally) mcnext! of every chain with its current path:
 //   delta = x - m; m += delta/(n+1); m2 += outer(delta, x - m)        src/mclog.jl:48-56
+// (all m segments in ONE launch: blockIdx.z = segment, the per-segment arrays come from a device table
+//  tab[0..m) = Xo, tab[m..2m) = Xc, tab[2m..3m) = mean, tab[3m..4m) = m2)
 template <int D>
-__global__ void k_seg_commit(long n, long ld, int N, const double *__restrict__ Xo, double *__restrict__ Xc, const unsigned char *__restrict__ accflag,
-                             double *__restrict__ mean, double *__restrict__ m2, double count)
+__global__ void k_seg_commit(long n, long ld, int N, int m, double *const *__restrict__ tab, const unsigned char *__restrict__ accflag, int want_stats, double count)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
+    const int i = blockIdx.y, sg = blockIdx.z;
     if (p >= n) return;
+    const double *__restrict__ Xo = tab[sg];
+    double *__restrict__ Xc = tab[m + sg];
+    double *__restrict__ mean = want_stats ? tab[2 * m + sg] : nullptr;
+    double *__restrict__ m2 = want_stats ? tab[3 * m + sg] : nullptr;
     double x[D];
     const bool a = accflag[p] != 0;
 #pragma unroll
