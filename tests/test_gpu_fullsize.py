@@ -408,3 +408,62 @@ def test_smoothing_loop_reaches_the_exact_linear_gaussian_smoothing_law(ctx):
     assert np.abs(X0.mean(0) - mean).max() > 10 * err.max() or np.abs(X0.var(0) / np.diag(cov) - 1).max() > 0.3
     acc = sc.state()[1]
     assert 0.1 < acc.mean() / iters < 0.95
+
+
+def test_device_built_guides_of_a_linear_target_sample_the_exact_smoothing_law(ctx):
+    """The device guide kernel end to end, distribution level.  Same linear-Gaussian smoothing problem as
+    above; the segments start with a deliberately wrong LinearAppr (B_i = -0.3, b_i = 0.06: the drift of a different linear
+    process), so phase A needs the Metropolis-Hastings correction.  bhip_segchains_adapt_device then re-linearises every chain
+    around its own running mean: bderiv of a LinPro is its B, so every chain's guide becomes the target's own
+    (linearisation exact, log-likelihood ratio 0): phase B accepts every proposal and must STILL sample the closed-form law --
+    which checks the chain-wise backward ODE, the gpupdate chain and pi0 = N(v, Hd) (mean and Cholesky factor) as built on
+    the device, not just their agreement with the oracle."""
+    beta, a = 0.8, 0.7
+    m, M, n = 3, 400, 32768
+    tgrid = np.linspace(0.0, 1.5, m * M + 1)
+    knots = tgrid[::M]
+    y = np.array([0.9, 0.2, -0.4, 0.5])
+    Sig, piH = 0.05, 1e3
+    P = bh.LinPro([[-beta]], [0.0], [[math.sqrt(a)]])
+    L, S = np.array([[1.0]]), np.array([[Sig]])
+    HT, vT = bh.gpupdate(np.array([[piH]]), np.zeros(1), L, S, y[m:m + 1])
+    H, v, segs = HT, vT, [None] * m
+    for i in range(m - 1, -1, -1):
+        N1 = M + 1
+        wrong = bh.LinearAppr(np.zeros((N1, 1)), np.full((N1, 1, 1), -0.3), np.full((N1, 1), 0.06), np.full((N1, 1, 1), math.sqrt(a)))
+        segs[i] = bh.GuidedBridge(tgrid[i * M:(i + 1) * M + 1].copy(), P, wrong, v, H, ctx=ctx)
+        H, v = bh.gpupdate(segs[i], L, S, y[i:i + 1])
+    Lam, eta = np.zeros((m + 1, m + 1)), np.zeros(m + 1)
+    for k in range(m + 1):
+        Lam[k, k] += 1 / Sig; eta[k] += y[k] / Sig
+    Lam[m, m] += 1 / piH
+    for k in range(m):
+        dl = knots[k + 1] - knots[k]
+        phi, q = math.exp(-beta * dl), a * (1 - math.exp(-2 * beta * dl)) / (2 * beta)
+        Lam[k, k] += phi * phi / q; Lam[k + 1, k + 1] += 1 / q
+        Lam[k, k + 1] -= phi / q; Lam[k + 1, k] -= phi / q
+    cov = np.linalg.inv(Lam)
+    mean = cov @ eta
+    se = np.sqrt(np.diag(cov) / n)
+    sc = bh.SegChains(segs, v, np.sqrt(H), n, seed=29, mcnext=True)
+
+    def knot_values():
+        return np.stack([sc.paths(i, 0, n)[0][:, 0, 0] for i in range(m)] + [sc.paths(m - 1, 0, n)[0][:, -1, 0]], 1)
+
+    def check(X):
+        assert (np.abs(X.mean(0) - mean) < 6 * se + 5e-3).all(), (X.mean(0), mean)
+        assert (np.abs(X.var(0) / np.diag(cov) - 1) < 0.035).all(), (X.var(0), np.diag(cov))
+    w_new = math.sqrt(0.5)
+    w_old = math.sqrt(1 - w_new ** 2)
+    sc.step(w_old, w_new, 300)                       # phase A: wrong auxiliary, MH corrects
+    accA = sc.state()[1].copy()
+    assert 0.1 < accA.mean() / 300 < 0.95
+    check(knot_values())
+    sc.adapt_device(L, S, y[:m].reshape(m, 1), HT, vT, newblock=True, doaccept=True)
+    g = sc.chain_guide(0, 123)
+    assert np.array_equal(g["B"], np.full((M, 1, 1), -beta))                           # linearappr of a LinPro: B_i = B
+    assert abs(g["mu"][0] - mean[0]) < 2e-3 and abs(g["chol"][0, 0] ** 2 / cov[0, 0] - 1) < 5e-3     # pi0 = the exact law of X(0)
+    sc.step(w_old, w_new, 60)                        # phase B: exact guides
+    ll, accB, _ = sc.state()
+    assert np.array_equal(accB - accA, np.full(n, 60)) and np.abs(ll).max() < 1e-9
+    check(knot_values())
