@@ -310,13 +310,13 @@ def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
     ms_pc = t(lambda: sc.step(wo, wn, 1), reps)
     ok = bool(np.isfinite(sc.state()[0]).all())
     b_sh = 96 + 24 + 48 + 192      # W slots r+w (m' = 3), Xo store, commit Xo -> Xc, mcnext! state r+w
-    b_pc = b_sh + 200              # + the chain's 25 coefficient doubles per step
+    b_pc = b_sh + 120              # + the chain's compact guide row per step: Hd (9), V (3), linearisation point (3)
     return {"workload": f"Lorenz smoothing: {m} GuidedBridge(LinearAppr) segments x {M} steps, {n} chains, joint MH + pCN start + mcnext! per iteration",
             "path_steps_per_iteration": ps, "finite": ok,
             "iteration_shared_guides": {"ms": ms_sh, "path_steps_per_s": ps / ms_sh * 1e3, "algorithmic_bytes_per_path_step": b_sh,
                                         "hbm_frac": ps * b_sh / ms_sh / 1e6 / HBM_PEAK_GBS},
             "adapt_device": {"ms": ms_ad, "guide_segments_per_s": n * m / ms_ad * 1e3,
-                             "algorithmic_bytes": n * m * (M + 1) * 224, "hbm_frac": n * m * (M + 1) * 224 / ms_ad / 1e6 / HBM_PEAK_GBS},
+                             "algorithmic_bytes": n * m * (M + 1) * 144, "hbm_frac": n * m * (M + 1) * 144 / ms_ad / 1e6 / HBM_PEAK_GBS},
             "iteration_per_chain_guides": {"ms": ms_pc, "path_steps_per_s": ps / ms_pc * 1e3, "algorithmic_bytes_per_path_step": b_pc,
                                            "hbm_frac": ps * b_pc / ms_pc / 1e6 / HBM_PEAK_GBS}}
 

@@ -146,6 +146,7 @@ struct bhip_chains {
     // per-chain coefficient rows / endpoint rule (owned by bhip_segchains after bhip_segchains_adapt_device), else null
     const double *prows = nullptr, *vend_pc = nullptr;
     const unsigned char *uv_pc = nullptr;
+    int lna = 0;                  // the per-chain rows carry LinearNoiseAppr slopes instead of linearisation points
 };
 
 static int fail(bhip_ctx *ctx, int code, const std::string &msg)
@@ -1307,7 +1308,7 @@ static int launch_ppr(bhip_chains *ch, int noise, KArgs &a)
 {
     bhip_ctx *ctx = ch->ctx;
     const bhip_proposal *po = ch->po;
-    a.prows = ch->prows; a.ldr = ch->ld; a.vend_pc = ch->vend_pc; a.uv_pc = ch->uv_pc;
+    a.prows = ch->prows; a.ldr = ch->ld; a.vend_pc = ch->vend_pc; a.uv_pc = ch->uv_pc; a.lna = ch->lna;
     const int fl = (noise == NOISE_PCN || noise == NOISE_PCN_LINES) ? (a.Xo ? 1 : 0) : 0;
     launch_fn f = find_launch_ppr(po->mh, noise, fl);
     if (!f) return fail(ctx, BHIP_EUNSUPPORTED, "no per-chain-guide kernel for this model");

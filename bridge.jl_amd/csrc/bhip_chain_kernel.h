@@ -90,10 +90,17 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
         double wc[MP];
 #pragma unroll
         for (int cc = 0; cc < MP; cc++) wc[cc] = mine[s * MP + cc];
-        if constexpr (PPR)
-            path_step<M, GK, MO, NOISE_PCN, FL, PerPathRow>(model, a, PerPathRow{rows + (size_t)i * RL::RS, a.prows + (size_t)i * (RL::LEN - 3) * a.ldr + p, a.ldr},
-                                                            i, nll, path, wc, nullptr, 0, xout, ldx, st);
-        else
+        if constexpr (PPR) {
+            constexpr int NPP = pp_row_len<D>();
+            double cr[NPP];
+            const double *src = a.prows + (size_t)i * NPP * a.ldr + p;
+#pragma unroll
+            for (int q = 0; q < NPP; q++) cr[q] = src[(size_t)q * a.ldr];
+            ExpRow<RL::LEN - 3> x;
+            x.sh = rows + (size_t)i * RL::RS;
+            expand_pp_row<M>(model, a.lna, cr, x.e);
+            path_step<M, GK, MO, NOISE_PCN, FL, ExpRow<RL::LEN - 3>>(model, a, x, i, nll, path, wc, nullptr, 0, xout, ldx, st);
+        } else
             path_step<M, GK, MO, NOISE_PCN, FL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wc, nullptr, 0, xout, ldx, st);
 #pragma unroll
         for (int cc = 0; cc < MP; cc++) mine[s * MP + cc] = st.wprev[cc];

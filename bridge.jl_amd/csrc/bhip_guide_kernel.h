@@ -13,86 +13,14 @@
 // PER CHAIN -- the case where the host cannot keep up.  Here a lane owns a chain and walks a segment's grid backwards with
 // (K, V) in registers; per grid point it evaluates the linearisation, does the two Heun steps and writes the chain's
 // coefficient row in the layout the path kernels read (RowLayout minus the three shared time entries), SoA over chains:
-//     prow[(i*PRL + q)*ld + p],   q: B~_i (d*d), beta~_i = b_i - B_i xx_i (d), guide part of pack_rows (cofactors, det, V)
+//     prow[(i*PRL + q)*ld + p],   q: Hd_i (d*d), V_i (d), xx_i (d) -- compact: the path kernels derive B~_i = bderiv(xx_i),
+//     beta~_i = b(xx_i) - B~_i xx_i, the cofactors and the determinant on the fly (bhip_smallmat.h: expand_pp_row)
 // The operations and their order are those of bhip_host.hpp (Mat products accumulate left to right, StaticArrays closed
 // forms for inv/det), so a chain's rows are bit-identical to what the host would compute for that chain's means.
 #pragma once
-#include "bhip_path_kernel.h"
+#include "bhip_path_kernel.h"   // (brings bhip_smallmat.h)
 
 namespace bhip {
-
-// ---- small static matrices, column-major; the operation order of bhip_host.hpp's Mat operators
-template <int R, int K, int C>
-BHIP_DEV void sm_mul(const double *A, const double *B, double *O)   // O(RxC) = A(RxK) * B(KxC)
-{
-#pragma unroll
-    for (int j = 0; j < C; j++)
-#pragma unroll
-        for (int i = 0; i < R; i++) {
-            double s = A[i] * B[K * j];
-#pragma unroll
-            for (int l = 1; l < K; l++) s += A[i + R * l] * B[l + K * j];
-            O[i + R * j] = s;
-        }
-}
-template <int R, int K, int C>
-BHIP_DEV void sm_mul_t(const double *A, const double *B, double *O)   // O(RxC) = A(RxK) * B'(KxC), B stored CxK
-{
-#pragma unroll
-    for (int j = 0; j < C; j++)
-#pragma unroll
-        for (int i = 0; i < R; i++) {
-            double s = A[i] * B[j];
-#pragma unroll
-            for (int l = 1; l < K; l++) s += A[i + R * l] * B[j + C * l];
-            O[i + R * j] = s;
-        }
-}
-template <int N>
-BHIP_DEV double sm_det(const double *a)   // StaticArrays det.jl
-{
-    if constexpr (N == 1) return a[0];
-    else if constexpr (N == 2) return a[0] * a[3] - a[2] * a[1];
-    else {
-        const double c0 = a[4] * a[8] - a[5] * a[7], c1 = a[5] * a[6] - a[3] * a[8], c2 = a[3] * a[7] - a[4] * a[6];
-        return a[0] * c0 + a[1] * c1 + a[2] * c2;
-    }
-}
-template <int N>
-BHIP_DEV void sm_inv(const double *a, double *R)   // StaticArrays inv.jl
-{
-    if constexpr (N == 1) R[0] = 1.0 / a[0];
-    else if constexpr (N == 2) {
-        const double d = sm_det<2>(a);
-        R[0] = a[3] / d; R[1] = -(a[1] / d); R[2] = -(a[2] / d); R[3] = a[0] / d;
-    } else {
-        double x0[3] = {a[0], a[1], a[2]};
-        const double x1[3] = {a[3], a[4], a[5]}, x2[3] = {a[6], a[7], a[8]};
-        double y0[3] = {x1[1] * x2[2] - x1[2] * x2[1], x1[2] * x2[0] - x1[0] * x2[2], x1[0] * x2[1] - x1[1] * x2[0]};
-        const double d = x0[0] * y0[0] + x0[1] * y0[1] + x0[2] * y0[2];
-#pragma unroll
-        for (int k = 0; k < 3; k++) { x0[k] = x0[k] / d; y0[k] = y0[k] / d; }
-        const double y1[3] = {x2[1] * x0[2] - x2[2] * x0[1], x2[2] * x0[0] - x2[0] * x0[2], x2[0] * x0[1] - x2[1] * x0[0]};
-        const double y2[3] = {x0[1] * x1[2] - x0[2] * x1[1], x0[2] * x1[0] - x0[0] * x1[2], x0[0] * x1[1] - x0[1] * x1[0]};
-        R[0] = y0[0]; R[1] = y1[0]; R[2] = y2[0]; R[3] = y0[1]; R[4] = y1[1]; R[5] = y2[1];
-        R[6] = y0[2]; R[7] = y1[2]; R[8] = y2[2];
-    }
-}
-
-// the guide part of a coefficient row for the (Hdiamond, V) guide: bhip_host.hpp pack_rows
-template <int D>
-BHIP_DEV void hv_row_part(const double *A, const double *V, double *q)
-{
-    if constexpr (D == 1) { q[0] = A[0]; q[1] = V[0]; }
-    else if constexpr (D == 2) { q[0] = A[0]; q[1] = A[1]; q[2] = A[2]; q[3] = A[3]; q[4] = sm_det<2>(A); q[5] = V[0]; q[6] = V[1]; }
-    else {
-        auto a = [&](int i, int j) { return A[(i - 1) + 3 * (j - 1)]; };
-        q[0] = a(2, 2) * a(3, 3) - a(2, 3) * a(3, 2); q[1] = a(1, 3) * a(3, 2) - a(1, 2) * a(3, 3); q[2] = a(1, 2) * a(2, 3) - a(1, 3) * a(2, 2);
-        q[3] = a(2, 3) * a(3, 1) - a(2, 1) * a(3, 3); q[4] = a(1, 1) * a(3, 3) - a(1, 3) * a(3, 1); q[5] = a(1, 3) * a(2, 1) - a(1, 1) * a(2, 3);
-        q[6] = a(2, 1) * a(3, 2) - a(2, 2) * a(3, 1); q[7] = a(1, 2) * a(3, 1) - a(1, 1) * a(3, 2); q[8] = a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1);
-        q[9] = sm_det<3>(A); q[10] = V[0]; q[11] = V[1]; q[12] = V[2];
-    }
-}
 
 // gpupdate(Hd, V, L, Sigma, v), finite branch  src/guip.jl:221-231 (bhip_host.hpp gpupdate).  Si = inv(Sigma) from the host.
 template <int D, int MO>
@@ -153,7 +81,6 @@ struct GArgs {
 };
 
 // per-chain rows: everything of RowLayout except (t, dt, sqrt(dt))
-template <int D> constexpr int pp_row_len() { return D * D + D + (D == 1 ? 2 : D == 2 ? 7 : 13); }
 
 template <class M, int MO>
 __global__ __launch_bounds__(64) void k_seg_guide(const GArgs g)
@@ -268,17 +195,13 @@ __global__ __launch_bounds__(64) void k_seg_guide(const GArgs g)
 #pragma unroll
             for (int k = 0; k < D; k++) w[k] = w[k] + (dt / 2) * (k1[k] + k2[k]);
         }
-        // the chain's coefficient row of step i
+        // the chain's COMPACT row of step i: Hd_i, V_i and the linearisation datum (xx_i, or the slope b_i of a LinearNoiseAppr);
+        // the path kernels expand it (expand_pp_row, bhip_smallmat.h) into B~_i, beta~_i, cofactors, det
         double row[PRL];
 #pragma unroll
-        for (int k = 0; k < DD; k++) row[k] = B0[k];
-        {
-            double Bx[D];
-            sm_mul<D, D, 1>(B0, x0, Bx);
+        for (int k = 0; k < DD; k++) row[k] = K[k];
 #pragma unroll
-            for (int k = 0; k < D; k++) row[DD + k] = b0[k] - Bx[k];   // beta((i,s), P) = P.b[i] - P.B[i]*P.xx[i]   src/linpro.jl:189
-        }
-        hv_row_part<D>(K, w, row + DD + D);
+        for (int k = 0; k < D; k++) { row[DD + k] = w[k]; row[DD + D + k] = g.lna ? b0[k] : x0[k]; }
         double *o = g.prow + (size_t)i * PRL * g.ld + p;
 #pragma unroll
         for (int q = 0; q < PRL; q++) o[(size_t)q * g.ld] = row[q];

@@ -20,6 +20,7 @@
 #pragma once
 #include "bhip_models.h"
 #include "bhip_rng.h"
+#include "bhip_smallmat.h"
 
 namespace bhip {
 
@@ -79,6 +80,7 @@ struct KArgs {
     // chain p's row of step i (the three time entries stay in the shared rows); per-chain endpoint rule
     const double *prows;
     long ldr;
+    int lna;                      // the per-chain rows carry LinearNoiseAppr data (slope) instead of the linearisation point
     const double *vend_pc;        // [D][ldr]
     const unsigned char *uv_pc;   // [ldr]
 };
@@ -92,12 +94,17 @@ struct PerPathRow {
     long ld;
     BHIP_DEV double operator[](int q) const { return q < 3 ? sh[q] : pp[(size_t)(q - 3) * ld]; }
 };
-// the same row with the chain's entries already in registers (fetched one step ahead by k_paths)
+// the chain's COMPACT entries (Hd, V, linearisation datum) in registers, fetched one step ahead by k_paths ...
 template <int NPP>
 struct RegRow {
-    cptr_t sh;
     double v[NPP];
-    BHIP_DEV double operator[](int q) const { return q < 3 ? sh[q] : v[q - 3]; }
+};
+// ... and the row the step reads, expanded from them (expand_pp_row)
+template <int NE>
+struct ExpRow {
+    cptr_t sh;
+    double e[NE];
+    BHIP_DEV double operator[](int q) const { return q < 3 ? sh[q] : e[q - 3]; }
 };
 typedef double d2v __attribute__((ext_vector_type(2)));   // one 16-byte chain slot
 
@@ -434,8 +441,8 @@ __global__ __launch_bounds__(256, PPR ? 2 : BHIP_WPE) void k_paths(const KArgs a
     const cptr_t rows = (cptr_t)(uintptr_t)a.rows;
     // per-chain rows: the chain's RL::LEN - 3 entries of step i+1 are fetched while step i is computed (two register
     // rows in rotation; the loop is unrolled by two) -- per-lane loads, unlike the shared rows' scalar loads
-    constexpr int NPP = PPR ? RL::LEN - 3 : 1;
-    using RowT = typename bhip_cond<PPR, RegRow<NPP>, cptr_t>::type;
+    constexpr int NPP = PPR ? pp_row_len<D>() : 1, NE = PPR ? RL::LEN - 3 : 1;
+    using RowT = typename bhip_cond<PPR, ExpRow<NE>, cptr_t>::type;
     RegRow<NPP> rr[2];
     auto fetch_row = [&](int i, RegRow<NPP> &r) {
         if constexpr (PPR) {
@@ -445,8 +452,12 @@ __global__ __launch_bounds__(256, PPR ? 2 : BHIP_WPE) void k_paths(const KArgs a
         }
     };
     auto rowat = [&](int i) {
-        if constexpr (PPR) { rr[i & 1].sh = rows + (size_t)i * RL::RS; return rr[i & 1]; }
-        else return rows + (size_t)i * RL::RS;
+        if constexpr (PPR) {
+            ExpRow<NE> x;
+            x.sh = rows + (size_t)i * RL::RS;
+            expand_pp_row<M>(model, a.lna, rr[i & 1].v, x.e);
+            return x;
+        } else return rows + (size_t)i * RL::RS;
     };
     fetch_row(0, rr[0]);
 

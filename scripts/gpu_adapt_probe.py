@@ -76,10 +76,10 @@ t_pc = timeit(lambda: sc.step(wo, wn, 1), 10)
 ll, acc, _ = sc.state()
 assert np.isfinite(ll).all()
 b_sh = (2 * 16 * 3 + 24 + 24 + 24) * ps          # W slots r+w (16 B x m' = 3 each way), Xo store, commit: Xo read + Xc write (accepted) -- upper figure
-b_pc = b_sh + 25 * 8 * ps
-b_ad = (24 + 25 * 8) * n * m * N
+b_pc = b_sh + 15 * 8 * ps
+b_ad = (24 + 15 * 8) * n * m * N
 print(f"Lorenz smoothing, m = {m} segments x {M} steps, {n} chains ({ps / 1e6:.1f} M path-steps per iteration)")
 print(f"step, shared guides     : {t_sh[0]:8.3f} ms (min {t_sh[1]:.3f})   {ps / t_sh[0] / 1e6:8.2f} G path-steps/s")
-print(f"adapt_device (per chain): {t_ad[0]:8.3f} ms (min {t_ad[1]:.3f})   {n * m / t_ad[0] / 1e3:8.2f} M guides/s, {b_ad / t_ad[0] / 1e6:7.1f} GB/s (reads 24 B + writes 200 B per chain and grid point)")
-print(f"step, per-chain guides  : {t_pc[0]:8.3f} ms (min {t_pc[1]:.3f})   {ps / t_pc[0] / 1e6:8.2f} G path-steps/s, + 200 B of coefficient rows per path-step: >= {25 * 8 * ps / t_pc[0] / 1e6:7.1f} GB/s")
+print(f"adapt_device (per chain): {t_ad[0]:8.3f} ms (min {t_ad[1]:.3f})   {n * m / t_ad[0] / 1e3:8.2f} M guides/s, {b_ad / t_ad[0] / 1e6:7.1f} GB/s (reads 24 B + writes 120 B per chain and grid point)")
+print(f"step, per-chain guides  : {t_pc[0]:8.3f} ms (min {t_pc[1]:.3f})   {ps / t_pc[0] / 1e6:8.2f} G path-steps/s, + 120 B of compact guide rows per path-step: >= {15 * 8 * ps / t_pc[0] / 1e6:7.1f} GB/s")
 print(f"host: ONE chain's {m} guides (linearappr + Heun + gpupdate, upload): {t_host * 1e3:.2f} ms  -> {n} chains would take {t_host * n:.1f} s on one core")
