@@ -133,7 +133,7 @@ struct bhip_chains {
     uint32_t iter = 0;
     bool inited = false;
     std::vector<double> x0;   // shared starting point (d doubles)
-    bool lines = false;     // noise dimension 1 or 2, d <= 3: W in the line layout of bhip_chain_kernel.h, else 16-byte slots
+    bool lines = false;     // d <= 3 (noise dimension <= 3): W in the line layout of bhip_chain_kernel.h, else 16-byte slots
     int nch = 0;            // lines per chain and parity half = ceil(N / 16)
     double *Wc = nullptr;   // W slots [N][mp][ld][2]  |  lines [2][nch][ld][16]
     double *Xo = nullptr;   // proposal paths [N][d][ld] (BHIP_CHAINS_STORE_X)
@@ -970,7 +970,7 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         // full 160 KB of dynamic LDS on gfx950 without an opt-in: probed, 48 ... 160 KB)
         int npair = 0, knoise = noise;
         const long groups = (a.P + 63) / 64;
-        if (ctx->wave_specialised && a.rdtp && (po->mh.mp == 1 || po->mh.mp == 2) && a.wstride == 1) {
+        if (ctx->wave_specialised && a.rdtp && po->mh.mp <= 3 && a.wstride == 1) {
             if (noise == NOISE_FRESH && a.P <= PC_FRESH_MAX_PATHS) knoise = NOISE_FRESH_PC;
             else if (noise == NOISE_PCN_LINES) knoise = NOISE_PCN_LINES_PC;
             if (knoise != noise) npair = groups <= PC_MAX_GROUPS_2PAIR ? 2 : groups <= PC_MAX_GROUPS_4PAIR ? 4 : 1;
@@ -991,7 +991,7 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         KArgs args = a;
         void *params[] = {&args};
         if (npair > 0) {
-            const int spc = LINE_DOUBLES / po->mh.mp;
+            const int spc = LINE_DOUBLES / line_mpp(po->mh.mp);
             const unsigned lds = npair == 1 ? (unsigned)PC_LDS : (unsigned)(sizeof(double) * (RNG_TAB_DOUBLES + npair * (2 * PC_TILE + 2 * spc * a.rs)));
             HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)((groups + npair - 1) / npair), 1, 1, 128 * npair, 1, 1, lds, ctx->stream, params, nullptr));
             return BHIP_OK;
@@ -1002,7 +1002,7 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         return BHIP_OK;
     }
     launch_fn f = nullptr;
-    if (ctx->wave_specialised && a.rdtp && (po->mh.mp == 1 || po->mh.mp == 2) && a.wstride == 1) {
+    if (ctx->wave_specialised && a.rdtp && po->mh.mp <= 3 && a.wstride == 1) {
         // producer/consumer waves (bhip_pc_kernel.h): same results, the kernel of choice wherever it is instantiated
         // Fresh proposals: with 4 waves per SIMD the one-lane-does-everything kernel already issues at ~85 % of the VALU
         // rate and the hand-over only costs; the split pays below that (profiles/r2_small_configs.txt).
@@ -1202,8 +1202,8 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     ctx_retain(ctx);
     ch->path0 = path0; ch->seed = seed; ch->flags = flags;
     const size_t N = po->tt.size();
-    ch->lines = po->mh.d <= 3 && (po->mh.mp == 1 || po->mh.mp == 2);
-    const size_t spc = LINE_DOUBLES / (ch->lines ? po->mh.mp : 1);   // grid points per line
+    ch->lines = po->mh.d <= 3 && po->mh.mp <= 3;
+    const size_t spc = LINE_DOUBLES / (ch->lines ? line_mpp(po->mh.mp) : 1);   // grid points per line (m' = 3: padded to 4 components)
     ch->nch = (int)((N + spc - 1) / spc);
     if (ch->nch > 65535) {   // the layout-conversion kernels index the chunks with gridDim.y: very long grids stay on the slots
         ch->lines = false;
@@ -1310,7 +1310,8 @@ static int launch_ppr(bhip_chains *ch, int noise, KArgs &a)
     const bhip_proposal *po = ch->po;
     a.prows = ch->prows; a.ldr = ch->ld; a.vend_pc = ch->vend_pc; a.uv_pc = ch->uv_pc; a.lna = ch->lna;
     const int fl = (noise == NOISE_PCN || noise == NOISE_PCN_LINES) ? (a.Xo ? 1 : 0) : 0;
-    launch_fn f = find_launch_ppr(po->mh, noise, fl);
+    // (bit 1 of the selector: the monolithic line kernel instead of the wave-specialised one)
+    launch_fn f = find_launch_ppr(po->mh, noise, fl | ((noise == NOISE_PCN_LINES && !(ctx->wave_specialised && a.rdtp)) ? 2 : 0));
     if (!f) return fail(ctx, BHIP_EUNSUPPORTED, "no per-chain-guide kernel for this model");
     HIPCHK(ctx, f(a, ctx->stream));
     return BHIP_OK;

@@ -23,6 +23,10 @@
 namespace bhip {
 
 constexpr int LINE_DOUBLES = 16;              // one 128-byte line
+// components per grid point INSIDE a line: m' itself when it divides 16, else padded (m' = 3 -> 4: a line holds 4 grid points,
+// the fourth slot of each is never read; 64 instead of 48 bytes of W per path-step each way -- still less than the 96 of the
+// 16-byte slots, and the layout the wave-specialised kernels need)
+constexpr int line_mpp(int mp) { return mp == 3 ? 4 : mp; }
 constexpr int LINE_ROW = LINE_DOUBLES + 1;    // padded LDS row: lane L reads column s of row L without bank conflicts
 
 BHIP_DEV size_t line_index(int h, int k, long chain, int nch, long ld)
@@ -41,8 +45,9 @@ template <class M, int GK, int MO, int FL, bool PPR = false /* per-chain coeffic
 __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(const KArgs a)
 {
     constexpr int D = M::D, MP = M::MP;
-    static_assert(MP == 1 || MP == 2, "a line holds 16/m' grid points: m' must divide 16 (and the tile budget allows 1 and 2)");
-    constexpr int SPC = LINE_DOUBLES / MP;   // grid points (steps) per chunk
+    static_assert(MP >= 1 && MP <= 3, "a line holds 16/m' grid points (m' = 3 padded to 4)");
+    constexpr int MPP = line_mpp(MP);
+    constexpr int SPC = LINE_DOUBLES / MPP;  // grid points (steps) per chunk
     using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
     extern __shared__ __attribute__((aligned(16))) double lds_tiles[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
     auto step = [&](int i, int s) {
         double wc[MP];
 #pragma unroll
-        for (int cc = 0; cc < MP; cc++) wc[cc] = mine[s * MP + cc];
+        for (int cc = 0; cc < MP; cc++) wc[cc] = mine[s * MPP + cc];
         if constexpr (PPR) {
             constexpr int NPP = pp_row_len<D>();
             double cr[NPP];
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
         } else
             path_step<M, GK, MO, NOISE_PCN, FL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wc, nullptr, 0, xout, ldx, st);
 #pragma unroll
-        for (int cc = 0; cc < MP; cc++) mine[s * MP + cc] = st.wprev[cc];
+        for (int cc = 0; cc < MP; cc++) mine[s * MPP + cc] = st.wprev[cc];
     };
 
     for (int k = 0; k < nch; k++) {
@@ -190,17 +195,18 @@ hipError_t launch_chain_lines(const KArgs &a, hipStream_t st)
 // SoA side is accessed 64 chains (512 bytes) at a time and the line side a whole line (8 lanes x 16 bytes) at a time.
 //   k_soa_to_lines: plain SoA W [N][m'][ldW] -> half 0 of the line layout (chain initialisation)
 //   k_lines_to_soa: the CURRENT halves of chains p0..p0+np -> plain SoA [N][m'][np]
-// (the SoA row index v = j*m' + c is also the position in the chain's sequence of line values: v = 16k + s)
+// (line position sl of line k <-> grid point j = (16/mpp)*k + sl/mpp, component c = sl%mpp, mpp = line_mpp(m'); SoA row j*m' + c)
 static __global__ __launch_bounds__(256) void k_soa_to_lines(const double *__restrict__ W, long ldW, int N, int mp, int nch, double *__restrict__ Wl, long ld, long P)
 {
     __shared__ double tile[64 * LINE_ROW];
     const int k = blockIdx.y, t = threadIdx.x;
     const long c0 = (long)blockIdx.x * 64;
+    const int mpp = line_mpp(mp), spc = LINE_DOUBLES / mpp;
 #pragma unroll
     for (int rep = 0; rep < 4; rep++) {   // line position sl = 4*rep + t/64 <-> SoA row (grid point, component), chain c0 + t%64
-        const int sl = 4 * rep + (t >> 6), v = k * LINE_DOUBLES + sl;   // v = j*mp + c
+        const int sl = 4 * rep + (t >> 6), j = k * spc + sl / mpp, c = sl % mpp;
         const long p = c0 + (t & 63);
-        tile[(t & 63) * LINE_ROW + sl] = (p < P && v < N * mp) ? W[(size_t)v * ldW + p] : 0.0;
+        tile[(t & 63) * LINE_ROW + sl] = (p < P && c < mp && j < N) ? W[((size_t)j * mp + c) * ldW + p] : 0.0;
     }
     __syncthreads();
 #pragma unroll
@@ -226,11 +232,12 @@ static __global__ __launch_bounds__(256) void k_lines_to_soa(const double *__res
         }
     }
     __syncthreads();
+    const int mpp = line_mpp(mp), spc = LINE_DOUBLES / mpp;
 #pragma unroll
     for (int rep = 0; rep < 4; rep++) {
-        const int sl = 4 * rep + (t >> 6), v = k * LINE_DOUBLES + sl;
+        const int sl = 4 * rep + (t >> 6), j = k * spc + sl / mpp, c = sl % mpp;
         const long q = q0 + (t & 63);
-        if (q < np && v < N * mp) W[(size_t)v * np + q] = tile[(t & 63) * LINE_ROW + sl];
+        if (q < np && c < mp && j < N) W[((size_t)j * mp + c) * np + q] = tile[(t & 63) * LINE_ROW + sl];
     }
 }
 

@@ -625,7 +625,7 @@ typedef hipError_t (*launch_fn)(const KArgs &, hipStream_t);
 
 template <class M, int GK, int MO, int FL, bool PPR = false>
 hipError_t launch_chain_lines(const KArgs &a, hipStream_t st);   // bhip_chain_kernel.h
-template <class M, int GK, int MO, int MODE, int FL>
+template <class M, int GK, int MO, int MODE, int FL, bool PPR = false>
 hipError_t launch_pc(const KArgs &a, hipStream_t st);            // bhip_pc_kernel.h
 
 template <class M, int GK, int MO, int NOISE, int FL, bool PPR = false>
@@ -645,8 +645,11 @@ launch_fn get_launch_ppr(int noise, int fl)
     switch (noise) {
     case NOISE_PCN: return (fl & 1) ? launch_paths<M, BHIP_GUIDE_HV, 1, NOISE_PCN, 1, true> : launch_paths<M, BHIP_GUIDE_HV, 1, NOISE_PCN, 0, true>;
     case NOISE_PCN_LINES:
-        if constexpr (M::MP == 1 || M::MP == 2)
-            return (fl & 1) ? launch_chain_lines<M, BHIP_GUIDE_HV, 1, 1, true> : launch_chain_lines<M, BHIP_GUIDE_HV, 1, 0, true>;
+        // wave-specialised kernel with per-chain rows in the consumer (rows fetched one step ahead); k_chain_lines<.., PPR> is its
+        // one-lane-does-everything twin (A/B, BHIP_OPT_WAVE_SPECIALISED = 0)
+        if constexpr (M::MP <= 3)
+            return (fl & 2) ? ((fl & 1) ? launch_chain_lines<M, BHIP_GUIDE_HV, 1, 1, true> : launch_chain_lines<M, BHIP_GUIDE_HV, 1, 0, true>)
+                            : ((fl & 1) ? launch_pc<M, BHIP_GUIDE_HV, 1, 7, 1, true> : launch_pc<M, BHIP_GUIDE_HV, 1, 7, 0, true>);
         return nullptr;
     case NOISE_LLONLY: return launch_paths<M, BHIP_GUIDE_HV, 1, NOISE_LLONLY, 0, true>;
     }
@@ -672,10 +675,10 @@ launch_fn get_launch_gk(int noise, int fl)
         if constexpr (GK != BHIP_GUIDE_NONE) return (fl & 1) ? launch_paths<M, GK, MO, NOISE_PCN, 1 | T> : launch_paths<M, GK, MO, NOISE_PCN, 0 | T>;
         return nullptr;
     case NOISE_PCN_LINES:
-        if constexpr (GK != BHIP_GUIDE_NONE && (M::MP == 1 || M::MP == 2)) return (fl & 1) ? launch_chain_lines<M, GK, MO, 1 | T> : launch_chain_lines<M, GK, MO, 0 | T>;
+        if constexpr (GK != BHIP_GUIDE_NONE && M::MP <= 3) return (fl & 1) ? launch_chain_lines<M, GK, MO, 1 | T> : launch_chain_lines<M, GK, MO, 0 | T>;
         return nullptr;
     case 6 /* NOISE_FRESH_PC */:
-        if constexpr (M::MP == 1 || M::MP == 2) {
+        if constexpr (M::MP <= 3) {
             switch (fl & 3) {
             case 0: return launch_pc<M, GK, MO, 6, 0 | T>;
             case 1: return launch_pc<M, GK, MO, 6, 1 | T>;
@@ -685,7 +688,7 @@ launch_fn get_launch_gk(int noise, int fl)
         }
         return nullptr;
     case 7 /* NOISE_PCN_LINES_PC */:
-        if constexpr (GK != BHIP_GUIDE_NONE && (M::MP == 1 || M::MP == 2)) return (fl & 1) ? launch_pc<M, GK, MO, 7, 1 | T> : launch_pc<M, GK, MO, 7, 0 | T>;
+        if constexpr (GK != BHIP_GUIDE_NONE && M::MP <= 3) return (fl & 1) ? launch_pc<M, GK, MO, 7, 1 | T> : launch_pc<M, GK, MO, 7, 0 | T>;
         return nullptr;
     case NOISE_LLONLY:
         if constexpr (GK != BHIP_GUIDE_NONE) return launch_paths<M, GK, MO, NOISE_LLONLY, 0 | T>;

@@ -48,14 +48,17 @@ typedef const __attribute__((address_space(3))) double *ldsrow_t;
 // the Wiener increment INTO grid point j, so that a chunk reads 16/m' consecutive, aligned values and grid point 0
 // (W[0] = 0 + 0*z = 0) needs no special case.
 
-template <class M, int GK, int MO, int MODE, int FL, int NPAIR>
-__global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(const KArgs a)
+template <class M, int GK, int MO, int MODE, int FL, int NPAIR, bool PPR = false /* per-chain guide rows (bhip_guide_kernel.h) */>
+__global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void k_pc(const KArgs a)
 {
     constexpr int D = M::D, MP = M::MP;
-    static_assert(MP == 1 || MP == 2, "a chunk holds 16/m' grid points");
+    static_assert(MP >= 1 && MP <= 3, "a chunk holds 16/m' grid points (m' = 3: lines padded to 4 components)");
     static_assert(MODE == NOISE_FRESH_PC || MODE == NOISE_PCN_LINES_PC, "producer/consumer kernel: fresh proposals or pCN on the line layout");
     constexpr bool PCN = MODE == NOISE_PCN_LINES_PC;
-    constexpr int SPC = LINE_DOUBLES / MP;   // grid points per chunk
+    constexpr int MPP = line_mpp(MP);        // components per grid point inside a line / tile row
+    constexpr int SPC = LINE_DOUBLES / MPP;  // grid points per chunk
+    constexpr int NB = SPC * MP / 2;         // Philox blocks per chunk: 8, 8, 6
+    constexpr bool CARRY = (MP & 1) != 0;    // odd m': a chunk's first normal is the second of a block drawn with the previous chunk
     using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
     // Workgroup = NPAIR producer/consumer pairs.  Small ensembles run 2 or 4 pairs per workgroup (and then RLDS): a
     // workgroup's waves are dealt to the four SIMDs of its CU in turn, so 4 waves sit on 4 different SIMDs and the 8 waves
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(cons
         double wprev[MP], w2prev[MP];
 #pragma unroll
         for (int c = 0; c < MP; c++) { wprev[c] = 0.0; w2prev[c] = 0.0; }
-        double carry = 0.0;   // m' = 1: second normal of the block that straddles the chunk boundary
+        double carry = 0.0;   // m' = 1, 3: second normal of the block that straddles the chunk boundary
         // cooperative line moves (pCN): instruction q moves the lines of chains c0 + 8q + lane/8; lane%8 selects 16 bytes
         const int sub = lane >> 3, part = 2 * (lane & 7);
         int par[8];
@@ -148,9 +151,12 @@ __global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(cons
                     __builtin_amdgcn_wave_barrier();
                     if (k + 1 < nch) fetch(k + 1);   // in flight while this chunk is mixed
                 }
-                // value v = s*MP + c of the chunk (grid point j = SPC*k + s, component c) takes normal n = (j-1)*MP + c:
+                // value v = s*MP + c of the chunk (grid point j = SPC*k + s, component c; tile position s*MPP + c) takes normal
+                // n = (j-1)*MP + c:
                 //   m' = 1: v = 2q   <- second normal of block 8k+q-1 (the carry), v = 2q+1 <- first normal of block 8k+q
                 //   m' = 2: v = 2q, 2q+1 <- both normals of block 8k+q-1   (k = 0, q = 0: block "-1", multiplied by rdtp[0] = 0)
+                //   m' = 3: 12 values, first normal n = 12k-3 (odd): as m' = 1 with blocks 6k-1+q, q = 0..5 (k = 0: values 0..2 are
+                //           grid point 0, multiplied by rdtp[0] = 0)
                 // RLDS (a producer that is alone on its SIMD): the chunk's 16/m' scales in one scalar load up front and the
                 // eight blocks fully unrolled -- otherwise every value waits for its own scalar load
                 double rd[SPC];
@@ -159,25 +165,25 @@ __global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(cons
                     for (int s = 0; s < SPC; s++) rd[s] = rdtp[(size_t)k * SPC + s];
                 }
                 auto value = [&](int v, double zz) {
-                    const int s = v / MP, c = v % MP, j = k * SPC + s;
+                    const int s = v / MP, c = v % MP, j = k * SPC + s, pos = s * MPP + c;
                     double rdt;
                     if constexpr (RLDS) rdt = rd[s];
                     else rdt = rdtp[j];                                           // wave-uniform: scalar load
                     if constexpr (!PCN) {
                         const double wn = wprev[c] + rdt * zz;                 // yy[i] = yy[i-1] + rootdt*randn   src/wiener.jl:55
                         wprev[c] = wn;
-                        mine[v] = wn;
+                        mine[pos] = wn;
                         if constexpr ((FL & 2) != 0) {
                             if (j < N) st_stream(&wout[((size_t)j * MP + c) * ldwo], wn);
                         }
                     } else {
-                        const double wc = mine[v];
+                        const double wc = mine[pos];
                         const double w2 = w2prev[c] + rdt * zz;
                         w2prev[c] = w2;
-                        mine[v] = a.rho * wc + a.srho * w2;                      // Wo = rho*W + sqrt(1-rho^2)*W2
+                        mine[pos] = a.rho * wc + a.srho * w2;                    // Wo = rho*W + sqrt(1-rho^2)*W2
                     }
                 };
-                const uint32_t b0 = (uint32_t)(8 * k) - (MP == 2 ? 1u : 0u);
+                const uint32_t b0 = MP == 1 ? (uint32_t)(8 * k) : MP == 2 ? (uint32_t)(8 * k) - 1u : (uint32_t)(6 * k) - 1u;
                 auto block = [&](int q) {
                     double z0, z1;
 #ifdef PC_KNOCKOUT_NOISE   /* measurement only: what the consumer alone costs */
@@ -185,15 +191,15 @@ __global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(cons
 #else
                     normal_pair(rtab, a.k0, a.k1, path, a.iter, b0 + q + a.blk0, z0, z1);
 #endif
-                    if constexpr (MP == 1) { value(2 * q, carry); value(2 * q + 1, z0); carry = z1; }
+                    if constexpr (CARRY) { value(2 * q, carry); value(2 * q + 1, z0); carry = z1; }
                     else { value(2 * q, z0); value(2 * q + 1, z1); }
                 };
                 if constexpr (RLDS) {
 #pragma unroll
-                    for (int q = 0; q < 8; q++) block(q);
+                    for (int q = 0; q < NB; q++) block(q);
                 } else {
 #pragma unroll PC_BLOCK_UNROLL
-                    for (int q = 0; q < 8; q++) block(q);
+                    for (int q = 0; q < NB; q++) block(q);
                 }
                 if constexpr (PCN) {
                     __builtin_amdgcn_wave_barrier();
@@ -226,6 +232,28 @@ __global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(cons
         else { xout = a.X; ldx = a.ldX; }
     }
     constexpr int CFL = FL & ~2;   // the W store belongs to the producer
+    // per-chain guides: the chain's compact row (Hd, V, linearisation datum) of step i+1 is fetched while step i is computed
+    // and expanded into the row entries right before its step (expand_pp_row); the three time entries stay shared
+    constexpr int NPP = PPR ? pp_row_len<D>() : 1, NE = PPR ? RL::LEN - 3 : 1;
+    RegRow<NPP> rcur, rnxt;
+    auto fetch_row = [&](int i, RegRow<NPP> &r) {
+        if constexpr (PPR) {
+            const double *src = a.prows + (size_t)min(i, N - 2) * NPP * a.ldr + p;
+#pragma unroll
+            for (int q = 0; q < NPP; q++) r.v[q] = src[(size_t)q * a.ldr];
+        }
+    };
+    auto ppr_step = [&](int i, const double *wn) {
+        if constexpr (PPR) {
+            ExpRow<NE> x;
+            x.sh = rows + (size_t)i * RL::RS;
+            expand_pp_row<M>(model, a.lna, rcur.v, x.e);
+            fetch_row(i + 1, rnxt);
+            path_step<M, GK, MO, NOISE_EXT, CFL, ExpRow<NE>>(model, a, x, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p);
+            rcur = rnxt;
+        }
+    };
+    fetch_row(0, rcur);
     for (int k = 0; k <= nch; k++) {
         if (k > 0) {
             const int kc = k - 1;
@@ -238,12 +266,13 @@ __global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(cons
                 for (int s = 0; s < SPC; s++) {
                     double wn[MP];
 #pragma unroll
-                    for (int c = 0; c < MP; c++) wn[c] = mine[s * MP + c];
+                    for (int c = 0; c < MP; c++) wn[c] = mine[s * MPP + c];
                     const int i = j0 + s - 1;
 #ifdef PC_KNOCKOUT_STEP   /* measurement only: what the producer alone costs */
                     st.ll += wn[0];
 #else
-                    if constexpr (RLDS) path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, lrows + s * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p);
+                    if constexpr (PPR) ppr_step(i, wn);
+                    else if constexpr (RLDS) path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, lrows + s * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p);
                     else path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p);
 #endif
                 }
@@ -255,8 +284,9 @@ __global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(cons
                     if (i < 0 || i >= nsteps) continue;
                     double wn[MP];
 #pragma unroll
-                    for (int c = 0; c < MP; c++) wn[c] = mine[s * MP + c];
-                    if constexpr (RLDS) path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, lrows + s * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p);
+                    for (int c = 0; c < MP; c++) wn[c] = mine[s * MPP + c];
+                    if constexpr (PPR) ppr_step(i, wn);
+                    else if constexpr (RLDS) path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, lrows + s * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p);
                     else path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p);
                 }
             }
@@ -264,7 +294,12 @@ __global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(cons
         __syncthreads();
     }
 
-    if (a.use_vend) {   // endpoint(y, P::GuidedBridge) src/euler.jl:241-242
+    if constexpr (PPR) {
+        if (a.uv_pc[p]) {
+#pragma unroll
+            for (int k = 0; k < D; k++) st.y[k] = a.vend_pc[(size_t)k * a.ldr + p];
+        }
+    } else if (a.use_vend) {   // endpoint(y, P::GuidedBridge) src/euler.jl:241-242
 #pragma unroll
         for (int k = 0; k < D; k++) st.y[k] = a.vend[k];
     }
@@ -301,22 +336,22 @@ __global__ __launch_bounds__(128 * NPAIR, NPAIR > 1 ? 2 : PC_WPE) void k_pc(cons
 #ifndef PC_MAX_GROUPS_4PAIR
 #define PC_MAX_GROUPS_4PAIR 1024
 #endif
-template <class M, int GK, int MO, int MODE, int FL, int NPAIR>
+template <class M, int GK, int MO, int MODE, int FL, int NPAIR, bool PPR = false>
 void launch_pc_n(const KArgs &a, hipStream_t st, long groups)
 {
     using RL = RowLayout<GK, M::D, MO, is_constdiff<M>::value>;
-    const size_t lds = NPAIR == 1 ? PC_LDS : sizeof(double) * (RNG_TAB_DOUBLES + NPAIR * (2 * PC_TILE + 2 * (LINE_DOUBLES / M::MP) * RL::RS));
+    const size_t lds = NPAIR == 1 ? PC_LDS : sizeof(double) * (RNG_TAB_DOUBLES + NPAIR * (2 * PC_TILE + 2 * (LINE_DOUBLES / line_mpp(M::MP)) * RL::RS));
     // more than the default 64 KB of dynamic LDS: opt in -- per device and cheap, so on every launch (a process may drive several devices)
-    if (lds > 65536) (void)hipFuncSetAttribute((const void *)k_pc<M, GK, MO, MODE, FL, NPAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_pc<M, GK, MO, MODE, FL, NPAIR>), dim3((unsigned)((groups + NPAIR - 1) / NPAIR)), dim3(128 * NPAIR), lds, st, a);
+    if (lds > 65536) (void)hipFuncSetAttribute((const void *)k_pc<M, GK, MO, MODE, FL, NPAIR, PPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_pc<M, GK, MO, MODE, FL, NPAIR, PPR>), dim3((unsigned)((groups + NPAIR - 1) / NPAIR)), dim3(128 * NPAIR), lds, st, a);
 }
-template <class M, int GK, int MO, int MODE, int FL>
+template <class M, int GK, int MO, int MODE, int FL, bool PPR>
 hipError_t launch_pc(const KArgs &a, hipStream_t st)
 {
     const long groups = (a.P + 63) / 64;
-    if (groups <= PC_MAX_GROUPS_2PAIR) launch_pc_n<M, GK, MO, MODE, FL, 2>(a, st, groups);
-    else if (groups <= PC_MAX_GROUPS_4PAIR) launch_pc_n<M, GK, MO, MODE, FL, 4>(a, st, groups);
-    else launch_pc_n<M, GK, MO, MODE, FL, 1>(a, st, groups);
+    if (groups <= PC_MAX_GROUPS_2PAIR) launch_pc_n<M, GK, MO, MODE, FL, 2, PPR>(a, st, groups);
+    else if (groups <= PC_MAX_GROUPS_4PAIR) launch_pc_n<M, GK, MO, MODE, FL, 4, PPR>(a, st, groups);
+    else launch_pc_n<M, GK, MO, MODE, FL, 1, PPR>(a, st, groups);
     return hipGetLastError();
 }
 
