@@ -182,23 +182,23 @@ def pc_pairs(P):
 MODES = {
     "mcmc": (build_proposal, 2, 1, X0, 262144, True, RHO,
              FHN_WORKLOAD + "pCN-MCMC rho=0.9: one step = one MH iteration of every chain",
-             lambda P: f"k_pc<bhip::MFHN, 2, 1, 7, 1, {pc_pairs(P)}>"),
+             lambda P: f"k_pc<bhip::MFHN, 2, 1, 7, 1, {pc_pairs(P)}, false>"),
     "c4shard": (build_proposal, 2, 1, X0, 32768, True, RHO,
                 FHN_WORKLOAD + "pCN-MCMC rho=0.9, SURVEY-C4 shard size (32 768 chains per GPU)",
-                lambda P: f"k_pc<bhip::MFHN, 2, 1, 7, 1, {pc_pairs(P)}>"),
+                lambda P: f"k_pc<bhip::MFHN, 2, 1, 7, 1, {pc_pairs(P)}, false>"),
     "proposals": (build_proposal, 2, 1, X0, 262144, False, None,
                   FHN_WORKLOAD + "independent fused proposals (sample!+solve!+llikelihood)",
-                  lambda P: (f"k_pc<bhip::MFHN, 2, 1, 6, 1, {pc_pairs(P)}>" if P <= 98304 else "k_paths<bhip::MFHN, 2, 1, 1, 1, false>")),
+                  lambda P: (f"k_pc<bhip::MFHN, 2, 1, 6, 1, {pc_pairs(P)}, false>" if P <= 98304 else "k_paths<bhip::MFHN, 2, 1, 1, 1, false>")),
     "c2": (_ou, 1, 1, (0.5,), 65536, False, None,
            "C2: 1-d OU target LinPro(-0.8,0,sqrt(.7)), GuidedBridge with auxiliary LinPro(-0.8,0.2,sqrt(.7)), 1001-point tau-grid T=2, "
            "independent fused proposals",
-           lambda P: (f"k_pc<bhip::MLinPro<1>, 1, 1, 6, 1, {pc_pairs(P)}>" if P <= 98304 else "k_paths<bhip::MLinPro<1>, 1, 1, 1, 1, false>")),
+           lambda P: (f"k_pc<bhip::MLinPro<1>, 1, 1, 6, 1, {pc_pairs(P)}, false>" if P <= 98304 else "k_paths<bhip::MLinPro<1>, 1, 1, 1, 1, false>")),
     "nclar": (_nclar, 3, 1, (0.0, 0.0, 0.0), 262144, False, None,
               "NCLAR 3-d PartialBridge (scalar noise, L=[1 0 0], v=5/128), 1001-point tau-grid T=0.5, independent fused proposals",
-              lambda P: (f"k_pc<bhip::MNCLAR, 2, 1, 6, 1, {pc_pairs(P)}>" if P <= 98304 else "k_paths<bhip::MNCLAR, 2, 1, 1, 1, false>")),
+              lambda P: (f"k_pc<bhip::MNCLAR, 2, 1, 6, 1, {pc_pairs(P)}, false>" if P <= 98304 else "k_paths<bhip::MNCLAR, 2, 1, 1, 1, false>")),
     "nclar_mcmc": (_nclar, 3, 1, (0.0, 0.0, 0.0), 262144, True, 0.95,
                    "NCLAR 3-d PartialBridge (scalar noise, L=[1 0 0], v=5/128), 1001-point tau-grid T=0.5, pCN-MCMC rho=0.95",
-                   lambda P: f"k_pc<bhip::MNCLAR, 2, 1, 7, 1, {pc_pairs(P)}>"),
+                   lambda P: f"k_pc<bhip::MNCLAR, 2, 1, 7, 1, {pc_pairs(P)}, false>"),
     "linpro32": (_linpro32, 32, 32, tuple([0.0] * 32), 65536, False, None,
                  "LinPro d=32 GuidedBridge (dense sigma, pre-inverted Hdiamond), 1001-point grid T=1, independent fused proposals",
                  lambda P: "k_tile<32, 1, false, bhip::NoUserDrift>"),
