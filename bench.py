@@ -309,7 +309,7 @@ def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
     ms_ad = t(lambda: sc.adapt_device(L, Sig, obs[:m], HT, vT), max(2, reps // 2))
     ms_pc = t(lambda: sc.step(wo, wn, 1), reps)
     ok = bool(np.isfinite(sc.state()[0]).all())
-    b_sh = 96 + 24 + 48 + 192      # W slots r+w (m' = 3), Xo store, commit Xo -> Xc, mcnext! state r+w
+    b_sh = 64 + 24 + 48 + 192      # W lines r+w (m' = 3 padded to 4: 32 + 32), Xo store, commit Xo -> Xc, mcnext! state r+w
     b_pc = b_sh + 120              # + the chain's compact guide row per step: Hd (9), V (3), linearisation point (3)
     return {"workload": f"Lorenz smoothing: {m} GuidedBridge(LinearAppr) segments x {M} steps, {n} chains, joint MH + pCN start + mcnext! per iteration",
             "path_steps_per_iteration": ps, "finite": ok,

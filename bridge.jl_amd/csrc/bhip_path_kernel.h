@@ -25,7 +25,7 @@
 namespace bhip {
 
 enum { NOISE_EXT = 0, NOISE_FRESH = 1, NOISE_PCN = 2, NOISE_LLONLY = 3, NOISE_INNOV = 4,
-       NOISE_PCN_LINES = 5 /* pCN step on the line layout, k_chain_lines in bhip_chain_kernel.h (m' = 1, 2) */ };
+       NOISE_PCN_LINES = 5 /* pCN step on the line layout, k_chain_lines in bhip_chain_kernel.h (m' <= 3) */ };
 
 template <bool C, class A, class B> struct bhip_cond { typedef A type; };   // (no <type_traits> under hipRTC)
 template <class A, class B> struct bhip_cond<false, A, B> { typedef B type; };

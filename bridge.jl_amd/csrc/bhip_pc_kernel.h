@@ -1,4 +1,4 @@
-// bhip_pc_kernel.h -- the fused path kernel with wave specialisation (d <= 3, noise dimension m' = 1 or 2).
+// bhip_pc_kernel.h -- the fused path kernel with wave specialisation (d <= 3, noise dimension m' <= 3).
 //
 // Same arithmetic as k_paths<.., NOISE_FRESH, ..> / k_chain_lines (it calls the same path_step), different division of
 // labour.  In those kernels one lane does everything for its path: the Philox / Box-Muller normal (state-independent,

@@ -240,7 +240,7 @@ int bhip_gpupdate(int d, int m, const double *Hd, const double *V, const double 
 /* ------------------------------------------------------------------ pCN Metropolis-Hastings ensemble
  * One chain per lane.  partialbridge_fitzhugh.jl:125-176, test/partialbridgenuH.jl:155-198
  * Chain state = (W, ll, parity): the current W and the proposal Wo live in the two parity halves of the
- * chain's storage (128-byte lines per half and 16-step chunk for scalar noise, 16-byte slots otherwise; DESIGN.md
+ * chain's storage (128-byte lines per half and chunk of 16/m' grid points -- m' = 3 padded to 4 components --, 16-byte slots only for very long grids; DESIGN.md
  * section 2) and an accept flips the chain's parity bit -- the reference's `W, Wo = Wo, W` swap
  * (test/partialbridgenuH.jl:186-187) without its copies.  With BHIP_CHAINS_STORE_X the proposal path
  * Xo (solve!(Euler(), Xo, x0, Wo, Po)) of the last iteration of every bhip_chains_step call is kept in
