@@ -3,7 +3,7 @@
 The producer wave draws the Wiener noise / does the pCN mix and the chain-state traffic, the consumer wave runs the
 Euler recurrence + log-likelihood of src/euler.jl:247-268, src/partialbridge.jl:67-77.  They must give, bit for bit,
 what the one-lane-does-everything kernels give (which the parity tests compare with the oracle): same Wiener paths,
-paths, log-likelihoods, accept decisions -- for every test problem with noise dimension 1 or 2, ragged ensemble sizes
+paths, log-likelihoods, accept decisions -- for every test problem with noise dimension 1, 2 or 3, ragged ensemble sizes
 (tails of the 64-path workgroup), grids that are not multiples of the 16-value chunk, with and without the stores.
 The default context runs the wave-specialised kernels, so the oracle parity tests of test_gpu_parity.py already go
 through them; here both variants are run side by side through the C ABI option BHIP_OPT_WAVE_SPECIALISED.
@@ -35,7 +35,7 @@ def both(ctx, fn):
     return out
 
 
-CASES = [c for c in problems.cases(143) + problems.forward_cases(143) if c.mp in (1, 2)]
+CASES = [c for c in problems.cases(143) + problems.forward_cases(143) if c.mp in (1, 2, 3)]   # m' = 3: lines padded to 4 components
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
@@ -70,11 +70,11 @@ def test_pcn_chains_equal_monolithic(ctx, case):
     assert 0 < a[3].sum() < 6 * 150
 
 
-@pytest.mark.parametrize("N", [2, 3, 16, 17, 18, 33, 129])
+@pytest.mark.parametrize("N", [2, 3, 4, 5, 6, 9, 16, 17, 18, 33, 129])
 def test_short_and_ragged_grids(ctx, N):
-    """grids around the chunk size: 16 values per chunk = 16 grid points (m' = 1) / 8 (m' = 2)"""
+    """grids around the chunk size: 16 values per chunk = 16 grid points (m' = 1) / 8 (m' = 2) / 4 (m' = 3, padded lines)"""
     # (FitzHugh-Nagumo is stiff: on grids this coarse its Euler scheme overflows, so the d = 1 bridge stands in below 129 points)
-    for name in (("fhn_partialbridge_extreme" if N >= 129 else "ou_guidedbridge"), "linpro2_guidedbridge"):
+    for name in (("fhn_partialbridge_extreme" if N >= 129 else "ou_guidedbridge"), "linpro2_guidedbridge", "linpro3_guidedbridge", "linpro3_partial_m2"):
         case = [c for c in problems.cases(N) if c.name == name][0]
         Po = case.bh_proposal(bh, ctx)
 
