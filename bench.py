@@ -309,12 +309,21 @@ def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
     ms_ad = t(lambda: sc.adapt_device(L, Sig, obs[:m], HT, vT), max(2, reps // 2))
     ms_pc = t(lambda: sc.step(wo, wn, 1), reps)
     ok = bool(np.isfinite(sc.state()[0]).all())
+    del sc
+    torch.cuda.empty_cache()
+    sm = bh.SegChains(segs, v, bh.cholupper_t(H), n, seed=1, mcnext_mean_only=True)   # the economy option: running means only
+    ms_mo = t(lambda: sm.step(wo, wn, 1), reps)
+    del sm
+    torch.cuda.empty_cache()
     b_sh = 64 + 24 + 48 + 192      # W lines r+w (m' = 3 padded to 4: 32 + 32), Xo store, commit Xo -> Xc, mcnext! state r+w
     b_pc = b_sh + 120              # + the chain's compact guide row per step: Hd (9), V (3), linearisation point (3)
     return {"workload": f"Lorenz smoothing: {m} GuidedBridge(LinearAppr) segments x {M} steps, {n} chains, joint MH + pCN start + mcnext! per iteration",
             "path_steps_per_iteration": ps, "finite": ok,
             "iteration_shared_guides": {"ms": ms_sh, "path_steps_per_s": ps / ms_sh * 1e3, "algorithmic_bytes_per_path_step": b_sh,
                                         "hbm_frac": ps * b_sh / ms_sh / 1e6 / HBM_PEAK_GBS},
+            "iteration_shared_guides_means_only": {"ms": ms_mo, "path_steps_per_s": ps / ms_mo * 1e3, "algorithmic_bytes_per_path_step": b_sh - 144,
+                                                   "hbm_frac": ps * (b_sh - 144) / ms_mo / 1e6 / HBM_PEAK_GBS,
+                                                   "note": "BHIP_SEGCHAINS_MCNEXT_MEAN: the per-chain running means only (all the adaptation reads); mcnext! proper keeps the 3 x 3 second moments too"},
             "adapt_device": {"ms": ms_ad, "guide_segments_per_s": n * m / ms_ad * 1e3,
                              "algorithmic_bytes": n * m * (M + 1) * 144, "hbm_frac": n * m * (M + 1) * 144 / ms_ad / 1e6 / HBM_PEAK_GBS},
             "iteration_per_chain_guides": {"ms": ms_pc, "path_steps_per_s": ps / ms_pc * 1e3, "algorithmic_bytes_per_path_step": b_pc,

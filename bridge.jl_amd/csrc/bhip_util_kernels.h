@@ -302,7 +302,7 @@ __global__ void k_seg_commit(long n, long ld, int N, int m, double *const *__res
     const double *__restrict__ Xo = tab[sg];
     double *__restrict__ Xc = tab[m + sg];
     double *__restrict__ mean = want_stats ? tab[2 * m + sg] : nullptr;
-    double *__restrict__ m2 = want_stats ? tab[3 * m + sg] : nullptr;
+    double *__restrict__ m2 = want_stats ? tab[3 * m + sg] : nullptr;   // null: the means only (BHIP_SEGCHAINS_MCNEXT_MEAN)
     double x[D];
     const bool a = accflag[p] != 0;
 #pragma unroll
@@ -322,13 +322,15 @@ __global__ void k_seg_commit(long n, long ld, int N, int m, double *const *__res
             mean[e] = mn;
             xm[k] = x[k] - mn;
         }
+        if (m2) {
 #pragma unroll
-        for (int c = 0; c < D; c++)
+            for (int c = 0; c < D; c++)
 #pragma unroll
-            for (int r = 0; r < D; r++) {
-                const size_t e = ((size_t)i * D * D + r + D * c) * ld + p;
-                m2[e] = m2[e] + delta[r] * xm[c];
-            }
+                for (int r = 0; r < D; r++) {
+                    const size_t e = ((size_t)i * D * D + r + D * c) * ld + p;
+                    m2[e] = m2[e] + delta[r] * xm[c];
+                }
+        }
     }
 }
 

@@ -285,3 +285,28 @@ def test_linear_target_per_chain_guides_are_the_targets_own_guide():
     sc.step(0.8, 0.6, 10)
     ll, acc, _ = sc.state()
     assert np.array_equal(acc - acc0, np.full(n, 10)) and np.abs(ll).max() < 1e-9
+
+
+def test_mean_only_statistics_drive_the_same_adaptation():
+    """BHIP_SEGCHAINS_MCNEXT_MEAN keeps the running means only (the adaptation reads nothing else): the chains, the means and the
+    device-built guides are bit-identical to the full mcnext! run; asking for the second moments is an error"""
+    ctx = bh.default_context(0)
+    m, M, n = 2, 40, 96
+    S = lorenz_setup(ctx, m, M, np.eye(3), 0.25 * np.eye(3), seed=4)
+    chol = o.chol_lower(S["H0"])
+    a = bh.SegChains(S["segs"], S["mu"], chol, n, seed=2, mcnext=True)
+    b = bh.SegChains(S["segs"], S["mu"], chol, n, seed=2, mcnext_mean_only=True)
+    for sc in (a, b):
+        sc.step(0.9, math.sqrt(1 - 0.81), 4)
+        sc.adapt_device(S["L"], S["Sig"], S["obs"][:m], S["HT"], S["vT"], newblock=True, doaccept=True)
+        sc.step(0.9, math.sqrt(1 - 0.81), 3)
+    for u, v in zip(a.state(), b.state()):
+        assert np.array_equal(u, v)
+    ga, gb = a.chain_guide(1, 50), b.chain_guide(1, 50)
+    assert np.array_equal(ga["G"], gb["G"]) and np.array_equal(ga["B"], gb["B"])
+    ma = a.mcstats(0, 50)[0]
+    mean_b = np.empty((M + 1, 3)); cnt = bh.api.C.c_int64()
+    ctx.check(ctx.lib.bhip_segchains_mcstats(b.h, 0, 50, bh.api._dptr(mean_b), None, bh.api.C.byref(cnt)))
+    assert np.array_equal(ma, mean_b) and cnt.value == 7
+    with pytest.raises(bh.BridgeError, match="second moments"):
+        b.mcstats(0, 50)
