@@ -262,10 +262,18 @@ class Workload:
         return r
 
 
-def kernel_times(w, steps, warmup):
-    """HIP-event duration of every launch (events on the stream the kernels go to: torch's current stream)"""
+def kernel_times(w, steps, warmup, min_ms=0.0):
+    """HIP-event duration of every launch (events on the stream the kernels go to: torch's current stream).
+    min_ms: sample at least that long (short launches measured for a few ms right after another workload see the clock
+    state that workload left behind, not their own)"""
     for _ in range(warmup):
         w.step()
+    if min_ms > 0.0:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); w.step(); e1.record(); torch.cuda.synchronize()
+        steps = max(steps, min(4000, int(min_ms / max(e0.elapsed_time(e1), 1e-3))))
+        for _ in range(steps // 4):      # settle the clocks on THIS kernel before sampling
+            w.step()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     for k in range(steps):
         evs[k].record()
@@ -485,7 +493,7 @@ def main():
         torch.cuda.empty_cache()
         for mode in ("c4shard", "c2", "proposals", "nclar", "nclar_mcmc", "linpro32", "linpro32_mcmc"):
             wo = Workload(mode, ctx, 0, rank)
-            ms = kernel_times(wo, args.steps, args.warmup)
+            ms = kernel_times(wo, args.steps, args.warmup, min_ms=100.0)
             others.append({"mode": mode, "workload": wo.workload, "paths": wo.P,
                            "path_steps_per_s": wo.P * steps_per_unit / (float(np.mean(ms)) * 1e-3), "roofline": wo.roofline(ms)})
             del wo
