@@ -322,4 +322,59 @@ function mcmc(Po::HIPProposal, x0, iterations; ρ = 0.9, nchains = 1, seed = 0, 
     acc, ll, ch, stats
 end
 
+# ---------------------------------------------------------------- the smoothing loop (supplements/smoothing/smoothing.jl:99-213)
+"""
+    SegChains(Po::Vector{<:HIPProposal}, π0μ, π0C, nchains; seed, path0, skip, mcnext)
+
+`nchains` copies of the smoothing loop over the chained segments `Po` (GuidedBridge's linked backwards by `Bridge.gpupdate`,
+built by the caller as the script does): pCN move of the start drawn from `π0 = Gaussian(π0μ, π0C*π0C')`, every segment
+proposed with the end point of the previous one, ONE accept per iteration, `mcnext!` per chain (bhip_segchains_*).
+`step!(sc, w_old, w_new)`: iterations with the script's weights `sqrt(1 - ρ_)`, `sqrt(ρ_)` per iteration;
+`adapt!(sc, L, Σ, obs, H♢T, vT)`: the adaptation block (:130-160) for every chain at once on the device.
+"""
+mutable struct SegChains
+    h::Ptr{Cvoid}
+    ctx::Context
+    m::Int
+    n::Int
+    keep::Vector{HIPProposal}        # the proposals must outlive the ensemble
+    function SegChains(Po::Vector{<:HIPProposal}, μ, C, nchains::Integer; seed = 0, path0 = 0, skip = 0, mcnext = true)
+        c = Po[1].ctx
+        hs = Ptr{Cvoid}[P.h for P in Po]
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(c, ccall((:bhip_segchains_create, lib), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}, Clong, UInt32, UInt64, Cint, Ref{Ptr{Cvoid}}),
+            c.h, length(Po), hs, nchains, path0, seed, mcnext ? 1 : 0, r))
+        sc = new(r[], c, length(Po), nchains, collect(HIPProposal, Po))
+        finalizer(x -> ccall((:bhip_segchains_destroy, lib), Cvoid, (Ptr{Cvoid},), x.h), sc)
+        check(c, ccall((:bhip_segchains_init, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint),
+            sc.h, collect(Float64, μ), vec(collect(Float64, C)), skip))
+        sc
+    end
+end
+function step!(sc::SegChains, w_old::AbstractVector, w_new::AbstractVector)
+    check(sc.ctx, ccall((:bhip_segchains_step, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint),
+        sc.h, collect(Float64, w_old), collect(Float64, w_new), length(w_old)))
+    sc
+end
+"`obs[i]`: the observation at the LEFT end of segment i (V.yy[i]); `(H♢T, vT) = gpupdate(prior, V.yy[end])`"
+function adapt!(sc::SegChains, L, Σ, obs::AbstractVector, H♢T, vT; hwindow = 0, newblock = true, doaccept = false)
+    mo = size(L, 1)
+    o = Float64[]
+    for i in 1:sc.m
+        append!(o, collect(Float64, obs[i]))
+    end
+    check(sc.ctx, ccall((:bhip_segchains_adapt_device, lib), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint),
+        sc.h, mo, vec(collect(Float64, L)), vec(collect(Float64, Σ)), o, vec(collect(Float64, H♢T)), collect(Float64, vT),
+        hwindow, (newblock ? 1 : 0) | (doaccept ? 2 : 0)))
+    sc
+end
+"(ll [m x nchains], acc, y0 [d x nchains]) of the ensemble"
+function state(sc::SegChains, d::Integer)
+    ll = Matrix{Float64}(undef, sc.n, sc.m); acc = Vector{Int64}(undef, sc.n); y0 = Matrix{Float64}(undef, d, sc.n)
+    check(sc.ctx, ccall((:bhip_segchains_get, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Int64}, Ptr{Cdouble}), sc.h, ll, acc, y0))
+    permutedims(ll), acc, y0      # the library writes ll as [m][nchains] row-major = an nchains x m column-major matrix
+end
+
 end # module
