@@ -150,6 +150,31 @@ def profiled_traffic(mode, kernel_name):
                                                            f"profiles/{PROFILE_TAG}_{mode}_write.txt")
 
 
+def profiled_valu(mode, kernel_name, paths):
+    """Issue-side context for the roofline record, from this round's committed SQ counter summaries of the same command
+    (profiles/r2_<mode>_sq.txt, _sq2.txt; summed over the 8 XCDs): VALU wave-instructions per path-step (SQ_INSTS_VALU x 64 lanes /
+    path-steps) and the fraction of the kernel's duration the SIMDs' VALU was issuing (SQ_ACTIVE_INST_VALU, in units of 4 cycles,
+    / (1024 SIMDs x GRBM_GUI_ACTIVE/8/4)).  ~0.7-0.85 for the kernels whose generator is the bottleneck, which is why their
+    fraction of the HBM roofline is what it is.  None when a summary lacks the kernel (stale profile)."""
+    import re
+
+    def counter(kind, c):
+        fn = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{mode}_{kind}.txt")
+        if not os.path.exists(fn):
+            return None
+        for line in open(fn):
+            if kernel_name in line and c in line:
+                m = re.search(c + r"\s+\d+\s+([0-9.]+)", line)
+                if m:
+                    return float(m.group(1))
+        return None
+    iv, av, g = counter("sq", "SQ_INSTS_VALU"), counter("sq", "SQ_ACTIVE_INST_VALU"), counter("sq2", "GRBM_GUI_ACTIVE")
+    if not (iv and av and g):
+        return None
+    return {"insts_per_path_step": iv * 64 / (paths * (N_GRID - 1)), "busy_frac": av / (1024 * g / 32),
+            "source": f"profiles/{PROFILE_TAG}_{mode}_sq.txt, _sq2.txt (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE)"}
+
+
 def _linpro32(ctx):
     d = 32
     rng = np.random.default_rng(5)
@@ -259,6 +284,7 @@ class Workload:
         if tr is not None and self.P != MODES[self.mode][4]:
             tr, src = None, "profiled at the mode's default size only"
         r["traffic"], r["traffic_source"] = tr, src
+        r["valu"] = profiled_valu(self.mode, self.kernel, self.P) if self.P == MODES[self.mode][4] else None
         return r
 
 
