@@ -88,6 +88,8 @@ SIGNATURES = {
     "bhip_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bhip_comm_allgather": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "bhip_comm_allgather_stats": (C.c_int, [vp, vp, vp]),
+    "bhip_comm_init": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(vp)]),
+    "bhip_allgather_stats": (C.c_int, [vp, vp, vp]),
     "bhip_comm_allgather_group": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_size_t]),
     "bhip_comm_destroy": (None, [vp]),
     "bhip_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -1733,6 +1733,8 @@ int bhip_comm_allgather_stats(bhip_comm *comm, const double *stats_dev, double *
 {
     return bhip_comm_allgather(comm, stats_dev, all_dev, BHIP_STATS_LEN);
 }
+int bhip_comm_init(int ndev, bhip_ctx *const *ctxs, bhip_comm **comms_out) { return bhip_comm_init_all(ndev, ctxs, comms_out); }
+int bhip_allgather_stats(bhip_comm *comm, const double *stats_dev, double *all_dev) { return bhip_comm_allgather_stats(comm, stats_dev, all_dev); }
 
 int bhip_comm_allgather_group(int n, bhip_comm *const *comms, const double *const *send_dev, double *const *recv_dev, size_t count)
 {

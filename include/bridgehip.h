@@ -373,6 +373,10 @@ int bhip_comm_info(const bhip_comm *comm, int *nranks, int *rank);
 int bhip_comm_allgather(bhip_comm *comm, const double *send_dev, double *recv_dev, size_t count);
 /* = bhip_comm_allgather(comm, stats_dev, all_dev, BHIP_STATS_LEN): all_dev [nranks][BHIP_STATS_LEN] */
 int bhip_comm_allgather_stats(bhip_comm *comm, const double *stats_dev, double *all_dev);
+/* the two names SURVEY.md 8(b) proposed for this pair: bhip_comm_init = bhip_comm_init_all (single-process form, one
+ * context per device), bhip_allgather_stats = bhip_comm_allgather_stats */
+int bhip_comm_init(int ndev, bhip_ctx *const *ctxs, bhip_comm **comms_out);
+int bhip_allgather_stats(bhip_comm *comm, const double *stats_dev, double *all_dev);
 /* single-process form: the n per-device gathers inside one ncclGroupStart/End */
 int bhip_comm_allgather_group(int n, bhip_comm *const *comms, const double *const *send_dev, double *const *recv_dev, size_t count);
 void bhip_comm_destroy(bhip_comm *comm);
