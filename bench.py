@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """bench.py -- guided-bridge path-steps/s on MI355X (BASELINE.json metric), one process per GPU.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (no launcher: ONE process drives the N devices, bhip_comm_init_all)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             (one process per GPU, bhip_comm_init_rank)
 
 Workload (BASELINE.json configs[2]/[3]): FitzHugh-Nagumo partial bridge
 (project_partialbridge/partialbridge_fitzhugh.jl: eps=0.1, s=0, gamma=1.5, beta=0.8, sigma=0.3,
@@ -398,8 +398,9 @@ def box_calibration(device):
 
 
 def timed_region(w, steps, world, ctx, stats, comm=None):
-    """the contract's timed region: K steps bracketed by barrier + synchronize on both sides, MAX over ranks; ends with
-    the device-side statistics reduction and (N > 1) the ONE all-gather of the statistics block"""
+    """the contract's timed region (one process per GPU, launched by torch.distributed.run): K steps bracketed by barrier +
+    synchronize on both sides, MAX over ranks; ends with the device-side statistics reduction and the ONE all-gather of the
+    statistics block"""
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -427,81 +428,173 @@ def timed_region(w, steps, world, ctx, stats, comm=None):
     return elapsed, [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)], gathered
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--chains", type=int, default=0, help="chains (paths) per GPU; 0 = the mode's named size")
-    ap.add_argument("--mode", choices=sorted(MODES), default="mcmc")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-modes", action="store_true")
-    args = ap.parse_args()
+def timed_region_local(ws, steps, stats, group):
+    """the same region with ONE process driving len(ws) devices (no launcher): synchronize every device, issue the K steps
+    round-robin (launches are asynchronous: one host thread keeps all devices busy), the per-device statistics reductions and
+    the ONE grouped all-gather (bhip_comm_allgather_group), synchronize every device.  The wall clock around it is by
+    construction the max over the devices.  Returns (elapsed s, per-launch ms of every device, gathered blocks,
+    per-device ms for the K steps, ms of the gather on device 0)."""
+    devs = [w.ctx.device for w in ws]
+    streams = [torch.cuda.default_stream(d) for d in devs]
+    n = len(ws)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] for _ in range(n)]
+    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for d in devs:
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        for r in range(n):
+            evs[r][k].record(streams[r])
+            ws[r].step()
+    for r in range(n):
+        evs[r][steps].record(streams[r])
+        if ws[r].chains is not None:
+            ws[r].chains.stats(stats[r])
+        else:
+            with torch.cuda.device(devs[r]):
+                stats[r].zero_()
+    g0.record(streams[0])
+    gathered = group.allgather(stats) if group is not None else [stats[0].reshape(1, -1)]
+    g1.record(streams[0])
+    for d in devs:
+        torch.cuda.synchronize(d)
+    elapsed = time.perf_counter() - t0
+    kern = [[evs[r][k].elapsed_time(evs[r][k + 1]) for k in range(steps)] for r in range(n)]
+    return elapsed, kern, gathered[0], [evs[r][0].elapsed_time(evs[r][steps]) for r in range(n)], g0.elapsed_time(g1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def base_record(args, world, w, elapsed, kern_ms, launch):
+    steps_per_unit = N_GRID - 1
+    total_pathsteps = float(world) * w.P * steps_per_unit * args.steps
+    return {
+        "metric": "guided-bridge path-steps/sec (whole node)",
+        "value": total_pathsteps / elapsed,
+        "unit": "path-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": w.workload, "mode": args.mode, "paths_per_gpu": w.P, "grid_points": N_GRID,
+                   "path_steps_per_step": w.P * steps_per_unit * world,
+                   "parallelism": f"chains sharded over {world} GPU(s) by contiguous global id, no data-path collective, one RCCL all-gather "
+                                  "of the 64-byte statistics block inside libbridgehip.so",
+                   "launch": launch},
+        "roofline": w.roofline(kern_ms),
+    }
+
+
+def add_chain_summary(out, gathered):
+    summary = bdist.combine_stats(gathered)
+    out["config"]["acceptance_rate"] = summary["acceptance_rate"]
+    out["config"]["mean_ll"] = summary["mean_ll"]
+    out["config"]["chains_total"] = summary["chains"]
+
+
+def main_per_rank(args, world):
+    """one process per GPU under torch.distributed.run (the driver's N > 1 form)"""
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # BENCH_SINGLE_DEVICE=1 (testing the N > 1 code path on a one-GPU box): every rank uses GPU 0 and the collectives
     # go over gloo, because RCCL refuses two ranks on one device.  Never set by the driver.
     single = os.environ.get("BENCH_SINGLE_DEVICE") == "1"
     if single:
         local = 0
+    elif local >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} needs device {local} but only {torch.cuda.device_count()} device(s) are visible")
     torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if single:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if single:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     ctx = bh.Context(local)
     # the data-path collective lives in the product: an RCCL communicator over the ranks (torch.distributed only carries
     # the id handshake, the barriers and the max-over-ranks of the clock)
-    comm = bdist.Comm.from_torch_dist(ctx) if (world > 1 and not single) else None
+    comm = None if single else bdist.Comm.from_torch_dist(ctx)
     w = Workload(args.mode, ctx, args.chains, rank)
-    P = w.P
     steps_per_unit = N_GRID - 1
     stats = ctx.empty(bh.STATS_LEN)
 
     for _ in range(args.warmup):
         w.step()
-    if world > 1:   # untimed: the first collective of each kind sets up RCCL's channels over xGMI
-        stats.zero_()
-        bdist.allgather_stats(stats, world, comm)
+    stats.zero_()   # untimed: the first collective sets up RCCL's channels over xGMI
+    bdist.allgather_stats(stats, world, comm)
     elapsed, kern_ms, gathered = timed_region(w, args.steps, world, ctx, stats, comm)
 
     out = None
     if rank == 0:
-        total_pathsteps = float(world) * P * steps_per_unit * args.steps
-        out = {
-            "metric": "guided-bridge path-steps/sec (whole node)",
-            "value": total_pathsteps / elapsed,
-            "unit": "path-steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": w.workload, "mode": args.mode, "paths_per_gpu": P, "grid_points": N_GRID,
-                       "path_steps_per_step": P * steps_per_unit * world,
-                       "parallelism": f"chains sharded over {world} GPU(s), one RCCL all-gather of the statistics block "
-                                      "(bhip_comm_allgather_stats, inside libbridgehip.so)"},
-            "roofline": w.roofline(kern_ms),
-        }
+        out = base_record(args, world, w, elapsed, kern_ms, "one process per GPU (torch.distributed.run); bhip_comm_init_rank + bhip_comm_allgather_stats")
         if w.chains is not None:
-            summary = bdist.combine_stats(gathered)
-            out["config"]["acceptance_rate"] = summary["acceptance_rate"]
-            out["config"]["mean_ll"] = summary["mean_ll"]
-            out["config"]["chains_total"] = summary["chains"]
+            add_chain_summary(out, gathered)
+    if args.mode == "mcmc" and args.chains == 0:
+        # SURVEY 8(d) C4 quotes 32 768 chains per GPU: the same protocol at that shard size, next to the headline
+        del w
+        torch.cuda.empty_cache()
+        wc = Workload("c4shard", ctx, 0, rank)
+        for _ in range(args.warmup):
+            wc.step()
+        el_c, ms_c, _ = timed_region(wc, args.steps, world, ctx, stats, comm)
+        if rank == 0:
+            tp = float(world) * wc.P * steps_per_unit * args.steps
+            out["survey_c4"] = {"chains_per_gpu": wc.P, "value": tp / el_c, "unit": "path-steps/s", "ms_per_step": el_c / args.steps * 1e3,
+                                "scaling": "weak", "roofline": wc.roofline(ms_c)}
+    if rank == 0:
+        emit_json(out)
+    if comm is not None:
+        comm.destroy()
+    dist.destroy_process_group()
+
+
+def main_local(args):
+    """`python bench.py --gpus N` without a launcher: ONE process drives the N devices through one context each, the
+    communicator comes from bhip_comm_init_all and the gather is bhip_comm_allgather_group -- at N = 1 a world of one through
+    the very same calls, so the single-GPU line exercises the collective path too."""
+    n = args.gpus
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n < 1 or n > ndev:
+        print(f"bench.py: --gpus {n} but only {ndev} device(s) visible to this process", file=sys.stderr)
+        sys.exit(2)
+    ctxs = [bh.Context(k) for k in range(n)]
+    comm_note = None
+    try:
+        group = bdist.CommGroup(ctxs)
+    except Exception as e:
+        if n > 1:
+            raise          # no collective, no multi-GPU line
+        group, comm_note = None, f"RCCL communicator unavailable on this box ({e}); a world of one needs no exchange"
+        print("bench.py: " + comm_note, file=sys.stderr)
+    ws = [Workload(args.mode, ctxs[k], args.chains, k) for k in range(n)]
+    w = ws[0]
+    P = w.P
+    steps_per_unit = N_GRID - 1
+    stats = [c.empty(bh.STATS_LEN) for c in ctxs]
+    for _ in range(args.warmup):
+        for x in ws:
+            x.step()
+    if group is not None:   # untimed: the first collective sets up RCCL's channels
+        for k, c in enumerate(ctxs):
+            with torch.cuda.device(c.device):
+                stats[k].zero_()
+        group.allgather(stats)
+    elapsed, kern, gathered, per_gpu_ms, gather_ms = timed_region_local(ws, args.steps, stats, group)
+    kern_ms = kern[0] if n == 1 else [float(np.mean([kern[r][k] for r in range(n)])) for k in range(args.steps)]
+    out = base_record(args, n, w, elapsed, kern_ms,
+                      "one process, one context per device; bhip_comm_init_all + bhip_comm_allgather_group" + (f" [{comm_note}]" if comm_note else ""))
+    out["per_gpu_ms_per_step"] = [t / args.steps for t in per_gpu_ms]
+    out["allgather_ms"] = gather_ms
+    if w.chains is not None:
+        add_chain_summary(out, gathered)
+    ctx = ctxs[0]
     default_run = args.mode == "mcmc" and args.chains == 0
-    if world == 1 and default_run and not args.no_other_modes:
+    if n == 1 and default_run and not args.no_other_modes:
         # >= 1 s of back-to-back launches of the headline kernel (the timed region above is K = 20 launches = 30-40 ms)
         n_sus = max(50, int(1.2e3 / max(float(np.mean(kern_ms)), 1e-3)))
         torch.cuda.synchronize()
@@ -515,10 +608,10 @@ def main():
                             "hbm_frac": P * steps_per_unit * n_sus * w.bytes_per_pathstep / t_sus / 1e9 / HBM_PEAK_GBS}
         # kernel-level figures of the other named configurations (outside the timed region above)
         others = []
-        del w
+        del w, ws
         torch.cuda.empty_cache()
         for mode in ("c4shard", "c2", "proposals", "nclar", "nclar_mcmc", "linpro32", "linpro32_mcmc"):
-            wo = Workload(mode, ctx, 0, rank)
+            wo = Workload(mode, ctx, 0, 0)
             ms = kernel_times(wo, args.steps, args.warmup, min_ms=100.0)
             others.append({"mode": mode, "workload": wo.workload, "paths": wo.P,
                            "path_steps_per_s": wo.P * steps_per_unit / (float(np.mean(ms)) * 1e-3), "roofline": wo.roofline(ms)})
@@ -527,26 +620,70 @@ def main():
         out["other_modes"] = others
         out["smoothing"] = smoothing_record(ctx)
         out["box"] = box_calibration(ctx.device)
-    elif world > 1 and default_run:
+    elif n > 1 and default_run:
         # SURVEY 8(d) C4 quotes 32 768 chains per GPU: the same protocol at that shard size, next to the headline
-        del w
-        torch.cuda.empty_cache()
-        wc = Workload("c4shard", ctx, 0, rank)
+        del w, ws
+        for c in ctxs:
+            with torch.cuda.device(c.device):
+                torch.cuda.empty_cache()
+        wcs = [Workload("c4shard", ctxs[k], 0, k) for k in range(n)]
         for _ in range(args.warmup):
-            wc.step()
-        el_c, ms_c, _ = timed_region(wc, args.steps, world, ctx, stats, comm)
-        if rank == 0:
-            tp = float(world) * wc.P * steps_per_unit * args.steps
-            out["survey_c4"] = {"chains_per_gpu": wc.P, "value": tp / el_c, "unit": "path-steps/s", "ms_per_step": el_c / args.steps * 1e3,
-                                "scaling": "weak", "roofline": wc.roofline(ms_c)}
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
-    if comm is not None:
-        comm.destroy()
+            for x in wcs:
+                x.step()
+        el_c, kern_c, _, pg_c, _ = timed_region_local(wcs, args.steps, stats, group)
+        tp = float(n) * wcs[0].P * steps_per_unit * args.steps
+        out["survey_c4"] = {"chains_per_gpu": wcs[0].P, "value": tp / el_c, "unit": "path-steps/s", "ms_per_step": el_c / args.steps * 1e3,
+                            "scaling": "weak", "per_gpu_ms_per_step": [t / args.steps for t in pg_c],
+                            "roofline": wcs[0].roofline([float(np.mean([kern_c[r][k] for r in range(n)])) for k in range(args.steps)]),
+                            "note": "one host thread issues the launches of all devices: at 0.2 ms per launch and 8 devices the single-process "
+                                    "form is close to launch-bound; the launcher form (one process per GPU) is not"}
+        del wcs
+    if n == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    emit_json(out)
+    if group is not None:
+        group.destroy()
+
+
+_JSON_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries below us write there too (RCCL prints a version banner at the first
+    communicator, flushed from C buffers at exit): from here on file descriptor 1 points to stderr, and only emit_json() writes
+    to the real stdout."""
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit_json(out):
+    line = (json.dumps(out) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--chains", type=int, default=0, help="chains (paths) per GPU; 0 = the mode's named size")
+    ap.add_argument("--mode", choices=sorted(MODES), default="mcmc")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-modes", action="store_true")
+    args = ap.parse_args()
+    claim_stdout()
+    # started by a launcher (torch.distributed.run sets WORLD_SIZE / RANK / LOCAL_RANK): one process per GPU.
+    # started bare (`python bench.py --gpus N`): this process drives all N devices itself.
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
     if world > 1:
-        dist.destroy_process_group()
+        main_per_rank(args, world)
+    else:
+        main_local(args)
 
 
 if __name__ == "__main__":

@@ -12,8 +12,11 @@
 #include "bhip_rtc.hpp"
 #include "bhip_util_kernels.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
+#include <mutex>
 #include <new>
+#include <unordered_set>
 
 using namespace bhip;
 
@@ -88,6 +91,10 @@ struct bhip_ctx {
     // the last child releases it.  A closed context's stream is no longer synchronised (it was borrowed and may be gone).
     int refs = 0;
     bool closed = false;
+    // buffers handed out by bhip_malloc: bhip_free releases the context's reference only for these (a foreign or already
+    // freed pointer must not underflow the count and free the context under its live children)
+    std::mutex buf_mu;
+    std::unordered_set<void *> bufs;
 };
 static void ctx_free(bhip_ctx *ctx)
 {
@@ -103,6 +110,7 @@ static void ctx_release(bhip_ctx *ctx)
 static void ctx_quiesce(bhip_ctx *ctx)
 {
     if (ctx->host_only) return;
+    (void)hipSetDevice(ctx->device);   // a process may drive several devices; finalizers run on whatever device is current
     if (!ctx->closed) (void)hipStreamSynchronize(ctx->stream);
     else (void)hipDeviceSynchronize();
 }
@@ -280,6 +288,7 @@ int bhip_malloc(bhip_ctx *ctx, size_t bytes, void **dev)
     NEED_DEVICE(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMalloc(dev, bytes ? bytes : 8));
+    { std::lock_guard<std::mutex> g(ctx->buf_mu); ctx->bufs.insert(*dev); }
     ctx_retain(ctx);   // a buffer is a child of its context too (a finalizer may free it after the context was destroyed)
     return BHIP_OK;
 }
@@ -288,7 +297,10 @@ int bhip_free(bhip_ctx *ctx, void *dev)
     if (!ctx) return BHIP_EINVAL;
     if (!dev) return BHIP_OK;
     if (ctx->host_only) return fail(ctx, BHIP_EHIP, "host-only context (device -1): no device memory");
-    (void)hipSetDevice(ctx->device);
+    {
+        std::lock_guard<std::mutex> g(ctx->buf_mu);
+        if (ctx->bufs.erase(dev) == 0) return fail(ctx, BHIP_EINVAL, "bhip_free: not a live bhip_malloc buffer of this context (foreign pointer or double free)");
+    }
     ctx_quiesce(ctx);
     const hipError_t e = hipFree(dev);
     ctx_release(ctx);
@@ -1499,8 +1511,9 @@ struct ChainStateHeader {
     int64_t n, N, mp, d;
     uint64_t seed;
     uint32_t path0, iter;
-    int32_t skip0, reserved;
+    int32_t skip0, rng_spec;   // rng_spec: version of the noise specification the chains were driven with (bhip-philox-v<rng_spec>)
 };
+constexpr int32_t RNG_SPEC_VERSION = 2;
 constexpr uint64_t CHAIN_MAGIC = 0x314E484350494842ULL;   // "BHIPCHN1" little endian
 }  // namespace
 
@@ -1521,7 +1534,7 @@ int bhip_chains_save(bhip_chains *ch, void *host_buf)
     const size_t N = ch->po->tt.size(), nW = N * ch->po->mh.mp * ch->n;
     ChainStateHeader h{};
     h.magic = CHAIN_MAGIC; h.n = ch->n; h.N = (int64_t)N; h.mp = ch->po->mh.mp; h.d = ch->po->mh.d;
-    h.seed = ch->seed; h.path0 = ch->path0; h.iter = ch->iter; h.skip0 = ch->skip0;
+    h.seed = ch->seed; h.path0 = ch->path0; h.iter = ch->iter; h.skip0 = ch->skip0; h.rng_spec = RNG_SPEC_VERSION;
     char *out = static_cast<char *>(host_buf);
     std::memcpy(out, &h, sizeof(h));
     double *tmp = nullptr;
@@ -1550,6 +1563,9 @@ int bhip_chains_load(bhip_chains *ch, const void *host_buf)
     const char *in = static_cast<const char *>(host_buf);
     std::memcpy(&h, in, sizeof(h));
     if (h.magic != CHAIN_MAGIC) return fail(ctx, BHIP_EINVAL, "bhip_chains_load: not a chain state buffer");
+    if (h.rng_spec != RNG_SPEC_VERSION)   // 0: saved before the field existed (bhip-philox-v1 builds)
+        return fail(ctx, BHIP_EINVAL, "bhip_chains_load: the state was saved under another noise specification (bhip-philox-v" + std::to_string(h.rng_spec ? h.rng_spec : 1) +
+                                      "); a resumed run would not reproduce the uninterrupted one");
     if (h.n != ch->n || h.N != (int64_t)N || h.mp != po->mh.mp || h.d != po->mh.d)
         return fail(ctx, BHIP_EINVAL, "bhip_chains_load: the state was saved for another ensemble shape (chains, grid, dimensions)");
     if (h.seed != ch->seed || h.path0 != ch->path0)
@@ -1639,6 +1655,10 @@ struct bhip_comm {
     bhip_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
     int nranks = 0, rank = 0;
+    // created by bhip_comm_init_all: every rank of the communicator is driven by THIS process.  RCCL then requires the
+    // ranks' calls of one collective to sit inside one ncclGroupStart/End (issued one after the other from one thread the
+    // first would wait for peers that are never reached): such a communicator gathers through bhip_comm_allgather_group only.
+    bool single_process = false;
 };
 
 static int rccl_fail(bhip_ctx *ctx, const char *what, ncclResult_t r)
@@ -1703,7 +1723,7 @@ int bhip_comm_init_all(int ndev, bhip_ctx *const *ctxs, bhip_comm **comms_out)
     for (int k = 0; k < ndev; k++) {
         bhip_comm *cm = new (std::nothrow) bhip_comm();
         if (!cm) return fail(ctx, BHIP_EHIP, "out of host memory");
-        cm->ctx = ctxs[k]; cm->comm = cs[k]; cm->nranks = ndev; cm->rank = k;
+        cm->ctx = ctxs[k]; cm->comm = cs[k]; cm->nranks = ndev; cm->rank = k; cm->single_process = true;
         ctx_retain(ctxs[k]);
         comms_out[k] = cm;
     }
@@ -1723,6 +1743,9 @@ int bhip_comm_allgather(bhip_comm *comm, const double *send_dev, double *recv_de
     if (!comm || !send_dev || !recv_dev || count == 0) return BHIP_EINVAL;
     bhip_ctx *ctx = comm->ctx;
     NEED_DEVICE(ctx);
+    if (comm->single_process && comm->nranks > 1)
+        return fail(ctx, BHIP_ESTATE, "this communicator came from bhip_comm_init_all (all ranks in one process): gather through "
+                                      "bhip_comm_allgather_group -- one ungrouped collective per rank from one thread would deadlock");
     RCCL_READY(ctx);
     const ncclResult_t r = api.AllGather(send_dev, recv_dev, count, ncclDouble, comm->comm, ctx->stream);
     if (r != ncclSuccess) return rccl_fail(ctx, "ncclAllGather", r);
@@ -1733,6 +1756,8 @@ int bhip_comm_allgather_stats(bhip_comm *comm, const double *stats_dev, double *
 {
     return bhip_comm_allgather(comm, stats_dev, all_dev, BHIP_STATS_LEN);
 }
+// SURVEY 8(b)'s proposed names.  bhip_comm_init is the single-process form; with more than one device its communicators
+// gather through bhip_comm_allgather_group (bhip_allgather_stats then returns BHIP_ESTATE, see bhip_comm_allgather).
 int bhip_comm_init(int ndev, bhip_ctx *const *ctxs, bhip_comm **comms_out) { return bhip_comm_init_all(ndev, ctxs, comms_out); }
 int bhip_allgather_stats(bhip_comm *comm, const double *stats_dev, double *all_dev) { return bhip_comm_allgather_stats(comm, stats_dev, all_dev); }
 

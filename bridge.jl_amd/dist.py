@@ -98,6 +98,45 @@ class Comm:
             pass
 
 
+class CommGroup:
+    """ONE process driving several devices: bhip_comm_init_all (ncclCommInitAll) over one context per device and the grouped
+    all-gather bhip_comm_allgather_group (every rank's ncclAllGather inside one ncclGroupStart/End, each on its context's
+    stream).  This is the form a single-threaded `ccall` host -- the reference is single-threaded Julia -- uses for the 8 GPUs
+    of a node; launches are asynchronous, so one host thread keeps all devices busy."""
+
+    def __init__(self, ctxs):
+        import ctypes as C
+        self.ctxs = list(ctxs)
+        n = self.nranks = len(self.ctxs)
+        hs = (C.c_void_p * n)(*[c.h for c in self.ctxs])
+        self._comms = (C.c_void_p * n)()
+        self.ctxs[0].check(self.ctxs[0].lib.bhip_comm_init_all(n, hs, self._comms))
+
+    def allgather(self, sends, recvs=None):
+        """sends[k]: contiguous float64 tensor [count] on device k; returns the list of [nranks, count] tensors (one per device)"""
+        import ctypes as C
+        n, count = self.nranks, sends[0].numel()
+        if recvs is None:
+            recvs = [torch.empty(n * count, dtype=torch.float64, device=s.device) for s in sends]
+        sp = (C.c_void_p * n)(*[s.data_ptr() for s in sends])
+        rp = (C.c_void_p * n)(*[r.data_ptr() for r in recvs])
+        self.ctxs[0].check(self.ctxs[0].lib.bhip_comm_allgather_group(n, self._comms, sp, rp, count))
+        return [r.reshape(n, -1) for r in recvs]
+
+    def destroy(self):
+        if getattr(self, "_comms", None) is not None:
+            for k in range(self.nranks):
+                if self._comms[k]:
+                    self.ctxs[0].lib.bhip_comm_destroy(self._comms[k])
+            self._comms = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 def allgather_stats(stats, world=None, comm=None):
     """ONE all-gather of the per-rank statistics block -> tensor [world, STATS_LEN] on every rank.
     comm: a Comm (the product's RCCL communicator); without it the torch.distributed group is used (gloo in the CPU tests)"""

@@ -374,7 +374,12 @@ int bhip_comm_allgather(bhip_comm *comm, const double *send_dev, double *recv_de
 /* = bhip_comm_allgather(comm, stats_dev, all_dev, BHIP_STATS_LEN): all_dev [nranks][BHIP_STATS_LEN] */
 int bhip_comm_allgather_stats(bhip_comm *comm, const double *stats_dev, double *all_dev);
 /* the two names SURVEY.md 8(b) proposed for this pair: bhip_comm_init = bhip_comm_init_all (single-process form, one
- * context per device), bhip_allgather_stats = bhip_comm_allgather_stats */
+ * context per device), bhip_allgather_stats = bhip_comm_allgather_stats.
+ * THREADING RULE: a communicator made by bhip_comm_init / bhip_comm_init_all has all its ranks in ONE process; RCCL then
+ * needs the ranks' calls of a collective inside one group (issued one after another from one thread, the first would wait
+ * for peers that are never reached).  On such a communicator with more than one rank bhip_comm_allgather,
+ * bhip_comm_allgather_stats and bhip_allgather_stats return BHIP_ESTATE: use bhip_comm_allgather_group (a world of one
+ * may use either). */
 int bhip_comm_init(int ndev, bhip_ctx *const *ctxs, bhip_comm **comms_out);
 int bhip_allgather_stats(bhip_comm *comm, const double *stats_dev, double *all_dev);
 /* single-process form: the n per-device gathers inside one ncclGroupStart/End */

@@ -23,7 +23,7 @@ def _build(tmp_path, name="fhn_chains"):
     return exe
 
 
-@pytest.mark.parametrize("name", ["fhn_chains", "lorenz_smoothing"])
+@pytest.mark.parametrize("name", ["fhn_chains", "lorenz_smoothing", "fhn_chains_multi"])
 def test_c_example_compiles_against_the_header(tmp_path, name):
     exe = _build(tmp_path, name)
     assert os.path.exists(exe)
@@ -98,3 +98,34 @@ def test_c_smoothing_example_matches_the_python_mirror(tmp_path):
         for i in range(m):
             s += ll[i, p]
         assert a == acc[p] and l == s, (p, a, acc[p], l, s)
+
+
+@pytest.mark.gpu
+def test_c_multi_gpu_example_equals_one_ensemble_with_all_the_chains(tmp_path):
+    """examples/fhn_chains_multi.c: ONE plain-C process drives every visible device through bhip_comm_init_all +
+    bhip_comm_allgather_group (on a one-GPU test box: a world of one through the same calls).  Device k owns the global
+    chain ids [k*n, (k+1)*n), so its chains and the combined statistics equal ONE ensemble of ndev*n chains, bit for bit."""
+    import bridgehip as bh
+    import problems
+    exe = _build(tmp_path, "fhn_chains_multi")
+    n, iters = 320, 5
+    out = subprocess.run([exe, str(n), str(iters)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    ndev = int(re.search(r"devices (\d+)", out.stdout).group(1))
+    assert ndev == bh._lib.load().bhip_device_count()
+    got = {int(m.group(1)): (int(m.group(2)), float.fromhex(m.group(3))) for m in re.finditer(r"chain (\d+) acc (\d+) ll (\S+)", out.stdout)}
+    assert sorted(got) == sorted(k * n + p for k in range(ndev) for p in range(2))
+    ctx = bh.default_context(0)
+    P = bh.FitzhughDiffusion(0.1, 0.0, 1.5, 0.8, 0.3)
+    Po = bh.PartialBridge(problems.tau_grid(2.0, 1001), P, bh.fitzhugh_aux_linearised_end(P, 1.1), [[1.0, 0.0]], [1.1], [[1e-10]], ctx=ctx)
+    ch = bh.Chains(Po, [-0.5, -0.6], ndev * n, seed=44, store_X=False)
+    ch.step(0.9, iters)
+    ll, acc = ch.ll(), ch.acc()
+    for p, (a, l) in got.items():
+        assert a == acc[p] and l == ll[p], (p, a, acc[p], l, ll[p])
+    m = re.search(r"chains (\d+) iterations (\d+) acceptance ([0-9.]+) mean ll (\S+)", out.stdout)
+    assert int(m.group(1)) == ndev * n and int(m.group(2)) == iters
+    assert abs(float(m.group(3)) - acc.sum() / (ndev * n * iters)) < 1e-6 and abs(float(m.group(4)) - ll.mean()) < 1e-7 * max(1.0, abs(ll.mean()))
+    # asking for more devices than the box has is refused up front
+    r = subprocess.run([exe, "64", "1", str(ndev + 1)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "visible" in r.stderr

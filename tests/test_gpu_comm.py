@@ -93,3 +93,59 @@ def test_bench_two_ranks_over_rccl_equal_one_rank(tmp_path):
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     assert j2["config"]["acceptance_rate"] == j1["config"]["acceptance_rate"] and j2["config"]["chains_total"] == 8192
+
+
+def test_bench_single_process_path_runs_the_collective_at_one_gpu():
+    """`python bench.py --gpus 1` with no launcher: one process, bhip_comm_init_all + bhip_comm_allgather_group with a world of one"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--chains", "4096", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-other-modes"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and "bhip_comm_init_all" in j["config"]["launch"] and "unavailable" not in j["config"]["launch"]
+    assert j["allgather_ms"] >= 0.0 and len(j["per_gpu_ms_per_step"]) == 1 and j["config"]["chains_total"] == 4096
+    assert j["per_gpu_ms_per_step"][0] <= j["ms_per_step"] * 1.0001
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` beyond the visible devices: rc != 0, a clear message, no JSON line (and no launcher message)"""
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 2 and f"only {n - 1} device(s) visible" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_bench_single_process_two_gpus_equal_one_gpu_with_twice_the_chains():
+    common = ["--steps", "4", "--warmup", "0", "--no-cpu-baseline", "--no-other-modes"]
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--chains", "4096"] + common,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--chains", "8192"] + common,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j2["config"]["acceptance_rate"] == j1["config"]["acceptance_rate"] and j2["config"]["chains_total"] == 8192
+
+
+def test_ungrouped_gather_on_a_single_process_communicator(ctx):
+    """advisor r2: the alias pair bhip_comm_init + bhip_allgather_stats must not deadlock on ndev > 1 -- a communicator from
+    bhip_comm_init[_all] with more than one rank refuses the ungrouped call (BHIP_ESTATE); a world of one may use either"""
+    ndev = torch.cuda.device_count()
+    ctxs = [ctx] + [bh.Context(k) for k in range(1, ndev)]
+    hs = (C.c_void_p * ndev)(*[c.h for c in ctxs])
+    comms = (C.c_void_p * ndev)()
+    ctx.check(ctx.lib.bhip_comm_init(ndev, hs, comms))
+    send = torch.arange(8, dtype=torch.float64, device=ctx.device)
+    recv = torch.zeros(8 * ndev, dtype=torch.float64, device=ctx.device)
+    rc = ctx.lib.bhip_allgather_stats(comms[0], C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()))
+    if ndev == 1:
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(recv, send)
+    else:
+        assert rc == -4 and b"bhip_comm_allgather_group" in ctx.lib.bhip_last_error(ctx.h)
+    for k in range(ndev):
+        ctx.lib.bhip_comm_destroy(comms[k])

@@ -42,3 +42,22 @@ def test_readme_quickstart_runs():
     env = dict(os.environ, QUICKSTART_PATHS="2048")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "quickstart.py")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "acceptance" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
+def test_bhip_free_of_a_foreign_or_freed_pointer_does_not_release_the_context():
+    """advisor r2: bhip_free released the context's reference for ANY pointer; a double free could free the context under
+    its live children"""
+    import ctypes as C
+    ctx = bh.Context(0)
+    L = ctx.lib
+    p = C.c_void_p()
+    assert L.bhip_malloc(ctx.h, 1024, C.byref(p)) == 0
+    assert L.bhip_free(ctx.h, p) == 0
+    assert L.bhip_free(ctx.h, p) == -1 and b"double free" in L.bhip_last_error(ctx.h)      # BHIP_EINVAL, reference count untouched
+    assert L.bhip_free(ctx.h, C.c_void_p(0x1000)) == -1
+    tt = np.linspace(0.0, 1.0, 33)
+    P = bh.LinPro([[-0.5]], [0.0], [[0.8]])
+    Po = bh.GuidedBridge(tt, P, P, [0.3], ctx=ctx)
+    ch = bh.Chains(Po, [0.1], 128, seed=1)
+    ch.step(0.9, 1)                                           # the context is alive and usable
+    assert np.isfinite(ch.ll()).all()

@@ -405,3 +405,8 @@ def test_chain_checkpoint_and_resume(ctx, name):
         bh.Chains(Po, c.x0, 100, seed=21, path0=9).load(state)
     with pytest.raises(bh.BridgeError, match="not a chain state"):
         b.load(np.zeros(len(state), dtype=np.uint8))
+    # ... and the noise specification it was driven with (advisor r2: a v1 state, whose header field was 0, must not resume silently)
+    old = state.copy()
+    old[60:64] = 0                                           # ChainStateHeader.rng_spec
+    with pytest.raises(bh.BridgeError, match="noise specification"):
+        b.load(old)

@@ -96,6 +96,27 @@ def test_segchains_argument_checks(ctx):
     sc.step(0.9, np.sqrt(1 - 0.81), 2)
     with pytest.raises(bh.BridgeError, match="MCNEXT"):
         sc.mcstats(0, 0)
+    # the pCN weights must lie on the unit circle (advisor r2: anything else silently targets another law)
+    for wo, wn in ((0.9, 0.5), (float("nan"), 0.1), (1.0, 1e-3)):
+        with pytest.raises(bh.BridgeError, match="w_old\\^2 \\+ w_new\\^2 = 1"):
+            sc.step(wo, wn, 1)
+    sc.step([0.9, 0.5], [np.sqrt(1 - 0.81), np.sqrt(0.75)])          # per-iteration weights, each pair on the circle
+
+
+def test_segchains_create_destroy_does_not_leak(ctx):
+    """advisor r2: segment 0's parity / count arrays were never released (5 * ld bytes per ensemble)"""
+    import torch
+    segs, refs, mu, chol, d = build_segments(ctx, "ou1", m=2)
+    n = 1 << 20                                           # 5 MiB of cur + acc per ensemble
+    def cycle():
+        sc = bh.SegChains(segs, mu, chol, n)
+        del sc
+    cycle(); torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(40):
+        cycle()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20   # 40 leaked ensembles would be 200 MiB
 
 
 def test_pooled_statistics_over_chains_and_iterations(ctx):

@@ -239,3 +239,18 @@ def test_coefficient_accessors_against_the_oracle():
     assert np.allclose(bh.Gamma(0.0, [0.3], P), [[4.0]]) and np.allclose(bh.sigma(0.0, [0.3], P), [[0.5]])
     with pytest.raises(bh.BridgeError):
         bh.b(0.0, [0.1, 0.2], bh.UserProcess(2, "o[0] = x[0]; o[1] = x[1];", [], [[1.0], [1.0]], ctx=h))
+
+
+def test_bench_without_launcher_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` started bare drives the N devices from one process; beyond the visible devices (here, on
+    a CPU box: none) it ends with rc 2, one clear line on stderr and no JSON -- never a "use a launcher" message"""
+    import subprocess
+    import sys
+    import torch
+    n = (torch.cuda.device_count() if torch.cuda.is_available() else 0) + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2, r.stderr[-1500:]
+    assert f"--gpus {n} but only {n - 1} device(s) visible" in r.stderr and "torch.distributed.run" not in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
