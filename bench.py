@@ -488,7 +488,10 @@ def base_record(args, world, w, elapsed, kern_ms, launch):
     }
 
 
-def add_chain_summary(out, gathered):
+def add_chain_summary(out, gathered, w=None):
+    if w is not None and w.chains is not None:
+        # BHIP_OPT_TUNE_PLACEMENT (setup, before any timing): allocations tried, ms per iteration on the first and the chosen one
+        out["config"]["placement"] = w.chains.placement()
     summary = bdist.combine_stats(gathered)
     out["config"]["acceptance_rate"] = summary["acceptance_rate"]
     out["config"]["mean_ll"] = summary["mean_ll"]
@@ -533,7 +536,7 @@ def main_per_rank(args, world):
     if rank == 0:
         out = base_record(args, world, w, elapsed, kern_ms, "one process per GPU (torch.distributed.run); bhip_comm_init_rank + bhip_comm_allgather_stats")
         if w.chains is not None:
-            add_chain_summary(out, gathered)
+            add_chain_summary(out, gathered, w)
     if args.mode == "mcmc" and args.chains == 0:
         # SURVEY 8(d) C4 quotes 32 768 chains per GPU: the same protocol at that shard size, next to the headline
         del w
@@ -591,7 +594,7 @@ def main_local(args):
     out["per_gpu_ms_per_step"] = [t / args.steps for t in per_gpu_ms]
     out["allgather_ms"] = gather_ms
     if w.chains is not None:
-        add_chain_summary(out, gathered)
+        add_chain_summary(out, gathered, w)
     ctx = ctxs[0]
     default_run = args.mode == "mcmc" and args.chains == 0
     if n == 1 and default_run and not args.no_other_modes:

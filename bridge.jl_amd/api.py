@@ -39,6 +39,7 @@ STATS_LEN = 8
 
 
 OPT_WAVE_SPECIALISED = 1   # BHIP_OPT_WAVE_SPECIALISED
+OPT_TUNE_PLACEMENT = 2     # BHIP_OPT_TUNE_PLACEMENT
 AUX_LINEARAPPR = 4         # BHIP_AUX_LINEARAPPR
 
 
@@ -841,6 +842,13 @@ class Chains:
         skip = self.skip if skip is None else int(skip)
         self.ctx.check(self.ctx.lib.bhip_chains_step(self.h, float(rho), int(iters), skip))
         self.iterations += iters
+
+    def placement(self):
+        """what the placement tuning did (bhip_chains_placement_info): allocations tried (0 = not tuned), ms per iteration on the
+        first and on the chosen allocation"""
+        n, a, b = C.c_int(), C.c_float(), C.c_float()
+        self.ctx.check(self.ctx.lib.bhip_chains_placement_info(self.h, C.byref(n), C.byref(a), C.byref(b)))
+        return {"tries": n.value, "ms_first": a.value, "ms_best": b.value}
 
     def stats(self, out=None):
         """device tensor [8]: {nchains, iterations, sum acc, sum ll, sum ll^2, min ll, max ll, sum acc^2}"""

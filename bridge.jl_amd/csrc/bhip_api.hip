@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <unordered_set>
@@ -86,6 +87,7 @@ struct bhip_ctx {
     double *scratch = nullptr;
     size_t scratch_bytes = 0;
     bool wave_specialised = true;   // BHIP_OPT_WAVE_SPECIALISED: producer/consumer kernels (bhip_pc_kernel.h) where they exist
+    bool tune_placement = true;     // BHIP_OPT_TUNE_PLACEMENT: large chain ensembles try a few allocations and keep the fastest (bhip_chains_init)
     // lifetime: every proposal / chain ensemble / communicator holds a reference.  bhip_ctx_destroy with live children only
     // closes the context (garbage collectors -- Python at interpreter exit, Julia finalizers -- destroy handles in any order);
     // the last child releases it.  A closed context's stream is no longer synchronised (it was borrowed and may be gone).
@@ -144,7 +146,11 @@ struct bhip_chains {
     bool lines = false;     // d <= 3 (noise dimension <= 3): W in the line layout of bhip_chain_kernel.h, else 16-byte slots
     int nch = 0;            // lines per chain and parity half = ceil(N / 16)
     double *Wc = nullptr;   // W slots [N][mp][ld][2]  |  lines [2][nch][ld][16]
-    double *Xo = nullptr;   // proposal paths [N][d][ld] (BHIP_CHAINS_STORE_X)
+    double *Xo = nullptr;   // proposal paths [N][d][ld] (BHIP_CHAINS_STORE_X); lives behind Wc in the same allocation
+    size_t wbytes = 0, xbytes = 0;
+    // placement tuning (bhip_chains_init): allocations tried, ms per pCN iteration of the first and of the chosen one
+    int place_tries = 0;
+    float place_ms_first = 0.f, place_ms_best = 0.f;
     int skip0 = 0;
     unsigned char *cur = nullptr;
     double *llcur = nullptr;
@@ -279,6 +285,7 @@ int bhip_ctx_set_option(bhip_ctx *ctx, int option, int value)
 {
     if (!ctx) return BHIP_EINVAL;
     if (option == BHIP_OPT_WAVE_SPECIALISED) { ctx->wave_specialised = value != 0; return BHIP_OK; }
+    if (option == BHIP_OPT_TUNE_PLACEMENT) { ctx->tune_placement = value != 0; return BHIP_OK; }
     return fail(ctx, BHIP_EINVAL, "bhip_ctx_set_option: unknown option");
 }
 
@@ -800,6 +807,17 @@ static int finish_guide(bhip_proposal *po)
     std::vector<double> rows;
     int rs = 0;
     pack_rows(po->tt, po->mh, po->has_aux ? &po->aux : nullptr, po->g, rows, rs);
+    if (po->g.kind == BHIP_GUIDE_HV) {
+        // the kernels divide by Hd_i (d = 1) / det(Hd_i) (d = 2, 3) through the row's reciprocal (bhip_smallmat.h sm_div_by): the
+        // bits of `/` as long as the hardware division would not pre-scale its operands
+        const int c_at = 3 + d * d + d + (d == 1 ? 0 : d == 2 ? 4 : 9);
+        for (int i = 0; i < N - 1; i++) {
+            const double c = std::fabs(rows[(size_t)i * rs + c_at]);
+            if (!(c > 0x1.0p-200 && c < 0x1.0p200))
+                return fail(ctx, BHIP_EUNSUPPORTED, "GuidedBridge: Hdiamond[" + std::to_string(i) + "] is singular, not finite or outside 2^-200 < |det| < 2^200: "
+                                                    "no device kernel divides by it the way the reference's `\\` would");
+        }
+    }
     if (po->d_rows) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(po->d_rows)); po->d_rows = nullptr; }
     HIPCHK(ctx, hipMalloc((void **)&po->d_rows, sizeof(double) * rows.size()));
     HIPCHK(ctx, hipMemcpy(po->d_rows, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice));
@@ -1198,6 +1216,18 @@ int bhip_gpupdate(int d, int m, const double *Hd, const double *V, const double 
 }
 
 /* ------------------------------------------------------------------ chains */
+// ONE allocation for the chain state W and the proposal paths Xo (Xo behind W, 2 MiB aligned)
+static hipError_t chains_alloc_state(const bhip_chains *ch, double **Wc, double **Xo)
+{
+    const size_t MB2 = (size_t)2 << 20;
+    const size_t wspan = (ch->wbytes + MB2 - 1) / MB2 * MB2;
+    const bool want_x = (ch->flags & BHIP_CHAINS_STORE_X) != 0;
+    *Wc = nullptr; *Xo = nullptr;
+    const hipError_t e = hipMalloc((void **)Wc, want_x ? wspan + ch->xbytes : ch->wbytes);
+    if (e == hipSuccess && want_x) *Xo = (double *)((char *)*Wc + wspan);
+    return e;
+}
+
 int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uint32_t path0, uint64_t seed, int flags, bhip_chains **out)
 {
     if (!ctx || !po || !out) return BHIP_EINVAL;
@@ -1211,6 +1241,7 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     bhip_chains *ch = new (std::nothrow) bhip_chains();
     if (!ch) return fail(ctx, BHIP_EHIP, "out of host memory");
     ch->ctx = ctx; ch->po = po; ch->n = nchains; ch->ld = (nchains + 63) / 64 * 64;
+    if (const char *sk = std::getenv("BHIP_LD_SKEW")) ch->ld += 64 * std::max(0L, std::atol(sk));   // experiment: leading dimension off the power of two
     ctx_retain(ctx);
     ch->path0 = path0; ch->seed = seed; ch->flags = flags;
     const size_t N = po->tt.size();
@@ -1225,8 +1256,8 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
                         : po->mh.d > 3 ? sizeof(double) * 2 * N * (tile_dim(po->mh.d) / 16) * ch->ld * 16   // tile lines (bhip_tile_kernel.h)
                                        : sizeof(double) * 2 * N * po->mh.mp * ch->ld;
     const size_t xbytes = sizeof(double) * N * po->mh.d * ch->ld;
-    hipError_t e = hipMalloc((void **)&ch->Wc, wbytes);
-    if (e == hipSuccess && (flags & BHIP_CHAINS_STORE_X)) e = hipMalloc((void **)&ch->Xo, xbytes);
+    ch->wbytes = wbytes; ch->xbytes = xbytes;
+    hipError_t e = chains_alloc_state(ch, &ch->Wc, &ch->Xo);
     if (e == hipSuccess) e = hipMalloc((void **)&ch->cur, ch->ld);
     if (e == hipSuccess) e = hipMalloc((void **)&ch->llcur, sizeof(double) * ch->ld);
     if (e == hipSuccess) e = hipMalloc((void **)&ch->acc, sizeof(unsigned int) * ch->ld);
@@ -1242,7 +1273,6 @@ void bhip_chains_destroy(bhip_chains *ch)
     bhip_ctx *ctx = ch->ctx;
     ctx_quiesce(ctx);
     if (ch->Wc) (void)hipFree(ch->Wc);
-    if (ch->Xo) (void)hipFree(ch->Xo);
     if (ch->cur && !ch->shares_state) (void)hipFree(ch->cur);
     if (ch->llcur && !ch->shares_state) (void)hipFree(ch->llcur);
     if (ch->acc && !ch->shares_state) (void)hipFree(ch->acc);
@@ -1307,10 +1337,79 @@ static int chains_init_impl(bhip_chains *ch, const double *x0, const double *x0_
     return BHIP_OK;
 }
 
+extern "C" int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip);
+// Placement tuning.  The pCN kernel runs three streams against each other (read W, write Wo, write Xo: 8.4 GB per iteration
+// of the bench workload), and on MI355X its time is a property of WHERE the ensemble's memory landed: the same kernel on the
+// same box takes 1.58 ms per iteration on one allocation and 1.75-1.81 ms on another, stable for the life of the allocation
+// and reproducible from process to process (profiles/r3_alloc_placement.txt: plain fills / copies show no slow region, only
+// the three-stream mix does; the first allocations of a fresh process are the slow ones).  Nothing at this level controls
+// physical placement, so large ensembles MEASURE it: bhip_chains_init times a few pCN iterations on the allocation it has,
+// then on up to three more (the earlier ones stay allocated meanwhile, so that each lands elsewhere), keeps the fastest,
+// frees the rest and initialises the state afresh.  ~10 ms and transiently up to 4x the state per ensemble, once.
+static int chains_time_iterations(bhip_chains *ch, int skip, float *ms)
+{
+    bhip_ctx *ctx = ch->ctx;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(ctx, hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(ctx, BHIP_EHIP, "hipEventCreate failed"); }
+    int rc = bhip_chains_step(ch, 0.9, 1, skip);   // untimed: instruction cache, page tables
+    hipError_t e = hipSuccess;
+    const int reps = 3;
+    if (!rc) e = hipEventRecord(e0, ctx->stream);
+    for (int k = 0; k < reps && !rc; k++) rc = bhip_chains_step(ch, 0.9, 1, skip);
+    if (!rc && e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (!rc && e == hipSuccess) e = hipEventSynchronize(e1);
+    if (!rc && e == hipSuccess) { e = hipEventElapsedTime(ms, e0, e1); *ms /= reps; }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(ctx, BHIP_EHIP, std::string("placement tuning: ") + hipGetErrorString(e));
+    return BHIP_OK;
+}
+
 int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
 {
     if (!ch || !x0) return BHIP_EINVAL;
-    return chains_init_impl(ch, x0, nullptr, 0, skip, 0u);
+    int rc = chains_init_impl(ch, x0, nullptr, 0, skip, 0u);
+    bhip_ctx *ctx = ch->ctx;
+    const bool big = ch->wbytes + ch->xbytes >= ((size_t)1 << 30);
+    if (rc || !ctx->tune_placement || !big || !ch->lines || !ch->Xo || ch->shares_state || ch->place_tries > 0) return rc;
+    struct Cand { double *Wc, *Xo; float ms; };
+    std::vector<Cand> cands;
+    Cand cur{ch->Wc, ch->Xo, 0.f};
+    rc = chains_time_iterations(ch, skip, &cur.ms);
+    if (rc) return rc;
+    cands.push_back(cur);
+    float worst = cur.ms, best = cur.ms;
+    const int max_tries = 4;
+    while ((int)cands.size() < max_tries && best > 0.93f * worst) {   // the two populations lie ~10 % apart
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * (ch->wbytes + ch->xbytes)) break;
+        Cand c{nullptr, nullptr, 0.f};
+        if (chains_alloc_state(ch, &c.Wc, &c.Xo) != hipSuccess) { (void)hipGetLastError(); break; }
+        ch->Wc = c.Wc; ch->Xo = c.Xo;
+        rc = chains_init_impl(ch, x0, nullptr, 0, skip, 0u);
+        if (!rc) rc = chains_time_iterations(ch, skip, &c.ms);
+        cands.push_back(c);
+        if (rc) break;
+        worst = std::max(worst, c.ms); best = std::min(best, c.ms);
+    }
+    size_t ib = 0;
+    for (size_t k = 1; k < cands.size(); k++) if (cands[k].ms > 0.f && cands[k].ms < cands[ib].ms) ib = k;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (size_t k = 0; k < cands.size(); k++) if (k != ib) (void)hipFree(cands[k].Wc);
+    ch->Wc = cands[ib].Wc; ch->Xo = cands[ib].Xo;
+    ch->place_tries = (int)cands.size(); ch->place_ms_first = cands[0].ms; ch->place_ms_best = cands[ib].ms;
+    if (rc) return rc;
+    return chains_init_impl(ch, x0, nullptr, 0, skip, 0u);   // the state of iteration 0, whatever the timing runs did to it
+}
+
+int bhip_chains_placement_info(const bhip_chains *ch, int *tries, float *ms_first, float *ms_best)
+{
+    if (!ch) return BHIP_EINVAL;
+    if (tries) *tries = ch->place_tries;
+    if (ms_first) *ms_first = ch->place_ms_first;
+    if (ms_best) *ms_best = ch->place_ms_best;
+    return BHIP_OK;
 }
 
 // ONE pCN proposal of every chain of a segment with the decision deferred (multi-segment ensembles): Wo = w_old*W + w_new*W2,

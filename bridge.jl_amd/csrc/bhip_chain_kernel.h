@@ -29,9 +29,14 @@ constexpr int LINE_DOUBLES = 16;              // one 128-byte line
 constexpr int line_mpp(int mp) { return mp == 3 ? 4 : mp; }
 constexpr int LINE_ROW = LINE_DOUBLES + 1;    // padded LDS row: lane L reads column s of row L without bank conflicts
 
+#ifndef BHIP_LINE_PAIRS
+#define BHIP_LINE_PAIRS 1
+#endif
 BHIP_DEV size_t line_index(int h, int k, long chain, int nch, long ld)
 {
-    return (((size_t)h * nch + k) * ld + chain) * LINE_DOUBLES;
+    // BHIP_LINE_PAIRS: the two parity halves of a chain's chunk are NEIGHBOURS (a 256-byte pair) instead of 2 GB apart
+    if constexpr (BHIP_LINE_PAIRS) return ((((size_t)k * ld + chain) * 2 + h)) * LINE_DOUBLES;
+    else return (((size_t)h * nch + k) * ld + chain) * LINE_DOUBLES;
 }
 
 // BHIP_LINES_STAGE 1: the next chunk's lines are fetched into 32 staging registers while the current chunk is
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
     LaneState<D, MP> st;
 #pragma unroll
     for (int k = 0; k < D; k++) st.y[k] = a.x0_dev ? a.x0_dev[k * a.ldx0 + p] : a.x0[k];
-    st.ll = 0.0; st.zc = 0.0;
+    st.ll = 0.0; st.zq[0] = st.zq[1] = st.zq[2] = 0.0;
 #pragma unroll
     for (int k = 0; k < MP; k++) { st.wprev[k] = 0.0; st.w2prev[k] = 0.0; }
     double *xout = nullptr;
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
     if (BHIP_LINES_STAGE) fetch(0);
 
     // one Euler step i (grid point j = i + 1 = SPC*k + s): the chain's current W[j] comes from the tile, the proposal goes back
-    auto step = [&](int i, int s) {
+    auto step = [&](int i, int s, int i4 = -1 /* i & 3 where static */) {
         double wc[MP];
 #pragma unroll
         for (int cc = 0; cc < MP; cc++) wc[cc] = mine[s * MPP + cc];
@@ -104,9 +109,9 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
             ExpRow<RL::LEN - 3> x;
             x.sh = rows + (size_t)i * RL::RS;
             expand_pp_row<M>(model, a.lna, cr, x.e);
-            path_step<M, GK, MO, NOISE_PCN, FL, ExpRow<RL::LEN - 3>>(model, a, x, i, nll, path, wc, nullptr, 0, xout, ldx, st);
+            path_step<M, GK, MO, NOISE_PCN, FL, ExpRow<RL::LEN - 3>>(model, a, x, i, nll, path, wc, nullptr, 0, xout, ldx, st, TabConst(), 0u, i4);
         } else
-            path_step<M, GK, MO, NOISE_PCN, FL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wc, nullptr, 0, xout, ldx, st);
+            path_step<M, GK, MO, NOISE_PCN, FL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wc, nullptr, 0, xout, ldx, st, TabConst(), 0u, i4);
 #pragma unroll
         for (int cc = 0; cc < MP; cc++) mine[s * MPP + cc] = st.wprev[cc];
     };
@@ -122,14 +127,17 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
         if (BHIP_LINES_STAGE && k + 1 < nch) fetch(k + 1);   // in flight while this chunk is computed
         const int j0 = k * SPC;
         if (k > 0 && j0 + SPC <= N) {
-            // interior chunk: SPC valid steps; pairs (i odd, i even) so that the Philox block parity is static
+            // interior chunk: SPC valid steps, four at a time (j0 is a multiple of 4) so that the position of a step's normals
+            // inside their Philox call is static
 #ifndef BHIP_LINES_UNROLL
 #define BHIP_LINES_UNROLL 1
 #endif
 #pragma unroll BHIP_LINES_UNROLL
-            for (int s = 0; s < SPC; s += 2) {
-                step(j0 + s - 1, s);
-                step(j0 + s, s + 1);
+            for (int s = 0; s < SPC; s += 4) {
+                step(j0 + s - 1, s, 3);
+                step(j0 + s, s + 1, 0);
+                step(j0 + s + 1, s + 2, 1);
+                step(j0 + s + 2, s + 3, 2);
             }
         } else {
             // first chunk (grid point 0 is W[0] = Wo[0] = 0, no step) and the ragged last chunk

@@ -519,7 +519,7 @@ inline int row_stride(int gk, int d, int mo, bool constdiff = true)
 {
     if (gk == BHIP_GUIDE_NONE) return 4;
     int glen = 0;
-    if (gk == BHIP_GUIDE_HV) glen = d == 1 ? 2 : d == 2 ? 7 : 13;
+    if (gk == BHIP_GUIDE_HV) glen = d == 1 ? 3 : d == 2 ? 8 : 14;   // + the reciprocal of the row's divisor (bhip_smallmat.h sm_recip)
     else if (gk == BHIP_GUIDE_LMMU) glen = mo * d + mo + 2 * d * mo + (constdiff ? 0 : 2 * d * d);
     else glen = d * d + d;
     const int len = 3 + d * d + d + glen;
@@ -583,13 +583,13 @@ inline void pack_rows(const std::vector<double> &tt, const ModelHost &mh, const 
         if (gk == BHIP_GUIDE_HV) {
             const Mat &A = g.Hd[i]; const Mat &V = g.V[i];
             auto a = [&](int ii, int jj) { return A(ii - 1, jj - 1); };
-            if (d == 1) { q[0] = A.a[0]; q[1] = V.a[0]; }
-            else if (d == 2) { std::memcpy(q, A.a.data(), 4 * sizeof(double)); q[4] = det(A); q[5] = V.a[0]; q[6] = V.a[1]; }
+            if (d == 1) { q[0] = A.a[0]; q[1] = V.a[0]; q[2] = 1.0 / q[0]; }
+            else if (d == 2) { std::memcpy(q, A.a.data(), 4 * sizeof(double)); q[4] = det(A); q[5] = V.a[0]; q[6] = V.a[1]; q[7] = 1.0 / q[4]; }
             else {   // cofactor rows of StaticArrays' 3x3 solve
                 q[0] = a(2, 2) * a(3, 3) - a(2, 3) * a(3, 2); q[1] = a(1, 3) * a(3, 2) - a(1, 2) * a(3, 3); q[2] = a(1, 2) * a(2, 3) - a(1, 3) * a(2, 2);
                 q[3] = a(2, 3) * a(3, 1) - a(2, 1) * a(3, 3); q[4] = a(1, 1) * a(3, 3) - a(1, 3) * a(3, 1); q[5] = a(1, 3) * a(2, 1) - a(1, 1) * a(2, 3);
                 q[6] = a(2, 1) * a(3, 2) - a(2, 2) * a(3, 1); q[7] = a(1, 2) * a(3, 1) - a(1, 1) * a(3, 2); q[8] = a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1);
-                q[9] = det(A); q[10] = V.a[0]; q[11] = V.a[1]; q[12] = V.a[2];
+                q[9] = det(A); q[10] = V.a[0]; q[11] = V.a[1]; q[12] = V.a[2]; q[13] = 1.0 / q[9];
             }
         } else if (gk == BHIP_GUIDE_LMMU) {
             const int m = g.m;

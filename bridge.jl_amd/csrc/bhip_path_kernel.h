@@ -137,7 +137,7 @@ struct RowLayout {
     static constexpr int B = 3;              // D*D col-major
     static constexpr int BETA = 3 + D * D;   // D
     static constexpr int G = 3 + D * D + D;  // guide part
-    static constexpr int GLEN = GK == BHIP_GUIDE_HV ? (D == 1 ? 2 : D == 2 ? 7 : 13)
+    static constexpr int GLEN = GK == BHIP_GUIDE_HV ? (D == 1 ? 3 : D == 2 ? 8 : 14)   // Hd / cofactors, det, V, 1/divisor
                               : GK == BHIP_GUIDE_LMMU ? (MO * D + MO + 2 * D * MO + (CD ? 0 : 2 * D * D))
                               : GK == BHIP_GUIDE_NUH ? (D * D + D) : 0;
     static constexpr int LM_H = G + MO * D + MO + 2 * D * MO;   // LMMU, !CD: H (D*D), then a~ (D*D)
@@ -152,17 +152,19 @@ BHIP_DEV void guide_terms(const M &model, double t, const double *g, const doubl
     constexpr int D = M::D;
     if constexpr (GK == BHIP_GUIDE_HV) {
         // Hd[i] \ (V[i] - x)                                   src/guip.jl:192-193
+        // the divisions by the row's Hd (d = 1) / det(Hd) (d = 2, 3) use the row's pre-computed reciprocal: three operations
+        // each, the bits of `/` (sm_div_by, bhip_smallmat.h)
         if constexpr (D == 1) {
-            r[0] = (g[1] - x[0]) / g[0];
+            r[0] = sm_div_by(g[1] - x[0], g[0], g[2]);
         } else if constexpr (D == 2) {
             const double w0 = g[5] - x[0], w1 = g[6] - x[1];
-            r[0] = (g[3] * w0 - g[2] * w1) / g[4];
-            r[1] = (g[0] * w1 - g[1] * w0) / g[4];
+            r[0] = sm_div_by(g[3] * w0 - g[2] * w1, g[4], g[7]);
+            r[1] = sm_div_by(g[0] * w1 - g[1] * w0, g[4], g[7]);
         } else {
             const double w0 = g[10] - x[0], w1 = g[11] - x[1], w2 = g[12] - x[2];
-            r[0] = (g[0] * w0 + g[1] * w1 + g[2] * w2) / g[9];
-            r[1] = (g[3] * w0 + g[4] * w1 + g[5] * w2) / g[9];
-            r[2] = (g[6] * w0 + g[7] * w1 + g[8] * w2) / g[9];
+            r[0] = sm_div_by(g[0] * w0 + g[1] * w1 + g[2] * w2, g[9], g[13]);
+            r[1] = sm_div_by(g[3] * w0 + g[4] * w1 + g[5] * w2, g[9], g[13]);
+            r[2] = sm_div_by(g[6] * w0 + g[7] * w1 + g[8] * w2, g[9], g[13]);
         }
         model.amul(t, x, r, gd);
     } else if constexpr (GK == BHIP_GUIDE_LMMU) {
@@ -253,7 +255,7 @@ struct LaneState {
     double y[D];
     double ll;
     double wprev[MP], w2prev[MP];
-    double zc;   // second normal of the current Philox block
+    double zq[3];   // normals 1..3 of the current Philox call (four normals per call, bhip_rng.h)
 };
 
 // One Euler step of one path, branch-free (a single basic block so that the scheduler can interleave
@@ -266,7 +268,8 @@ struct LaneState {
 template <class M, int GK, int MO, int NOISE, int FL, class RowPtr = cptr_t, class Tab = TabConst>
 BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int nll, uint32_t path, const double *win_k,
                         double *wout, long ldwo, double *xout, long ldx, LaneState<M::D, M::MP> &st, const Tab &tab = Tab(),
-                        uint32_t xl = 0u /* lane offset when xout is the wave-uniform base: address = scalar base + 32-bit lane offset */)
+                        uint32_t xl = 0u /* lane offset when xout is the wave-uniform base: address = scalar base + 32-bit lane offset */,
+                        int i4 = -1 /* i & 3 where the caller knows it statically (unrolled time loops); -1: taken from i */)
 {
     constexpr int D = M::D, MP = M::MP;
     using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
@@ -318,10 +321,13 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int n
         const double rdt = rw[RL::RDT];
 #pragma unroll
         for (int k = 0; k < MP; k++) {
-            const int n = i * MP + k;
+            // normal n = i*MP + k is number n & 3 of Philox call n >> 2: drawn with the call's first normal, then taken from the
+            // lane state.  The callers unroll the time loop so that n & 3 is static (one basic block); in their ragged tails it is a
+            // wave-uniform branch.
+            const int n = i * MP + k, ph = ((i4 >= 0 ? i4 : (i & 3)) * MP + k) & 3;
             double z;
-            if ((n & 1) == 0) normal_pair(tab, a.k0, a.k1, path, a.iter, (uint32_t)(n >> 1) + a.blk0, z, st.zc);
-            else z = st.zc;
+            if (ph == 0) normal_quad(tab, a.k0, a.k1, path, a.iter, (uint32_t)(n >> 2) + (a.blk0 >> 1), z, st.zq[0], st.zq[1], st.zq[2]);
+            else z = ph == 1 ? st.zq[0] : ph == 2 ? st.zq[1] : st.zq[2];
             if constexpr (NOISE == NOISE_FRESH) {
                 const double wn = st.wprev[k] + rdt * z;          // yy[i] = yy[i-1] + rootdt*randn
                 dw[k] = wn - st.wprev[k];                          // ww[i+1] - ww[i]
@@ -451,11 +457,11 @@ __global__ __launch_bounds__(256, PPR ? 2 : BHIP_WPE) void k_paths(const KArgs a
             for (int q = 0; q < NPP; q++) r.v[q] = src[(size_t)q * a.ldr];
         }
     };
-    auto rowat = [&](int i) {
+    auto rowat = [&](int i, const RegRow<NPP> &r) {
         if constexpr (PPR) {
             ExpRow<NE> x;
             x.sh = rows + (size_t)i * RL::RS;
-            expand_pp_row<M>(model, a.lna, rr[i & 1].v, x.e);
+            expand_pp_row<M>(model, a.lna, r.v, x.e);
             return x;
         } else return rows + (size_t)i * RL::RS;
     };
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(256, PPR ? 2 : BHIP_WPE) void k_paths(const KArgs a
 #pragma unroll
     for (int k = 0; k < D; k++) st.y[k] = a.x0_dev ? a.x0_dev[k * a.ldx0 + p] : a.x0[k];
     st.ll = 0.0;
-    st.zc = 0.0;
+    st.zq[0] = st.zq[1] = st.zq[2] = 0.0;
 #pragma unroll
     for (int k = 0; k < MP; k++) { st.wprev[k] = 0.0; st.w2prev[k] = 0.0; }
 
@@ -562,23 +568,28 @@ __global__ __launch_bounds__(256, PPR ? 2 : BHIP_WPE) void k_paths(const KArgs a
                 st_stream(&wslot[((size_t)(i + 1) * MP + k) * a.ldC], c ? d2v{st.wprev[k], slot[k].y} : d2v{slot[k].x, st.wprev[k]});
         }
     };
+    // unrolled so that the position of a step's normals inside their Philox call (four normals per call) and the register row
+    // of the per-chain coefficients are static: four steps per iteration where normals are drawn (two for m' = 2), else two
+    constexpr int UNR = DRAWS ? (MP == 2 ? 2 : 4) : 2;
     int i = 0;
-    for (; i + 1 < nsteps; i += 2) {
+    for (; i + UNR - 1 < nsteps; i += UNR) {
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {   // i is a multiple of UNR: u is the step's static phase
+            double cur[NIN];
+            advance(i + u, cur);
+            fetch_row(i + u + 1, rr[(u + 1) & 1]);
+            path_step<M, GK, MO, NOISE, FL, RowT, TabT>(model, a, rowat(i + u, rr[u & 1]), i + u, nll, path, cur, wout, ldwo, xout, ldx, st, tab, 0u, u);
+            commit(i + u);
+        }
+    }
+#pragma unroll 1
+    for (; i < nsteps; i++) {   // ragged tail (< UNR steps): dynamic phase, the current per-chain row always in rr[0]
         double cur[NIN];
         advance(i, cur);
         fetch_row(i + 1, rr[1]);
-        path_step<M, GK, MO, NOISE, FL, RowT, TabT>(model, a, rowat(i), i, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
+        path_step<M, GK, MO, NOISE, FL, RowT, TabT>(model, a, rowat(i, rr[0]), i, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
         commit(i);
-        advance(i + 1, cur);
-        fetch_row(i + 2, rr[0]);
-        path_step<M, GK, MO, NOISE, FL, RowT, TabT>(model, a, rowat(i + 1), i + 1, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
-        commit(i + 1);
-    }
-    if (i < nsteps) {
-        double cur[NIN];
-        advance(i, cur);
-        path_step<M, GK, MO, NOISE, FL, RowT, TabT>(model, a, rowat(i), i, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
-        commit(i);
+        rr[0] = rr[1];
     }
 
     if constexpr (NOISE == NOISE_INNOV) {

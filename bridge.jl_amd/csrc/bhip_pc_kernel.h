@@ -34,8 +34,8 @@ namespace bhip {
 
 enum { NOISE_FRESH_PC = 6, NOISE_PCN_LINES_PC = 7 };
 
-#ifndef PC_BLOCK_UNROLL
-#define PC_BLOCK_UNROLL 2   // Philox blocks in flight per producer lane (instruction-level parallelism vs registers)
+#ifndef PC_QUAD_UNROLL
+#define PC_QUAD_UNROLL 1    // Philox calls (two Box-Muller pairs each) in flight per producer lane: instruction-level parallelism vs registers
 #endif
 #ifndef PC_WPE
 #define PC_WPE 4            // minimum waves per SIMD the register allocation must allow (8 workgroups per CU by LDS)
@@ -57,8 +57,8 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
     constexpr bool PCN = MODE == NOISE_PCN_LINES_PC;
     constexpr int MPP = line_mpp(MP);        // components per grid point inside a line / tile row
     constexpr int SPC = LINE_DOUBLES / MPP;  // grid points per chunk
-    constexpr int NB = SPC * MP / 2;         // Philox blocks per chunk: 8, 8, 6
-    constexpr bool CARRY = (MP & 1) != 0;    // odd m': a chunk's first normal is the second of a block drawn with the previous chunk
+    constexpr int NV = SPC * MP;             // values (normals) per chunk: 16, 16, 12
+    constexpr int NQ = NV / 4;               // Philox calls per chunk (four normals each, bhip_rng.h): 4, 4, 3
     using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
     // Workgroup = NPAIR producer/consumer pairs.  Small ensembles run 2 or 4 pairs per workgroup (and then RLDS): a
     // workgroup's waves are dealt to the four SIMDs of its CU in turn, so 4 waves sit on 4 different SIMDs and the 8 waves
@@ -97,7 +97,11 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
         double wprev[MP], w2prev[MP];
 #pragma unroll
         for (int c = 0; c < MP; c++) { wprev[c] = 0.0; w2prev[c] = 0.0; }
-        double carry = 0.0;   // m' = 1, 3: second normal of the block that straddles the chunk boundary
+        // grid point j, component c takes normal (j-1)*m' + c: a chunk's first m' values are the LAST m' normals of the Philox
+        // call drawn at the end of the previous chunk (chunk 0: grid point 0, multiplied by rdtp[0] = 0)
+        double carry[MP];
+#pragma unroll
+        for (int c = 0; c < MP; c++) carry[c] = 0.0;
         // cooperative line moves (pCN): instruction q moves the lines of chains c0 + 8q + lane/8; lane%8 selects 16 bytes
         const int sub = lane >> 3, part = 2 * (lane & 7);
         int par[8];
@@ -152,13 +156,11 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
                     if (k + 1 < nch) fetch(k + 1);   // in flight while this chunk is mixed
                 }
                 // value v = s*MP + c of the chunk (grid point j = SPC*k + s, component c; tile position s*MPP + c) takes normal
-                // n = (j-1)*MP + c:
-                //   m' = 1: v = 2q   <- second normal of block 8k+q-1 (the carry), v = 2q+1 <- first normal of block 8k+q
-                //   m' = 2: v = 2q, 2q+1 <- both normals of block 8k+q-1   (k = 0, q = 0: block "-1", multiplied by rdtp[0] = 0)
-                //   m' = 3: 12 values, first normal n = 12k-3 (odd): as m' = 1 with blocks 6k-1+q, q = 0..5 (k = 0: values 0..2 are
-                //           grid point 0, multiplied by rdtp[0] = 0)
+                // n = (j-1)*MP + c = NV*k - MP + v.  The chunk draws the Philox calls NQ*k .. NQ*k + NQ-1 = normals NV*k .. NV*k + NV-1:
+                // values 0 .. MP-1 come from the carry, normal t of the chunk's own draws is value t + MP, and the last MP of them
+                // are carried into the next chunk.
                 // RLDS (a producer that is alone on its SIMD): the chunk's 16/m' scales in one scalar load up front and the
-                // eight blocks fully unrolled -- otherwise every value waits for its own scalar load
+                // calls fully unrolled -- otherwise every value waits for its own scalar load
                 double rd[SPC];
                 if constexpr (RLDS) {
 #pragma unroll
@@ -183,23 +185,34 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
                         mine[pos] = a.rho * wc + a.srho * w2;                    // Wo = rho*W + sqrt(1-rho^2)*W2
                     }
                 };
-                const uint32_t b0 = MP == 1 ? (uint32_t)(8 * k) : MP == 2 ? (uint32_t)(8 * k) - 1u : (uint32_t)(6 * k) - 1u;
-                auto block = [&](int q) {
-                    double z0, z1;
+                const uint32_t q0 = (uint32_t)(NQ * k) + (a.blk0 >> 1);   // blk0 counts pairs (two per call) and is even
+                auto draw = [&](int i, double (&z)[4]) {
 #ifdef PC_KNOCKOUT_NOISE   /* measurement only: what the consumer alone costs */
-                    z0 = 0.25; z1 = -0.5;
+                    z[0] = 0.25; z[1] = -0.5; z[2] = 0.125; z[3] = -0.75;
 #else
-                    normal_pair(rtab, a.k0, a.k1, path, a.iter, b0 + q + a.blk0, z0, z1);
+                    normal_quad(rtab, a.k0, a.k1, path, a.iter, q0 + (uint32_t)i, z[0], z[1], z[2], z[3]);
 #endif
-                    if constexpr (CARRY) { value(2 * q, carry); value(2 * q + 1, z0); carry = z1; }
-                    else { value(2 * q, z0); value(2 * q + 1, z1); }
                 };
-                if constexpr (RLDS) {
 #pragma unroll
-                    for (int q = 0; q < NB; q++) block(q);
-                } else {
-#pragma unroll PC_BLOCK_UNROLL
-                    for (int q = 0; q < NB; q++) block(q);
+                for (int c = 0; c < MP; c++) value(c, carry[c]);
+                // every call but the last: all four normals are values of this chunk (component index static for m' = 1, 2 at any
+                // unrolling; m' = 3 -- three calls -- is unrolled fully)
+                constexpr int QU = (RLDS || MP == 3) ? NQ : PC_QUAD_UNROLL;
+#pragma unroll QU
+                for (int i = 0; i < NQ - 1; i++) {
+                    double z[4];
+                    draw(i, z);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) value(4 * i + u + MP, z[u]);
+                }
+                {
+                    double z[4];
+                    draw(NQ - 1, z);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (u < 4 - MP) value(NV - 4 + u + MP, z[u]);
+                        else carry[u - (4 - MP)] = z[u];
+                    }
                 }
                 if constexpr (PCN) {
                     __builtin_amdgcn_wave_barrier();
@@ -222,7 +235,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
     LaneState<D, MP> st;
 #pragma unroll
     for (int k = 0; k < D; k++) st.y[k] = a.x0_dev ? a.x0_dev[k * a.ldx0 + p] : a.x0[k];
-    st.ll = 0.0; st.zc = 0.0;
+    st.ll = 0.0; st.zq[0] = st.zq[1] = st.zq[2] = 0.0;
 #pragma unroll
     for (int k = 0; k < MP; k++) { st.wprev[k] = 0.0; st.w2prev[k] = 0.0; }
     double *xout = nullptr;

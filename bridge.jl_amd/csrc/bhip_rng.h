@@ -1,4 +1,4 @@
-// bhip_rng.h -- RNG specification "bhip-philox-v2" (host + device).
+// bhip_rng.h -- RNG specification "bhip-philox-v3" (host + device).
 //
 // Replaces the reference's global randn() (src/wiener.jl:31,44,55), which is not reproducible
 // outside Julia, with a counter-based generator whose output depends only on
@@ -6,22 +6,27 @@
 // launch geometry, and a chain can be resumed from its counters alone.
 //
 //   Philox4x32-10 (the generator behind rocRAND's default PHILOX4_32_10; Random123 KAT vectors in
-//   tests/), key = (seed_lo, seed_hi), counter = (path, stream, iter, block).
-//   stream 0: block j -> standard normals 2j (cos branch) and 2j+1 (sin branch) by Box-Muller,
-//             u1 = (bits53(r0,r1)+1)*2^-53 in (0,1],  u2 = bits53(r2,r3)*2^-53 in [0,1)
-//   stream 1: block 0 -> the Metropolis-Hastings uniform U = (bits53(r0,r1)+1)*2^-53
+//   tests/), key = (seed_lo, seed_hi), counter = (path, stream, iter, call).
+//   stream 0: call q -> FOUR standard normals 4q .. 4q+3 by two Box-Muller transforms, one per half of the 128 output
+//             bits.  Half s (words a = r[2s], b = r[2s+1]) = "pair" h = 2q + s -> normals 2h (cos branch), 2h+1 (sin):
+//               u1 = (K40 + 1)*2^-40 in (0,1],  K40 = (b >> 24)*2^32 + a      (40 bits: radius up to 7.45)
+//               u2 = K24*2^-24 in [0,1),        K24 = b & 0xffffff            (24 bits of angle)
+//   stream 1: call 0 -> the Metropolis-Hastings uniform U = (bits53(r0,r1)+1)*2^-53
 //   stream 2: normals of the pCN move of the starting point (multi-segment chains, bhip_segchains_*), same construction
-//   Blocks of stream 0 are offset by segment*2^24 in multi-segment chains (KArgs::blk0): one noise stream per segment.
+//   Pairs of stream 0 are offset by segment*2^24 in multi-segment chains (KArgs::blk0): one noise stream per segment.
 //
 // -2*log(u1) and sin/cos(2*pi*u2) are built from integer operations, +, -, *, fma and two small constant
 // tables (bhip_rng_tables.h, generated correctly rounded by scripts/gen_rng_tables.py), so that every host and
 // device evaluates bit-identical normals (no libm / ocml dependence).
 //
-// v1 -> v2 (round 2): v1 evaluated log as 2*atanh((m-1)/(m+1)) (a division and an 11-term series) and sin/cos
-// by quadrant reduction and 7 + 8 Taylor terms: ~147 VALU instructions per Philox block, the largest single
-// share of every path kernel.  v2 reduces the arguments by table lookup (129 x 16 B for the log, 32 x 16 B
-// for the rotation) so that 6 + 4 + 5 polynomial terms suffice: ~119 per block.  Same Philox counters, same
-// uniforms; the normals differ from v1 in the last bits only (both are accurate to ~1 ulp).
+// v1 -> v2 (round 2): table-driven argument reduction for the log and the rotation instead of a division + 11-term series
+// and 7 + 8 Taylor terms: ~147 -> ~119 VALU instructions per Philox call (then: two normals).
+// v2 -> v3 (round 3): v2 spent all 128 bits of a Philox call on ONE Box-Muller pair (53 + 53 bits); the ten Philox rounds
+// (49 instructions) were the largest single item of every path kernel.  v3 draws two pairs per call -- what rocRAND's own
+// single-precision normals do with the four words -- with 40 bits of radius and 24 bits of angle each: ~43 VALU per normal
+// instead of ~60.  What the split means for the law: |z| <= sqrt(80 ln 2) = 7.45 (mass beyond: 9e-14 -- v2: 8.6 sigma; a
+// launch of 2.6e8 normals expects 2e-5 draws out there), and the angle lives on a 2^24 grid (Kolmogorov distance of the
+// marginal to N(0,1) <= 2^-24, invisible below ~1e14 samples).  log / sqrt / sin / cos are the v2 functions, unchanged.
 #pragma once
 #include <stdint.h>
 #include "bhip_rng_tables.h"
@@ -71,6 +76,14 @@ BHIP_HD double u53_bits(uint32_t lo, uint32_t hi, double lo_magic)
 }
 BHIP_HD double u53_open0(uint32_t lo, uint32_t hi) { return u53_bits(lo, hi, 0.5 - 0x1.0p-53); }   // (k+1)*2^-53 in (0,1]
 BHIP_HD double u53_open1(uint32_t lo, uint32_t hi) { return u53_bits(lo, hi, 0.5); }               // k*2^-53 in [0,1)
+// (K40 + 1)*2^-40, K40 = (b >> 24)*2^32 + a: the 40 bits go to the top of the mantissa field of a double in [1,2), so that
+// it reads 1 + K40*2^-40; the subtraction of 1 - 2^-40 is exact (the result has at most 41 significant bits).
+BHIP_HD double u40_open0(uint32_t a, uint32_t b)
+{
+    union { uint64_t u; double d; } v;
+    v.u = 0x3FF0000000000000ULL | ((uint64_t)(b >> 24) << 44) | ((uint64_t)a << 12);
+    return v.d - (1.0 - 0x1.0p-40);
+}
 // sqrt(x) as the compiler expands it (reciprocal-square-root seed, Newton steps on fma, final residual
 // correction = correctly rounded), WITHOUT the exponent pre-scaling and special-value fix-ups that only matter
 // outside the range used here: x in [0, 1500].
@@ -96,6 +109,11 @@ BHIP_HD double u53_open1(uint32_t lo, uint32_t hi)   // [0,1)
 {
     const uint64_t a = ((uint64_t)hi << 32) | lo;
     return (double)(a >> 11) * 0x1.0p-53;
+}
+BHIP_HD double u40_open0(uint32_t a, uint32_t b)   // (0,1]
+{
+    const uint64_t k = ((uint64_t)(b >> 24) << 32) | a;
+    return (double)(k + 1) * 0x1.0p-40;
 }
 BHIP_HD double sqrt_fixed_range(double x) { return __builtin_sqrt(x); }
 #endif
@@ -181,16 +199,13 @@ BHIP_HD double det_m2log(double x, const Tab &tab)
 template <class Tab> BHIP_HD double det_log(double x, const Tab &tab) { return -0.5 * det_m2log(x, tab); }
 BHIP_HD double det_log(double x) { return det_log(x, TabConst()); }
 
-// sin/cos(2*pi*u), u = K*2^-53 in [0,1) whose top 32 source bits are `w`: jr = round(32u) (from the top 6 bits),
-// f = u - jr/32 (exact), x = 2*pi*f with |x| <= pi/32; Taylor sin/cos of x, rotated by the table row jr mod 32.
+// sin/cos(2*pi*u) from the reduced argument: u = jr/32 + f with jr = round(32u) and x = 2*pi*f, |x| <= pi/32; Taylor sin/cos
+// of x, rotated by the table row jr mod 32.
 template <class Tab>
-BHIP_HD void det_sincos2pi(double u, uint32_t w, const Tab &tab, double &sn, double &cs)
+BHIP_HD void det_sincos_reduced(double x, uint32_t jr, const Tab &tab, double &sn, double &cs)
 {
-    const uint32_t jr = ((w >> 26) + 1u) >> 1;
-    const double f = fma_((double)jr, -0.03125, u);
     double ck, sk;
     tab.sc(jr & 31u, ck, sk);
-    const double x = f * 6.283185307179586;
     const double z = x * x;
     double ps = 1.0 / 362880.0;
     ps = fma_(ps, z, -1.0 / 5040.0);
@@ -206,20 +221,54 @@ BHIP_HD void det_sincos2pi(double u, uint32_t w, const Tab &tab, double &sn, dou
     cs = fma_(-sk, sf, ck * cf);
     sn = fma_(ck, sf, sk * cf);
 }
-
-// block `blk` of stream 0 -> normals 2*blk (z0) and 2*blk+1 (z1)
+// u = K*2^-53 in [0,1) whose top 32 source bits are `w` (53-bit angles; kept for the tests of the function itself)
 template <class Tab>
-BHIP_HD void normal_pair(const Tab &tab, uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t blk, double &z0, double &z1,
-                         uint32_t stream = 0u)
+BHIP_HD void det_sincos2pi(double u, uint32_t w, const Tab &tab, double &sn, double &cs)
 {
-    const u32x4 r = philox4x32_10(path, stream, iter, blk, k0, k1);
-    const double u1 = u53_open0(r.x, r.y);
-    const double u2 = u53_open1(r.z, r.w);
-    const double rad = sqrt_fixed_range(det_m2log(u1, tab));
+    const uint32_t jr = ((w >> 26) + 1u) >> 1;
+    const double f = fma_((double)jr, -0.03125, u);
+    det_sincos_reduced(f * 6.283185307179586, jr, tab, sn, cs);
+}
+// u = K24*2^-24: jr = round(32u) from the top six bits, f = u - jr/32 = (K24 - jr*2^19)*2^-24 exactly (an integer of at most
+// 19 bits), x = fl(2 pi)*f -- the same x the 53-bit form computes for this u
+template <class Tab>
+BHIP_HD void det_sincos2pi_k24(uint32_t k24, const Tab &tab, double &sn, double &cs)
+{
+    const uint32_t jr = ((k24 >> 18) + 1u) >> 1;
+    const int m = (int)k24 - (int)(jr << 19);
+    det_sincos_reduced((double)m * (6.283185307179586 * 0x1.0p-24), jr, tab, sn, cs);
+}
+
+// one Box-Muller transform from 64 of a Philox call's bits (words a, b): normals z0 (cos branch), z1 (sin branch)
+template <class Tab>
+BHIP_HD void box_muller_40_24(const Tab &tab, uint32_t a, uint32_t b, double &z0, double &z1)
+{
+    const double rad = sqrt_fixed_range(det_m2log(u40_open0(a, b), tab));
     double s, c;
-    det_sincos2pi(u2, r.w, tab, s, c);
+    det_sincos2pi_k24(b & 0xffffffu, tab, s, c);
     z0 = rad * c;
     z1 = rad * s;
+}
+
+// Philox call `q` of stream 0 -> normals 4q .. 4q+3
+template <class Tab>
+BHIP_HD void normal_quad(const Tab &tab, uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t q, double &z0, double &z1, double &z2,
+                         double &z3, uint32_t stream = 0u)
+{
+    const u32x4 r = philox4x32_10(path, stream, iter, q, k0, k1);
+    box_muller_40_24(tab, r.x, r.y, z0, z1);
+    box_muller_40_24(tab, r.z, r.w, z2, z3);
+}
+
+// pair `h` of stream 0 -> normals 2h (z0) and 2h+1 (z1): half h & 1 of Philox call h >> 1.  The generic form (host, the
+// kernels that draw few normals); the hot kernels draw whole calls with normal_quad.
+template <class Tab>
+BHIP_HD void normal_pair(const Tab &tab, uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t h, double &z0, double &z1,
+                         uint32_t stream = 0u)
+{
+    const u32x4 r = philox4x32_10(path, stream, iter, h >> 1, k0, k1);
+    const bool second = (h & 1u) != 0u;
+    box_muller_40_24(tab, second ? r.z : r.x, second ? r.w : r.y, z0, z1);
 }
 BHIP_HD void normal_pair(uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t blk, double &z0, double &z1)
 {

@@ -64,18 +64,44 @@ BHIP_DEV void sm_inv(const double *a, double *R)   // StaticArrays inv.jl
     }
 }
 
+// The divisions of the (Hdiamond, V) guide -- r = Hd_i \ (V_i - x), src/guip.jl:192-193: (V - x)/Hd for d = 1, cofactor
+// products over det(Hd_i) for d = 2, 3 (StaticArrays' closed forms) -- all divide by a value that belongs to the ROW, not to the
+// path.  The correctly rounded fp64 division the compiler emits is: reciprocal seed, two Newton steps (divisor only), then
+// q0 = a*y, rem = fma(-c, q0, a), q = fma(rem, y, q0).  The divisor-only part is done once per row -- on the host for shared
+// rows (1.0/c, the correctly rounded reciprocal the Newton steps converge to), here for per-chain rows -- and the step keeps
+// the three operations that depend on the path: the same bits as `a / c` (what the oracle computes) for 2^-200 < |c| < 2^200,
+// checked on the host for shared rows (UniformDivisor in bhip_models.h is the same construction for model constants).
+BHIP_DEV double sm_recip(double c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y0 = __builtin_amdgcn_rcp(c);
+    const double e0 = __builtin_fma(-c, y0, 1.0);
+    const double y1 = __builtin_fma(y0, e0, y0);
+    const double e1 = __builtin_fma(-c, y1, 1.0);
+    return __builtin_fma(y1, e1, y1);
+#else
+    return 1.0 / c;
+#endif
+}
+BHIP_DEV double sm_div_by(double a, double c, double y /* = sm_recip(c) */)
+{
+    const double q0 = a * y;
+    const double rem = __builtin_fma(-c, q0, a);
+    return __builtin_fma(rem, y, q0);
+}
+
 // the guide part of a coefficient row for the (Hdiamond, V) guide: bhip_host.hpp pack_rows
 template <int D>
 BHIP_DEV void hv_row_part(const double *A, const double *V, double *q)
 {
-    if constexpr (D == 1) { q[0] = A[0]; q[1] = V[0]; }
-    else if constexpr (D == 2) { q[0] = A[0]; q[1] = A[1]; q[2] = A[2]; q[3] = A[3]; q[4] = sm_det<2>(A); q[5] = V[0]; q[6] = V[1]; }
+    if constexpr (D == 1) { q[0] = A[0]; q[1] = V[0]; q[2] = sm_recip(A[0]); }
+    else if constexpr (D == 2) { q[0] = A[0]; q[1] = A[1]; q[2] = A[2]; q[3] = A[3]; q[4] = sm_det<2>(A); q[5] = V[0]; q[6] = V[1]; q[7] = sm_recip(q[4]); }
     else {
         auto a = [&](int i, int j) { return A[(i - 1) + 3 * (j - 1)]; };
         q[0] = a(2, 2) * a(3, 3) - a(2, 3) * a(3, 2); q[1] = a(1, 3) * a(3, 2) - a(1, 2) * a(3, 3); q[2] = a(1, 2) * a(2, 3) - a(1, 3) * a(2, 2);
         q[3] = a(2, 3) * a(3, 1) - a(2, 1) * a(3, 3); q[4] = a(1, 1) * a(3, 3) - a(1, 3) * a(3, 1); q[5] = a(1, 3) * a(2, 1) - a(1, 1) * a(2, 3);
         q[6] = a(2, 1) * a(3, 2) - a(2, 2) * a(3, 1); q[7] = a(1, 2) * a(3, 1) - a(1, 1) * a(3, 2); q[8] = a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1);
-        q[9] = sm_det<3>(A); q[10] = V[0]; q[11] = V[1]; q[12] = V[2];
+        q[9] = sm_det<3>(A); q[10] = V[0]; q[11] = V[1]; q[12] = V[2]; q[13] = sm_recip(q[9]);
     }
 }
 

@@ -97,6 +97,11 @@ int bhip_ctx_sync(bhip_ctx *ctx);
  * Euler recurrence and the log-likelihood; 0 selects the one-lane-does-everything kernels.  Results are bit-identical;
  * the switch exists for A/B measurements and for the test that proves the identity. */
 #define BHIP_OPT_WAVE_SPECIALISED 1
+/* BHIP_OPT_TUNE_PLACEMENT (default 1): chain ensembles of 1 GiB or more measure where their memory landed -- on MI355X the
+ * pCN iteration (three streams: read W, write Wo, write Xo) runs up to 15 % slower on some allocations than on others, for the
+ * life of the allocation.  bhip_chains_init then times a few iterations on up to four allocations, keeps the fastest and
+ * re-initialises (see bhip_chains_placement_info); 0 keeps the first allocation.  Results do not depend on it. */
+#define BHIP_OPT_TUNE_PLACEMENT 2
 int bhip_ctx_set_option(bhip_ctx *ctx, int option, int value);
 const char *bhip_last_error(const bhip_ctx *ctx);
 /* device memory helpers for callers without their own allocator */
@@ -255,6 +260,9 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
 void bhip_chains_destroy(bhip_chains *ch);
 /* iteration 0: W = sample(tt, Wiener()); solve!(X, x0, W, Po); ll = llikelihood(X, Po; skip) */
 int bhip_chains_init(bhip_chains *ch, const double *x0, int skip);
+/* what BHIP_OPT_TUNE_PLACEMENT did for this ensemble: allocations tried (0: not tuned), ms per pCN iteration on the first
+ * and on the chosen one */
+int bhip_chains_placement_info(const bhip_chains *ch, int *tries, float *ms_first, float *ms_best);
 /* `iters` pCN iterations: sample!(W2); Wo = rho*W + sqrt(1-rho^2)*W2; solve!; llo; accept iff
  * log(U) <= llo - ll.  skip applies to llo like partialbridge_nclar.jl:121; pass BHIP_SKIP_OF_INIT to use the skip the
  * ensemble was initialised with, so that llo and ll sum the same terms (partialbridge_fitzhugh.jl:131,155 passes its

@@ -223,7 +223,7 @@ double bo_logpdfnormal(int d, const double *x, const double *Sigma)
 }
 
 /* ------------------------------------------------------------------------------------------
- * RNG, specification "bhip-philox-v2" (DESIGN.md).  The reference draws from Julia's global
+ * RNG, specification "bhip-philox-v3" (DESIGN.md).  The reference draws from Julia's global
  * randn (src/wiener.jl:31,44,55) which cannot be reproduced outside Julia; this is
  * the counter-based replacement shared, by specification, with the HIP kernels.
  * ------------------------------------------------------------------------------------------ */
@@ -300,18 +300,45 @@ BO_CLONES void bo_sincos2pi(double u, uint32_t w, double *sn, double *cs)
     *sn = fma(ck, sf, sk * cf);
 }
 
-/* one Philox block -> two standard normals (Box-Muller).  counter = (path, stream, iter, block),
- * key = (seed_lo, seed_hi); stream 0 = Wiener normals, 1 = accept uniforms. */
-BO_CLONES void bo_normal_pair_stream(uint64_t seed, uint32_t path, uint32_t stream, uint32_t iter, uint32_t block, double z[2])
+/* sin/cos(2 pi u) for u = K24 2^-24 (24 bits of angle): jr = round(32 u) from the top six bits, f = u - jr/32 =
+ * (K24 - jr 2^19) 2^-24 exactly, x = fl(2 pi) f; then as bo_sincos2pi. */
+BO_CLONES void bo_sincos2pi_k24(uint32_t k24, double *sn, double *cs)
 {
-    uint32_t ctr[4] = {path, stream, iter, block}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, r[4];
+    uint32_t jr = ((k24 >> 18) + 1u) / 2u;
+    int32_t m = (int32_t)k24 - (int32_t)(jr << 19);
+    double f = (double)m * 0x1.0p-24;                    /* = u - jr/32, exact */
+    double ck = BO_SCTAB[2 * (jr % 32u)], sk = BO_SCTAB[2 * (jr % 32u) + 1];
+    double x = f * 6.283185307179586;
+    double z = x * x;
+    double ps = 1.0 / 362880.0;
+    ps = fma(ps, z, -1.0 / 5040.0);
+    ps = fma(ps, z, 1.0 / 120.0);
+    ps = fma(ps, z, -1.0 / 6.0);
+    double sf = fma(x * z, ps, x);
+    double pc = -1.0 / 3628800.0;
+    pc = fma(pc, z, 1.0 / 40320.0);
+    pc = fma(pc, z, -1.0 / 720.0);
+    pc = fma(pc, z, 1.0 / 24.0);
+    pc = fma(pc, z, -0.5);
+    double cf = fma(z, pc, 1.0);
+    *cs = fma(-sk, sf, ck * cf);
+    *sn = fma(ck, sf, sk * cf);
+}
+
+/* Specification v3: one Philox call -> FOUR standard normals, two Box-Muller pairs.  counter = (path, stream, iter, call),
+ * key = (seed_lo, seed_hi); stream 0 = Wiener normals, 1 = accept uniforms, 2 = pCN move of the start.
+ * Pair h (normals 2h, 2h+1) = half h & 1 of call h >> 1: words a = r[2s], b = r[2s+1];
+ *   u1 = (K40 + 1) 2^-40 in (0,1], K40 = (b >> 24) 2^32 + a;   u2 = K24 2^-24, K24 = b & 0xffffff. */
+BO_CLONES void bo_normal_pair_stream(uint64_t seed, uint32_t path, uint32_t stream, uint32_t iter, uint32_t h, double z[2])
+{
+    uint32_t ctr[4] = {path, stream, iter, h >> 1}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, r[4];
     bo_philox4x32_10(ctr, key, r);
-    uint64_t a = ((uint64_t)r[1] << 32) | r[0], b = ((uint64_t)r[3] << 32) | r[2];
-    double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;   /* (0,1] */
-    double u2 = (double)(b >> 11) * 0x1.0p-53;         /* [0,1) */
+    uint32_t a = r[2 * (h & 1u)], b = r[2 * (h & 1u) + 1];
+    uint64_t k40 = ((uint64_t)(b >> 24) << 32) | a;
+    double u1 = (double)(k40 + 1) * 0x1.0p-40;          /* (0,1] */
     double rad = sqrt(bo_m2log(u1));
     double s, c;
-    bo_sincos2pi(u2, r[3], &s, &c);
+    bo_sincos2pi_k24(b & 0xffffffu, &s, &c);
     z[0] = rad * c;
     z[1] = rad * s;
 }

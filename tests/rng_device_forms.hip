@@ -1,4 +1,4 @@
-// The device forms in bridge.jl_amd/csrc/bhip_rng.h (u53_bits, sqrt_fixed_range) against the portable expressions
+// The device forms in bridge.jl_amd/csrc/bhip_rng.h (u53_bits, u40_open0, sqrt_fixed_range, det_sincos2pi_k24) against the portable expressions
 // they replace -- integer->double conversion, IEEE square root -- on 2^32 pseudo-random inputs from the ranges the
 // generator uses, plus the range edges; and the table-driven -2*log / sincos read from LDS (TabLDS, the producer
 // waves' and the tile kernel's path) against the constant-memory reads (TabConst).  Any differing bit fails.
@@ -23,12 +23,21 @@ __global__ void k(unsigned long long *bad, int rounds)
         const unsigned long long a = ((unsigned long long)v.y << 32) | v.x;
         const double p0 = (double)((a >> 11) + 1) * 0x1.0p-53, p1 = (double)(a >> 11) * 0x1.0p-53;
         nb += !same(p0, bhip::u53_open0(v.x, v.y)) + !same(p1, bhip::u53_open1(v.x, v.y));
-        // the two table homes give the same normals
+        // specification v3: the 40-bit radius uniform (mantissa-field construction vs integer -> double conversion), the 24-bit
+        // angle (integer reduction vs the 53-bit routine on the same u), a whole call == its two pairs, LDS tables == constant tables
         {
-            double z0, z1, y0, y1;
-            bhip::normal_pair(bhip::TabConst(), 0x1234u, 0x5678u, t, (unsigned)r, 3u, z0, z1);
-            bhip::normal_pair(lds, 0x1234u, 0x5678u, t, (unsigned)r, 3u, y0, y1);
-            nb += !same(z0, y0) + !same(z1, y1);
+            const unsigned long long k40 = ((unsigned long long)(v.y >> 24) << 32) | v.x;
+            nb += !same((double)(k40 + 1) * 0x1.0p-40, bhip::u40_open0(v.x, v.y));
+            const unsigned k24 = v.w & 0xffffffu;
+            double s0, c0, s1, c1;
+            bhip::det_sincos2pi_k24(k24, lds, s0, c0);
+            bhip::det_sincos2pi((double)k24 * 0x1.0p-24, k24 << 8, bhip::TabConst(), s1, c1);
+            nb += !same(s0, s1) + !same(c0, c1);
+            double z0, z1, z2, z3, y0, y1, y2, y3;
+            bhip::normal_quad(lds, 0x1234u, 0x5678u, t, (unsigned)r, 3u, z0, z1, z2, z3);
+            bhip::normal_pair(bhip::TabConst(), 0x1234u, 0x5678u, t, (unsigned)r, 6u, y0, y1);
+            bhip::normal_pair(bhip::TabConst(), 0x1234u, 0x5678u, t, (unsigned)r, 7u, y2, y3);
+            nb += !same(z0, y0) + !same(z1, y1) + !same(z2, y2) + !same(z3, y3);
             nb += !(bhip::det_m2log(p0, lds) >= 0.0);
         }
         // square root: -2 log(u) with u spread over (0,1] including values next to 0 and next to 1
@@ -42,6 +51,7 @@ __global__ void k(unsigned long long *bad, int rounds)
         nb += !same(bhip::u53_open0(0xFFFFFFFFu, 0xFFFFFFFFu), 1.0) + !same(bhip::u53_open1(0u, 0u), 0.0) + !same(bhip::u53_open0(0u, 0u), 0x1.0p-53);
         nb += !same(bhip::u53_open1(0xFFFFFFFFu, 0xFFFFFFFFu), 1.0 - 0x1.0p-53);
         nb += !same(bhip::det_m2log(1.0, lds), 0.0) + !(bhip::det_m2log(1.0 - 0x1.0p-53, lds) > 0.0);
+        nb += !same(bhip::u40_open0(0xFFFFFFFFu, 0xFFFFFFFFu), 1.0) + !same(bhip::u40_open0(0u, 0x00FFFFFFu), 0x1.0p-40) + !same(bhip::u40_open0(0u, 0x01000000u), 0x1.0p-8 + 0x1.0p-40);
     }
     if (nb) atomicAdd(bad, nb);
 }

@@ -303,25 +303,22 @@ def test_device_forms_of_the_generator_are_bit_identical(tmp_path):
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("version", ["v2", "v3"])
 @pytest.mark.parametrize("case", problems.cases(101) + problems.forward_cases(101), ids=lambda c: c.name)
-def test_committed_golden_vectors_on_device(ctx, case, version):
-    """the frozen vectors (tests/golden/guided_paths_v2.npz, _v3.npz) through the C ABI: in-kernel noise, guided
-    solve, fused log-likelihood and a pCN chain reproduce them without the oracle being involved (v2 was written before the
-    shared sin / cos restatement: its sin-drift problems compare to 1e-9, everything in v3 bit for bit)"""
+def test_committed_golden_vectors_on_device(ctx, case):
+    """the frozen vectors (tests/golden/guided_paths_v4.npz, noise specification v3) through the C ABI: in-kernel noise, guided
+    solve, fused log-likelihood and a pCN chain reproduce them bit for bit without the oracle being involved"""
     import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"guided_paths_{version}.npz"))
-    lt = version == "v2"
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "guided_paths_v4.npz"))
     N, npaths, seed, iters = (int(v) for v in g["meta"])
     rho = float(g["rho"])
     Po = case.bh_proposal(bh, ctx)
     X, W, ll = bh.sample_solve(case.x0, Po, npaths, seed=seed, store_W=True)
     assert np.array_equal(W.paths(), g[case.name + "/W"])
-    check_paths(case, X.paths(), g[case.name + "/X"], libm_trig=lt)
+    check_paths(case, X.paths(), g[case.name + "/X"])
     if case.kind == o.GUIDE_NONE:
         return
-    check_ll(case, ll.cpu().numpy(), g[case.name + "/ll"], libm_trig=lt)
-    if case.exact and not (lt and case.trig) and (case.name + "/chain_W") in g.files:
+    check_ll(case, ll.cpu().numpy(), g[case.name + "/ll"])
+    if case.exact and (case.name + "/chain_W") in g.files:
         ch = bh.Chains(Po, case.x0, 2, seed=seed)
         ch.step(rho, iters)
         Xc, Wc = ch.paths(1, 1)
@@ -329,22 +326,25 @@ def test_committed_golden_vectors_on_device(ctx, case, version):
         assert ch.ll()[1] == g[case.name + "/chain_ll_acc"][0] and ch.acc()[1] == g[case.name + "/chain_ll_acc"][1]
 
 
+@pytest.mark.parametrize("version", ["v1", "v2", "v3"])
 @pytest.mark.parametrize("case", problems.cases(101) + problems.forward_cases(101), ids=lambda c: c.name)
-def test_round1_golden_paths_given_their_wiener_paths_on_device(ctx, case):
-    """guided_paths_v1.npz (noise specification v1): the guided paths and log-likelihoods GIVEN its stored Wiener paths
-    do not involve the generator; the external-W solve must still reproduce them (frozen round-1 arithmetic)"""
+def test_earlier_golden_paths_given_their_wiener_paths_on_device(ctx, case, version):
+    """guided_paths_v1.npz (noise specification v1), _v2.npz, _v3.npz (specification v2): the guided paths and
+    log-likelihoods GIVEN their stored Wiener paths do not involve the generator; the external-W solve must still reproduce
+    them (the frozen arithmetic of rounds 1 and 2 guards the solver across the changes of the noise specification)"""
     import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "guided_paths_v1.npz"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"guided_paths_{version}.npz"))
+    lt = version in ("v1", "v2")          # written before the shared fdlibm-form sin / cos
     Po = case.bh_proposal(bh, ctx)
     W = bh.EnsemblePath.from_paths(case.tt, g[case.name + "/W"], ctx)
     if case.kind == o.GUIDE_NONE:
         X = bh.solve(bh.EulerMaruyama(), case.x0, W, Po)
-        check_paths(case, X.paths(), g[case.name + "/X"], libm_trig=True)
+        check_paths(case, X.paths(), g[case.name + "/X"], libm_trig=lt)
         return
     ll = ctx.empty(W.npaths)
     X = bh.solve(bh.Euler(), case.x0, W, Po, ll=ll)
-    check_paths(case, X.paths(), g[case.name + "/X"], libm_trig=True)
-    check_ll(case, ll.cpu().numpy(), g[case.name + "/ll"], libm_trig=True)
+    check_paths(case, X.paths(), g[case.name + "/X"], libm_trig=lt)
+    check_ll(case, ll.cpu().numpy(), g[case.name + "/ll"], libm_trig=lt)
 
 
 def test_chains_with_skip_match_oracle(ctx):

@@ -119,3 +119,29 @@ def test_no_store_variants_and_per_path_starts(ctx):
         W = o.wiener_sample(case.tt, 1, 5, p, 1)
         Xr = o.solve_guided(ref, x0s[p], W)
         assert np.array_equal(a[2][p], Xr) and a[0][p] == o.llikelihood(ref, Xr)
+
+
+def test_placement_tuning_changes_nothing_but_the_allocation(ctx):
+    """BHIP_OPT_TUNE_PLACEMENT: an ensemble of 1 GiB or more times a few pCN iterations on up to four allocations and keeps the
+    fastest; the state is initialised afresh afterwards, so chains, paths and statistics are those of an untuned ensemble"""
+    import torch
+    case = [c for c in problems.cases(1001) if c.name == "fhn_partialbridge_extreme"][0]
+    Po = case.bh_proposal(bh, ctx)
+    n = 36000                                            # x 32 KB of state per chain > 1 GiB
+    a = bh.Chains(Po, case.x0, n, seed=9)
+    info = a.placement()
+    assert 1 <= info["tries"] <= 4 and 0 < info["ms_best"] <= info["ms_first"]
+    a.step(0.9, 3)
+    ctx.set_option(bh.OPT_TUNE_PLACEMENT, 0)
+    try:
+        b = bh.Chains(Po, case.x0, n, seed=9)
+    finally:
+        ctx.set_option(bh.OPT_TUNE_PLACEMENT, 1)
+    assert b.placement()["tries"] == 0
+    b.step(0.9, 3)
+    assert np.array_equal(a.ll(), b.ll()) and np.array_equal(a.acc(), b.acc()) and torch.equal(a.stats(), b.stats())
+    Xa, Wa = a.paths(n - 3, 3)
+    Xb, Wb = b.paths(n - 3, 3)
+    assert np.array_equal(Xa, Xb) and np.array_equal(Wa, Wb)
+    small = bh.Chains(Po, case.x0, 512, seed=9)          # small ensembles are not tuned
+    assert small.placement()["tries"] == 0

@@ -443,16 +443,19 @@ def _check_given_W(g, with_noise, libm_trig=False):
 
 
 def test_oracle_reproduces_committed_golden_vectors():
-    """tests/golden/guided_paths_v2.npz (written by tests/golden/make_golden.py) freezes the oracle and the noise
-    specification bhip-philox-v2: Wiener paths, guided paths, log-likelihoods and a short pCN chain for every test problem."""
+    """tests/golden/guided_paths_v4.npz (written by tests/golden/make_golden.py) freezes the oracle and the noise
+    specification bhip-philox-v3: Wiener paths, guided paths, log-likelihoods and a short pCN chain for every test problem,
+    all bit for bit."""
     assert os.path.exists(os.path.join(GOLD, "make_golden.py"))
-    _check_given_W(np.load(os.path.join(GOLD, "guided_paths_v2.npz")), True, libm_trig=True)
+    _check_given_W(np.load(os.path.join(GOLD, "guided_paths_v4.npz")), True)
 
 
-def test_oracle_reproduces_golden_vectors_v3_all_exact():
-    """guided_paths_v3.npz: written after sin / cos of the drift functions got their shared fdlibm-form restatement (bo_sin /
-    bo_cos = bhip_trig.h): every d <= 3 problem, the sin-drift ones included, is reproduced bit for bit, chains too."""
-    _check_given_W(np.load(os.path.join(GOLD, "guided_paths_v3.npz")), True)
+def test_oracle_reproduces_earlier_golden_vectors_given_their_wiener_paths():
+    """guided_paths_v2.npz / _v3.npz were written under the noise specification v2 (round 2): their Wiener paths are no longer
+    what the generator draws, but the guided paths and log-likelihoods GIVEN those stored paths do not involve it and must
+    still come out bit for bit (v2 predates the shared sin / cos restatement: its sin-drift problems compare to 1e-12)."""
+    _check_given_W(np.load(os.path.join(GOLD, "guided_paths_v2.npz")), False, libm_trig=True)
+    _check_given_W(np.load(os.path.join(GOLD, "guided_paths_v3.npz")), False)
 
 
 def test_drift_sin_cos_restatement_is_accurate():
