@@ -289,7 +289,7 @@ class UserProcess(ContinuousTimeProcess):
 
 
 class UserProcessComponents(ContinuousTimeProcess):
-    """A user-defined target at LARGE state dimension (even 4 <= d <= 32, dense constant sigma [d, d]): the body of
+    """A user-defined target at LARGE state dimension (4 <= d <= 32, dense constant sigma [d, d]): the body of
     `Bridge.b(t, x, P)` given COMPONENT-WISE as HIP C++ text -- it sees `int k` (component), `int d`, `double t`,
     `const double* x`, `const double* par` and writes `double o` -- compiled into the fp64-MFMA tile kernel with hipRTC:
 

@@ -397,7 +397,7 @@ static int model_define(bhip_ctx *ctx, int d, int mp, int npar, const char *drif
 int bhip_model_define_components(bhip_ctx *ctx, int d, int npar, const char *component_src, int *model_id)
 {
     if (!ctx || !component_src || !model_id) return BHIP_EINVAL;
-    if (d < 4 || d > 32 || (d & 1)) return fail(ctx, BHIP_EUNSUPPORTED, "bhip_model_define_components: even state dimension 4 <= d <= 32 (the MFMA tile kernel); d <= 3: bhip_model_define");
+    if (d < 4 || d > 32) return fail(ctx, BHIP_EUNSUPPORTED, "bhip_model_define_components: state dimension 4 <= d <= 32 (the MFMA tile kernel); d <= 3: bhip_model_define");
     if (npar < 0 || npar > 16) return fail(ctx, BHIP_EINVAL, "bhip_model_define_components: at most 16 drift parameters");
     std::unique_ptr<UserModel> um(new UserModel());
     um->d = d; um->mp = d; um->npar = npar; um->drift = component_src; um->components = true;
@@ -674,11 +674,11 @@ static int build_tile_data(bhip_proposal *po)
     bhip_ctx *ctx = po->ctx;
     const int N = (int)po->tt.size(), d = po->mh.d;
     const bool plain = po->g.kind == BHIP_GUIDE_NONE;   // forward Euler-Maruyama: the guide matrices are zero
-    // The tile kernel is instantiated for 16 and 32 components; other EVEN dimensions 4..30 run zero padded (an even
-    // dimension keeps a Philox block inside one grid point, which the lane-pair exchange of the normals relies on).
+    // The tile kernel is instantiated for 16 and 32 components; every other dimension 4..31 runs zero padded (the noise keeps
+    // the d-component counter layout: normal i*d + row, whatever the parity of d -- bhip_tile_kernel.h).
     const bool user = po->mh.id >= USER_MODEL_BASE;   // component-wise hipRTC drift (bhip_model_define_components): no B, mu
-    if ((po->mh.id != BHIP_MODEL_LINPRO && !user) || d > 32 || (d & 1))
-        return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: LinPro target or a component-wise user drift, even dimension 4 <= d <= 32");
+    if ((po->mh.id != BHIP_MODEL_LINPRO && !user) || d > 32)
+        return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: LinPro target or a component-wise user drift, dimension 4 <= d <= 32");
     if (!plain && (!po->has_aux || (po->aux.kind != BHIP_AUX_AFFINE && po->aux.kind != BHIP_AUX_LINPRO)))
         return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: time-constant auxiliary process");
     const int Dp = tile_dim(d);

@@ -19,9 +19,9 @@
 // The path-independent per-step matrix Hm_i (8 KiB at d = 32) is streamed global -> LDS once per block
 // and step (double-buffered, one barrier per step) and shared by the block's 4 waves; the four
 // constant matrices live in LDS for the whole kernel.  Noise: every lane needs 8 normals per step; a
-// Philox block yields the normals of rows 2m and 2m+1, which sit in partner lanes (lane ^ 16), so each
-// lane generates half of the pair's blocks and they exchange by shuffle.  The per-path log-weight is
-// reduced over the 4 row groups of a path with two wavefront shuffles.
+// Philox call yields the normals of four consecutive rows, which sit in the four lanes of the path's
+// column, so each lane draws a quarter of the path's calls and they exchange through a small LDS
+// transpose.  The per-path log-weight is reduced over the 4 row groups of a path with two wavefront shuffles.
 //
 // Numerics: MFMA accumulates with fused multiply-adds in k order and the guide solve is replaced by a
 // product with the pre-inverted matrix, so parity with the oracle is tolerance-based here
@@ -33,6 +33,7 @@
 namespace bhip {
 
 typedef double double4v __attribute__((ext_vector_type(4)));
+constexpr int TILE_ZB = 16 * 18;   // doubles of noise-exchange buffer per wave (k_tile): 16 columns x 16 normals, row stride 18
 
 // Timing experiments only (results become WRONG): bit0 no per-step barrier / matrix staging, bit1 no normal
 // generation, bit2 no MFMA products, bit3 no chain-state loads, bit4 no chain-state stores (pCN instantiation).  scripts/gpu_tile_probe.py runs the variants (profiles/r1_tile_breakdown.txt).
@@ -121,7 +122,8 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     double *hb = lds + 4 * DD + 5 * D; // 2 * STEP
     double *rtab_lds = hb + 2 * STEP;  // the generator's tables (RNG_TAB_DOUBLES), for the noise-drawing instantiations
     double *xs_lds = rtab_lds + RNG_TAB_DOUBLES;   // UD::ON: the state vectors of the block's 64 paths, [4 waves][16 paths][D]
-    double *wb_lds = xs_lds + (UD::ON ? 64 * D : 0);   // NOISE == 2: per wave 2T x 64 16-byte pieces of the chain's current W (LDS-DMA target)
+    double *zb_lds = xs_lds + (UD::ON ? 64 * D : 0);   // noise exchange: per wave 16 paths x 16 normals (row stride 18: conflict-free)
+    double *wb_lds = zb_lds + 4 * TILE_ZB;             // NOISE == 2: per wave 2T x 64 16-byte pieces of the chain's current W (LDS-DMA target)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, j = lane & 15;
     const long p_raw = (long)blockIdx.x * 64 + wave * 16 + j;
@@ -277,20 +279,41 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                         wcur[t][2 * jj] = v.x; wcur[t][2 * jj + 1] = v.y;
                     }
             }
-            // normal index n = i*D + row; block n>>1 = i*D/2 + 2*ks + (kq>>1), element kq&1 (ks = 4t+r).
-            // lanes kq and kq^1 share blocks: the even lane draws ks = 0..2T-1, the odd one ks = 2T..4T-1.
-            const bool odd = (kq & 1) != 0;
-            double mine[4 * T];   // statically indexed (values are selected, never indices)
+            // Row `row` of the path takes normal n = i*dtr + row = number n & 3 of Philox call n >> 2 (bhip_rng.h: four normals per
+            // call).  Per pass t the path's rows 16t .. 16t+15 are the normals nb .. nb+15, nb = i*dtr + 16t: four calls, one per
+            // lane kq of the path's column, whose normals land in the column's 16-entry exchange row in LDS -- lane kq writes
+            // entries 4kq .. 4kq+3 and reads back entries 4r + kq, the rows it holds: a 4 x 4 transpose among the four lanes.
+            // PAD (any dtr, odd ones too): nb need not be a multiple of 4; the window then straddles five calls and lane 0
+            // draws the fifth.
+            double mine[4 * T];   // statically indexed
+            double *zb = zb_lds + (size_t)wave * TILE_ZB + j * 18;
 #pragma unroll
-            for (int h = 0; h < 2 * T; h++) {
-                const int ks = h + (odd ? 2 * T : 0);
-                double z0, z1;
-                if constexpr ((BHIP_TILE_EXP & 2) != 0) { z0 = 1e-3 * (double)(lane + ks); z1 = -z0; }
-                else normal_pair(rtab, a.k0, a.k1, path, a.iter, (uint32_t)(i * (dtr / 2) + 2 * ks + (kq >> 1)), z0, z1);
-                const double keep = odd ? z1 : z0, give = odd ? z0 : z1;
-                const double got = __shfl_xor(give, 16, 64);   // partner's block: h (partner even) or h + 2T (partner odd)
-                mine[h] = odd ? got : keep;            // K-slice h       : drawn by the even lane
-                mine[h + 2 * T] = odd ? keep : got;    // K-slice h + 2T  : drawn by the odd lane
+            for (int t = 0; t < T; t++) {
+                const uint32_t nb = (uint32_t)i * (uint32_t)dtr + 16u * (uint32_t)t;
+                double z[4];
+                if constexpr ((BHIP_TILE_EXP & 2) != 0) { z[0] = 1e-3 * (double)(lane + t); z[1] = -z[0]; z[2] = 0.5 * z[0]; z[3] = -z[2]; }
+                else normal_quad(rtab, a.k0, a.k1, path, a.iter, (nb >> 2) + (uint32_t)kq, z[0], z[1], z[2], z[3]);
+                if constexpr (!PAD) {
+                    *(tile_d2v *)(zb + 4 * kq) = tile_d2v{z[0], z[1]};
+                    *(tile_d2v *)(zb + 4 * kq + 2) = tile_d2v{z[2], z[3]};
+                } else {
+                    const int off = (int)(nb & 3u);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int pos = 4 * kq + u - off;
+                        if (pos >= 0) zb[pos] = z[u];          // (pos <= 15 always)
+                    }
+                    if (off != 0 && kq == 0) {                 // wave-uniform `off`: the window's last entries come from a fifth call
+                        normal_quad(rtab, a.k0, a.k1, path, a.iter, (nb >> 2) + 4u, z[0], z[1], z[2], z[3]);
+#pragma unroll
+                        for (int u = 0; u < 3; u++)
+                            if (u < off) zb[16 + u - off] = z[u];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();   // one wave's LDS operations execute in order: the writes precede the reads
+#pragma unroll
+                for (int r = 0; r < 4; r++) mine[4 * t + r] = zb[4 * r + kq];
+                __builtin_amdgcn_wave_barrier();   // ... and the reads precede the next pass's writes
             }
             double *qo = wop;
 #pragma unroll
@@ -430,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 // dynamic LDS of k_tile<D, ., ., UD>: constants, two step buffers, generator tables (+ the gathered states for a user drift)
 constexpr size_t tile_lds_bytes(int D, bool user, bool chains = true)
 {
-    return sizeof(double) * (4 * D * D + 5 * D + 2 * (D * D + D + 2) + RNG_TAB_DOUBLES + (user ? 64 * D : 0) + (chains ? 4 * 2 * (D / 16) * 128 : 0));
+    return sizeof(double) * (4 * D * D + 5 * D + 2 * (D * D + D + 2) + RNG_TAB_DOUBLES + (user ? 64 * D : 0) + 4 * TILE_ZB + (chains ? 4 * 2 * (D / 16) * 128 : 0));
 }
 
 template <int D, int NOISE, bool PAD = false>

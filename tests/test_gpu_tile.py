@@ -159,11 +159,11 @@ def test_tile_kernel_pcn_chains(ctx, d, kind):
     assert np.abs(m2[40] - (Xall[:, 40] - mean[40]).T @ (Xall[:, 40] - mean[40])).max() < 1e-10
 
 
-@pytest.mark.parametrize("d", [4, 6, 10, 24, 30])
-def test_tile_kernel_other_even_dimensions_run_zero_padded(ctx, d):
-    """LinPro targets of any even dimension 4..30 run on the 16- or 32-component instantiation with zero padding: the
-    noise keeps the d-component counter layout (Wiener paths bit-exact), the ensembles hold d rows, results agree with
-    the oracle to the MFMA tolerance; odd dimensions are refused."""
+@pytest.mark.parametrize("d", [4, 5, 6, 7, 10, 15, 17, 24, 30, 31])
+def test_tile_kernel_other_dimensions_run_zero_padded(ctx, d):
+    """LinPro targets of any dimension 4..31 -- odd ones too since round 3 -- run on the 16- or 32-component instantiation with
+    zero padding: the noise keeps the d-component counter layout (normal i*d + row of Philox call (i*d + row) >> 2: Wiener paths
+    bit-exact), the ensembles hold d rows, results agree with the oracle to the MFMA tolerance."""
     c = problems.linpro_big_case(d, 81)
     P = 40
     Po, ref = c.bh_proposal(bh, ctx), c.oracle_proposal()
@@ -194,10 +194,10 @@ def test_tile_kernel_other_even_dimensions_run_zero_padded(ctx, d):
     assert abs(ch.ll()[17] - r["ll"]) <= 1e-8 * (1 + abs(r["ll"]))
 
 
-def test_tile_kernel_refuses_odd_and_too_large_dimensions(ctx):
-    for d in (5, 33):
+def test_tile_kernel_refuses_too_large_dimensions(ctx):
+    for d in (33, 40):
         B, sig = -np.eye(d), 0.5 * np.eye(d)
-        with pytest.raises(bh.BridgeError, match="even dimension"):
+        with pytest.raises(bh.BridgeError, match="dimension 4 <= d <= 32"):
             bh.GuidedBridge(np.linspace(0, 1, 11), bh.LinPro(B, np.zeros(d), sig), bh.LinPro(B, np.zeros(d), sig), np.zeros(d), ctx=ctx)
 
 

@@ -32,12 +32,13 @@ def test_component_text_is_validated_without_a_gpu():
     assert P.model_id >= 1000 and len(P.params()) == 1 + 256
     with pytest.raises(bh.BridgeError, match="error"):
         bh.UserProcessComponents(16, "o = undefined_symbol(x[k]);", [2.0], 0.5 * np.eye(16), ctx=hctx)
-    with pytest.raises(bh.BridgeError, match="even state dimension"):
-        bh.UserProcessComponents(7, L96, [2.0], np.eye(7), ctx=hctx)
+    with pytest.raises(bh.BridgeError, match="state dimension 4 <= d <= 32"):
+        bh.UserProcessComponents(33, L96, [2.0], np.eye(33), ctx=hctx)
+    assert bh.UserProcessComponents(7, L96, [2.0], np.eye(7), ctx=hctx).model_id >= 1000      # odd dimensions too (round 3)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("d", [16, 32, 8])        # 8: zero padded onto the 16-component instantiation
+@pytest.mark.parametrize("d", [16, 32, 8, 9])     # 8, 9: zero padded onto the 16-component instantiation
 def test_lorenz96_guided_bridge_on_the_tile_kernel(d):
     ctx = bh.default_context(0)
     tt, x0, v, sig, Baux, F = problem(d)
