@@ -417,7 +417,15 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 if (idx < STEP) hb[(cur ^ 1) * STEP + idx] = stage[c];
             }
         }
-        if constexpr (NOISE == 2 && BHIP_TILE_LDSDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of W[i+2] has landed (issued a step ago)
+        if constexpr (NOISE == 2 && BHIP_TILE_LDSDMA) {
+            // The DMA of W[i+2] (issued at the top of this step) must have landed before the next step reads it.  vmcnt counts
+            // loads and stores in issue order, so it is enough that at most the operations issued AFTER the DMA are still
+            // outstanding: this step's 2T proposal-line stores (unconditional) and, unpadded with the path store on, its 4T path
+            // stores.  vmcnt(0) here -- round 2 -- also waited for those stores to be acknowledged by the L2: a write round trip
+            // per step, the 2.7 ms the chain kernel took over the proposal kernel.
+            if (!PAD && NOISE != 3 && a.X) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * T) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * T) : "memory");
+        }
         if constexpr ((BHIP_TILE_EXP & 1) == 0) __syncthreads();
     }
 

@@ -142,3 +142,121 @@ def test_fhn_path_against_50_digit_arithmetic():
     err = np.abs(Xo - X).max()
     assert err < 1e-9 * (1 + np.abs(X).max()), err
     assert abs(llo - float(ll)) < 1e-8 * (1 + abs(float(ll))), (llo, float(ll))
+
+
+# --------------------------------------------------------------------------- round 3: the application loop (f1 / f2 twins)
+class _SpecNoise:
+    """The noise of the specification (bhip-philox-v3) handed to the second restatement: Wiener paths of segment i at iteration
+    `it` (stream 0, pairs offset by i*2^24 = normals offset by i*2^25), the normals of rand(pi0) (stream 2), the uniform
+    (stream 1).  Only the generator comes from the oracle library; every use of the numbers is the restatement's own."""
+
+    def __init__(self, tts, mp, d, seed, path):
+        self.tts, self.mp, self.d, self.seed, self.path = tts, mp, d, seed, path
+
+    def wiener(self, i, it):
+        tt = self.tts[i]
+        N = len(tt)
+        z = o.normals(self.seed, self.path, it, i << 25, (N - 1) * self.mp).reshape(N - 1, self.mp)
+        W = np.zeros((N, self.mp))
+        for j in range(1, N):
+            W[j] = W[j - 1] + np.sqrt(tt[j] - tt[j - 1]) * z[j - 1]
+        return W
+
+    def randn(self, it):
+        import ctypes as C
+        lib = o.lib()
+        out, pr = np.zeros(self.d + 1), (C.c_double * 2)()
+        for k in range(0, self.d, 2):
+            lib.bo_normal_pair_stream(C.c_uint64(self.seed), C.c_uint32(self.path), C.c_uint32(2), C.c_uint32(it), C.c_uint32(k >> 1), pr)
+            out[k], out[k + 1] = pr[0], pr[1]
+        return out[:self.d]
+
+    def rand(self, it):
+        return o.uniform_accept(self.seed, self.path, it)
+
+
+def test_smoothing_loop_with_shared_guides_second_restatement():
+    """f1: chained GuidedBridge segments (LinPro-2 target, a different LinPro auxiliary), gpupdate links, pCN on the start, joint
+    accept, mcnext! -- bo_smooth_mcmc against the numpy restatement of smoothing.jl:99-213, on the same specification noise"""
+    rng = np.random.default_rng(5)
+    m, M, d = 3, 40, 2
+    B = np.array([[-1, 0.1], [-0.2, -1]])
+    sig = 2 * np.array([[-0.212887, 0.0687025], [0.193157, 0.388997]])
+    L, Sig = np.array([[1.0, 0.0]]), np.array([[0.05]])
+    tgrid = np.linspace(0, 0.3 * m, m * M + 1)
+    obs = rng.standard_normal((m + 1, 1))
+    P, Pt = jr.LinPro(B, [0.02, 0.03], sig), jr.LinPro(0.8 * B, [0.0, 0.0], sig)
+    par, apar = o.linpro_par(B, [0.02, 0.03], sig), o.linpro_par(0.8 * B, [0.0, 0.0], sig)
+    # both sides build their own chain of proposals backwards (test/smoothing.jl:73-85)
+    H, v = jr.gpupdate(np.diag([np.inf] * d), np.zeros(d), np.eye(d), 0.5 * np.eye(d), np.array([obs[m, 0], 0.0]))
+    Ho, vo = o.gpupdate(np.diag([np.inf] * d), np.zeros(d), np.eye(d), 0.5 * np.eye(d), np.array([obs[m, 0], 0.0]))
+    assert np.allclose(H, Ho, rtol=1e-12) and np.allclose(v, vo, rtol=1e-12)
+    tts, Po, refs = [None] * m, [None] * m, [None] * m
+    for i in range(m - 1, -1, -1):
+        tts[i] = tgrid[i * M:(i + 1) * M + 1].copy()
+        Po[i] = jr.GuidedBridge(tts[i], P, Pt, v, H)
+        Hd, V = o.gp_hv(tts[i], d, d, o.AUX_LINPRO, apar, vo, Ho)
+        refs[i] = o.proposal_hv(tts[i], d, d, o.MODEL_LINPRO, par, o.AUX_LINPRO, apar, Hd, V)
+        H, v = jr.gpupdate(Po[i].Hd[0], Po[i].V[0], L, Sig, obs[i])
+        Ho, vo = o.gpupdate(Hd[0], V[0], L, Sig, obs[i])
+        assert np.allclose(H, Ho, rtol=1e-10) and np.allclose(v, vo, rtol=1e-10)
+    iters = 25
+    w_new = np.sqrt(rng.uniform(0.05, 0.5, iters)); w_old = np.sqrt(1 - w_new ** 2)
+    seed, path = 17, 41
+    ro = o.smooth_mcmc(refs, vo, o.chol_lower(Ho), w_old, w_new, seed, path, stats=True)
+    rj = jr.smooth((v, H), tts, P, Po, jr.llikelihood, _SpecNoise(tts, d, d, seed, path), iters, w_new, w_old)
+    assert rj["acc"] == ro["acc"] and 0 < ro["acc"] < iters
+    for k, tol in (("X", 1e-9), ("W", 1e-12), ("y0", 1e-9), ("mean", 1e-9), ("m2", 1e-8), ("ll", 1e-8)):
+        assert np.abs(rj[k] - ro[k]).max() <= tol * (1 + np.abs(ro[k]).max()), k
+
+
+def test_adaptive_smoothing_loop_second_restatement():
+    """f2: Lorenz, LinearAppr auxiliaries along a path, the index-based Heun guide, gpupdate, and the adaptation of
+    smoothing.jl:130-160 (re-linearisation around the chain's mcnext! means, new pi0, newblock, doaccept) -- bo_smooth_adaptive
+    (and its pieces bo_linearappr, bo_gp_hv_heuni, bo_gpupdate, bo_mcnext) against the numpy restatement, same noise"""
+    m, M = 2, 30
+    par = [10.0, 20.0, 8 / 3, 3.0, 3.0, 3.0]
+    P = jr.Lorenz(par[:3], par[3:])
+    tgrid = np.linspace(0.0, 0.12, m * M + 1)
+    Yall = np.stack([1.5 + tgrid, -1.5 + 2 * tgrid, 25.0 - tgrid], 1)
+    tts = [tgrid[i * M:(i + 1) * M + 1].copy() for i in range(m)]
+    Y0 = [Yall[i * M:(i + 1) * M + 1] for i in range(m)]
+    L, Sig = np.eye(3), 0.5 * np.eye(3)
+    obs = Yall[::M] + 0.3
+    HT, vT = jr.gpupdate(1e3 * np.eye(3), np.zeros(3), L, Sig, obs[m])
+    HTo, vTo = o.gpupdate(1e3 * np.eye(3), np.zeros(3), L, Sig, obs[m])
+    assert np.allclose(HT, HTo, rtol=1e-12) and np.allclose(vT, vTo, rtol=1e-12)
+    # the pieces: linearappr and the index-based Heun guide of one segment
+    Bo, bo_, So = o.linearappr(o.MODEL_LORENZ, 3, 3, par, tts[1], Y0[1])
+    la = jr.LinearAppr(tts[1], Y0[1], P)
+    assert np.allclose(np.stack(la.Bs), Bo, rtol=1e-14) and np.allclose(np.stack(la.bs), bo_, rtol=1e-14)
+    Hdo, Vo = o.gp_hv_heuni(tts[1], 3, 3, Y0[1], Bo, bo_, So, vTo, HTo)
+    gb = jr.GuidedBridgeLA(tts[1], P, la, vT, HT)
+    assert np.abs(np.stack(gb.Hd) - Hdo).max() <= 1e-11 * np.abs(Hdo).max() and np.abs(np.stack(gb.V) - Vo).max() <= 1e-11 * np.abs(Vo).max()
+    # the loop, through two adaptations
+    iters, adaptit = 14, 5
+    rng = np.random.default_rng(3)
+    w_new = np.sqrt(rng.uniform(0.05, 0.4, iters)); w_old = np.sqrt(1 - w_new ** 2)
+    seed, path = 7, 3
+    ro = o.smooth_adaptive(o.MODEL_LORENZ, 3, 3, par, np.stack(tts), np.stack(Y0), L, Sig, obs[:m], HTo, vTo, w_old, w_new, adaptit, 10 ** 6, seed, path)
+    H, v, Po = HT, vT, [None] * m
+    for i in range(m - 1, -1, -1):
+        Po[i] = jr.GuidedBridgeLA(tts[i], P, jr.LinearAppr(tts[i], Y0[i], P), v, H)
+        H, v = jr.gpupdate(Po[i].Hd[0], Po[i].V[0], L, Sig, obs[i])
+    rj = jr.smooth((v, H), tts, P, Po, jr.llikelihood_indexed, _SpecNoise(tts, 3, 3, seed, path), iters, w_new, w_old,
+                   L=L, Sigma=Sig, obs=obs, HT=HT, vT=vT, adaptit=adaptit, adaptmax=10 ** 6)
+    assert rj["acc"] == ro["acc"] and ro["acc"] >= 2
+    for k, tol in (("X", 1e-9), ("W", 1e-12), ("y0", 1e-9), ("mean", 1e-9), ("m2", 1e-8), ("ll", 1e-8), ("mu", 1e-9), ("H", 1e-9)):
+        assert np.abs(rj[k] - ro[k]).max() <= tol * (1 + np.abs(ro[k]).max()), k
+    assert np.abs(np.stack([np.stack(p.Hd) for p in rj["Po"]]) - ro["Hd"]).max() <= 1e-9 * np.abs(ro["Hd"]).max()
+    # with the moving-average variant of the re-linearisation (smoothmean, hwindow)
+    ro = o.smooth_adaptive(o.MODEL_LORENZ, 3, 3, par, np.stack(tts), np.stack(Y0), L, Sig, obs[:m], HTo, vTo, w_old, w_new, adaptit, 10 ** 6, seed, path, hwindow=4)
+    H, v, Po = HT, vT, [None] * m
+    for i in range(m - 1, -1, -1):
+        Po[i] = jr.GuidedBridgeLA(tts[i], P, jr.LinearAppr(tts[i], Y0[i], P), v, H)
+        H, v = jr.gpupdate(Po[i].Hd[0], Po[i].V[0], L, Sig, obs[i])
+    rj = jr.smooth((v, H), tts, P, Po, jr.llikelihood_indexed, _SpecNoise(tts, 3, 3, seed, path), iters, w_new, w_old,
+                   L=L, Sigma=Sig, obs=obs, HT=HT, vT=vT, adaptit=adaptit, adaptmax=10 ** 6, smoothmean=True, hwindow=4)
+    assert rj["acc"] == ro["acc"]
+    for k in ("X", "mean", "mu"):
+        assert np.abs(rj[k] - ro[k]).max() <= 1e-9 * (1 + np.abs(ro[k]).max()), k
