@@ -23,6 +23,7 @@ Other modes (`--mode`), each a named BASELINE / SURVEY 8(d) configuration:
   nclar       D1's "3-d": NCLAR partial bridge, 262 144 fresh proposals (24 B/path-step)
   nclar_mcmc  the same as pCN chains (40 B/path-step)
   linpro32    C5: LinPro d = 32 on the fp64 matrix cores, 65 536 paths;  linpro32_mcmc: its pCN chains
+  linpro4     the same process family at d = 4: one path per lane (4 <= d <= 8), 262 144 paths
 At N = 1 the default run appends the kernel-level figures of all of them as `other_modes` (measured after the timed
 region), a `smoothing` record (the application loop of SURVEY 8(f) 1-2: joint MH over chained Lorenz segments with shared
 and with per-chain device-built guides), a `sustained` record (>= 1 s of back-to-back launches) and the CPU baseline.  At N > 1 the SURVEY-C4 shard size
@@ -122,12 +123,12 @@ def cpu_baseline(seconds_budget=20.0):
                       "C restatement of Bridge.jl's four-pass loop (no Julia on this box), not Bridge.jl itself"}
 
 
-PROFILE_TAG = "r2"   # profiles/<PROFILE_TAG>_<mode>_{trace,fetch,write}.txt, written by scripts/gpu_profile.sh this round
+PROFILE_TAG = "r3"   # profiles/<PROFILE_TAG>_<mode>_{trace,fetch,write}.txt, written by scripts/gpu_profile.sh this round
 
 
 def profiled_traffic(mode, kernel_name):
     """HBM bytes per launch of the dominant kernel from this round's committed rocprofv3 PMC summaries
-    (profiles/r2_<mode>_fetch.txt, _write.txt; separate --pmc passes of `bench.py --mode <mode>`, scripts/gpu_profile.sh).
+    (profiles/r3_<mode>_fetch.txt, _write.txt; separate --pmc passes of `bench.py --mode <mode>`, scripts/gpu_profile.sh).
     FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream
     (MI355X_MICROARCH.md, HBM section), hence the factor 2.  The kernel is looked up by the exact name the current
     build launches: a summary that does not contain it (kernel changed, profile stale) gives NO figure -- loudly."""
@@ -152,7 +153,7 @@ def profiled_traffic(mode, kernel_name):
 
 def profiled_valu(mode, kernel_name, paths):
     """Issue-side context for the roofline record, from this round's committed SQ counter summaries of the same command
-    (profiles/r2_<mode>_sq.txt, _sq2.txt; summed over the 8 XCDs): VALU wave-instructions per path-step (SQ_INSTS_VALU x 64 lanes /
+    (profiles/r3_<mode>_sq.txt, _sq2.txt; summed over the 8 XCDs): VALU wave-instructions per path-step (SQ_INSTS_VALU x 64 lanes /
     path-steps) and the fraction of the kernel's duration the SIMDs' VALU was issuing (SQ_ACTIVE_INST_VALU, in units of 4 cycles,
     / (1024 SIMDs x GRBM_GUI_ACTIVE/8/4)).  ~0.7-0.85 for the kernels whose generator is the bottleneck, which is why their
     fraction of the HBM roofline is what it is.  None when a summary lacks the kernel (stale profile)."""
@@ -176,7 +177,10 @@ def profiled_valu(mode, kernel_name, paths):
 
 
 def _linpro32(ctx):
-    d = 32
+    return _linpro(ctx, 32)
+
+
+def _linpro(ctx, d):
     rng = np.random.default_rng(5)
     G, G2 = rng.standard_normal((d, d)) / np.sqrt(d), rng.standard_normal((d, d)) / np.sqrt(d)
     sig = 0.5 * np.eye(d) + 0.05 * G2
@@ -203,6 +207,12 @@ def pc_pairs(P):
     return 2 if g <= 512 else 4 if g <= 1024 else 1
 
 
+def fresh_small(margs, P):
+    """fresh proposals of a small ensemble: the wave-specialised kernel with 2 / 4 / 1 producer-consumer pairs per workgroup"""
+    g = (P + 63) // 64
+    return f"k_pc<{margs}, 6, 1, {2 if g <= 512 else 4 if g <= 1024 else 1}, false>"
+
+
 # mode -> (proposal builder, d, m', x0, default paths, chains?, rho, workload text, kernel-name builder)
 MODES = {
     "mcmc": (build_proposal, 2, 1, X0, 262144, True, RHO,
@@ -213,17 +223,21 @@ MODES = {
                 lambda P: f"k_pc<bhip::MFHN, 2, 1, 7, 1, {pc_pairs(P)}, false>"),
     "proposals": (build_proposal, 2, 1, X0, 262144, False, None,
                   FHN_WORKLOAD + "independent fused proposals (sample!+solve!+llikelihood)",
-                  lambda P: (f"k_pc<bhip::MFHN, 2, 1, 6, 1, {pc_pairs(P)}, false>" if P <= 98304 else "k_paths<bhip::MFHN, 2, 1, 1, 1, false>")),
+                  lambda P: (fresh_small("bhip::MFHN, 2, 1", P) if P <= 98304 else "k_paths<bhip::MFHN, 2, 1, 1, 1, false>")),
     "c2": (_ou, 1, 1, (0.5,), 65536, False, None,
            "C2: 1-d OU target LinPro(-0.8,0,sqrt(.7)), GuidedBridge with auxiliary LinPro(-0.8,0.2,sqrt(.7)), 1001-point tau-grid T=2, "
            "independent fused proposals",
-           lambda P: (f"k_pc<bhip::MLinPro<1>, 1, 1, 6, 1, {pc_pairs(P)}, false>" if P <= 98304 else "k_paths<bhip::MLinPro<1>, 1, 1, 1, 1, false>")),
+           lambda P: (fresh_small("bhip::MLinPro<1, double const*>, 1, 1", P) if P <= 98304 else "k_paths<bhip::MLinPro<1, double const*>, 1, 1, 1, 1, false>")),
     "nclar": (_nclar, 3, 1, (0.0, 0.0, 0.0), 262144, False, None,
               "NCLAR 3-d PartialBridge (scalar noise, L=[1 0 0], v=5/128), 1001-point tau-grid T=0.5, independent fused proposals",
-              lambda P: (f"k_pc<bhip::MNCLAR, 2, 1, 6, 1, {pc_pairs(P)}, false>" if P <= 98304 else "k_paths<bhip::MNCLAR, 2, 1, 1, 1, false>")),
+              lambda P: (fresh_small("bhip::MNCLAR, 2, 1", P) if P <= 98304 else "k_paths<bhip::MNCLAR, 2, 1, 1, 1, false>")),
     "nclar_mcmc": (_nclar, 3, 1, (0.0, 0.0, 0.0), 262144, True, 0.95,
                    "NCLAR 3-d PartialBridge (scalar noise, L=[1 0 0], v=5/128), 1001-point tau-grid T=0.5, pCN-MCMC rho=0.95",
                    lambda P: f"k_pc<bhip::MNCLAR, 2, 1, 7, 1, {pc_pairs(P)}, false>"),
+    "linpro4": (lambda ctx: _linpro(ctx, 4), 4, 4, tuple([0.0] * 4), 262144, False, None,
+                "LinPro d=4 GuidedBridge (dense sigma, pre-inverted Hdiamond), 1001-point grid T=1, independent fused proposals: one path per lane "
+                "(dimensions 4..8 stay off the matrix cores)",
+                lambda P: "k_paths<bhip::MLinPro<4, double const AS4*>, 3, 1, 1, 1, false>"),
     "linpro32": (_linpro32, 32, 32, tuple([0.0] * 32), 65536, False, None,
                  "LinPro d=32 GuidedBridge (dense sigma, pre-inverted Hdiamond), 1001-point grid T=1, independent fused proposals",
                  lambda P: "k_tile<32, 1, false, bhip::NoUserDrift>"),
@@ -244,7 +258,7 @@ class Workload:
         self.Po = build(ctx)
         self.workload = text
         self.kernel = kname(self.P)
-        self.flops_per_pathstep = 5 * 2 * d * d if d > 3 else None   # d = 32: five d x d mat-vecs per path-step
+        self.flops_per_pathstep = 5 * 2 * d * d if d > 8 else None   # d = 32: five d x d mat-vecs per path-step on the matrix cores
         self.chains = None
         if is_chains:
             self.chains = bh.Chains(self.Po, np.array(x0), self.P, seed=4, path0=self.path0, store_X=True)
@@ -285,6 +299,15 @@ class Workload:
             tr, src = None, "profiled at the mode's default size only"
         r["traffic"], r["traffic_source"] = tr, src
         r["valu"] = profiled_valu(self.mode, self.kernel, self.P) if self.P == MODES[self.mode][4] else None
+        v = r["valu"]
+        if v and r["bound"] == "hbm" and v["busy_frac"] > 0.6:
+            # the kernel's SIMDs spend most of its duration ISSUING vector instructions: what binds it is the instruction count
+            # per byte, not the memory system.  achieved / peak / frac stay the HBM figures (the contract's yardstick);
+            # valu_frac = share of the duration the VALU was issuing, hbm_frac_at_full_issue = the roofline fraction this
+            # instruction stream would reach at 100 % issue -- the ceiling that actually applies
+            r["bound"] = "valu"
+            r["valu_frac"] = v["busy_frac"]
+            r["hbm_frac_at_full_issue"] = r["frac"] / v["busy_frac"]
         return r
 
 
@@ -613,7 +636,7 @@ def main_local(args):
         others = []
         del w, ws
         torch.cuda.empty_cache()
-        for mode in ("c4shard", "c2", "proposals", "nclar", "nclar_mcmc", "linpro32", "linpro32_mcmc"):
+        for mode in ("c4shard", "c2", "proposals", "nclar", "nclar_mcmc", "linpro4", "linpro32", "linpro32_mcmc"):
             wo = Workload(mode, ctx, 0, 0)
             ms = kernel_times(wo, args.steps, args.warmup, min_ms=100.0)
             others.append({"mode": mode, "workload": wo.workload, "paths": wo.P,

@@ -37,6 +37,11 @@ launch_fn get_launch_wiener1(int, int, int, int);
 launch_fn get_launch_wiener2(int, int, int, int);
 launch_fn get_launch_wiener3(int, int, int, int);
 launch_fn get_launch_ppr_lorenz(int, int);
+launch_fn get_launch_mid4(int, int, int);
+launch_fn get_launch_mid5(int, int, int);
+launch_fn get_launch_mid6(int, int, int);
+launch_fn get_launch_mid7(int, int, int);
+launch_fn get_launch_mid8(int, int, int);
 launch_fn get_launch_ppr_pendulum(int, int);
 guide_launch_fn get_guide_launch_lorenz(int);
 guide_launch_fn get_guide_launch_pendulum(int);
@@ -87,6 +92,7 @@ struct bhip_ctx {
     double *scratch = nullptr;
     size_t scratch_bytes = 0;
     bool wave_specialised = true;   // BHIP_OPT_WAVE_SPECIALISED: producer/consumer kernels (bhip_pc_kernel.h) where they exist
+    bool mid_valu = true;           // BHIP_OPT_MID_VALU: LinPro targets of dimension 4..8 one path per lane (0: zero padded on the MFMA tile kernel)
     bool tune_placement = true;     // BHIP_OPT_TUNE_PLACEMENT: large chain ensembles try a few allocations and keep the fastest (bhip_chains_init)
     // lifetime: every proposal / chain ensemble / communicator holds a reference.  bhip_ctx_destroy with live children only
     // closes the context (garbage collectors -- Python at interpreter exit, Julia finalizers -- destroy handles in any order);
@@ -128,7 +134,11 @@ struct bhip_proposal {
     int rs = 0;
     double *d_rdtp = nullptr;   // rdtp[j] = sqrt(tt[j] - tt[j-1]), rdtp[0] = 0, zero padded to a multiple of 16 (bhip_pc_kernel.h)
     bool use_vend = false;
-    double vend[3] = {0, 0, 0};
+    double vend[BHIP_MAXD_LANE] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // LinPro target of dimension 4..8: d_rows holds the coefficient rows in the (nu, H) form for the path-per-lane kernel (the
+    // tile data serve its chains)
+    bool mid = false;
+    double *d_mpar = nullptr;
     // large-d (tile kernel) data: per-step fragment matrices, step header, constants
     double *d_steps = nullptr, *d_hdr = nullptr, *d_cst = nullptr, *d_tt = nullptr;
 };
@@ -286,6 +296,7 @@ int bhip_ctx_set_option(bhip_ctx *ctx, int option, int value)
     if (!ctx) return BHIP_EINVAL;
     if (option == BHIP_OPT_WAVE_SPECIALISED) { ctx->wave_specialised = value != 0; return BHIP_OK; }
     if (option == BHIP_OPT_TUNE_PLACEMENT) { ctx->tune_placement = value != 0; return BHIP_OK; }
+    if (option == BHIP_OPT_MID_VALU) { ctx->mid_valu = value != 0; return BHIP_OK; }
     return fail(ctx, BHIP_EINVAL, "bhip_ctx_set_option: unknown option");
 }
 
@@ -499,6 +510,7 @@ void bhip_proposal_destroy(bhip_proposal *po)
         if (po->d_steps) (void)hipFree(po->d_steps);
         if (po->d_hdr) (void)hipFree(po->d_hdr);
         if (po->d_cst) (void)hipFree(po->d_cst);
+        if (po->d_mpar) (void)hipFree(po->d_mpar);
     }
     delete po;
     ctx_release(ctx);
@@ -799,13 +811,39 @@ static int finish_guide(bhip_proposal *po)
         for (double x : po->g.Hd[N - 1].a) n1 += std::fabs(x);
         if (n1 < 2.220446049250313e-16) {
             po->use_vend = true;
-            for (int k = 0; k < d && k < 3; k++) po->vend[k] = po->g.V[N - 1].a[k];
+            for (int k = 0; k < d && k < BHIP_MAXD_LANE; k++) po->vend[k] = po->g.V[N - 1].a[k];
         }
     }
     if (ctx->host_only) return BHIP_OK;   // coefficients stay on the host (bhip_proposal_guide_get)
-    if (d > 3) return build_tile_data(po);
+    po->mid = false;
+    if (d > 3) {
+        const int rct = build_tile_data(po);
+        if (rct || d > BHIP_MAXD_LANE || po->mh.id != BHIP_MODEL_LINPRO) return rct;
+        po->mid = true;   // ... and the rows below, for one path per lane
+    }
     std::vector<double> rows;
     int rs = 0;
+    if (po->mid) {
+        // the guide in the form r = H_i (nu_i - x), as build_tile_data brings it for the tile kernel:
+        //   GuidedBridge: H = inv(Hdiamond_i) (LU, path-independent), nu = V_i;  (L,M,mu): H = L'ML, nu = L'(LL')^-1 (v - mu);  (nu,H) as is
+        Guide g2;
+        g2.kind = po->g.kind == BHIP_GUIDE_NONE ? BHIP_GUIDE_NONE : BHIP_GUIDE_NUH;
+        g2.m = po->g.m;
+        if (g2.kind != BHIP_GUIDE_NONE) {
+            g2.H.resize(N); g2.nu.resize(N);
+            for (int i = 0; i < N; i++) {
+                if (po->g.kind == BHIP_GUIDE_HV) { g2.H[i] = i < N - 1 ? inv(po->g.Hd[i]) : Mat(d, d); g2.nu[i] = po->g.V[i]; }
+                else if (po->g.kind == BHIP_GUIDE_LMMU) {
+                    const Mat &L = po->g.L[i];
+                    g2.H[i] = (tr(L) * po->g.M[i]) * L;
+                    g2.nu[i] = tr(L) * solve(L * tr(L), po->g.v - po->g.mu[i]);
+                } else { g2.H[i] = po->g.H[i]; g2.nu[i] = po->g.nu[i]; }
+            }
+        }
+        pack_rows(po->tt, po->mh, po->has_aux ? &po->aux : nullptr, g2, rows, rs);
+        if (!po->d_mpar) HIPCHK(ctx, hipMalloc((void **)&po->d_mpar, sizeof(double) * po->mh.dpar.size()));
+        HIPCHK(ctx, hipMemcpy(po->d_mpar, po->mh.dpar.data(), sizeof(double) * po->mh.dpar.size(), hipMemcpyHostToDevice));
+    } else
     pack_rows(po->tt, po->mh, po->has_aux ? &po->aux : nullptr, po->g, rows, rs);
     if (po->g.kind == BHIP_GUIDE_HV) {
         // the kernels divide by Hd_i (d = 1) / det(Hd_i) (d = 2, 3) through the row's reciprocal (bhip_smallmat.h sm_div_by): the
@@ -955,7 +993,7 @@ static int fill_common(const bhip_proposal *po, KArgs &a, const double *x0, cons
     const int d = po->mh.d;
     std::memset(&a, 0, sizeof(a));
     NEED_DEVICE(ctx);
-    if (d > 3) return fail(ctx, BHIP_EUNSUPPORTED, "path-per-lane kernel covers d <= 3");
+    if (d > 3 && !po->mid) return fail(ctx, BHIP_EUNSUPPORTED, "path-per-lane kernel covers d <= 3 (LinPro targets: d <= 8)");
     if (!po->d_rows) return fail(ctx, BHIP_ESTATE, "proposal has no coefficient rows (compute a guide first)");
     if (npaths < 1) return fail(ctx, BHIP_EINVAL, "npaths must be positive");
     if (skip < 0) return fail(ctx, BHIP_EINVAL, "skip must be >= 0");
@@ -971,8 +1009,11 @@ static int fill_common(const bhip_proposal *po, KArgs &a, const double *x0, cons
         a.vend[k] = po->vend[k];
         a.mu_aux[k] = aux_linpro ? po->aux.mu()[k] : 0.0;
     }
-    if ((int)po->mh.dpar.size() > 40) return fail(ctx, BHIP_EINVAL, "model parameter block too large");
-    for (size_t k = 0; k < po->mh.dpar.size(); k++) a.mpar[k] = po->mh.dpar[k];
+    if (po->mid) a.mpar_dev = po->d_mpar;   // the parameter block of a LinPro<4..8> target stays in device memory
+    else {
+        if ((int)po->mh.dpar.size() > 40) return fail(ctx, BHIP_EINVAL, "model parameter block too large");
+        for (size_t k = 0; k < po->mh.dpar.size(); k++) a.mpar[k] = po->mh.dpar[k];
+    }
     return BHIP_OK;
 }
 
@@ -984,6 +1025,21 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
     int fl = 0;
     if (noise == NOISE_PCN || noise == NOISE_PCN_LINES) fl = a.Xo ? 1 : 0;
     else fl = (a.X ? 1 : 0) | (a.Wout ? 2 : 0);
+    if (po->mid) {   // LinPro, d = 4..8: rows in the (nu, H) form, one kernel family
+        const int gkm = po->g.kind == BHIP_GUIDE_NONE ? BHIP_GUIDE_NONE : BHIP_GUIDE_NUH;
+        if (a.rs != row_stride(gkm, po->mh.d, 1, true)) return fail(ctx, BHIP_ESTATE, "row stride mismatch");
+        launch_fn fm = nullptr;
+        switch (po->mh.d) {
+        case 4: fm = get_launch_mid4(gkm, noise, fl); break;
+        case 5: fm = get_launch_mid5(gkm, noise, fl); break;
+        case 6: fm = get_launch_mid6(gkm, noise, fl); break;
+        case 7: fm = get_launch_mid7(gkm, noise, fl); break;
+        case 8: fm = get_launch_mid8(gkm, noise, fl); break;
+        }
+        if (!fm) return fail(ctx, BHIP_EUNSUPPORTED, "no path-per-lane kernel for this mode at 4 <= d <= 8");
+        HIPCHK(ctx, fm(a, ctx->stream));
+        return BHIP_OK;
+    }
     if (a.rs != row_stride(gk, po->mh.d, po->g.m, po->mh.constdiff)) return fail(ctx, BHIP_ESTATE, "row stride mismatch");
     if (!po->mh.constdiff) {
         // constdiff(P) == false.  The reference's extra log-likelihood terms exist for PartialBridge only
@@ -1081,7 +1137,7 @@ int bhip_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, const d
     }
     if (ldW < npaths || (X_dev && ldX < npaths)) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
     if (x0_dev && ldX < npaths) return fail(ctx, BHIP_ELENGTH, "per-path starting points x0_dev are laid out [d][ldX]: ldX must be >= npaths");
-    if (po->mh.d > 3)
+    if (po->mh.d > 3 && !(po->mid && ctx->mid_valu))
         return launch_tile_path(po, x0, W_dev, ldW, nullptr, 0, X_dev, ldX, ll_dev, skip, npaths, 0, 0, 0, 0, 1, nullptr, 0.0, x0_dev, ldX);
     KArgs a;
     int rc = fill_common(po, a, x0, x0_dev, npaths, skip);
@@ -1104,7 +1160,7 @@ int bhip_sample_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, 
     if ((W_dev && ldW < npaths) || (X_dev && ldX < npaths)) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
     if (x0_dev && ldX < npaths) return fail(ctx, BHIP_ELENGTH, "per-path starting points x0_dev are laid out [d][ldX]: ldX must be >= npaths");
     PATH_RANGE(ctx, path0, npaths > 0 ? npaths : 0);
-    if (po->mh.d > 3)
+    if (po->mh.d > 3 && !(po->mid && ctx->mid_valu))
         return launch_tile_path(po, x0, nullptr, 0, W_dev, ldW, X_dev, ldX, ll_dev, skip, npaths, 1, seed, iter, path0, 1, nullptr, 0.0, x0_dev, ldX);
     KArgs a;
     int rc = fill_common(po, a, x0, x0_dev, npaths, skip);
@@ -1120,13 +1176,13 @@ int bhip_llikelihood(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev
     if (!ctx || !po || !X_dev || !ll_dev) return BHIP_EINVAL;
     SAME_CTX(ctx, po);
     if (po->g.kind == BHIP_GUIDE_NONE) return fail(ctx, BHIP_EINVAL, "bhip_llikelihood: needs a guided proposal");
-    if (po->mh.d > 3) {
+    if (po->mh.d > 3 && !(po->mid && ctx->mid_valu)) {
         if (ldX < npaths) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
         const std::vector<double> zero(po->mh.d, 0.0);
         return launch_tile_path(po, zero.data(), X_dev, ldX, nullptr, 0, nullptr, 0, ll_dev, skip, npaths, 3, 0, 0, 0);
     }
     KArgs a;
-    const double zero[3] = {0, 0, 0};
+    const double zero[BHIP_MAXD_LANE] = {0, 0, 0, 0, 0, 0, 0, 0};
     int rc = fill_common(po, a, zero, nullptr, npaths, skip);
     if (rc) return rc;
     if (ldX < npaths) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");

@@ -46,7 +46,17 @@ guide_launch_fn get_guide_launch_wiener2(int mo) { return get_guide_launch<MWien
 launch_fn get_launch_wiener3(int gk, int mo, int noise, int fl) { return get_launch<MWiener<3>>(gk, mo, noise, fl); }
 launch_fn get_launch_ppr_wiener3(int noise, int fl) { return get_launch_ppr<MWiener<3>>(noise, fl); }
 guide_launch_fn get_guide_launch_wiener3(int mo) { return get_guide_launch<MWiener<3>>(mo); }
+#elif BHIP_INST == 11
+launch_fn get_launch_mid4(int gk, int noise, int fl) { return get_launch_mid<MLinPro<4, bhip_cptr_t>>(gk, noise, fl); }
+#elif BHIP_INST == 12
+launch_fn get_launch_mid5(int gk, int noise, int fl) { return get_launch_mid<MLinPro<5, bhip_cptr_t>>(gk, noise, fl); }
+#elif BHIP_INST == 13
+launch_fn get_launch_mid6(int gk, int noise, int fl) { return get_launch_mid<MLinPro<6, bhip_cptr_t>>(gk, noise, fl); }
+#elif BHIP_INST == 14
+launch_fn get_launch_mid7(int gk, int noise, int fl) { return get_launch_mid<MLinPro<7, bhip_cptr_t>>(gk, noise, fl); }
+#elif BHIP_INST == 15
+launch_fn get_launch_mid8(int gk, int noise, int fl) { return get_launch_mid<MLinPro<8, bhip_cptr_t>>(gk, noise, fl); }
 #else
-#error "BHIP_INST must be 0..10"
+#error "BHIP_INST must be 0..15"
 #endif
 }  // namespace bhip

@@ -16,6 +16,9 @@
 namespace bhip {
 
 #define BHIP_DEV __device__ __forceinline__
+}  // namespace bhip
+#include "bhip_stream.h"
+namespace bhip {
 
 // x / c for a divisor c that is constant over the kernel (a model parameter).  This is the compiler's own
 // correctly rounded fp64 division sequence -- reciprocal seed, two Newton steps, quotient, residual
@@ -55,22 +58,30 @@ struct MOU {
 
 // ---- LinPro: b = B*(x - mu), sigma, a = sigma*sigma'       src/linpro.jl:65-87
 // dp = B(D*D) mu(D) sigma(D*D) a(D*D), column-major
-template <int D_>
+// PTR: where the parameter block is read from -- the kernel arguments (d <= 3), or, for 4 <= d <= 8, a device copy read
+// through the constant address space and re-opened at every time step (STREAMED): B, sigma and a are then 3*d*d scalar-unit
+// operands too many to keep resident next to the step's coefficient row (d = 4: the compiler parked them in spilled
+// scalar registers and fetched every operand back with a v_readlane, 150 per step)
+template <int D_, class PTR = const double *>
 struct MLinPro {
     static constexpr int D = D_, MP = D_, ID = BHIP_MODEL_LINPRO;
+    static constexpr bool STREAMED = D_ > 3;
     static constexpr bool noisy(int) { return true; }
-    const double *p;
-    BHIP_DEV explicit MLinPro(const double *p_) : p(p_) {}
+    PTR p;
+    BHIP_DEV explicit MLinPro(PTR p_) : p(p_) {}
     BHIP_DEV void b(double, const double *x, double *o) const
     {
+        PTR q = p;
+        if constexpr (STREAMED) bhip_after(q, x[D - 1]);
         double xm[D];
 #pragma unroll
-        for (int k = 0; k < D; k++) xm[k] = x[k] - p[D * D + k];
+        for (int k = 0; k < D; k++) xm[k] = x[k] - q[D * D + k];
+        if constexpr (STREAMED) { matvec_streamed<D, PTR>(q, xm, o); return; }
 #pragma unroll
         for (int i = 0; i < D; i++) {
-            double s = p[i] * xm[0];
+            double s = q[i] * xm[0];
 #pragma unroll
-            for (int j = 1; j < D; j++) s += p[i + D * j] * xm[j];
+            for (int j = 1; j < D; j++) s += q[i + D * j] * xm[j];
             o[i] = s;
         }
     }
@@ -82,7 +93,8 @@ struct MLinPro {
     }
     BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const
     {
-        const double *S = p + D * D + D;
+        PTR S = p + D * D + D;
+        if constexpr (STREAMED) { bhip_after(S, dw[D - 1]); matvec_streamed<D, PTR>(S, dw, o); return; }
 #pragma unroll
         for (int i = 0; i < D; i++) {
             double s = S[i] * dw[0];
@@ -93,7 +105,8 @@ struct MLinPro {
     }
     BHIP_DEV void amul(double, const double *, const double *r, double *o) const
     {
-        const double *A = p + 2 * D * D + D;
+        PTR A = p + 2 * D * D + D;
+        if constexpr (STREAMED) { bhip_after(A, r[D - 1]); matvec_streamed<D, PTR>(A, r, o); return; }
 #pragma unroll
         for (int i = 0; i < D; i++) {
             double s = A[i] * r[0];
@@ -104,7 +117,7 @@ struct MLinPro {
     }
     BHIP_DEV void sinv_mul(const double *v, double *o) const   // inv(P.sigma)*v
     {
-        const double *Si = p + 3 * D * D + D;
+        const PTR Si = p + 3 * D * D + D;
 #pragma unroll
         for (int i = 0; i < D; i++) {
             double s = Si[i] * v[0];

@@ -40,6 +40,12 @@ template <class M> struct has_sinv<M, bhip_void_t<decltype(&M::sinv_mul)>> { sta
 template <class M, class = void> struct is_constdiff { static constexpr bool value = true; };
 template <class M> struct is_constdiff<M, bhip_void_t<decltype(M::STATE_SIGMA)>> { static constexpr bool value = !M::STATE_SIGMA; };
 
+constexpr int BHIP_MAXD_LANE = 8;
+
+// processes whose parameter block is re-opened from device memory at every step (MLinPro<4..8, bhip_cptr_t>)
+template <class M, class = void> struct is_streamed { static constexpr bool value = false; };
+template <class M> struct is_streamed<M, bhip_void_t<decltype(M::STREAMED)>> { static constexpr bool value = M::STREAMED; };
+
 struct KArgs {
     const double *rows;   // [N-1][rs] packed per-step coefficients (device)
     const double *rdtp;   // rdtp[j] = sqrt(tt[j] - tt[j-1]) (0 for j = 0), zero padded to a multiple of 16 (bhip_pc_kernel.h)
@@ -72,10 +78,11 @@ struct KArgs {
     uint32_t k0, k1, iter, path0;
     uint32_t blk0;        // offset of the Philox block index (multi-segment chains: segment << 24; 0 otherwise)
     int defer_accept;     // pCN modes: do not decide -- only report llo in `ll` (joint accept over segments, bhip_segchains_*)
-    double x0[3];
-    double vend[3];
-    double mu_aux[3];
+    double x0[BHIP_MAXD_LANE];       // d <= 3 for every process; LinPro targets of dimension 4..8 run one path per lane too
+    double vend[BHIP_MAXD_LANE];
+    double mu_aux[BHIP_MAXD_LANE];
     double mpar[40];
+    const double *mpar_dev;   // 4 <= d <= 8: the parameter block in device memory (MLinPro<D, bhip_cptr_t>)
     // per-chain coefficient rows (device-built guides, bhip_guide_kernel.h): prows[(i*PRL + q)*ldr + p] holds entry 3 + q of
     // chain p's row of step i (the three time entries stay in the shared rows); per-chain endpoint rule
     const double *prows;
@@ -146,8 +153,8 @@ struct RowLayout {
 };
 
 // r((i,t),x,Po) and g = a*L'*M*q | a*r, from the packed row
-template <class M, int GK, int MO>
-BHIP_DEV void guide_terms(const M &model, double t, const double *g, const double *x, double *r, double *gd)
+template <class M, int GK, int MO, class GP = const double *>
+BHIP_DEV void guide_terms(const M &model, double t, GP g, const double *x, double *r, double *gd)
 {
     constexpr int D = M::D;
     if constexpr (GK == BHIP_GUIDE_HV) {
@@ -177,7 +184,7 @@ BHIP_DEV void guide_terms(const M &model, double t, const double *g, const doubl
             for (int k = 1; k < D; k++) s += g[j + MO * k] * x[k];
             q[j] = g[MO * D + j] - s;
         }
-        const double *R = g + MO * D + MO, *G = g + MO * D + MO + D * MO;
+        const GP R = g + MO * D + MO, G = g + MO * D + MO + D * MO;
         if constexpr (is_constdiff<M>::value) {
 #pragma unroll
             for (int i = 0; i < D; i++) {
@@ -228,12 +235,15 @@ BHIP_DEV void guide_terms(const M &model, double t, const double *g, const doubl
         double w[D];
 #pragma unroll
         for (int k = 0; k < D; k++) w[k] = g[D * D + k] - x[k];
+        if constexpr (is_streamed<M>::value) matvec_streamed<D, GP>(g, w, r);
+        else {
 #pragma unroll
-        for (int i = 0; i < D; i++) {
-            double s = g[i] * w[0];
+            for (int i = 0; i < D; i++) {
+                double s = g[i] * w[0];
 #pragma unroll
-            for (int j = 1; j < D; j++) s += g[i + D * j] * w[j];
-            r[i] = s;
+                for (int j = 1; j < D; j++) s += g[i + D * j] * w[j];
+                r[i] = s;
+            }
         }
         model.amul(t, x, r, gd);
     }
@@ -274,9 +284,12 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int n
     constexpr int D = M::D, MP = M::MP;
     using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
     // the whole coefficient row through the scalar unit, one wait
+    // (STREAMED models, 4 <= d <= 8: only the time entries now; the guide and auxiliary parts are read phase by phase below,
+    // each pinned behind the phase before it -- the whole row and the model's matrices do not fit the scalar registers together)
+    constexpr bool STR = is_streamed<M>::value;
     double rw[RL::RS];
 #pragma unroll
-    for (int q = 0; q < RL::LEN; q++) rw[q] = row[q];
+    for (int q = 0; q < (STR ? 3 : RL::LEN); q++) rw[q] = row[q];
     const double t = rw[RL::T], dt = rw[RL::DT];
 
     if constexpr (NOISE == NOISE_LLONLY) {
@@ -354,18 +367,32 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int n
     model.b(t, st.y, bT);
     if constexpr (GK != BHIP_GUIDE_NONE) {
         double r[D], g[D];
-        guide_terms<M, GK, MO>(model, t, rw + RL::G, st.y, r, g);
+        if constexpr (STR) {
+            RowPtr rg = row;
+            bhip_after(rg, bT[D - 1]);
+            guide_terms<M, GK, MO, RowPtr>(model, t, rg + RL::G, st.y, r, g);
+        } else guide_terms<M, GK, MO>(model, t, rw + RL::G, st.y, r, g);
         // ---- LOOP C: som += dot(b - b~, r)*dt ;  b~ = B~(x - mu~) + beta~  (mu~ = 0 for the affine form
         // B~x + beta~, beta~ = 0 for the LinPro form B~(x - mu~): adding/subtracting 0.0 is exact)
         double xm[D], bA[D];
 #pragma unroll
         for (int k = 0; k < D; k++) xm[k] = st.y[k] - a.mu_aux[k];
+        if constexpr (STR) {
+            RowPtr rb = row;
+            bhip_after(rb, g[D - 1]);
+            matvec_streamed<D, RowPtr>(rb + RL::B, xm, bA);
+            RowPtr rbe = row;
+            bhip_after(rbe, bA[D - 1]);
 #pragma unroll
-        for (int q = 0; q < D; q++) {
-            double s = rw[RL::B + q] * xm[0];
+            for (int q = 0; q < D; q++) bA[q] = bA[q] + rbe[RL::BETA + q];
+        } else {
 #pragma unroll
-            for (int j = 1; j < D; j++) s += rw[RL::B + q + D * j] * xm[j];
-            bA[q] = s + rw[RL::BETA + q];
+            for (int q = 0; q < D; q++) {
+                double s = rw[RL::B + q] * xm[0];
+#pragma unroll
+                for (int j = 1; j < D; j++) s += rw[RL::B + q + D * j] * xm[j];
+                bA[q] = s + rw[RL::BETA + q];
+            }
         }
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         if constexpr ((FL & 4) != 0) {
@@ -426,7 +453,7 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int n
 #endif
 
 template <class M, int GK, int MO, int NOISE, int FL, bool PPR = false /* per-chain coefficient rows */>
-__global__ __launch_bounds__(256, PPR ? 2 : BHIP_WPE) void k_paths(const KArgs a)
+__global__ __launch_bounds__(256, (PPR || M::D > 4) ? 2 : BHIP_WPE) void k_paths(const KArgs a)
 {
     constexpr int D = M::D, MP = M::MP;
     using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
@@ -441,7 +468,15 @@ __global__ __launch_bounds__(256, PPR ? 2 : BHIP_WPE) void k_paths(const KArgs a
     const TabT tab = [&]() { if constexpr (DRAWS) return TabLDS(rng_tab); else return TabConst(); }();
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.P) return;
-    const M model(a.mpar);
+    // the model functor: built once from the kernel arguments, or (STREAMED) re-opened from the device copy at every step
+    auto make_model = [&]() {
+        if constexpr (is_streamed<M>::value) {
+            bhip_cptr_t mp = (bhip_cptr_t)(uintptr_t)a.mpar_dev;
+            asm volatile("" : "+s"(mp));   // opaque: the loads of this step's operands cannot be hoisted out of the time loop
+            return M(mp);
+        } else return M(a.mpar);
+    };
+    const M model = make_model();
     const int N = a.N;
     const int nll = N - 1 - a.skip;
     const cptr_t rows = (cptr_t)(uintptr_t)a.rows;
@@ -570,7 +605,7 @@ __global__ __launch_bounds__(256, PPR ? 2 : BHIP_WPE) void k_paths(const KArgs a
     };
     // unrolled so that the position of a step's normals inside their Philox call (four normals per call) and the register row
     // of the per-chain coefficients are static: four steps per iteration where normals are drawn (two for m' = 2), else two
-    constexpr int UNR = DRAWS ? (MP == 2 ? 2 : 4) : 2;
+    constexpr int UNR = DRAWS ? ((MP == 2 || MP % 4 == 0) ? 2 : 4) : 2;
     int i = 0;
     for (; i + UNR - 1 < nsteps; i += UNR) {
 #pragma unroll
@@ -578,7 +613,7 @@ __global__ __launch_bounds__(256, PPR ? 2 : BHIP_WPE) void k_paths(const KArgs a
             double cur[NIN];
             advance(i + u, cur);
             fetch_row(i + u + 1, rr[(u + 1) & 1]);
-            path_step<M, GK, MO, NOISE, FL, RowT, TabT>(model, a, rowat(i + u, rr[u & 1]), i + u, nll, path, cur, wout, ldwo, xout, ldx, st, tab, 0u, u);
+            path_step<M, GK, MO, NOISE, FL, RowT, TabT>(is_streamed<M>::value ? make_model() : model, a, rowat(i + u, rr[u & 1]), i + u, nll, path, cur, wout, ldwo, xout, ldx, st, tab, 0u, u);
             commit(i + u);
         }
     }
@@ -587,7 +622,7 @@ __global__ __launch_bounds__(256, PPR ? 2 : BHIP_WPE) void k_paths(const KArgs a
         double cur[NIN];
         advance(i, cur);
         fetch_row(i + 1, rr[1]);
-        path_step<M, GK, MO, NOISE, FL, RowT, TabT>(model, a, rowat(i, rr[0]), i, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
+        path_step<M, GK, MO, NOISE, FL, RowT, TabT>(is_streamed<M>::value ? make_model() : model, a, rowat(i, rr[0]), i, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
         commit(i);
         rr[0] = rr[1];
     }
@@ -707,6 +742,39 @@ launch_fn get_launch_gk(int noise, int fl)
     case NOISE_INNOV:
         if constexpr (has_sinv<M>::value && !TWO) return launch_paths<M, GK, MO, NOISE_INNOV, 2>;
         return nullptr;
+    }
+    return nullptr;
+}
+
+// LinPro targets of dimension 4..8 (one path per lane, matrices through the scalar unit): the guide always in the form
+// r = H_i (nu_i - x) -- GuidedBridge pre-inverted on the host like on the MFMA tile kernel, (L,M,mu) mapped likewise --,
+// external or fresh noise, stand-alone llikelihood, plain Euler-Maruyama.  (Chains at these dimensions stay on the tile kernel.)
+template <class M>
+launch_fn get_launch_mid(int gk, int noise, int fl)
+{
+    if (gk == BHIP_GUIDE_NONE) {
+        switch (noise) {
+        case NOISE_EXT: return (fl & 1) ? launch_paths<M, BHIP_GUIDE_NONE, 1, NOISE_EXT, 1> : launch_paths<M, BHIP_GUIDE_NONE, 1, NOISE_EXT, 0>;
+        case NOISE_FRESH:
+            switch (fl & 3) {
+            case 0: return launch_paths<M, BHIP_GUIDE_NONE, 1, NOISE_FRESH, 0>;
+            case 1: return launch_paths<M, BHIP_GUIDE_NONE, 1, NOISE_FRESH, 1>;
+            case 2: return launch_paths<M, BHIP_GUIDE_NONE, 1, NOISE_FRESH, 2>;
+            default: return launch_paths<M, BHIP_GUIDE_NONE, 1, NOISE_FRESH, 3>;
+            }
+        }
+        return nullptr;
+    }
+    switch (noise) {
+    case NOISE_EXT: return (fl & 1) ? launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_EXT, 1> : launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_EXT, 0>;
+    case NOISE_FRESH:
+        switch (fl & 3) {
+        case 0: return launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_FRESH, 0>;
+        case 1: return launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_FRESH, 1>;
+        case 2: return launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_FRESH, 2>;
+        default: return launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_FRESH, 3>;
+        }
+    case NOISE_LLONLY: return launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_LLONLY, 0>;
     }
     return nullptr;
 }

@@ -102,6 +102,12 @@ int bhip_ctx_sync(bhip_ctx *ctx);
  * life of the allocation.  bhip_chains_init then times a few iterations on up to four allocations, keeps the fastest and
  * re-initialises (see bhip_chains_placement_info); 0 keeps the first allocation.  Results do not depend on it. */
 #define BHIP_OPT_TUNE_PLACEMENT 2
+/* BHIP_OPT_MID_VALU (default 1): LinPro targets of dimension 4 <= d <= 8 run one path per lane like the d <= 3 processes (the
+ * d x d products as scalar FMAs, coefficients through the scalar unit) in bhip_sample_solve, bhip_solve and bhip_llikelihood; 0
+ * runs them zero padded on the 16-row MFMA tile kernel, as their chains do.  On MI355X the fp64 matrix cores have no rate
+ * advantage over fp64 FMAs, and a 16x16x4 instruction cannot skip padding: d = 4 is ~7x faster per lane.  Same results to the
+ * tile kernel's tolerance (the guide solve is a product with the pre-inverted matrix in both). */
+#define BHIP_OPT_MID_VALU 3
 int bhip_ctx_set_option(bhip_ctx *ctx, int option, int value);
 const char *bhip_last_error(const bhip_ctx *ctx);
 /* device memory helpers for callers without their own allocator */

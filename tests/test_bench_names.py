@@ -1,5 +1,5 @@
 """bench.py looks the PMC traffic of a mode up by the EXACT name of the kernel the current build launches for it
-(profiles/r2_<mode>_{fetch,write}.txt).  Kernel templates gain arguments now and then; this test keeps the name builders
+(profiles/r3_<mode>_{fetch,write}.txt).  Kernel templates gain arguments now and then; this test keeps the name builders
 honest against the code objects of the current build (CPU only: reads bridge.jl_amd/csrc/build/*.o with the LLVM tools),
 and checks that the committed profile summaries carry those names (no STALE / MISSING traffic in the bench line)."""
 import glob

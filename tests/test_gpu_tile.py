@@ -215,3 +215,51 @@ def test_tile_kernel_per_path_starting_points(ctx):
         Xr = o.solve_guided(ref, starts[p], Wh[p])
         _close(Xh[p], Xr, llh[p:p + 1], np.array([o.llikelihood(ref, Xr)]))
         assert np.array_equal(Xh[p, 0], starts[p])
+
+
+@pytest.mark.parametrize("d", [4, 5, 6, 7, 8])
+def test_dimensions_4_to_8_run_one_path_per_lane(ctx, d):
+    """LinPro targets of dimension 4..8 (round 3): bhip_sample_solve / bhip_solve / bhip_llikelihood run them on the path-per-lane
+    kernel (k_paths<MLinPro<d>, (nu,H) form>: scalar FMAs, coefficients through the scalar unit) instead of zero padded on the
+    16-row MFMA tile.  Wiener paths bit-exact vs the oracle, paths / ll at the large-d tolerance (pre-inverted guide matrix),
+    agreement with the tile kernel (BHIP_OPT_MID_VALU = 0), ragged ensemble sizes, plain Euler-Maruyama, per-path starts."""
+    c = problems.linpro_big_case(d, 81)
+    Po, ref = c.bh_proposal(bh, ctx), c.oracle_proposal()
+    for P in (150, 256 + 17):
+        X, W, ll = bh.sample_solve(c.x0, Po, P, seed=6, iter=2, path0=100, store_W=True)
+        Xh, Wh, llh = X.paths(), W.paths(), ll.cpu().numpy()
+        for p in (0, 15, 16, 63, 64, P - 1):
+            Wr = o.wiener_sample(c.tt, d, 6, 100 + p, 2)
+            assert np.array_equal(Wh[p], Wr), (d, p)
+            Xr = o.solve_guided(ref, c.x0, Wr)
+            _close(Xh[p], Xr, llh[p:p + 1], np.array([o.llikelihood(ref, Xr)]))
+        assert np.array_equal(Xh[:, -1, :], np.tile(c.v, (P, 1)))
+        ll2 = ctx.empty(P)
+        X2 = bh.solve(bh.Euler(), c.x0, W, Po, ll=ll2)
+        assert torch.equal(X2.data, X.data) and torch.equal(ll2, ll)
+        ll3 = bh.llikelihood(bh.LeftRule(), X, Po)
+        assert float((ll3 - ll).abs().max()) <= 1e-9 * (1 + float(ll.abs().max()))
+        ctx.set_option(bh.OPT_MID_VALU, 0)
+        try:
+            Xp, Wp, llp = bh.sample_solve(c.x0, Po, P, seed=6, iter=2, path0=100, store_W=True)
+        finally:
+            ctx.set_option(bh.OPT_MID_VALU, 1)
+        assert torch.equal(Wp.data, W.data)
+        assert float((Xp.data - X.data).abs().max()) <= 1e-9 * (1 + float(X.data.abs().max()))
+        assert float((llp - ll).abs().max()) <= 1e-8 * (1 + float(ll.abs().max()))
+    proc = bh.PlainProcess(c.tt, c.bh_process(bh), ctx=ctx)
+    Xf = bh.solve(bh.EulerMaruyama(), 0.2 * np.ones(d), W, proc).paths()
+    Xfr = o.solve_em(o.MODEL_LINPRO, d, d, c.par, c.tt, 0.2 * np.ones(d), Wh[7])
+    assert np.abs(Xf[7] - Xfr).max() <= 1e-9 * (1 + np.abs(Xfr).max())
+    rng = np.random.default_rng(1)
+    starts = c.x0[None, :] + 0.2 * rng.standard_normal((P, d))
+    u = torch.tensor(np.ascontiguousarray(starts.T), dtype=torch.float64, device=ctx.device)
+    Xs = bh.solve(bh.Euler(), u, W, Po).paths()
+    for p in (0, P - 1):
+        Xr = o.solve_guided(ref, starts[p], Wh[p])
+        assert np.abs(Xs[p] - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max()) and np.array_equal(Xs[p, 0], starts[p])
+    # chains at these dimensions (tile kernel) are unaffected by the switch
+    ch = bh.Chains(Po, c.x0, 40, seed=8)
+    ch.step(0.9, 3)
+    r = o.mcmc(ref, c.x0, 0.9, 3, 8, 17)
+    assert ch.acc()[17] == r["acc"] and abs(ch.ll()[17] - r["ll"]) <= 1e-8 * (1 + abs(r["ll"]))
