@@ -1297,7 +1297,6 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     bhip_chains *ch = new (std::nothrow) bhip_chains();
     if (!ch) return fail(ctx, BHIP_EHIP, "out of host memory");
     ch->ctx = ctx; ch->po = po; ch->n = nchains; ch->ld = (nchains + 63) / 64 * 64;
-    if (const char *sk = std::getenv("BHIP_LD_SKEW")) ch->ld += 64 * std::max(0L, std::atol(sk));   // experiment: leading dimension off the power of two
     ctx_retain(ctx);
     ch->path0 = path0; ch->seed = seed; ch->flags = flags;
     const size_t N = po->tt.size();
