@@ -29,14 +29,12 @@ constexpr int LINE_DOUBLES = 16;              // one 128-byte line
 constexpr int line_mpp(int mp) { return mp == 3 ? 4 : mp; }
 constexpr int LINE_ROW = LINE_DOUBLES + 1;    // padded LDS row: lane L reads column s of row L without bank conflicts
 
-#ifndef BHIP_LINE_PAIRS
-#define BHIP_LINE_PAIRS 1
-#endif
-BHIP_DEV size_t line_index(int h, int k, long chain, int nch, long ld)
+// the two parity halves of a chain's chunk are NEIGHBOURS (a 256-byte pair; round 2 kept them 2 GB apart: every allocation 3-4 %
+// slower, profiles/r3_alloc_placement.txt).  line_index(h, 0, j, ..) of a group's j-th chain is also the offset inside the
+// group's contiguous block of chunk k, and flipping the half is `^ LINE_DOUBLES` (bhip_pc_kernel.h relies on both).
+BHIP_DEV size_t line_index(int h, int k, long chain, int /*nch*/, long ld)
 {
-    // BHIP_LINE_PAIRS: the two parity halves of a chain's chunk are NEIGHBOURS (a 256-byte pair) instead of 2 GB apart
-    if constexpr (BHIP_LINE_PAIRS) return ((((size_t)k * ld + chain) * 2 + h)) * LINE_DOUBLES;
-    else return (((size_t)h * nch + k) * ld + chain) * LINE_DOUBLES;
+    return ((((size_t)k * ld + chain) * 2 + h)) * LINE_DOUBLES;
 }
 
 // BHIP_LINES_STAGE 1: the next chunk's lines are fetched into 32 staging registers while the current chunk is

@@ -69,6 +69,7 @@ BHIP_DEV void sm_chol_lower(const double *A, double *C)
 struct GArgs {
     long n, ld;
     int N, rs, hwindow;
+    int lane_shift;        // chains per wave = 64 >> lane_shift (small ensembles: more, narrower waves)
     int lna;               // LinearNoiseAppr auxiliaries (src/guip.jl:114-146): B_j = 0, xx_j = 0, b_j = slope of the mean path at max(j, 1)
     const double *srows;   // the segment's shared rows: t_i, dt_i at [i*rs + 0], [i*rs + 1]
     const double *mean;    // [N][D][ld]: the chains' linearisation paths (running means, mcnext!)
@@ -86,7 +87,12 @@ template <class M, int MO>
 __global__ __launch_bounds__(64) void k_seg_guide(const GArgs g)
 {
     constexpr int D = M::D, MP = M::MP, DD = D * D, PRL = pp_row_len<D>();
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // a lane walks its chain's grid alone and a wave is bound by the latency of that walk, not by issue slots: ensembles too
+    // small to give every SIMD a wave of 64 chains run 32 or 16 chains per wave (the other lanes leave) -- twice / four times
+    // the SIMDs at work for the same time per wave
+    const int lanes = (int)blockDim.x >> g.lane_shift;
+    if ((int)threadIdx.x >= lanes) return;
+    const long p = (long)blockIdx.x * lanes + threadIdx.x;
     if (p >= g.n) return;
     const M model(g.mpar);
     const int N = g.N;
@@ -154,29 +160,54 @@ __global__ __launch_bounds__(64) void k_seg_guide(const GArgs g)
 #pragma unroll
         for (int k = 0; k < D; k++) g.vend[(size_t)k * g.ld + p] = w[k];
     }
+    // Without the moving average the means are read THREE grid points ahead of their use (round 3): a lane walks its chain's grid
+    // alone -- one wave per SIMD at 32 768 chains -- and the load of the next point's mean used to be exposed once per point
+    // (~2 us of the ~3 us a point took).  Registers: yn = y_{j+1} (kept for the LinearNoiseAppr slope at j = 0), yc = y_j,
+    // m1 = y_{j-1}, m2 = y_{j-2}, each clamped at index 0.
+    const bool ring = g.hwindow <= 0;
+    double yn[D], yc[D], m1[D], m2[D];
+    auto loadRaw = [&](int j, double *y) {
+#pragma unroll
+        for (int k = 0; k < D; k++) y[k] = g.mean[((size_t)max(j, 0) * D + k) * g.ld + p];
+    };
+    if (ring) { loadRaw(N - 1, yc); loadRaw(N - 2, m1); loadRaw(N - 3, m2); loadRaw(N - 1, yn); }
+    auto advance = [&](int j /* the index yc moves to */) {
+#pragma unroll
+        for (int k = 0; k < D; k++) { yn[k] = yc[k]; yc[k] = m1[k]; m1[k] = m2[k]; }
+        loadRaw(j - 2, m2);
+    };
     // the linearisation at grid index j: LinearAppr (linearappr!, src/linpro.jl:196-204) or LinearNoiseAppr (Pt.Y.yy[:] = xx)
     auto linearise = [&](int j, double *B, double *b, double *xx) {
         if (g.lna) {
             const int jj = max(j, 1);
             double ya[D], yb[D];
-            loadY(jj, ya); loadY(jj - 1, yb);
+            if (ring) {
+#pragma unroll
+                for (int k = 0; k < D; k++) { ya[k] = j >= 1 ? yc[k] : yn[k]; yb[k] = j >= 1 ? m1[k] : yc[k]; }
+            } else { loadY(jj, ya); loadY(jj - 1, yb); }
             const double h = srows[(size_t)(jj - 1) * g.rs + 1];   // tt[jj] - tt[jj-1]
 #pragma unroll
             for (int k = 0; k < D; k++) { b[k] = (ya[k] - yb[k]) / h; xx[k] = 0.0; }
 #pragma unroll
             for (int k = 0; k < DD; k++) B[k] = 0.0;
         } else {
-            loadY(j, xx);
+            if (ring) {
+#pragma unroll
+                for (int k = 0; k < D; k++) xx[k] = yc[k];
+            } else loadY(j, xx);
             model.bderiv(0.0, xx, B);   // (bderiv and b of these processes do not depend on t)
             model.b(0.0, xx, b);
         }
     };
     double B1[DD], b1[D], x1[D];
     linearise(N - 1, B1, b1, x1);
+    double dtn = -srows[(size_t)(N - 2) * g.rs + 1];   // tt[i] - tt[i+1] = -(tt[i+1] - tt[i]) exactly; read one point ahead as well
     for (int i = N - 2; i >= 0; i--) {
         double B0[DD], b0[D], x0[D];
+        if (ring) advance(i);
         linearise(i, B0, b0, x0);
-        const double dt = -srows[(size_t)i * g.rs + 1];   // tt[i] - tt[i+1] = -(tt[i+1] - tt[i]) exactly
+        const double dt = dtn;
+        dtn = -srows[(size_t)max(i - 1, 0) * g.rs + 1];
         {
             double k1[DD], k2[DD], yp[DD];
             fH(B0, K, k1);
@@ -239,7 +270,10 @@ typedef hipError_t (*guide_launch_fn)(const GArgs &, hipStream_t);
 template <class M, int MO>
 hipError_t launch_seg_guide(const GArgs &g, hipStream_t st)
 {
-    hipLaunchKernelGGL((k_seg_guide<M, MO>), dim3((unsigned)((g.n + 63) / 64)), dim3(64), 0, st, g);
+    GArgs a = g;
+    a.lane_shift = g.n >= 65536 ? 0 : g.n >= 24576 ? 1 : 2;   // 64, 32 or 16 chains per wave: >= ~1024 waves where the ensemble allows
+    const long per = 64 >> a.lane_shift;
+    hipLaunchKernelGGL((k_seg_guide<M, MO>), dim3((unsigned)((g.n + per - 1) / per)), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 template <class M>

@@ -104,16 +104,21 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
         for (int c = 0; c < MP; c++) carry[c] = 0.0;
         // cooperative line moves (pCN): instruction q moves the lines of chains c0 + 8q + lane/8; lane%8 selects 16 bytes
         const int sub = lane >> 3, part = 2 * (lane & 7);
-        int par[8];
+        // addresses: a wave-uniform base per chunk (the 64 chains' 256-byte pairs of chunk k are contiguous) + a small per-lane
+        // offset that never changes -- line (8q + sub) of the group, parity half, 16-byte piece -- whose half bit is flipped for
+        // the store: 8 registers instead of 2 x 8 64-bit addresses (which spilled at the 128-register cap)
+        int voff[8];
         d2v stage[8];
+        auto chunk_base = [&](int k) { return a.Wc + line_index(0, k, c0, nch, a.ldC); };
         auto fetch = [&](int k) {
+            const double *kb = chunk_base(k);
 #pragma unroll
-            for (int q = 0; q < 8; q++)
-                stage[q] = ld_stream((const d2v *)(a.Wc + line_index(par[q], k, c0 + 8 * q + sub, nch, a.ldC) + part));
+            for (int q = 0; q < 8; q++) stage[q] = ld_stream((const d2v *)(kb + voff[q]));
         };
         if constexpr (PCN) {
 #pragma unroll
-            for (int q = 0; q < 8; q++) par[q] = a.cur[c0 + 8 * q + sub];   // cur[] is allocated (and zeroed) up to ld
+            for (int q = 0; q < 8; q++)   // cur[] is allocated (and zeroed) up to ld
+                voff[q] = (int)line_index(a.cur[c0 + 8 * q + sub], 0, 8 * q + sub, nch, a.ldC) + part;
             fetch(0);
         }
         double *wout = nullptr;
@@ -216,10 +221,11 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
                 }
                 if constexpr (PCN) {
                     __builtin_amdgcn_wave_barrier();
+                    double *kb = chunk_base(k);
 #pragma unroll
                     for (int q = 0; q < 8; q++) {   // tile -> the lines of the other halves
                         const double *d = tile + (8 * q + sub) * LINE_ROW + part;
-                        st_stream((d2v *)(a.Wc + line_index(par[q] ^ 1, k, c0 + 8 * q + sub, nch, a.ldC) + part), d2v{d[0], d[1]});
+                        st_stream((d2v *)(kb + (voff[q] ^ LINE_DOUBLES)), d2v{d[0], d[1]});
                     }
                 }
             }
