@@ -248,16 +248,23 @@ MODES = {
 
 
 class Workload:
-    """one bench mode: owns its device buffers; step() = one launch of the dominant kernel"""
+    """one bench mode: owns its device buffers; step() = one launch of the dominant kernel.
+    `<mode>_fused`: the same workload under BHIP_OPT_FUSED_ARITHMETIC (the d <= 3 kernels built with a*b + c contracted: results to
+    1e-9 / 1e-8 instead of bit for bit, tests/test_gpu_fused.py) on a context of its own."""
 
     def __init__(self, mode, ctx, chains, rank):
+        self.fused = mode.endswith("_fused")
+        if self.fused:
+            mode = mode[:-len("_fused")]
+            ctx = bh.Context(ctx.device.index)
+            ctx.set_option(bh.OPT_FUSED_ARITHMETIC, 1)
         build, d, mp, x0, default_P, is_chains, rho, text, kname = MODES[mode]
         self.mode, self.ctx = mode, ctx
         self.P = chains if chains else default_P
         self.path0 = rank * self.P                   # contiguous shard of the global ids; the RNG is keyed by the global id
         self.Po = build(ctx)
-        self.workload = text
-        self.kernel = kname(self.P)
+        self.workload = text + (" [BHIP_OPT_FUSED_ARITHMETIC: tolerance parity 1e-9 / 1e-8]" if self.fused else "")
+        self.kernel = kname(self.P).replace("bhip::", "bhip_fused::") if self.fused else kname(self.P)
         self.flops_per_pathstep = 5 * 2 * d * d if d > 8 else None   # d = 32: five d x d mat-vecs per path-step on the matrix cores
         self.chains = None
         if is_chains:
@@ -294,11 +301,11 @@ class Workload:
             tf = per_launch * self.flops_per_pathstep / avg_s / 1e12
             r.update({"bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TF,
                       "algorithmic_flops_per_path_step": self.flops_per_pathstep, "hbm_algorithmic_GBs": gbs})
-        tr, src = profiled_traffic(self.mode, self.kernel)
+        tr, src = (None, "not profiled (fused build)") if self.fused else profiled_traffic(self.mode, self.kernel)
         if tr is not None and self.P != MODES[self.mode][4]:
             tr, src = None, "profiled at the mode's default size only"
         r["traffic"], r["traffic_source"] = tr, src
-        r["valu"] = profiled_valu(self.mode, self.kernel, self.P) if self.P == MODES[self.mode][4] else None
+        r["valu"] = profiled_valu(self.mode, self.kernel, self.P) if (self.P == MODES[self.mode][4] and not self.fused) else None
         v = r["valu"]
         if v and r["bound"] == "hbm" and v["busy_frac"] > 0.6:
             # the kernel's SIMDs spend most of its duration ISSUING vector instructions: what binds it is the instruction count
@@ -636,10 +643,10 @@ def main_local(args):
         others = []
         del w, ws
         torch.cuda.empty_cache()
-        for mode in ("c4shard", "c2", "proposals", "nclar", "nclar_mcmc", "linpro4", "linpro32", "linpro32_mcmc"):
+        for mode in ("c4shard", "c2", "proposals", "nclar", "nclar_mcmc", "linpro4", "linpro32", "linpro32_mcmc", "c2_fused", "proposals_fused", "nclar_fused"):
             wo = Workload(mode, ctx, 0, 0)
             ms = kernel_times(wo, args.steps, args.warmup, min_ms=100.0)
-            others.append({"mode": mode, "workload": wo.workload, "paths": wo.P,
+            others.append({"mode": mode + ("_fused" if wo.fused and not mode.endswith("_fused") else ""), "workload": wo.workload, "paths": wo.P,
                            "path_steps_per_s": wo.P * steps_per_unit / (float(np.mean(ms)) * 1e-3), "roofline": wo.roofline(ms)})
             del wo
             torch.cuda.empty_cache()
@@ -698,7 +705,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chains", type=int, default=0, help="chains (paths) per GPU; 0 = the mode's named size")
-    ap.add_argument("--mode", choices=sorted(MODES), default="mcmc")
+    ap.add_argument("--mode", choices=sorted(MODES) + sorted(m + "_fused" for m in MODES if MODES[m][1] <= 3), default="mcmc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true")
     args = ap.parse_args()

@@ -41,6 +41,7 @@ STATS_LEN = 8
 OPT_WAVE_SPECIALISED = 1   # BHIP_OPT_WAVE_SPECIALISED
 OPT_TUNE_PLACEMENT = 2     # BHIP_OPT_TUNE_PLACEMENT
 OPT_MID_VALU = 3           # BHIP_OPT_MID_VALU
+OPT_FUSED_ARITHMETIC = 4   # BHIP_OPT_FUSED_ARITHMETIC
 AUX_LINEARAPPR = 4         # BHIP_AUX_LINEARAPPR
 
 

@@ -79,6 +79,23 @@ static guide_launch_fn find_guide_launch(const ModelHost &mh, int mo)
     return nullptr;
 }
 }  // namespace bhip
+// the same getters of the fused builds (bhip_inst.hip compiled with -DBHIP_FUSED -ffp-contract=fast; their launch_fn is the
+// layout-identical type of their own namespace)
+namespace bhip_fused {
+bhip::launch_fn get_launch_ou(int, int, int, int);
+bhip::launch_fn get_launch_linpro1(int, int, int, int);
+bhip::launch_fn get_launch_linpro2(int, int, int, int);
+bhip::launch_fn get_launch_linpro3(int, int, int, int);
+bhip::launch_fn get_launch_fhn(int, int, int, int);
+bhip::launch_fn get_launch_nclar(int, int, int, int);
+bhip::launch_fn get_launch_intdiff(int, int, int, int);
+bhip::launch_fn get_launch_lorenz(int, int, int, int);
+bhip::launch_fn get_launch_fhn2(int, int, int, int);
+bhip::launch_fn get_launch_pendulum(int, int, int, int);
+bhip::launch_fn get_launch_wiener1(int, int, int, int);
+bhip::launch_fn get_launch_wiener2(int, int, int, int);
+bhip::launch_fn get_launch_wiener3(int, int, int, int);
+}  // namespace bhip_fused
 
 #ifndef PC_FRESH_MAX_PATHS
 #define PC_FRESH_MAX_PATHS 98304
@@ -93,6 +110,7 @@ struct bhip_ctx {
     size_t scratch_bytes = 0;
     bool wave_specialised = true;   // BHIP_OPT_WAVE_SPECIALISED: producer/consumer kernels (bhip_pc_kernel.h) where they exist
     bool mid_valu = true;           // BHIP_OPT_MID_VALU: LinPro targets of dimension 4..8 one path per lane (0: zero padded on the MFMA tile kernel)
+    bool fused = false;             // BHIP_OPT_FUSED_ARITHMETIC: the d <= 3 kernels built with a*b + c contracted (tolerance parity)
     bool tune_placement = true;     // BHIP_OPT_TUNE_PLACEMENT: large chain ensembles try a few allocations and keep the fastest (bhip_chains_init)
     // lifetime: every proposal / chain ensemble / communicator holds a reference.  bhip_ctx_destroy with live children only
     // closes the context (garbage collectors -- Python at interpreter exit, Julia finalizers -- destroy handles in any order);
@@ -212,7 +230,7 @@ static int ensure_scratch(bhip_ctx *ctx, size_t bytes)
     return BHIP_OK;
 }
 
-static launch_fn find_launch(const ModelHost &mh, int gk, int mo, int noise, int fl)
+static launch_fn find_launch_exact(const ModelHost &mh, int gk, int mo, int noise, int fl)
 {
     switch (mh.id) {
     case BHIP_MODEL_OU: return get_launch_ou(gk, mo, noise, fl);
@@ -234,6 +252,35 @@ static launch_fn find_launch(const ModelHost &mh, int gk, int mo, int noise, int
         return nullptr;
     }
     return nullptr;
+}
+
+static launch_fn find_launch_fused(const ModelHost &mh, int gk, int mo, int noise, int fl)
+{
+    switch (mh.id) {
+    case BHIP_MODEL_OU: return bhip_fused::get_launch_ou(gk, mo, noise, fl);
+    case BHIP_MODEL_LINPRO:
+        if (mh.d == 1) return bhip_fused::get_launch_linpro1(gk, mo, noise, fl);
+        if (mh.d == 2) return bhip_fused::get_launch_linpro2(gk, mo, noise, fl);
+        if (mh.d == 3) return bhip_fused::get_launch_linpro3(gk, mo, noise, fl);
+        return nullptr;
+    case BHIP_MODEL_FHN: return bhip_fused::get_launch_fhn(gk, mo, noise, fl);
+    case BHIP_MODEL_NCLAR: return bhip_fused::get_launch_nclar(gk, mo, noise, fl);
+    case BHIP_MODEL_INTDIFF: return bhip_fused::get_launch_intdiff(gk, mo, noise, fl);
+    case BHIP_MODEL_LORENZ: return bhip_fused::get_launch_lorenz(gk, mo, noise, fl);
+    case BHIP_MODEL_FHN2: return bhip_fused::get_launch_fhn2(gk, mo, noise, fl);
+    case BHIP_MODEL_PENDULUM: return bhip_fused::get_launch_pendulum(gk, mo, noise, fl);
+    case BHIP_MODEL_WIENER:
+        if (mh.d == 1) return bhip_fused::get_launch_wiener1(gk, mo, noise, fl);
+        if (mh.d == 2) return bhip_fused::get_launch_wiener2(gk, mo, noise, fl);
+        if (mh.d == 3) return bhip_fused::get_launch_wiener3(gk, mo, noise, fl);
+        return nullptr;
+    }
+    return nullptr;
+}
+
+static launch_fn find_launch(const ModelHost &mh, int gk, int mo, int noise, int fl, bool fused = false)
+{
+    return fused ? find_launch_fused(mh, gk, mo, noise, fl) : find_launch_exact(mh, gk, mo, noise, fl);
 }
 
 extern "C" {
@@ -297,6 +344,7 @@ int bhip_ctx_set_option(bhip_ctx *ctx, int option, int value)
     if (option == BHIP_OPT_WAVE_SPECIALISED) { ctx->wave_specialised = value != 0; return BHIP_OK; }
     if (option == BHIP_OPT_TUNE_PLACEMENT) { ctx->tune_placement = value != 0; return BHIP_OK; }
     if (option == BHIP_OPT_MID_VALU) { ctx->mid_valu = value != 0; return BHIP_OK; }
+    if (option == BHIP_OPT_FUSED_ARITHMETIC) { ctx->fused = value != 0; return BHIP_OK; }
     return fail(ctx, BHIP_EINVAL, "bhip_ctx_set_option: unknown option");
 }
 
@@ -1092,10 +1140,10 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         // producer/consumer waves (bhip_pc_kernel.h): same results, the kernel of choice wherever it is instantiated
         // Fresh proposals: with 4 waves per SIMD the one-lane-does-everything kernel already issues at ~85 % of the VALU
         // rate and the hand-over only costs; the split pays below that (profiles/r2_small_configs.txt).
-        if (noise == NOISE_FRESH && a.P <= PC_FRESH_MAX_PATHS) f = find_launch(po->mh, gk_dispatch, mo, NOISE_FRESH_PC, fl);
-        else if (noise == NOISE_PCN_LINES) f = find_launch(po->mh, gk_dispatch, mo, NOISE_PCN_LINES_PC, fl);
+        if (noise == NOISE_FRESH && a.P <= PC_FRESH_MAX_PATHS) f = find_launch(po->mh, gk_dispatch, mo, NOISE_FRESH_PC, fl, ctx->fused);
+        else if (noise == NOISE_PCN_LINES) f = find_launch(po->mh, gk_dispatch, mo, NOISE_PCN_LINES_PC, fl, ctx->fused);
     }
-    if (!f) f = find_launch(po->mh, gk_dispatch, mo, noise, fl);
+    if (!f) f = find_launch(po->mh, gk_dispatch, mo, noise, fl, ctx->fused);
     if (!f) return fail(ctx, BHIP_EUNSUPPORTED, "no device kernel for this (model, guide, noise) combination");
     HIPCHK(ctx, f(a, ctx->stream));
     return BHIP_OK;

@@ -108,6 +108,13 @@ int bhip_ctx_sync(bhip_ctx *ctx);
  * advantage over fp64 FMAs, and a 16x16x4 instruction cannot skip padding: d = 4 is ~7x faster per lane.  Same results to the
  * tile kernel's tolerance (the guide solve is a product with the pre-inverted matrix in both). */
 #define BHIP_OPT_MID_VALU 3
+/* BHIP_OPT_FUSED_ARITHMETIC (default 0): 1 runs the d <= 3 path kernels (built-in processes; ensembles and chains with a guide
+ * shared by the ensemble) from a second build of the same source in which the compiler may contract a*b + c into one fused
+ * multiply-add.  The default build rounds every product like the reference (Julia never fuses) and is compared with the CPU
+ * restatement bit for bit; the fused build agrees with it to 1e-9 on paths and 1e-8 on log-likelihoods (tests) -- the stated
+ * fp64 tolerance -- and issues ~15 % fewer vector instructions in the instruction-bound modes.  Noise is unaffected up to the
+ * last bit of the Wiener cumulation W[i] + sqrt(dt)*xi.  Per-chain device-built guides and hipRTC user processes ignore it. */
+#define BHIP_OPT_FUSED_ARITHMETIC 4
 int bhip_ctx_set_option(bhip_ctx *ctx, int option, int value);
 const char *bhip_last_error(const bhip_ctx *ctx);
 /* device memory helpers for callers without their own allocator */
