@@ -945,6 +945,7 @@ class SegChains:
     def __init__(self, pos, mu, chol, nchains, seed=0, path0=0, skip=0, mcnext=False, pooled=False, mcnext_mean_only=False):
         self.pos, self.ctx = list(pos), pos[0].ctx
         self.m, self.n, self.d, self.mp, self.N = len(self.pos), int(nchains), pos[0].d, pos[0].mp, len(pos[0].tt)
+        self.mean_only = bool(mcnext_mean_only) and not mcnext
         hs = (vp * self.m)(*[P.h for P in self.pos])
         h = vp()
         self.ctx.check(self.ctx.lib.bhip_segchains_create(self.ctx.h, self.m, hs, self.n, path0, seed, (1 if mcnext else 0) | (2 if pooled else 0) | (4 if mcnext_mean_only else 0), C.byref(h)))
@@ -1037,9 +1038,10 @@ class SegChains:
 
     def mcstats(self, segment, chain):
         """the mcnext! state of one chain: (mean [N, d], m2 [N, d, d], count)   src/mclog.jl:48-56"""
-        mean, m2, cnt = np.empty((self.N, self.d)), np.empty((self.N, self.d * self.d)), C.c_int64()
-        self.ctx.check(self.ctx.lib.bhip_segchains_mcstats(self.h, segment, chain, _dptr(mean), _dptr(m2), C.byref(cnt)))
-        return mean, _uncm(m2, self.d, self.d), cnt.value
+        mean, cnt = np.empty((self.N, self.d)), C.c_int64()
+        m2 = None if self.mean_only else np.empty((self.N, self.d * self.d))       # BHIP_SEGCHAINS_MCNEXT_MEAN keeps the running means only
+        self.ctx.check(self.ctx.lib.bhip_segchains_mcstats(self.h, segment, chain, _dptr(mean), None if m2 is None else _dptr(m2), C.byref(cnt)))
+        return mean, (None if m2 is None else _uncm(m2, self.d, self.d)), cnt.value
 
     def __del__(self):
         try:

@@ -794,7 +794,8 @@ static int build_tile_data(bhip_proposal *po)
 
 static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const double *W_in, long ldWin, double *W_out, long ldWout,
                             double *X, long ldX, double *ll, int skip, long npaths, int noise, uint64_t seed, uint32_t iter, uint32_t path0,
-                            int wstride = 1, const bhip_chains *ch = nullptr, double rho = 0.0, const double *x0_dev = nullptr, long ldx0 = 0)
+                            int wstride = 1, const bhip_chains *ch = nullptr, double rho = 0.0, const double *x0_dev = nullptr, long ldx0 = 0,
+                            uint32_t blk0 = 0, int defer_accept = 0, double w_new = -1.0 /* >= 0: the weight of the fresh noise given explicitly */)
 {
     const bhip_proposal *po = po_c;
     bhip_ctx *ctx = po->ctx;
@@ -815,8 +816,9 @@ static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const d
     a.wstride = wstride;
     if (noise == 2) {   // pCN chain step
         a.Wc = ch->Wc; a.ldC = ch->ld; a.cur = ch->cur; a.llcur = ch->llcur; a.acc = ch->acc;
-        a.rho = rho; a.srho = std::sqrt(1 - rho * rho);
+        a.rho = rho; a.srho = w_new >= 0.0 ? w_new : std::sqrt(1 - rho * rho);
     }
+    a.blk0 = blk0; a.defer_accept = defer_accept;
     if (po->mh.id >= USER_MODEL_BASE) {   // component-wise user drift: the hipRTC instantiation k_tile<D, noise, PAD, MUserBig>
         const int D = tile_dim(d);
         const bool pad = d != D;
@@ -1397,12 +1399,11 @@ static int chains_init_impl(bhip_chains *ch, const double *x0, const double *x0_
         HIPCHK(ctx, hipMemsetAsync(ch->cur, 0, ch->ld, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ch->acc, 0, sizeof(unsigned int) * ch->ld, ctx->stream));
     }
-    if (po->mh.d > 3 && (x0_dev || blk0)) return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: shared starting point, single segment only");
     if (po->mh.d > 3) {   // MFMA tile kernel: fresh W into a plain SoA scratch array, re-arranged into half 0 of the tile lines; X and ll of the initial state
         const int N = (int)po->tt.size(), d = po->mh.d, T = tile_dim(d) / 16;
         double *tmpW = nullptr;
         HIPCHK(ctx, hipMalloc((void **)&tmpW, sizeof(double) * N * d * ch->n));
-        int rct = launch_tile_path(po, x0, nullptr, 0, tmpW, ch->n, ch->Xo, ch->ld, ch->llcur, skip, ch->n, 1, ch->seed, 0, ch->path0, 1);
+        int rct = launch_tile_path(po, x0, nullptr, 0, tmpW, ch->n, ch->Xo, ch->ld, ch->llcur, skip, ch->n, 1, ch->seed, 0, ch->path0, 1, nullptr, 0.0, x0_dev, ldx0, blk0);
         if (!rct) {
             const long tot = (long)N * 16 * T * ch->n;
             hipLaunchKernelGGL(k_soa_to_tlines, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, tmpW, ch->Wc, N, d, T, ch->ld, ch->n);
@@ -1535,6 +1536,9 @@ static int chains_propose_deferred(bhip_chains *ch, double w_old, double w_new, 
                                    double *llo_dev, int skip)
 {
     const bhip_proposal *po = ch->po;
+    if (po->mh.d > 3)   // the MFMA tile kernel's chain step with the decision deferred
+        return launch_tile_path(po, ch->x0.data(), nullptr, 0, nullptr, 0, ch->Xo, ch->ld, llo_dev, skip, ch->n, 2, ch->seed, iter, ch->path0, 1, ch, w_old,
+                                x0_dev, ldx0, blk0, 1, w_new);
     KArgs a;
     int rc = fill_common(po, a, ch->x0.data(), x0_dev, ch->n, skip);
     if (rc) return rc;

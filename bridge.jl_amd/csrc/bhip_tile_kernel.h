@@ -67,6 +67,8 @@ struct TArgs {
     const double *tt;
     const double *x0_dev;   // optional per-path starting points [d][ldx0] (segment chaining: src/euler.jl:267 returns the end point)
     long ldx0;
+    uint32_t blk0;          // offset of the noise stream in pairs (multi-segment chains: segment << 24), as KArgs::blk0
+    int defer_accept;       // pCN: do not decide -- only report llo in `ll` (joint accept over segments, bhip_segchains_*)
 };
 // The target drift of the built-in instantiations is LinPro's B(x - mu), one of the five MFMA products.  A hipRTC user process
 // supplies its drift COMPONENT-WISE instead: UD::bk(k, t, x, par) = b_k(t, x, P), where x points to the path's whole state
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 const uint32_t nb = (uint32_t)i * (uint32_t)dtr + 16u * (uint32_t)t;
                 double z[4];
                 if constexpr ((BHIP_TILE_EXP & 2) != 0) { z[0] = 1e-3 * (double)(lane + t); z[1] = -z[0]; z[2] = 0.5 * z[0]; z[3] = -z[2]; }
-                else normal_quad(rtab, a.k0, a.k1, path, a.iter, (nb >> 2) + (uint32_t)kq, z[0], z[1], z[2], z[3]);
+                else normal_quad(rtab, a.k0, a.k1, path, a.iter, (nb >> 2) + (uint32_t)kq + (a.blk0 >> 1), z[0], z[1], z[2], z[3]);
                 if constexpr (!PAD) {
                     *(tile_d2v *)(zb + 4 * kq) = tile_d2v{z[0], z[1]};
                     *(tile_d2v *)(zb + 4 * kq + 2) = tile_d2v{z[2], z[3]};
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                         if (pos >= 0) zb[pos] = z[u];          // (pos <= 15 always)
                     }
                     if (off != 0 && kq == 0) {                 // wave-uniform `off`: the window's last entries come from a fifth call
-                        normal_quad(rtab, a.k0, a.k1, path, a.iter, (nb >> 2) + 4u, z[0], z[1], z[2], z[3]);
+                        normal_quad(rtab, a.k0, a.k1, path, a.iter, (nb >> 2) + 4u + (a.blk0 >> 1), z[0], z[1], z[2], z[3]);
 #pragma unroll
                         for (int u = 0; u < 3; u++)
                             if (u < off) zb[16 + u - off] = z[u];
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     }
     if constexpr (NOISE == 2) {
         // if log(rand()) <= llo - ll: W <- Wo (parity flip), ll <- llo, acc += 1     partialbridge_fitzhugh.jl:160-167
-        if (live && kq == 0) {
+        if (live && kq == 0 && !a.defer_accept) {
             const double u = accept_uniform(a.k0, a.k1, path, a.iter);
             if (det_log(u, rtab) <= ll - a.llcur[p]) {
                 a.cur[p] = (unsigned char)(cpar ^ 1);

@@ -268,6 +268,46 @@ __global__ void k_seg_y0(long n, long ld, double w_old, double w_new, const doub
     }
 }
 
+// the same at any state dimension (d > 3: the MFMA tile kernel's chains): mu [d], chol [d*d] (column-major) in device memory
+static __global__ void k_seg_y0_big(long n, long ld, int d, double w_old, double w_new, const double *__restrict__ y0, double *__restrict__ y0o,
+                                    uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0, const double *__restrict__ mu,
+                                    const double *__restrict__ chol, const unsigned char *__restrict__ newblock)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (newblock && newblock[p]) {
+        for (int r = 0; r < d; r++) y0o[r * ld + p] = y0[r * ld + p];
+        return;
+    }
+    double xi[34];   // d <= 32
+    for (int k = 0; k < d; k += 2) normal_pair(TabConst(), k0, k1, path0 + (uint32_t)p, iter, (uint32_t)(k >> 1), xi[k], xi[k + 1], 2u);
+    for (int r = 0; r < d; r++) {
+        double cz = chol[r] * xi[0];
+        for (int c = 1; c < d; c++) cz += chol[r + d * c] * xi[c];
+        const double z = mu[r] + cz;                                       // rand(pi0) = mu + C*randn   src/gaussian.jl:54
+        y0o[r * ld + p] = mu[r] + w_new * (z - mu[r]) + w_old * (y0[r * ld + p] - mu[r]);
+    }
+}
+
+// commit (+ the running means of mcnext!) at any state dimension: blockIdx.y = grid point, blockIdx.z = segment
+static __global__ void k_seg_commit_big(long n, long ld, int N, int m, int d, double *const *__restrict__ tab, const unsigned char *__restrict__ accflag,
+                                        int want_stats, double count)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y, sg = blockIdx.z;
+    if (p >= n) return;
+    const double *__restrict__ Xo = tab[sg];
+    double *__restrict__ Xc = tab[m + sg];
+    double *__restrict__ mean = want_stats ? tab[2 * m + sg] : nullptr;
+    const bool a = accflag[p] != 0;
+    for (int k = 0; k < d; k++) {
+        const size_t e = ((size_t)i * d + k) * ld + p;
+        const double x = a ? Xo[e] : Xc[e];
+        if (a) Xc[e] = x;
+        if (mean) { const double mk = mean[e]; mean[e] = mk + (x - mk) / (count + 1.0); }   // m += delta/(n+1)   src/mclog.jl:52
+    }
+}
+
 static __global__ void k_seg_accept(long n, long ld, int m, int d, const double *__restrict__ llo, double *__restrict__ ll,
                                     unsigned char *__restrict__ cur, unsigned int *__restrict__ acc, unsigned char *__restrict__ accflag,
                                     double *__restrict__ y0, const double *__restrict__ y0o, uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0,

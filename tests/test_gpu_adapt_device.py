@@ -308,5 +308,7 @@ def test_mean_only_statistics_drive_the_same_adaptation():
     mean_b = np.empty((M + 1, 3)); cnt = bh.api.C.c_int64()
     ctx.check(ctx.lib.bhip_segchains_mcstats(b.h, 0, 50, bh.api._dptr(mean_b), None, bh.api.C.byref(cnt)))
     assert np.array_equal(ma, mean_b) and cnt.value == 7
-    with pytest.raises(bh.BridgeError, match="second moments"):
-        b.mcstats(0, 50)
+    mb, m2b, cb = b.mcstats(0, 50)                                   # the mirror hands back what is kept: the means, no second moments
+    assert np.array_equal(mb, ma) and m2b is None and cb == 7
+    m2 = np.empty((M + 1, 9))
+    assert ctx.lib.bhip_segchains_mcstats(b.h, 0, 50, None, bh.api._dptr(m2), None) == -4 and b"second moments" in ctx.lib.bhip_last_error(ctx.h)

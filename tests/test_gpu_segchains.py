@@ -136,3 +136,52 @@ def test_pooled_statistics_over_chains_and_iterations(ctx):
         assert np.allclose(mean, S.mean(0), rtol=1e-12, atol=1e-13)
         dev = S - S.mean(0)
         assert np.allclose(m2, np.einsum("sni,snj->nij", dev, dev), rtol=1e-10, atol=1e-11)
+
+
+@pytest.mark.parametrize("d", [16, 5])
+def test_joint_mh_over_segments_at_large_dimension(ctx, d):
+    """round 3: multi-segment chains on the MFMA tile kernel (d = 16; d = 5 zero padded): per-chain starts from the previous
+    segment's end point, one noise stream per segment, the accept deferred to the joint decision, the pCN move of a d-vector start,
+    running means.  Against bo_smooth_mcmc at the tile kernel's tolerance (pre-inverted guide matrix, fused MFMA accumulation):
+    identical accept decisions, Wiener paths bit for bit, paths 1e-9, ll 1e-8."""
+    rng = np.random.default_rng(11)
+    m, M = 3, 30
+    G = rng.standard_normal((d, d)) / np.sqrt(d); G2 = rng.standard_normal((d, d)) / np.sqrt(d)
+    B, sig = -np.eye(d) + 0.1 * G, 0.5 * np.eye(d) + 0.05 * G2
+    P, Pt = bh.LinPro(B, np.zeros(d), sig), bh.LinPro(-np.eye(d), np.zeros(d), sig)
+    par, apar = o.linpro_par(B, np.zeros(d), sig), o.linpro_par(-np.eye(d), np.zeros(d), sig)
+    L, Sig = np.eye(d), 0.3 * np.eye(d)
+    tgrid = np.linspace(0, 0.2 * m, m * M + 1)
+    obs = 0.3 * rng.standard_normal((m + 1, d))
+    H, v = bh.gpupdate(np.diag([np.inf] * d), np.zeros(d), np.eye(d), 0.5 * np.eye(d), obs[m])
+    segs, refs = [None] * m, [None] * m
+    for i in range(m - 1, -1, -1):
+        tt = tgrid[i * M:(i + 1) * M + 1].copy()
+        segs[i] = bh.GuidedBridge(tt, P, Pt, v, H, ctx=ctx)
+        refs[i] = o.proposal_hv(tt, d, d, o.MODEL_LINPRO, par, o.AUX_LINPRO, apar, segs[i].Hd, segs[i].V)
+        H, v = bh.gpupdate(segs[i], L, Sig, obs[i])
+    chol = np.linalg.cholesky((H + H.T) / 2)
+    n, iters = 100, 6
+    w_new = np.sqrt(rng.uniform(0.05, 0.4, iters)); w_old = np.sqrt(1 - w_new ** 2)
+    with pytest.raises(bh.BridgeError, match="MCNEXT_MEAN"):
+        bh.SegChains(segs, v, chol, n, mcnext=True)                      # d + d*d doubles per chain and grid point: refused
+    sc = bh.SegChains(segs, v, chol, n, seed=23, path0=5, mcnext_mean_only=True)
+    sc.step(w_old[:2], w_new[:2])
+    sc.step(w_old[2:], w_new[2:])
+    ll, acc, y0 = sc.state()
+    for p in (0, 15, 16, 99):
+        r = o.smooth_mcmc(refs, v, chol, w_old, w_new, 23, 5 + p, stats=True)
+        assert acc[p] == r["acc"], (p, acc[p], r["acc"])
+        assert np.abs(y0[p] - r["y0"]).max() <= 1e-12 * (1 + np.abs(r["y0"]).max())
+        for i in range(m):
+            X, W = sc.paths(i, p, 1)
+            assert np.array_equal(W[0], r["W"][i]) or np.abs(W[0] - r["W"][i]).max() <= 1e-14 * (1 + np.abs(r["W"][i]).max())
+            assert np.abs(X[0] - r["X"][i]).max() <= 1e-9 * (1 + np.abs(r["X"][i]).max()), (p, i)
+            assert abs(ll[i, p] - r["ll"][i]) <= 1e-8 * (1 + abs(r["ll"][i]))
+            mean, _, cnt = sc.mcstats(i, p)
+            assert cnt == iters and np.abs(mean - r["mean"][i]).max() <= 1e-9 * (1 + np.abs(r["mean"][i]).max())
+    assert 0 < acc.sum() < n * iters
+    for i in range(m - 1):                                                # continuity at the joints
+        Xa, _ = sc.paths(i, 0, n)
+        Xb, _ = sc.paths(i + 1, 0, n)
+        assert np.array_equal(Xa[:, -1, :], Xb[:, 0, :])
