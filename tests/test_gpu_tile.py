@@ -263,3 +263,19 @@ def test_dimensions_4_to_8_run_one_path_per_lane(ctx, d):
     ch.step(0.9, 3)
     r = o.mcmc(ref, c.x0, 0.9, 3, 8, 17)
     assert ch.acc()[17] == r["acc"] and abs(ch.ll()[17] - r["ll"]) <= 1e-8 * (1 + abs(r["ll"]))
+
+
+@pytest.mark.parametrize("N", [2, 3, 4, 5, 6, 9])
+@pytest.mark.parametrize("d", [4, 7, 8])
+def test_one_path_per_lane_short_grids_and_loop_remainders(ctx, d, N):
+    """the unrolled time loop of k_paths<MLinPro<d>> (two or four steps per iteration, ragged tail with a dynamic position inside
+    the Philox call) on grids shorter than / not a multiple of the unrolling, ensembles that do not fill a workgroup"""
+    c = problems.linpro_big_case(d, N)
+    Po, ref = c.bh_proposal(bh, ctx), c.oracle_proposal()
+    X, W, ll = bh.sample_solve(c.x0, Po, 67, seed=3, iter=5, path0=9, store_W=True)
+    Xh, Wh, llh = X.paths(), W.paths(), ll.cpu().numpy()
+    for p in (0, 63, 66):
+        Wr = o.wiener_sample(c.tt, d, 3, 9 + p, 5)
+        assert np.array_equal(Wh[p], Wr), (d, N, p)
+        Xr = o.solve_guided(ref, c.x0, Wr)
+        _close(Xh[p], Xr, llh[p:p + 1], np.array([o.llikelihood(ref, Xr)]))
