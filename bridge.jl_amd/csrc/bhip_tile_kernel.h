@@ -74,6 +74,7 @@ struct TArgs {
 // supplies its drift COMPONENT-WISE instead: UD::bk(k, t, x, par) = b_k(t, x, P), where x points to the path's whole state
 // vector (gathered per wave in LDS -- a lane holds only 8 of a path's 32 components).
 struct NoUserDrift { static constexpr bool ON = false; };
+template <bool B> struct TileTag { static constexpr bool value = B; };
 typedef double tile_d2v __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) double *tile_cptr_t;   // constant address space: wave-uniform reads go through the scalar unit
 // the ensembles and the chain state are streamed: written / read once per launch (same hint as the d <= 3 kernels)
@@ -213,6 +214,13 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     dma_w();              // grid point 1 ...
     if constexpr (NOISE == 2 && BHIP_TILE_LDSDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... landed before step 0 reads it
 
+    // The time loop, specialised on whether the path (and, fresh noise, the Wiener path) is stored: the number of vector-memory
+    // operations per step is then STATIC.  With the wave-uniform `if (a.X)` inside the loop the compiler merged the two paths'
+    // counters conservatively and waited with vmcnt(0) for the staged matrix loads -- i.e. for the step's own stores to be
+    // acknowledged by the L2, a write round trip per step (round 3: that, not the stores themselves, was what the knock-out
+    // of the stores saved).
+    auto time_loop = [&](auto hasx_tag, auto hasw_tag) {
+    constexpr bool HASX = decltype(hasx_tag)::value, HASW = decltype(hasw_tag)::value;
     for (int i = 0; i < nsteps; i++) {
         const int cur = (BHIP_TILE_EXP & 1) ? 0 : i & 1;
         const double *hm = hb + cur * STEP, *nu = hm + DD;
@@ -226,6 +234,24 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 stage[c] = idx < STEP ? a.steps[(size_t)(i + 1) * STEP + idx] : 0.0;
             }
         }
+        // The step's vector-memory schedule (round 3).  LLVM treats loads and stores pending in the one vmcnt counter as
+        // completing out of order with each other, so ANY wait for a load result while stores are pending is vmcnt(0): a wait for
+        // those stores to be acknowledged by the L2.  Round 2 had that wait at the END of the step (staged matrix -> LDS, and the
+        // workgroup fence of __syncthreads, which on gfx950 is vmcnt(0) as well): every step ended with a write round trip for
+        // the stores it had just issued -- the knock-out of the stores saved 2 ms of 17 because of it.  Now: the step's loads
+        // (next matrix, chain-state DMA) are issued at its top, drained ONCE right before its first store (by then the
+        // previous step's stores are a step old and long acknowledged), the staged matrix goes to LDS there, the stores are
+        // issued after it and nothing in the rest of the step waits on vector memory; the barrier at the end is LDS-only.
+        auto land_stage = [&]() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (more) {
+#pragma unroll
+                for (int c = 0; c < (STEP + 255) / 256; c++) {
+                    const int idx = tid + 256 * c;
+                    if (idx < STEP) hb[(cur ^ 1) * STEP + idx] = stage[c];
+                }
+            }
+        };
         // (dt, sqrt(dt)) ride along with the staged matrix: a vector load here would be waited for with vmcnt(0) -- the
         // compiler's rule while an LDS-DMA is in flight -- i.e. for the chain-state DMA issued just above, a full memory
         // latency per step; a scalar load would turn every lgkmcnt(N) of the LDS -> MFMA pipeline into lgkmcnt(0)
@@ -246,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                     wprev[t][r] = wn;
                 }
             winp += (size_t)dtr * a.ldWin;
+            land_stage();
         } else if constexpr (NOISE == 3) {
             // stand-alone llikelihood(LeftRule(), X, Po): x_i comes from the stored path, nothing is propagated
             const double *q = winp;
@@ -258,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                     dw[t][r] = 0.0;
                 }
             winp += (size_t)dtr * a.ldWin;
+            land_stage();
         } else {
             double wcur[NOISE == 2 ? T : 1][4];
             if constexpr (NOISE == 2 && BHIP_TILE_LDSDMA) {
@@ -317,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 for (int r = 0; r < 4; r++) mine[4 * t + r] = zb[4 * r + kq];
                 __builtin_amdgcn_wave_barrier();   // ... and the reads precede the next pass's writes
             }
+            land_stage();
             double *qo = wop;
 #pragma unroll
             for (int t = 0; t < T; t++)
@@ -340,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                     }
                 }
             if constexpr (NOISE == 2) { if (!BHIP_TILE_LDSDMA) wrd += tl_grid; wwr += tl_grid; }
-            if (NOISE == 1 && a.Wout) {   // one wave-uniform test for the whole row group
+            if constexpr (NOISE == 1 && HASW) {
 #pragma unroll
                 for (int t = 0; t < T; t++)
 #pragma unroll
@@ -350,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
         }
 
         // ---- X[i] = x (before the update, src/euler.jl:263)
-        if (NOISE != 3 && a.X) {   // wave-uniform test (xp itself is a per-lane value)
+        if constexpr (NOISE != 3 && HASX) {
             double *q = xp;
 #pragma unroll
             for (int t = 0; t < T; t++)
@@ -412,23 +441,17 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 for (int r = 0; r < 4; r++) x[t][r] = x[t][r] + (bT[t][r] + g[t][r]) * dt + s[t][r];
         }
 
-        if (more) {
-#pragma unroll
-            for (int c = 0; c < (STEP + 255) / 256; c++) {
-                const int idx = tid + 256 * c;
-                if (idx < STEP) hb[(cur ^ 1) * STEP + idx] = stage[c];
-            }
-        }
-        if constexpr (NOISE == 2 && BHIP_TILE_LDSDMA) {
-            // The DMA of W[i+2] (issued at the top of this step) must have landed before the next step reads it.  vmcnt counts
-            // loads and stores in issue order, so it is enough that at most the operations issued AFTER the DMA are still
-            // outstanding: this step's 2T proposal-line stores (unconditional) and, unpadded with the path store on, its 4T path
-            // stores.  vmcnt(0) here -- round 2 -- also waited for those stores to be acknowledged by the L2: a write round trip
-            // per step, the 2.7 ms the chain kernel took over the proposal kernel.
-            if (!PAD && NOISE != 3 && a.X) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * T) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * T) : "memory");
-        }
-        if constexpr ((BHIP_TILE_EXP & 1) == 0) __syncthreads();
+        // LDS-only barrier: this wave's reads of hb[cur] and its writes of hb[cur ^ 1] are done (lgkmcnt), the block meets; no
+        // wait on vector memory (a __syncthreads would drain the stores just issued)
+        if constexpr ((BHIP_TILE_EXP & 1) == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    };
+    if (NOISE != 3 && a.X) {
+        if (NOISE == 1 && a.Wout) time_loop(TileTag<true>(), TileTag<true>());
+        else time_loop(TileTag<true>(), TileTag<false>());
+    } else {
+        if (NOISE == 1 && a.Wout) time_loop(TileTag<false>(), TileTag<true>());
+        else time_loop(TileTag<false>(), TileTag<false>());
     }
 
     if (a.use_vend) {
