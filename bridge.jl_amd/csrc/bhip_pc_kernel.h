@@ -44,6 +44,12 @@ constexpr int PC_TILE = 64 * LINE_ROW;                          // doubles per h
 constexpr size_t PC_LDS = sizeof(double) * (RNG_TAB_DOUBLES + 2 * PC_TILE);   // 19 984 bytes: 8 workgroups per CU
 typedef const __attribute__((address_space(3))) double *ldsrow_t;
 
+// The hand-over barrier of a chunk: the wave's LDS operations are done, the workgroup meets.  NOT __syncthreads: its
+// workgroup fence is `s_waitcnt vmcnt(0)` on gfx950 -- a wait for every store the wave has issued (the consumer's path stores, the
+// producer's line stores) to be acknowledged by the L2, once per chunk, which the waves of a small ensemble (one or two per
+// SIMD) cannot hide.  Nothing but LDS is handed over between the waves of a pair.
+__device__ __forceinline__ void pc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // KArgs::rdtp (device): rdtp[j] = sqrt(tt[j] - tt[j-1]) for 1 <= j <= N-1, rdtp[0] = 0, zero padded to a multiple of 16:
 // the Wiener increment INTO grid point j, so that a chunk reads 16/m' consecutive, aligned values and grid point 0
 // (W[0] = 0 + 0*z = 0) needs no special case.
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
                     }
                 }
             }
-            __syncthreads();   // chunk k is complete; the consumer has finished chunk k-1 (the tile written next)
+            pc_barrier();   // chunk k is complete; the consumer has finished chunk k-1 (the tile written next)
         }
         return;
     }
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
                 }
             }
         }
-        __syncthreads();
+        pc_barrier();
     }
 
     if constexpr (PPR) {
