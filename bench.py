@@ -493,6 +493,20 @@ def timed_region_local(ws, steps, stats, group):
     return elapsed, kern, gathered[0], [evs[r][0].elapsed_time(evs[r][steps]) for r in range(n)], g0.elapsed_time(g1)
 
 
+class _HostGather:
+    """BENCH_SAME_DEVICE test double of dist.CommGroup: the blocks of all "ranks" stacked (they live on one device)"""
+
+    def __init__(self, n):
+        self.nranks = n
+
+    def allgather(self, sends):
+        g = torch.stack([s.reshape(-1) for s in sends])
+        return [g.clone() for _ in sends]
+
+    def destroy(self):
+        pass
+
+
 def base_record(args, world, w, elapsed, kern_ms, launch):
     steps_per_unit = N_GRID - 1
     total_pathsteps = float(world) * w.P * steps_per_unit * args.steps
@@ -592,13 +606,16 @@ def main_local(args):
     the very same calls, so the single-GPU line exercises the collective path too."""
     n = args.gpus
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if n < 1 or n > ndev:
+    # BENCH_SAME_DEVICE=1 (testing the N > 1 code of this function on a one-GPU box): N contexts on device 0, the gather emulated
+    # on the host, because RCCL refuses two ranks on one device.  Never set by the driver.
+    same = os.environ.get("BENCH_SAME_DEVICE") == "1"
+    if n < 1 or (n > ndev and not (same and ndev >= 1)):
         print(f"bench.py: --gpus {n} but only {ndev} device(s) visible to this process", file=sys.stderr)
         sys.exit(2)
-    ctxs = [bh.Context(k) for k in range(n)]
+    ctxs = [bh.Context(0 if same else k) for k in range(n)]
     comm_note = None
     try:
-        group = bdist.CommGroup(ctxs)
+        group = _HostGather(n) if same and n > 1 else bdist.CommGroup(ctxs)
     except Exception as e:
         if n > 1:
             raise          # no collective, no multi-GPU line

@@ -149,3 +149,28 @@ def test_ungrouped_gather_on_a_single_process_communicator(ctx):
         assert rc == -4 and b"bhip_comm_allgather_group" in ctx.lib.bhip_last_error(ctx.h)
     for k in range(ndev):
         ctx.lib.bhip_comm_destroy(comms[k])
+
+
+def test_bench_single_process_n_device_code_path_on_one_gpu():
+    """the N > 1 branch of bench.py's launcher-less path (round-robin launches on one context per "device", per-device events,
+    grouped gather, max over devices, the SURVEY-C4 shard record) exercised on a one-GPU box: BENCH_SAME_DEVICE=1 puts the N contexts on
+    device 0 and emulates the gather on the host (RCCL refuses two ranks on one device).  2 x 4096 chains == 1 x 8192 chains."""
+    env = dict(os.environ, BENCH_SAME_DEVICE="1")
+    common = ["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-other-modes"]
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--chains", "4096"] + common,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--chains", "8192"] + common,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and len(j2["per_gpu_ms_per_step"]) == 2 and j2["config"]["chains_total"] == 8192
+    assert j2["config"]["acceptance_rate"] == j1["config"]["acceptance_rate"]
+    assert abs(j2["config"]["mean_ll"] - j1["config"]["mean_ll"]) <= 1e-12 * abs(j1["config"]["mean_ll"])
+    assert j2["config"]["path_steps_per_step"] == 8192 * 1000 and j2["scaling"] == "weak"
+    # the default-size form adds the 32 768-chains-per-GPU record
+    full = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert full.returncode == 0, full.stdout[-2000:] + full.stderr[-2000:]
+    jf = json.loads([l for l in full.stdout.splitlines() if l.startswith("{")][-1])
+    assert jf["n_gpus"] == 2 and jf["survey_c4"]["chains_per_gpu"] == 32768 and jf["value"] > 0 and jf["survey_c4"]["value"] > 0
