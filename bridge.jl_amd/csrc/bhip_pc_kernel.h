@@ -37,6 +37,10 @@ enum { NOISE_FRESH_PC = 6, NOISE_PCN_LINES_PC = 7 };
 #ifndef PC_QUAD_UNROLL
 #define PC_QUAD_UNROLL 1    // Philox calls (two Box-Muller pairs each) in flight per producer lane: instruction-level parallelism vs registers
 #endif
+#ifndef PC_CONS_UNROLL_SMALL
+#define PC_CONS_UNROLL_SMALL 8   // steps of the consumer's interior loop per iteration in the small-ensemble workgroups (a consumer alone on
+#endif                           // its SIMD: the LDS reads of eight steps batched ahead of their use; 2 at the 128-register cap of the large ones).
+                                 // Same-box A/B 2 -> 8: FHN pCN 32 768 0.225 -> 0.209 ms, FHN fresh 65 536 0.319 -> 0.298, C2 0.219 -> 0.212
 #ifndef PC_WPE
 #define PC_WPE 4            // minimum waves per SIMD the register allocation must allow (8 workgroups per CU by LDS)
 #endif
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
             const int j0 = kc * SPC;
             if (kc > 0 && j0 + SPC <= N) {
                 // interior chunk: SPC steps  i = j - 1
-#pragma unroll 2
+#pragma unroll (RLDS ? PC_CONS_UNROLL_SMALL : 2)
                 for (int s = 0; s < SPC; s++) {
                     double wn[MP];
 #pragma unroll
