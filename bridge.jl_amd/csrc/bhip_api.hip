@@ -1719,7 +1719,7 @@ struct ChainStateHeader {
     uint32_t path0, iter;
     int32_t skip0, rng_spec;   // rng_spec: version of the noise specification the chains were driven with (bhip-philox-v<rng_spec>)
 };
-constexpr int32_t RNG_SPEC_VERSION = 2;
+constexpr int32_t RNG_SPEC_VERSION = 3;   // bhip_rng.h: bhip-philox-v3
 constexpr uint64_t CHAIN_MAGIC = 0x314E484350494842ULL;   // "BHIPCHN1" little endian
 }  // namespace
 

@@ -308,6 +308,42 @@ static __global__ void k_seg_commit_big(long n, long ld, int N, int m, int d, do
     }
 }
 
+// the same with the full per-chain mcnext! state (mean, m2) at any state dimension d <= 32: 64 chains per workgroup; a chain's
+// delta = x - m and x - m_new (src/mclog.jl:50-54) wait in LDS ([k][lane]: conflict free) while the d*d entries of m2 stream
+// through -- 16 d*d bytes per chain and grid point and iteration, the pass is as long as that state is large.
+static __global__ void __launch_bounds__(64) k_seg_commit_big_m2(long n, long ld, int N, int m, int d, double *const *__restrict__ tab,
+                                                                 const unsigned char *__restrict__ accflag, double count)
+{
+    __shared__ double sh_delta[32 * 64], sh_xm[32 * 64];
+    const long p = (long)blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y, sg = blockIdx.z, t = threadIdx.x;
+    if (p >= n) return;
+    const double *__restrict__ Xo = tab[sg];
+    double *__restrict__ Xc = tab[m + sg];
+    double *__restrict__ mean = tab[2 * m + sg];
+    double *__restrict__ m2 = tab[3 * m + sg];
+    const bool a = accflag[p] != 0;
+    for (int k = 0; k < d; k++) {
+        const size_t e = ((size_t)i * d + k) * ld + p;
+        const double x = a ? Xo[e] : Xc[e];
+        if (a) Xc[e] = x;
+        const double mk = mean[e];
+        const double delta = x - mk;
+        const double mn = mk + delta / (count + 1.0);
+        mean[e] = mn;
+        sh_delta[k * 64 + t] = delta;
+        sh_xm[k * 64 + t] = x - mn;
+    }
+    // a lane only reads what it wrote: no barrier
+    for (int c = 0; c < d; c++) {
+        const double xc = sh_xm[c * 64 + t];
+        for (int r = 0; r < d; r++) {
+            const size_t e = ((size_t)i * d * d + r + (size_t)d * c) * ld + p;
+            m2[e] = m2[e] + sh_delta[r * 64 + t] * xc;
+        }
+    }
+}
+
 static __global__ void k_seg_accept(long n, long ld, int m, int d, const double *__restrict__ llo, double *__restrict__ ll,
                                     unsigned char *__restrict__ cur, unsigned int *__restrict__ acc, unsigned char *__restrict__ accflag,
                                     double *__restrict__ y0, const double *__restrict__ y0o, uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0,

@@ -410,3 +410,7 @@ def test_chain_checkpoint_and_resume(ctx, name):
     old[60:64] = 0                                           # ChainStateHeader.rng_spec
     with pytest.raises(bh.BridgeError, match="noise specification"):
         b.load(old)
+    assert int(np.frombuffer(state[60:64].tobytes(), dtype=np.int32)[0]) == 3   # bhip-philox-v3
+    old[60:64] = np.frombuffer(np.int32(2).tobytes(), dtype=np.uint8)           # a round-2 (v2) state
+    with pytest.raises(bh.BridgeError, match="bhip-philox-v2"):
+        b.load(old)

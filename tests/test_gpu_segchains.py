@@ -142,7 +142,7 @@ def test_pooled_statistics_over_chains_and_iterations(ctx):
 def test_joint_mh_over_segments_at_large_dimension(ctx, d):
     """round 3: multi-segment chains on the MFMA tile kernel (d = 16; d = 5 zero padded): per-chain starts from the previous
     segment's end point, one noise stream per segment, the accept deferred to the joint decision, the pCN move of a d-vector start,
-    running means.  Against bo_smooth_mcmc at the tile kernel's tolerance (pre-inverted guide matrix, fused MFMA accumulation):
+    running means and the full per-chain mcnext! state.  Against bo_smooth_mcmc at the tile kernel's tolerance (pre-inverted guide matrix, fused MFMA accumulation):
     identical accept decisions, Wiener paths bit for bit, paths 1e-9, ll 1e-8."""
     rng = np.random.default_rng(11)
     m, M = 3, 30
@@ -163,12 +163,14 @@ def test_joint_mh_over_segments_at_large_dimension(ctx, d):
     chol = np.linalg.cholesky((H + H.T) / 2)
     n, iters = 100, 6
     w_new = np.sqrt(rng.uniform(0.05, 0.4, iters)); w_old = np.sqrt(1 - w_new ** 2)
-    with pytest.raises(bh.BridgeError, match="MCNEXT_MEAN"):
-        bh.SegChains(segs, v, chol, n, mcnext=True)                      # d + d*d doubles per chain and grid point: refused
     sc = bh.SegChains(segs, v, chol, n, seed=23, path0=5, mcnext_mean_only=True)
-    sc.step(w_old[:2], w_new[:2])
-    sc.step(w_old[2:], w_new[2:])
+    full = bh.SegChains(segs, v, chol, n, seed=23, path0=5, mcnext=True)     # mcnext! literally: d + d*d doubles per chain and grid point
+    for c in (sc, full):
+        c.step(w_old[:2], w_new[:2])
+        c.step(w_old[2:], w_new[2:])
     ll, acc, y0 = sc.state()
+    llf, accf, y0f = full.state()
+    assert np.array_equal(ll, llf) and np.array_equal(acc, accf) and np.array_equal(y0, y0f)
     for p in (0, 15, 16, 99):
         r = o.smooth_mcmc(refs, v, chol, w_old, w_new, 23, 5 + p, stats=True)
         assert acc[p] == r["acc"], (p, acc[p], r["acc"])
@@ -180,6 +182,9 @@ def test_joint_mh_over_segments_at_large_dimension(ctx, d):
             assert abs(ll[i, p] - r["ll"][i]) <= 1e-8 * (1 + abs(r["ll"][i]))
             mean, _, cnt = sc.mcstats(i, p)
             assert cnt == iters and np.abs(mean - r["mean"][i]).max() <= 1e-9 * (1 + np.abs(r["mean"][i]).max())
+            meanf, m2f, cntf = full.mcstats(i, p)
+            assert cntf == iters and np.array_equal(meanf, mean)
+            assert np.abs(m2f - r["m2"][i]).max() <= 1e-9 * (1 + np.abs(r["m2"][i]).max())
     assert 0 < acc.sum() < n * iters
     for i in range(m - 1):                                                # continuity at the joints
         Xa, _ = sc.paths(i, 0, n)
