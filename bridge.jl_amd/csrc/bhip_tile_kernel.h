@@ -83,14 +83,30 @@ typedef const __attribute__((address_space(4))) double *tile_cptr_t;   // consta
 #endif
 // pCN chains: the chain's current W[i+2] is fetched global -> LDS directly (global_load_lds_dwordx4, no staging registers)
 // while step i is computed -- a full step of latency cover; 0: plain loads at the top of the step that consumes them
+#ifndef BHIP_TILE_SPREAD
+#define BHIP_TILE_SPREAD 2
+#endif
+#ifndef BHIP_TILE_DMA_LATE
+#define BHIP_TILE_DMA_LATE 0
+#endif
+#ifndef BHIP_TILE_MDMA
+#define BHIP_TILE_MDMA 1
+#endif
+#ifndef BHIP_TILE_SB_MASK
+#define BHIP_TILE_SB_MASK 0x106   // what may still move across a store group: LDS reads (the next fragments), VALU, SALU
+#endif
+#ifndef BHIP_TILE_SPREAD_EVERY
+#define BHIP_TILE_SPREAD_EVERY 2
+#endif
 #ifndef BHIP_TILE_LDSDMA
 #define BHIP_TILE_LDSDMA 1
 #endif
 template <class V> __device__ __forceinline__ void tile_st(V *p, V v) { if constexpr (BHIP_TILE_NT) __builtin_nontemporal_store(v, p); else *p = v; }
 template <class V> __device__ __forceinline__ V tile_ld(const V *p) { if constexpr (BHIP_TILE_NT) return __builtin_nontemporal_load(p); else return *p; }
 
-template <int T>
-__device__ __forceinline__ void tile_mv(const double *__restrict__ Mf, const double (&v)[T][4], double (&out)[T][4], int lane)
+struct TileNoHook { __device__ __forceinline__ void operator()(int) const {} };
+template <int T, class HOOK = TileNoHook>
+__device__ __forceinline__ void tile_mv(const double *__restrict__ Mf, const double (&v)[T][4], double (&out)[T][4], int lane, HOOK hook = HOOK())
 {
     if constexpr ((BHIP_TILE_EXP & 4) != 0) {
 #pragma unroll
@@ -107,6 +123,7 @@ __device__ __forceinline__ void tile_mv(const double *__restrict__ Mf, const dou
 #pragma unroll
         for (int tp = 0; tp < T; tp++)
             acc[tp] = __builtin_amdgcn_mfma_f64_16x16x4f64(Mf[(tp * 4 * T + ks) * 64 + lane], v[ks >> 2][ks & 3], acc[tp], 0, 0, 0);
+        hook(ks);   // (statically unrolled: ks is a constant in the hook)
     }
 #pragma unroll
     for (int tp = 0; tp < T; tp++) {
@@ -164,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     // (the 16-byte slots of round 1 moved the unchanged half too: 1280 instead of 768 B per path-step at d = 32).
     const size_t tl_grid = (size_t)T * a.ldC * 16, tl_half = (size_t)N * tl_grid;   // doubles per grid point / per half
     const double *wrd = nullptr;
-    double *wwr = nullptr;
+    double *wwr = nullptr, *wst = nullptr;   // wst: where the step in flight stores its proposal line (BHIP_TILE_SPREAD)
 
     double x[T][4], wprev[T][4];
     {
@@ -202,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     }
     double *wb = wb_lds + (size_t)wave * (2 * T * 128);
     auto dma_w = [&]() {   // the chain's current W at the grid point wrd stands on -> wb (lane L's piece q at wb + (q*64 + L)*2)
-        if constexpr (NOISE == 2 && BHIP_TILE_LDSDMA) {
+        if constexpr (NOISE == 2 && BHIP_TILE_LDSDMA && (BHIP_TILE_EXP & 32) == 0) {
 #pragma unroll
             for (int t = 0; t < T; t++)
 #pragma unroll
@@ -225,30 +242,39 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
         const int cur = (BHIP_TILE_EXP & 1) ? 0 : i & 1;
         const double *hm = hb + cur * STEP, *nu = hm + DD;
         // stage step i+1's matrix: global -> registers now, registers -> LDS after the compute
+        // (unconditional loads from clamped indices: a conditional `idx < STEP ? load : 0.0` made the compiler clear the staging
+        // registers at the top of the step, and a register that a load of the previous step may still be writing cannot be cleared
+        // without s_waitcnt vmcnt(0) -- issued right after the first load of the step: its whole round trip, every step, in every
+        // instantiation.  The last step re-reads its own row and lands it in the buffer nobody reads.)
+        constexpr bool MDMA = NOISE == 2 && BHIP_TILE_LDSDMA && BHIP_TILE_MDMA;   // the matrix travels by LDS-DMA too (below)
         double stage[(STEP + 255) / 256];
-        const bool more = (BHIP_TILE_EXP & 1) ? false : i + 1 < nsteps;
-        if (more) {
+        if constexpr ((BHIP_TILE_EXP & 1) == 0 && !MDMA) {
+            // the previous step's stores (issued between its matrix products, a product or more ago) are waited for HERE, where
+            // nothing else is pending: from now on the compiler sees loads only.  (The builtin, not inline assembly: its wait-count
+            // pass reads s_waitcnt instructions, not asm text.)
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt and lgkmcnt untouched (gfx9 encoding)
+            const double *src = a.steps + (size_t)min(i + 1, nsteps - 1) * STEP;
 #pragma unroll
-            for (int c = 0; c < (STEP + 255) / 256; c++) {
-                const int idx = tid + 256 * c;
-                stage[c] = idx < STEP ? a.steps[(size_t)(i + 1) * STEP + idx] : 0.0;
-            }
+            for (int c = 0; c < (STEP + 255) / 256; c++) stage[c] = src[min(tid + 256 * c, STEP - 1)];
         }
-        // The step's vector-memory schedule (round 3).  LLVM treats loads and stores pending in the one vmcnt counter as
-        // completing out of order with each other, so ANY wait for a load result while stores are pending is vmcnt(0): a wait for
-        // those stores to be acknowledged by the L2.  Round 2 had that wait at the END of the step (staged matrix -> LDS, and the
-        // workgroup fence of __syncthreads, which on gfx950 is vmcnt(0) as well): every step ended with a write round trip for
-        // the stores it had just issued -- the knock-out of the stores saved 2 ms of 17 because of it.  Now: the step's loads
-        // (next matrix, chain-state DMA) are issued at its top, drained ONCE right before its first store (by then the
-        // previous step's stores are a step old and long acknowledged), the staged matrix goes to LDS there, the stores are
-        // issued after it and nothing in the rest of the step waits on vector memory; the barrier at the end is LDS-only.
+        // The step's vector-memory schedule (round 3).  The compiler's wait-count pass treats the vmcnt counter as out of order as
+        // soon as stores (or an LDS-DMA) are pending, so ANY wait for a load result is then vmcnt(0): a wait for everything in flight.
+        //   * The step's stores are not issued in one burst in front of the matrix products but one by one between them (store_op /
+        //     hook_at below): a store that has to wait for room in the memory pipeline waits behind a running MFMA chain.
+        //   * Chains (NOISE == 2): the next matrix row AND the chain's W[i+2] travel global -> LDS by DMA, issued at the top of the step,
+        //     no staging registers, nothing in the step waits for them; ONE vmcnt(0) -- DMAs and stores, all at least 34 MFMAs old --
+        //     at the barrier that ends the step.
+        //   * The other instantiations stage the matrix row through registers: loads at the top (after a vmcnt(0) for the previous
+        //     step's stores, which are a product or more old), landed in LDS after the noise has been drawn.
+        // d = 32, 65 536 paths x 1000 steps, same box: proposals 14.1 -> 13.55 ms (0.63 of the fp64 matrix peak), chains 17.4 -> 16.3 (0.52).
         auto land_stage = [&]() {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (more) {
+            if constexpr ((BHIP_TILE_EXP & 1) == 0 && !MDMA) {
 #pragma unroll
                 for (int c = 0; c < (STEP + 255) / 256; c++) {
                     const int idx = tid + 256 * c;
-                    if (idx < STEP) hb[(cur ^ 1) * STEP + idx] = stage[c];
+                    if (idx < STEP) {
+                        hb[(cur ^ 1) * STEP + idx] = stage[c];
+                    }
                 }
             }
         };
@@ -258,6 +284,33 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
         // (the instantiations without a DMA keep the plain load: measured 2 % faster there than the LDS read)
         const double dt = (NOISE == 2 && BHIP_TILE_LDSDMA) ? hm[DD + D] : a.hdr[2 * i], rdt = (NOISE == 2 && BHIP_TILE_LDSDMA) ? hm[DD + D + 1] : a.hdr[2 * i + 1];
 
+        auto issue_dmas = [&]() {
+            if constexpr (NOISE == 2 && BHIP_TILE_LDSDMA) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the DMA may overwrite the pieces
+                wrd += tl_grid;
+                if (i + 1 < nsteps) {
+                    if constexpr (MDMA) {
+                        // step i+1's matrix row (Hm, nu, dt, sqrt(dt): STEP/2 16-byte pieces) global -> hb[cur ^ 1] without staging
+                        // registers: nothing in the step has to wait for it (a register landing is waited for by the compiler with
+                        // vmcnt(0) -- after an LDS-DMA it treats the counter as out of order -- which also drained the DMA of
+                        // W[i+2] 1500 cycles after its issue: less than an HBM round trip under this kernel's load).  Both DMAs now
+                        // have the whole step; they are waited for once, with the step's stores, at the barrier that ends it.
+                        constexpr int NP = STEP / 2;
+                        static_assert(STEP % 2 == 0, "16-byte pieces");
+                        const double *src = a.steps + (size_t)(i + 1) * STEP;
+                        double *dst = hb + (cur ^ 1) * STEP;
+#pragma unroll
+                        for (int c = 0; c < (NP + 255) / 256; c++) {
+                            const int q0 = c * 256 + wave * 64;   // wave-uniform
+                            if (q0 + lane < NP)
+                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 2 * (q0 + lane)),
+                                                                 (__attribute__((address_space(3))) void *)(dst + 2 * q0), 16, 0, 0);
+                        }
+                    }
+                    dma_w();
+                }
+            }
+        };
         // ---- the Wiener increment tile
         double dw[T][4];
         if constexpr (NOISE == 0) {
@@ -297,9 +350,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                         const tile_d2v v = *(const tile_d2v *)(wb + ((t * 2 + jj) * 64 + lane) * 2);
                         wcur[t][2 * jj] = v.x; wcur[t][2 * jj + 1] = v.y;
                     }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the DMA may overwrite the pieces
-                wrd += tl_grid;
-                if (i + 1 < nsteps) dma_w();
+                if constexpr (!BHIP_TILE_DMA_LATE) issue_dmas();
             } else if constexpr (NOISE == 2) {   // the chain's current W[i+1]: issued first, consumed after the normals
 #pragma unroll
                 for (int t = 0; t < T; t++)
@@ -345,6 +396,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 for (int r = 0; r < 4; r++) mine[4 * t + r] = zb[4 * r + kq];
                 __builtin_amdgcn_wave_barrier();   // ... and the reads precede the next pass's writes
             }
+            if constexpr (BHIP_TILE_DMA_LATE) issue_dmas();   // the reads of wb are long done; the DMAs still have the products' time
             land_stage();
             double *qo = wop;
 #pragma unroll
@@ -359,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                         dw[t][r] = wo - wprev[t][r];
                         w2prev[t][r] = w2;
                         wprev[t][r] = wo;
-                        if constexpr ((BHIP_TILE_EXP & 16) == 0) {   // (zero-padded rows carry exact zeros)
+                        if constexpr ((BHIP_TILE_EXP & 16) == 0 && !BHIP_TILE_SPREAD) {   // (zero-padded rows carry exact zeros)
                             if ((r & 1) == 1) tile_st((tile_d2v *)(wwr + (size_t)t * a.ldC * 16 + 8 * (r >> 1)), tile_d2v{wprev[t][r - 1], wo});
                         }
                     } else {
@@ -368,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                         wprev[t][r] = wn;
                     }
                 }
-            if constexpr (NOISE == 2) { if (!BHIP_TILE_LDSDMA) wrd += tl_grid; wwr += tl_grid; }
+            if constexpr (NOISE == 2) { wst = wwr; if (!BHIP_TILE_LDSDMA) wrd += tl_grid; wwr += tl_grid; }
             if constexpr (NOISE == 1 && HASW) {
 #pragma unroll
                 for (int t = 0; t < T; t++)
@@ -379,12 +431,66 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
         }
 
         // ---- X[i] = x (before the update, src/euler.jl:263)
-        if constexpr (NOISE != 3 && HASX) {
-            double *q = xp;
+        // BHIP_TILE_SPREAD: a step's stores (the proposal's W lines, X[i]) are not issued in one burst ahead of the matrix products but
+        // in groups of 2-4 between them: a wave whose store has to wait for room in the memory pipeline then waits behind a running
+        // MFMA chain, not in front of it (the values stay in their registers until the update at the end of the step).
+        double *const xst = xp;
+        auto store_w = [&](int t) {
+            if constexpr (NOISE == 2 && BHIP_TILE_SPREAD == 1 && (BHIP_TILE_EXP & 16) == 0) {
 #pragma unroll
-            for (int t = 0; t < T; t++)
+                for (int jj = 0; jj < 2; jj++) tile_st((tile_d2v *)(wst + (size_t)t * a.ldC * 16 + 8 * jj), tile_d2v{wprev[t][2 * jj], wprev[t][2 * jj + 1]});
+            }
+        };
+        auto store_x = [&](int t) {
+            if constexpr (NOISE != 3 && HASX && BHIP_TILE_SPREAD == 1) {
+                double *q = xst + (size_t)(4 * t) * rsX;
 #pragma unroll
                 for (int r = 0; r < 4; r++) { if (ok(t, r)) tile_st(q, x[t][r]); q += rsX; }
+            }
+        };
+        auto spread = [&](int slot) {   // slot 0: before the first product, k: after the k-th
+            if constexpr (BHIP_TILE_SPREAD == 1) {
+                __builtin_amdgcn_sched_barrier(BHIP_TILE_SB_MASK);
+                if (slot < T) store_w(slot);
+                else if (slot - T < T) store_x(slot - T);
+                __builtin_amdgcn_sched_barrier(BHIP_TILE_SB_MASK);
+            }
+        };
+        // BHIP_TILE_SPREAD == 2: one store after every BHIP_TILE_SPREAD_EVERY-th group of T MFMAs (T * 64 cycles of matrix pipe)
+        auto store_op = [&](int k) {   // op 0 .. 2T-1: the W pieces; 2T .. 6T-1: the X rows
+            if (k < 2 * T) {
+                if constexpr (NOISE == 2 && (BHIP_TILE_EXP & 16) == 0) {
+                    const int t = k >> 1, jj = k & 1;
+                    tile_st((tile_d2v *)(wst + (size_t)t * a.ldC * 16 + 8 * jj), tile_d2v{wprev[t][2 * jj], wprev[t][2 * jj + 1]});
+                }
+            } else if (k < 6 * T) {
+                if constexpr (NOISE != 3 && HASX) {
+                    const int e = k - 2 * T, t = e >> 2, r = e & 3;
+                    if (ok(t, r)) tile_st(xst + (size_t)e * rsX, x[t][r]);
+                }
+            }
+        };
+        static_assert(BHIP_TILE_SPREAD != 2 || 6 * T * BHIP_TILE_SPREAD_EVERY <= 4 * 4 * T, "every store of the step needs its slot among the products that always run");
+        auto hook_at = [&](int mv) {
+            return [&, mv](int ks) {
+                if constexpr (BHIP_TILE_SPREAD == 2) {
+                    const int slot = mv * 4 * T + ks;
+                    if (slot % BHIP_TILE_SPREAD_EVERY == 0) {
+                        __builtin_amdgcn_sched_barrier(BHIP_TILE_SB_MASK);
+                        store_op(slot / BHIP_TILE_SPREAD_EVERY);
+                        __builtin_amdgcn_sched_barrier(BHIP_TILE_SB_MASK);
+                    }
+                }
+            };
+        };
+        if constexpr (NOISE != 3 && HASX) {
+            if constexpr (!BHIP_TILE_SPREAD) {
+                double *q = xp;
+#pragma unroll
+                for (int t = 0; t < T; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { if (ok(t, r)) tile_st(q, x[t][r]); q += rsX; }
+            }
             xp += (size_t)dtr * a.ldX;
         }
 
@@ -399,7 +505,9 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 xa[t][r] = x[t][r] - mua[row];
             }
         double rr[T][4], bT[T][4], bA[T][4], g[T][4], s[T][4];
-        tile_mv<T>(hm, w, rr, lane);
+        spread(0);
+        tile_mv<T>(hm, w, rr, lane, hook_at(0));
+        spread(1);
         if constexpr (UD::ON) {
             // gather the path's state (its components sit in 4 lanes x 8 registers) and evaluate b_k for this lane's rows
             double *xv = xs_lds + (size_t)(wave * 16 + j) * D;
@@ -417,11 +525,13 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                     const int row = 16 * t + 4 * r + kq;
                     bT[t][r] = (!PAD || row < dtr) ? UD::bk(row, ti, xv, a.upar) : 0.0;
                 }
-        } else tile_mv<T>(Bf, xm, bT, lane);
-        tile_mv<T>(Btf, xa, bA, lane);
+        } else tile_mv<T>(Bf, xm, bT, lane, hook_at(1));
+        spread(2);
+        tile_mv<T>(Btf, xa, bA, lane, hook_at(UD::ON ? 1 : 2));
+        spread(3);
         if constexpr (NOISE != 3) {
-            tile_mv<T>(Af, rr, g, lane);
-            tile_mv<T>(Sf, dw, s, lane);
+            tile_mv<T>(Af, rr, g, lane, hook_at(UD::ON ? 2 : 3));
+            tile_mv<T>(Sf, dw, s, lane, hook_at(UD::ON ? 3 : 4));
         }
 
         // ---- llikelihood: som += dot(b - b~, r)*dt, reduced over the path's 4 row groups
@@ -443,7 +553,10 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 
         // LDS-only barrier: this wave's reads of hb[cur] and its writes of hb[cur ^ 1] are done (lgkmcnt), the block meets; no
         // wait on vector memory (a __syncthreads would drain the stores just issued)
-        if constexpr ((BHIP_TILE_EXP & 1) == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr ((BHIP_TILE_EXP & 1) == 0) {
+            if constexpr (MDMA) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // + this wave's DMAs (the others read its pieces) and stores
+            else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
     }
     };
     if (NOISE != 3 && a.X) {
