@@ -262,6 +262,11 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
     LaneState<D, MP> st;
 #pragma unroll
     for (int k = 0; k < D; k++) st.y[k] = a.x0_dev ? a.x0_dev[k * a.ldx0 + p] : a.x0[k];
+    // The per-chain start is the consumer's only vector load.  Left to itself the compiler defers the wait for it to the first use
+    // of the state it can find on every path -- the join block at the end of a chunk, INSIDE the chunk loop: an s_waitcnt vmcnt(0)
+    // per chunk, i.e. a wait for the acknowledgement of every path store the wave has issued, once per chunk.  Waiting here,
+    // once, (the builtin: the wait-count pass reads instructions, not asm text) leaves the loop without one.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), gfx9 encoding; expcnt / lgkmcnt untouched
     st.ll = 0.0; st.zq[0] = st.zq[1] = st.zq[2] = 0.0;
 #pragma unroll
     for (int k = 0; k < MP; k++) { st.wprev[k] = 0.0; st.w2prev[k] = 0.0; }
