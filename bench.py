@@ -307,11 +307,12 @@ class Workload:
         r["traffic"], r["traffic_source"] = tr, src
         r["valu"] = profiled_valu(self.mode, self.kernel, self.P) if (self.P == MODES[self.mode][4] and not self.fused) else None
         v = r["valu"]
-        if v and r["bound"] == "hbm" and v["busy_frac"] > 0.6:
+        if v and r["bound"] == "hbm" and v["busy_frac"] > 0.6 and r["frac"] / v["busy_frac"] < 0.9:
             # the kernel's SIMDs spend most of its duration ISSUING vector instructions: what binds it is the instruction count
             # per byte, not the memory system.  achieved / peak / frac stay the HBM figures (the contract's yardstick);
             # valu_frac = share of the duration the VALU was issuing, hbm_frac_at_full_issue = the roofline fraction this
-            # instruction stream would reach at 100 % issue -- the ceiling that actually applies
+            # instruction stream would reach at 100 % issue -- the ceiling that actually applies (a kernel whose ceiling at full
+            # issue lies at or above the HBM roofline keeps "hbm": its instructions are not what stops it)
             r["bound"] = "valu"
             r["valu_frac"] = v["busy_frac"]
             r["hbm_frac_at_full_issue"] = r["frac"] / v["busy_frac"]

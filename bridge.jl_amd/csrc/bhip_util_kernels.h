@@ -80,21 +80,23 @@ __global__ __launch_bounds__(256) void k_wiener(const double *__restrict__ rootd
 #pragma unroll
     for (int k = 0; k < MP; k++) { w[k] = 0.0; out[(size_t)k * ld] = 0.0; }
     out += (size_t)MP * ld;
-    // two grid steps per iteration = 2*MP normals = MP whole Philox blocks: the block parity is static
+    // four grid steps per iteration = 4*MP normals = MP whole Philox calls (bhip_rng.h: four normals per call): normal n = i*MP + k is
+    // number n & 3 of call n >> 2, so a call is drawn once (through normal_pair every call was computed twice, once per half)
     int i = 0;
-    for (; i + 1 < N - 1; i += 2) {
-        const double rdt0 = rootdt[i], rdt1 = rootdt[i + 1];
-        double z[2 * MP];
+    for (; i + 3 < N - 1; i += 4) {
+        double z[4 * MP];
 #pragma unroll
-        for (int b = 0; b < MP; b++) normal_pair(k0, k1, path, iter, (uint32_t)(i / 2 * MP + b), z[2 * b], z[2 * b + 1]);
+        for (int b = 0; b < MP; b++)
+            normal_quad(TabConst(), k0, k1, path, iter, (uint32_t)(i / 4 * MP + b), z[4 * b], z[4 * b + 1], z[4 * b + 2], z[4 * b + 3]);
 #pragma unroll
-        for (int k = 0; k < MP; k++) { w[k] = w[k] + rdt0 * z[k]; __builtin_nontemporal_store(w[k], out + (size_t)k * ld); }
-        out += (size_t)MP * ld;
+        for (int s = 0; s < 4; s++) {
+            const double rdt = rootdt[i + s];
 #pragma unroll
-        for (int k = 0; k < MP; k++) { w[k] = w[k] + rdt1 * z[MP + k]; __builtin_nontemporal_store(w[k], out + (size_t)k * ld); }
-        out += (size_t)MP * ld;
+            for (int k = 0; k < MP; k++) { w[k] = w[k] + rdt * z[s * MP + k]; __builtin_nontemporal_store(w[k], out + (size_t)k * ld); }
+            out += (size_t)MP * ld;
+        }
     }
-    if (i < N - 1) {   // odd number of steps: the last step takes the first MP normals of the following blocks
+    for (; i < N - 1; i++) {   // the last steps (fewer than four): single normals, the half of the call that holds them
         const double rdt0 = rootdt[i];
 #pragma unroll
         for (int k = 0; k < MP; k++) {
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256) void k_wiener(const double *__restrict__ rootd
             w[k] = w[k] + rdt0 * ((n & 1) ? z1 : z0);
             out[(size_t)k * ld] = w[k];
         }
+        out += (size_t)MP * ld;
     }
 }
 // mp > 4 (large-d Wiener): state kept in memory instead of registers

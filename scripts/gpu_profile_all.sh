@@ -12,3 +12,5 @@ if [ -z "$NO_BENCH" ]; then
   mkdir -p profiles && cp gpurun_out/r3_*_{trace,fetch,write,sq,sq2}.txt profiles/ 2>/dev/null
   python bench.py > gpurun_out/r3_bench_samebox.json 2> gpurun_out/r3_bench_samebox.err
 fi
+# the reference-shaped three-call sequence (sample! / solve! / llikelihood as separate launches), same box
+python scripts/gpu_ext_probe.py 2>/dev/null | grep "B/path-step" > gpurun_out/r3_separate_calls.txt
