@@ -172,6 +172,7 @@ struct bhip_chains {
     bool inited = false;
     std::vector<double> x0;   // shared starting point (d doubles)
     bool lines = false;     // d <= 3 (noise dimension <= 3): W in the line layout of bhip_chain_kernel.h, else 16-byte slots
+    bool tile = false;      // d > 3 on the MFMA tile kernel (tile-line layout); LinPro targets of dimension 4..8 stay on the path-per-lane kernel (slots)
     int nch = 0;            // lines per chain and parity half = ceil(N / 16)
     double *Wc = nullptr;   // W slots [N][mp][ld][2]  |  lines [2][nch][ld][16]
     double *Xo = nullptr;   // proposal paths [N][d][ld] (BHIP_CHAINS_STORE_X); lives behind Wc in the same allocation
@@ -1350,6 +1351,7 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     ctx_retain(ctx);
     ch->path0 = path0; ch->seed = seed; ch->flags = flags;
     const size_t N = po->tt.size();
+    ch->tile = po->mh.d > 3 && !(po->mid && ctx->mid_valu);
     ch->lines = po->mh.d <= 3 && po->mh.mp <= 3;
     const size_t spc = LINE_DOUBLES / (ch->lines ? line_mpp(po->mh.mp) : 1);   // grid points per line (m' = 3: padded to 4 components)
     ch->nch = (int)((N + spc - 1) / spc);
@@ -1358,7 +1360,7 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
         ch->nch = 0;
     }
     const size_t wbytes = ch->lines ? sizeof(double) * 2 * ch->nch * ch->ld * LINE_DOUBLES
-                        : po->mh.d > 3 ? sizeof(double) * 2 * N * (tile_dim(po->mh.d) / 16) * ch->ld * 16   // tile lines (bhip_tile_kernel.h)
+                        : ch->tile ? sizeof(double) * 2 * N * (tile_dim(po->mh.d) / 16) * ch->ld * 16   // tile lines (bhip_tile_kernel.h)
                                        : sizeof(double) * 2 * N * po->mh.mp * ch->ld;
     const size_t xbytes = sizeof(double) * N * po->mh.d * ch->ld;
     ch->wbytes = wbytes; ch->xbytes = xbytes;
@@ -1399,7 +1401,7 @@ static int chains_init_impl(bhip_chains *ch, const double *x0, const double *x0_
         HIPCHK(ctx, hipMemsetAsync(ch->cur, 0, ch->ld, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ch->acc, 0, sizeof(unsigned int) * ch->ld, ctx->stream));
     }
-    if (po->mh.d > 3) {   // MFMA tile kernel: fresh W into a plain SoA scratch array, re-arranged into half 0 of the tile lines; X and ll of the initial state
+    if (ch->tile) {   // MFMA tile kernel: fresh W into a plain SoA scratch array, re-arranged into half 0 of the tile lines; X and ll of the initial state
         const int N = (int)po->tt.size(), d = po->mh.d, T = tile_dim(d) / 16;
         double *tmpW = nullptr;
         HIPCHK(ctx, hipMalloc((void **)&tmpW, sizeof(double) * N * d * ch->n));
@@ -1536,7 +1538,7 @@ static int chains_propose_deferred(bhip_chains *ch, double w_old, double w_new, 
                                    double *llo_dev, int skip)
 {
     const bhip_proposal *po = ch->po;
-    if (po->mh.d > 3)   // the MFMA tile kernel's chain step with the decision deferred
+    if (ch->tile)   // the MFMA tile kernel's chain step with the decision deferred
         return launch_tile_path(po, ch->x0.data(), nullptr, 0, nullptr, 0, ch->Xo, ch->ld, llo_dev, skip, ch->n, 2, ch->seed, iter, ch->path0, 1, ch, w_old,
                                 x0_dev, ldx0, blk0, 1, w_new);
     KArgs a;
@@ -1570,7 +1572,7 @@ int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip)
     if (!(rho >= -1.0 && rho <= 1.0)) return fail(ctx, BHIP_EINVAL, "rho must lie in [-1, 1] (sqrt(1 - rho^2) is the weight of the fresh noise)");
     if (skip == BHIP_SKIP_OF_INIT) skip = ch->skip0;   // llo and ll then always sum the same terms
     const bhip_proposal *po = ch->po;
-    if (po->mh.d > 3) {
+    if (ch->tile) {
         if (skip < 0) return fail(ctx, BHIP_EINVAL, "skip must be >= 0");
         for (int it = 0; it < iters; it++) {
             ++ch->iter;
@@ -1639,7 +1641,7 @@ static int gather_current_W(bhip_chains *ch, long p0, long np, double *W_soa)
         HIPCHK(ctx, hipGetLastError());
         return BHIP_OK;
     }
-    if (ch->po->mh.d > 3) {
+    if (ch->tile) {
         const int N = (int)ch->po->tt.size(), d = ch->po->mh.d, T = tile_dim(d) / 16;
         const long tot = (long)N * d * np;
         hipLaunchKernelGGL(k_tlines_to_soa, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ch->Wc, ch->cur, W_soa, N, d, T, ch->ld, p0, np);
@@ -1660,7 +1662,7 @@ static int current_X(bhip_chains *ch, long p0, long np, double *W_soa, double *X
 {
     int rc = gather_current_W(ch, p0, np, W_soa);
     if (rc) return rc;
-    if (ch->po->mh.d > 3) return launch_tile_path(ch->po, ch->x0.data(), W_soa, np, nullptr, 0, X_soa, np, nullptr, 0, np, 0, 0, 0, 0);
+    if (ch->tile) return launch_tile_path(ch->po, ch->x0.data(), W_soa, np, nullptr, 0, X_soa, np, nullptr, 0, np, 0, 0, 0, 0);
     KArgs a;
     rc = fill_common(ch->po, a, ch->x0.data(), nullptr, np, 0);
     if (rc) return rc;
@@ -1699,7 +1701,7 @@ int bhip_chains_current_X(bhip_chains *ch, double *X_dev, long ldX)
     double *tmp = nullptr;
     HIPCHK(ctx, hipMalloc((void **)&tmp, sizeof(double) * (size_t)N * mp * ch->n));
     int rc = gather_current_W(ch, 0, ch->n, tmp);
-    if (!rc && ch->po->mh.d > 3) rc = launch_tile_path(ch->po, ch->x0.data(), tmp, ch->n, nullptr, 0, X_dev, ldX, nullptr, 0, ch->n, 0, 0, 0, 0);
+    if (!rc && ch->tile) rc = launch_tile_path(ch->po, ch->x0.data(), tmp, ch->n, nullptr, 0, X_dev, ldX, nullptr, 0, ch->n, 0, 0, 0, 0);
     else if (!rc) {
         KArgs a;
         rc = fill_common(ch->po, a, ch->x0.data(), nullptr, ch->n, 0);
@@ -1787,7 +1789,7 @@ int bhip_chains_load(bhip_chains *ch, const void *host_buf)
         if (ch->lines) {
             hipLaunchKernelGGL(k_soa_to_lines, dim3((unsigned)(ch->ld / 64), (unsigned)ch->nch), dim3(256), 0, ctx->stream, tmp, ch->n, (int)N, po->mh.mp, ch->nch,
                                ch->Wc, ch->ld, ch->n);
-        } else if (po->mh.d > 3) {
+        } else if (ch->tile) {
             const int T = tile_dim(po->mh.d) / 16;
             const long tot = (long)N * 16 * T * ch->n;
             hipLaunchKernelGGL(k_soa_to_tlines, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, tmp, ch->Wc, (int)N, po->mh.d, T, ch->ld, ch->n);

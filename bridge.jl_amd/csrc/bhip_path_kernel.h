@@ -453,7 +453,7 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int n
 #endif
 
 template <class M, int GK, int MO, int NOISE, int FL, bool PPR = false /* per-chain coefficient rows */>
-__global__ __launch_bounds__(256, (PPR || M::D > 4) ? 2 : BHIP_WPE) void k_paths(const KArgs a)
+__global__ __launch_bounds__(256, (PPR || M::D > 4 || (M::D > 3 && NOISE == NOISE_PCN)) ? 2 : BHIP_WPE) void k_paths(const KArgs a)
 {
     constexpr int D = M::D, MP = M::MP;
     using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256, (PPR || M::D > 4) ? 2 : BHIP_WPE) void k_paths
     // for the stand-alone llikelihood) is issued while step i is computed, so PF loads per lane are in
     // flight and their latency overlaps arithmetic instead of being exposed once per step.  Stores are
     // fire-and-forget.  The loop is unrolled by two so that the Philox block parity is static.
-    constexpr int PF = NOISE == NOISE_PCN ? BHIP_KCH_PCN : BHIP_KCH;
+    constexpr int PF = NOISE == NOISE_PCN ? (MP > 6 ? 1 : BHIP_KCH_PCN) : BHIP_KCH;   // (m' = 7, 8: two slot rows ahead do not fit the register file)
     constexpr int NIN = (NOISE == NOISE_LLONLY || NOISE == NOISE_INNOV) ? D : MP;
     constexpr bool READS = NOISE == NOISE_EXT || NOISE == NOISE_LLONLY || NOISE == NOISE_INNOV;
     constexpr int OFF = NOISE == NOISE_LLONLY ? 0 : 1;   // INNOV reads X[i+1] (X[0] is loaded up front)
@@ -748,7 +748,8 @@ launch_fn get_launch_gk(int noise, int fl)
 
 // LinPro targets of dimension 4..8 (one path per lane, matrices through the scalar unit): the guide always in the form
 // r = H_i (nu_i - x) -- GuidedBridge pre-inverted on the host like on the MFMA tile kernel, (L,M,mu) mapped likewise --,
-// external or fresh noise, stand-alone llikelihood, plain Euler-Maruyama.  (Chains at these dimensions stay on the tile kernel.)
+// external or fresh noise, stand-alone llikelihood, plain Euler-Maruyama, pCN chains (16-byte slots: current and proposal value of a
+// component side by side, the layout of the d <= 3 fall-back).
 template <class M>
 launch_fn get_launch_mid(int gk, int noise, int fl)
 {
@@ -775,6 +776,7 @@ launch_fn get_launch_mid(int gk, int noise, int fl)
         default: return launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_FRESH, 3>;
         }
     case NOISE_LLONLY: return launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_LLONLY, 0>;
+    case NOISE_PCN: return (fl & 1) ? launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_PCN, 1> : launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_PCN, 0>;   // pCN chains on the 16-byte slots
     }
     return nullptr;
 }

@@ -222,7 +222,8 @@ def test_dimensions_4_to_8_run_one_path_per_lane(ctx, d):
     """LinPro targets of dimension 4..8 (round 3): bhip_sample_solve / bhip_solve / bhip_llikelihood run them on the path-per-lane
     kernel (k_paths<MLinPro<d>, (nu,H) form>: scalar FMAs, coefficients through the scalar unit) instead of zero padded on the
     16-row MFMA tile.  Wiener paths bit-exact vs the oracle, paths / ll at the large-d tolerance (pre-inverted guide matrix),
-    agreement with the tile kernel (BHIP_OPT_MID_VALU = 0), ragged ensemble sizes, plain Euler-Maruyama, per-path starts."""
+    agreement with the tile kernel (BHIP_OPT_MID_VALU = 0), ragged ensemble sizes, plain Euler-Maruyama, per-path starts, pCN chains
+    (slots) against the oracle, a saved state and the tile kernel's chains."""
     c = problems.linpro_big_case(d, 81)
     Po, ref = c.bh_proposal(bh, ctx), c.oracle_proposal()
     for P in (150, 256 + 17):
@@ -258,11 +259,40 @@ def test_dimensions_4_to_8_run_one_path_per_lane(ctx, d):
     for p in (0, P - 1):
         Xr = o.solve_guided(ref, starts[p], Wh[p])
         assert np.abs(Xs[p] - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max()) and np.array_equal(Xs[p, 0], starts[p])
-    # chains at these dimensions (tile kernel) are unaffected by the switch
-    ch = bh.Chains(Po, c.x0, 40, seed=8)
-    ch.step(0.9, 3)
-    r = o.mcmc(ref, c.x0, 0.9, 3, 8, 17)
-    assert ch.acc()[17] == r["acc"] and abs(ch.ll()[17] - r["ll"]) <= 1e-8 * (1 + abs(r["ll"]))
+    # pCN chains at these dimensions run on the same kernel family (16-byte slots: current and proposal value side by side) ...
+    n, iters, rho = 100, 5, 0.9
+    ch = bh.Chains(Po, c.x0, n, seed=8, path0=3)
+    ch.step(rho, 2)
+    state = ch.save()
+    ch.step(rho, iters - 2)
+    acc, llc = ch.acc(), ch.ll()
+    Xc, Wc = ch.paths(0, n)
+    assert 0 < acc.sum() < n * iters
+    for p in (0, 17, 63, 64, n - 1):
+        r = o.mcmc(ref, c.x0, rho, iters, 8, 3 + p)
+        assert acc[p] == r["acc"] and np.array_equal(Wc[p], r["W"]), (d, p)      # same decisions -> the same W, bit for bit
+        _close(Xc[p], r["X"], np.array([llc[p]]), np.array([r["ll"]]))
+    st = ch.stats().cpu().numpy()
+    assert st[0] == n and st[1] == iters and st[2] == acc.sum() and st[5] == llc.min() and st[6] == llc.max()
+    assert np.array_equal(ch.current_X().paths(5, 1)[0], Xc[5])                  # the re-materialised current X
+    Xo = ch.proposal_X()
+    assert bool(torch.isfinite(Xo).all())
+    # ... resume from a saved state: the same chain
+    ch2 = bh.Chains(Po, c.x0, n, seed=8, path0=3)
+    ch2.load(state)
+    ch2.step(rho, iters - 2)
+    assert np.array_equal(ch2.acc(), acc) and np.array_equal(ch2.ll(), llc)
+    # ... and agree with the zero-padded chains of the MFMA tile kernel (BHIP_OPT_MID_VALU = 0): decisions and W identical
+    ctx.set_option(bh.OPT_MID_VALU, 0)
+    try:
+        cht = bh.Chains(Po, c.x0, n, seed=8, path0=3)
+        cht.step(rho, iters)
+        Xt, Wt = cht.paths(0, n)
+        acct, llt = cht.acc(), cht.ll()
+    finally:
+        ctx.set_option(bh.OPT_MID_VALU, 1)
+    assert np.array_equal(acct, acc) and np.array_equal(Wt, Wc)
+    assert np.abs(Xt - Xc).max() <= 1e-9 * (1 + np.abs(Xc).max()) and np.abs(llt - llc).max() <= 1e-8 * (1 + np.abs(llc).max())
 
 
 @pytest.mark.parametrize("N", [2, 3, 4, 5, 6, 9])
