@@ -1246,13 +1246,14 @@ int bhip_innovations(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev
     if (!ctx || !po || !X_dev || !W_dev) return BHIP_EINVAL;
     SAME_CTX(ctx, po);
     if (po->mh.d != po->mh.mp) return fail(ctx, BHIP_EINVAL, "bhip_innovations: needs a square, invertible sigma (d == m')");
-    if (po->mh.d > 3) return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: innovations not built");
+    if (po->mh.d > 3 && !(po->mid && ctx->mid_valu))
+        return fail(ctx, BHIP_EUNSUPPORTED, "innovations: d <= 3, or a LinPro target of dimension 4..8 (the path-per-lane kernels)");
     if (po->g.kind == BHIP_GUIDE_NONE) {
         int rc = ensure_plain_rows(const_cast<bhip_proposal *>(po));
         if (rc) return rc;
     }
     KArgs a;
-    const double zero[3] = {0, 0, 0};
+    const double zero[BHIP_MAXD_LANE] = {0};
     int rc = fill_common(po, a, zero, nullptr, npaths, 0);
     if (rc) return rc;
     if (ldX < npaths || ldW < npaths) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");

@@ -117,6 +117,12 @@ struct MLinPro {
     }
     BHIP_DEV void sinv_mul(const double *v, double *o) const   // inv(P.sigma)*v
     {
+        if constexpr (STREAMED) {
+            PTR Sq = p + 3 * D * D + D;
+            bhip_after(Sq, v[D - 1]);
+            matvec_streamed<D, PTR>(Sq, v, o);
+            return;
+        }
         const PTR Si = p + 3 * D * D + D;
 #pragma unroll
         for (int i = 0; i < D; i++) {

@@ -307,7 +307,11 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int n
         model.b(t, st.y, bI);
         if constexpr (GK != BHIP_GUIDE_NONE) {
             double r[D], g[D];
-            guide_terms<M, GK, MO>(model, t, rw + RL::G, st.y, r, g);
+            if constexpr (STR) {
+                RowPtr rg = row;
+                bhip_after(rg, bI[D - 1]);
+                guide_terms<M, GK, MO, RowPtr>(model, t, rg + RL::G, st.y, r, g);
+            } else guide_terms<M, GK, MO>(model, t, rw + RL::G, st.y, r, g);
 #pragma unroll
             for (int k = 0; k < D; k++)
                 if (M::noisy(k)) bI[k] = bI[k] + g[k];
@@ -756,6 +760,7 @@ launch_fn get_launch_mid(int gk, int noise, int fl)
     if (gk == BHIP_GUIDE_NONE) {
         switch (noise) {
         case NOISE_EXT: return (fl & 1) ? launch_paths<M, BHIP_GUIDE_NONE, 1, NOISE_EXT, 1> : launch_paths<M, BHIP_GUIDE_NONE, 1, NOISE_EXT, 0>;
+        case NOISE_INNOV: return launch_paths<M, BHIP_GUIDE_NONE, 1, NOISE_INNOV, 2>;
         case NOISE_FRESH:
             switch (fl & 3) {
             case 0: return launch_paths<M, BHIP_GUIDE_NONE, 1, NOISE_FRESH, 0>;
@@ -777,6 +782,7 @@ launch_fn get_launch_mid(int gk, int noise, int fl)
         }
     case NOISE_LLONLY: return launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_LLONLY, 0>;
     case NOISE_PCN: return (fl & 1) ? launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_PCN, 1> : launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_PCN, 0>;   // pCN chains on the 16-byte slots
+    case NOISE_INNOV: return launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_INNOV, 2>;   // innovations!: inv(sigma) by LU on the host, streamed like the other matrices
     }
     return nullptr;
 }

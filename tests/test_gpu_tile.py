@@ -222,7 +222,7 @@ def test_dimensions_4_to_8_run_one_path_per_lane(ctx, d):
     """LinPro targets of dimension 4..8 (round 3): bhip_sample_solve / bhip_solve / bhip_llikelihood run them on the path-per-lane
     kernel (k_paths<MLinPro<d>, (nu,H) form>: scalar FMAs, coefficients through the scalar unit) instead of zero padded on the
     16-row MFMA tile.  Wiener paths bit-exact vs the oracle, paths / ll at the large-d tolerance (pre-inverted guide matrix),
-    agreement with the tile kernel (BHIP_OPT_MID_VALU = 0), ragged ensemble sizes, plain Euler-Maruyama, per-path starts, pCN chains
+    agreement with the tile kernel (BHIP_OPT_MID_VALU = 0), ragged ensemble sizes, plain Euler-Maruyama, per-path starts, innovations!, pCN chains
     (slots) against the oracle, a saved state and the tile kernel's chains."""
     c = problems.linpro_big_case(d, 81)
     Po, ref = c.bh_proposal(bh, ctx), c.oracle_proposal()
@@ -259,6 +259,17 @@ def test_dimensions_4_to_8_run_one_path_per_lane(ctx, d):
     for p in (0, P - 1):
         Xr = o.solve_guided(ref, starts[p], Wh[p])
         assert np.abs(Xs[p] - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max()) and np.array_equal(Xs[p, 0], starts[p])
+    # innovations!(EulerMaruyama, W, Y, P) (src/euler.jl:358-376): the inverse map of solve!, inv(sigma) by LU on the host; guided and plain
+    Wi = bh.innovations(bh.EulerMaruyama(), X, Po).paths()
+    for p in (0, 64, P - 1):
+        Wo_ = o.innovations(ref, Xh[p])
+        assert np.abs(Wi[p] - Wo_).max() <= 1e-9 * (1 + np.abs(Wo_).max()), (d, p)
+        assert np.abs(Wi[p][:-1] - Wh[p][:-1]).max() <= 1e-7 * (1 + np.abs(Wh[p]).max())   # it IS the driving noise (the endpoint rule replaced X[N])
+    Xem = bh.solve(bh.EulerMaruyama(), 0.2 * np.ones(d), W, proc)
+    Wem = bh.innovations(bh.EulerMaruyama(), Xem, proc).paths()
+    assert np.abs(Wem - Wh).max() <= 1e-8 * (1 + np.abs(Wh).max())
+    Wem_o = o.innovations(None, Xem.paths()[7], model=o.MODEL_LINPRO, d=d, mp=d, par=c.par, tt=c.tt)
+    assert np.abs(Wem[7] - Wem_o).max() <= 1e-9 * (1 + np.abs(Wem_o).max())
     # pCN chains at these dimensions run on the same kernel family (16-byte slots: current and proposal value side by side) ...
     n, iters, rho = 100, 5, 0.9
     ch = bh.Chains(Po, c.x0, n, seed=8, path0=3)
