@@ -255,6 +255,9 @@ BHIP_DEV void guide_terms(const M &model, double t, GP g, const double *x, doubl
 // depth of the prefetch window of the pCN kernel (a 16-byte slot per step in flight).  Measured on the bench
 // workload: 1, 2, 3 and 4 steps ahead run within 2 % of each other; 2 keeps the kernel at 118 VGPRs, 3 and 4 sit
 // on the 128-register cap of 4 waves per SIMD and spill a few loop-invariant values to scratch.
+#ifndef BHIP_PATHS_UNR_MULT
+#define BHIP_PATHS_UNR_MULT 1   // (2: twice the steps per loop iteration in the noise-drawing d <= 3 kernels -- measured, no gain)
+#endif
 #ifndef BHIP_KCH_PCN
 #define BHIP_KCH_PCN 2
 #endif
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(256, (PPR || M::D > 4 || (M::D > 3 && NOISE == NOIS
     };
     // unrolled so that the position of a step's normals inside their Philox call (four normals per call) and the register row
     // of the per-chain coefficients are static: four steps per iteration where normals are drawn (two for m' = 2), else two
-    constexpr int UNR = DRAWS ? ((MP == 2 || MP % 4 == 0) ? 2 : 4) : 2;
+    constexpr int UNR = (DRAWS ? ((MP == 2 || MP % 4 == 0) ? 2 : 4) : 2) * ((DRAWS && !PPR && M::D <= 3) ? BHIP_PATHS_UNR_MULT : 1);
     int i = 0;
     for (; i + UNR - 1 < nsteps; i += UNR) {
 #pragma unroll
