@@ -1451,8 +1451,8 @@ extern "C" int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip
 // and reproducible from process to process (profiles/r3_alloc_placement.txt: plain fills / copies show no slow region, only
 // the three-stream mix does; the first allocations of a fresh process are the slow ones).  Nothing at this level controls
 // physical placement, so large ensembles MEASURE it: bhip_chains_init times a few pCN iterations on the allocation it has,
-// then on up to three more (the earlier ones stay allocated meanwhile, so that each lands elsewhere), keeps the fastest,
-// frees the rest and initialises the state afresh.  ~10 ms and transiently up to 4x the state per ensemble, once.
+// then on up to five more (the earlier ones stay allocated meanwhile, so that each lands elsewhere), keeps the fastest,
+// frees the rest and initialises the state afresh.  ~10 ms per allocation and transiently up to 6x the state per ensemble (as far as the device has it free), once.
 static int chains_time_iterations(bhip_chains *ch, int skip, float *ms)
 {
     bhip_ctx *ctx = ch->ctx;
@@ -1487,7 +1487,7 @@ int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
     if (rc) return rc;
     cands.push_back(cur);
     float worst = cur.ms, best = cur.ms;
-    const int max_tries = 4;
+    const int max_tries = 6;   // (stops at the first allocation 7 % faster than the slowest seen; six alike cost ~60 ms of set-up)
     while ((int)cands.size() < max_tries && best > 0.93f * worst) {   // the two populations lie ~10 % apart
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * (ch->wbytes + ch->xbytes)) break;

@@ -120,18 +120,22 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
         // addresses: a wave-uniform base per chunk (the 64 chains' 256-byte pairs of chunk k are contiguous) + a small per-lane
         // offset that never changes -- line (8q + sub) of the group, parity half, 16-byte piece -- whose half bit is flipped for
         // the store: 8 registers instead of 2 x 8 64-bit addresses (which spilled at the 128-register cap)
-        int voff[8];
+        // (the eight offsets differ by q * 256 doubles and by the parity bit of chain 8q + sub: ONE register of offset and ONE of
+        // parity bits, the rest is two integer operations per access -- eight registers of offsets were what spilled)
+        const int vbase = (int)line_index(0, 0, sub, nch, a.ldC) + part;
+        uint32_t hbits = 0u;
+        auto voff = [&](int q) { return vbase + q * (8 * 2 * LINE_DOUBLES) + (int)((hbits >> q) & 1u) * LINE_DOUBLES; };
         d2v stage[8];
         auto chunk_base = [&](int k) { return a.Wc + line_index(0, k, c0, nch, a.ldC); };
         auto fetch = [&](int k) {
             const double *kb = chunk_base(k);
 #pragma unroll
-            for (int q = 0; q < 8; q++) stage[q] = ld_stream((const d2v *)(kb + voff[q]));
+            for (int q = 0; q < 8; q++) stage[q] = ld_stream((const d2v *)(kb + voff(q)));
         };
         if constexpr (PCN) {
 #pragma unroll
             for (int q = 0; q < 8; q++)   // cur[] is allocated (and zeroed) up to ld
-                voff[q] = (int)line_index(a.cur[c0 + 8 * q + sub], 0, 8 * q + sub, nch, a.ldC) + part;
+                hbits |= (uint32_t)(a.cur[c0 + 8 * q + sub] & 1) << q;
             fetch(0);
         }
         double *wout = nullptr;
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
 #pragma unroll
                     for (int q = 0; q < 8; q++) {   // tile -> the lines of the other halves
                         const double *d = tile + (8 * q + sub) * LINE_ROW + part;
-                        st_stream((d2v *)(kb + (voff[q] ^ LINE_DOUBLES)), d2v{d[0], d[1]});
+                        st_stream((d2v *)(kb + (voff(q) ^ LINE_DOUBLES)), d2v{d[0], d[1]});
                     }
                 }
             }

@@ -99,14 +99,15 @@ int bhip_ctx_sync(bhip_ctx *ctx);
 #define BHIP_OPT_WAVE_SPECIALISED 1
 /* BHIP_OPT_TUNE_PLACEMENT (default 1): chain ensembles of 1 GiB or more measure where their memory landed -- on MI355X the
  * pCN iteration (three streams: read W, write Wo, write Xo) runs up to 15 % slower on some allocations than on others, for the
- * life of the allocation.  bhip_chains_init then times a few iterations on up to four allocations, keeps the fastest and
+ * life of the allocation.  bhip_chains_init then times a few iterations on up to six allocations, keeps the fastest and
  * re-initialises (see bhip_chains_placement_info); 0 keeps the first allocation.  Results do not depend on it. */
 #define BHIP_OPT_TUNE_PLACEMENT 2
 /* BHIP_OPT_MID_VALU (default 1): LinPro targets of dimension 4 <= d <= 8 run one path per lane like the d <= 3 processes (the
- * d x d products as scalar FMAs, coefficients through the scalar unit) in bhip_sample_solve, bhip_solve and bhip_llikelihood; 0
- * runs them zero padded on the 16-row MFMA tile kernel, as their chains do.  On MI355X the fp64 matrix cores have no rate
- * advantage over fp64 FMAs, and a 16x16x4 instruction cannot skip padding: d = 4 is ~7x faster per lane.  Same results to the
- * tile kernel's tolerance (the guide solve is a product with the pre-inverted matrix in both). */
+ * d x d products as scalar FMAs, coefficients through the scalar unit) in bhip_sample_solve, bhip_solve, bhip_llikelihood,
+ * bhip_innovations and bhip_chains_* / bhip_segchains_* (read when the ensemble is created); 0 runs them zero padded on the 16-row
+ * MFMA tile kernel (no innovations there).  On MI355X the fp64 matrix cores have no rate advantage over fp64 FMAs, and a 16x16x4
+ * instruction cannot skip padding: d = 4 is 5.7x faster for proposals, 3.2x for chains.  Same results to the tile kernel's
+ * tolerance (the guide solve is a product with the pre-inverted matrix in both), identical accept decisions and Wiener states. */
 #define BHIP_OPT_MID_VALU 3
 /* BHIP_OPT_FUSED_ARITHMETIC (default 0): 1 runs the d <= 3 path kernels (built-in processes; ensembles and chains with a guide
  * shared by the ensemble) from a second build of the same source in which the compiler may contract a*b + c into one fused
@@ -236,7 +237,8 @@ int bhip_llikelihood(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev
 /* innovations!(EulerMaruyama(), W, X, P): the inverse map X -> W of the Euler scheme,
  *   W[0] = 0,  W[i+1] = W[i] + inv(sigma)*(X[i+1] - X[i] - _b((i,t_i), X[i], P)*(t_{i+1}-t_i))
  * for every path of the ensemble (P: the plain target or a guided proposal); needs a square,
- * invertible sigma (d == m').  src/euler.jl:358-376 -- used by the non-centred parameter updates
+ * invertible sigma (d == m'); d <= 3, or a LinPro target of dimension 4..8 (inv(sigma) by LU on the host: 1e-9 against the
+ * reference's sigma \ v).  src/euler.jl:358-376 -- used by the non-centred parameter updates
  * (example/fitzhugh_nagumo_full.jl:353). */
 int bhip_innovations(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev, long ldX, double *W_dev, long ldW, long npaths);
 

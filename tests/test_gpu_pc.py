@@ -130,7 +130,7 @@ def test_placement_tuning_changes_nothing_but_the_allocation(ctx):
     n = 36000                                            # x 32 KB of state per chain > 1 GiB
     a = bh.Chains(Po, case.x0, n, seed=9)
     info = a.placement()
-    assert 1 <= info["tries"] <= 4 and 0 < info["ms_best"] <= info["ms_first"]
+    assert 1 <= info["tries"] <= 6 and 0 < info["ms_best"] <= info["ms_first"]
     a.step(0.9, 3)
     ctx.set_option(bh.OPT_TUNE_PLACEMENT, 0)
     try:
