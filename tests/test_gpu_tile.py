@@ -320,3 +320,13 @@ def test_one_path_per_lane_short_grids_and_loop_remainders(ctx, d, N):
         assert np.array_equal(Wh[p], Wr), (d, N, p)
         Xr = o.solve_guided(ref, c.x0, Wr)
         _close(Xh[p], Xr, llh[p:p + 1], np.array([o.llikelihood(ref, Xr)]))
+    # the chain step on the same short grids (slot prefetch clamped to the grid), with a skipped first term where there is one
+    skip = 1 if N > 3 else 0
+    ch = bh.Chains(Po, c.x0, 70, seed=4, path0=2, skip=skip)
+    ch.step(0.8, 4)
+    acc, llc = ch.acc(), ch.ll()
+    Xc, Wc = ch.paths(0, 70)
+    for p in (0, 63, 64, 69):
+        r = o.mcmc(ref, c.x0, 0.8, 4, 4, 2 + p, skip=skip)
+        assert acc[p] == r["acc"] and np.array_equal(Wc[p], r["W"]), (d, N, p)
+        _close(Xc[p], r["X"], np.array([llc[p]]), np.array([r["ll"]]))
