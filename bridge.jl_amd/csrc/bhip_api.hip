@@ -510,8 +510,17 @@ int bhip_proposal_create(bhip_ctx *ctx, const double *tt, int N, int model, int 
                 ModelHost &mh = po->mh;
                 mh.id = model; mh.d = um->d; mh.mp = um->d;
                 mh.par.assign(par, par + npar);
-                mh.a = outer(Mat(um->d, um->d, par + um->npar));
+                const Mat S(um->d, um->d, par + um->npar);
+                mh.a = outer(S);
                 mh.dpar.assign(par, par + um->npar);
+                if (um->d <= BHIP_MAXD_LANE) {
+                    // dimensions 4..8 also run one path per lane (k_paths<MUser>, hipRTC): the device block behind the drift
+                    // parameters holds sigma, a = sigma*sigma' and inv(sigma) (LU), streamed through the scalar unit like LinPro's
+                    mh.dpar.insert(mh.dpar.end(), S.a.begin(), S.a.end());
+                    mh.dpar.insert(mh.dpar.end(), mh.a.a.begin(), mh.a.a.end());
+                    const Mat Si = det(S) != 0.0 ? inv(S) : Mat(um->d, um->d);
+                    mh.dpar.insert(mh.dpar.end(), Si.a.begin(), Si.a.end());
+                }
             }
         }
         else if (!um->sigma.empty()) {   // state-dependent sigma(t,x,P): nothing to derive on the host
@@ -767,7 +776,7 @@ static int build_tile_data(bhip_proposal *po)
     }
     std::vector<double> cst(4 * DD + 5 * Dp, 0.0);
     const double *par = po->mh.par.data();
-    const double *sig = user ? par + po->mh.dpar.size() : par + dd + d;          // user: [drift parameters, sigma]; LinPro: [B, mu, sigma]
+    const double *sig = user ? par + (po->mh.par.size() - (size_t)dd) : par + dd + d;   // user: [drift parameters, sigma]; LinPro: [B, mu, sigma]
     if (!user) to_fragments(pad_mat(Mat(d, d, par), Dp), &cst[0]);               // B (user drift: evaluated component-wise, no matrix)
     if (!plain) to_fragments(pad_mat(po->aux.B(po->tt[0]), Dp), &cst[DD]);       // B~
     to_fragments(pad_mat(po->mh.a, Dp), &cst[2 * DD]);                           // a = sigma*sigma'
@@ -823,7 +832,7 @@ static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const d
     if (po->mh.id >= USER_MODEL_BASE) {   // component-wise user drift: the hipRTC instantiation k_tile<D, noise, PAD, MUserBig>
         const int D = tile_dim(d);
         const bool pad = d != D;
-        for (size_t k = 0; k < po->mh.dpar.size() && k < 16; k++) a.upar[k] = po->mh.dpar[k];
+        for (size_t k = 0; k < po->mh.par.size() - (size_t)po->mh.d * po->mh.d && k < 16; k++) a.upar[k] = po->mh.dpar[k];   // the drift parameters
         a.tt = po->d_tt;
         hipFunction_t fn = nullptr;
         {
@@ -869,8 +878,14 @@ static int finish_guide(bhip_proposal *po)
     po->mid = false;
     if (d > 3) {
         const int rct = build_tile_data(po);
-        if (rct || d > BHIP_MAXD_LANE || po->mh.id != BHIP_MODEL_LINPRO) return rct;
-        po->mid = true;   // ... and the rows below, for one path per lane
+        bool comp = false;
+        if (po->mh.id >= USER_MODEL_BASE) {
+            std::lock_guard<std::mutex> lk(user_models_mutex());
+            const UserModel *um = find_user_model(po->mh.id);
+            comp = um && um->components;
+        }
+        if (rct || d > BHIP_MAXD_LANE || !(po->mh.id == BHIP_MODEL_LINPRO || comp)) return rct;
+        po->mid = true;   // ... and the rows below, for one path per lane (LinPro targets and component-wise user drifts)
     }
     std::vector<double> rows;
     int rs = 0;
@@ -1079,6 +1094,29 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
     if (po->mid) {   // LinPro, d = 4..8: rows in the (nu, H) form, one kernel family
         const int gkm = po->g.kind == BHIP_GUIDE_NONE ? BHIP_GUIDE_NONE : BHIP_GUIDE_NUH;
         if (a.rs != row_stride(gkm, po->mh.d, 1, true)) return fail(ctx, BHIP_ESTATE, "row stride mismatch");
+        if (po->mh.id >= USER_MODEL_BASE) {   // component-wise user drift: k_paths<MUser (streamed), gk, 1, noise, fl> through hipRTC
+            if (!(noise == NOISE_EXT || noise == NOISE_FRESH || noise == NOISE_PCN || noise == NOISE_LLONLY || noise == NOISE_INNOV) ||
+                (gkm == BHIP_GUIDE_NONE && (noise == NOISE_PCN || noise == NOISE_LLONLY)))
+                return fail(ctx, BHIP_EUNSUPPORTED, "no path-per-lane kernel for this mode at 4 <= d <= 8");
+            const int flk = noise == NOISE_INNOV ? 2 : fl;
+            hipFunction_t fn = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(user_models_mutex());
+                UserModel *um = find_user_model(po->mh.id);
+                if (!um) return fail(ctx, BHIP_EINVAL, "unknown user model id");
+                const std::vector<int> key = {ctx->device, gkm, 1, noise, flk, -1};   // (-1: the streamed one-path-per-lane family)
+                auto it = um->fns.find(key);
+                if (it == um->fns.end()) {
+                    const std::string log = rtc_build(*um, gkm, 1, noise, flk, &fn, 0);
+                    if (!log.empty()) return fail(ctx, BHIP_EHIP, log);
+                    um->fns[key] = fn;
+                } else fn = it->second;
+            }
+            KArgs args = a;
+            void *params[] = {&args};
+            HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)((a.P + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr));
+            return BHIP_OK;
+        }
         launch_fn fm = nullptr;
         switch (po->mh.d) {
         case 4: fm = get_launch_mid4(gkm, noise, fl); break;

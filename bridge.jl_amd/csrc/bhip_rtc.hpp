@@ -69,8 +69,55 @@ inline std::string rtc_kernel_name(int gk, int mo, int noise, int fl, int npair,
     return ns + "k_paths<" + ns + "MUser, " + args + std::to_string(noise) + ", " + std::to_string(fl) + ">";
 }
 
+// component-wise drift at 4 <= d <= 8: one path per lane, MUser STREAMED like MLinPro<D, bhip_cptr_t> (bhip_models.h) -- the device block
+// [drift parameters | sigma | a | inv(sigma)] is read through the scalar unit, every matrix in column blocks behind the phase before it
+inline std::string rtc_source_components(const UserModel &um, int gk, int mo, int noise, int fl)
+{
+    std::string s = RTC_PREFIX;
+    const std::string D = std::to_string(um.d), NP = std::to_string(um.npar);
+    s += "\nnamespace bhip {\nstruct MUser {\n";
+    s += "    static constexpr int D = " + D + ", MP = " + D + ", NP = " + NP + ", ID = 1000;\n";
+    s += "    static constexpr bool STREAMED = true;\n    static constexpr bool noisy(int) { return true; }\n    bhip_cptr_t p;\n";
+    s += "    BHIP_DEV explicit MUser(bhip_cptr_t p_) : p(p_) {}\n";
+    s += "    static BHIP_DEV double bk(int k, double t, const double *x, const double *par)\n    {\n";
+    s += "        const int d = D; (void)d; (void)t; (void)par; (void)k;\n        double o = 0.0;\n        " + um.drift + "\n        return o;\n    }\n";
+    s += R"(    BHIP_DEV void b(double t, const double *x, double *o) const
+    {
+        bhip_cptr_t q = p;
+        bhip_after(q, x[D - 1]);
+        double par[NP > 0 ? NP : 1];
+#pragma unroll
+        for (int k = 0; k < NP; k++) par[k] = q[k];
+#pragma unroll
+        for (int k = 0; k < D; k++) o[k] = bk(k, t, x, par);   // (k is a constant after unrolling: x stays in registers)
+    }
+    BHIP_DEV void sdw(double, const double *, const double *dw, double *o) const
+    {
+        bhip_cptr_t S = p + NP;
+        bhip_after(S, dw[D - 1]);
+        matvec_streamed<D, bhip_cptr_t>(S, dw, o);
+    }
+    BHIP_DEV void amul(double, const double *, const double *r, double *o) const
+    {
+        bhip_cptr_t A = p + NP + D * D;
+        bhip_after(A, r[D - 1]);
+        matvec_streamed<D, bhip_cptr_t>(A, r, o);
+    }
+    BHIP_DEV void sinv_mul(const double *v, double *o) const
+    {
+        bhip_cptr_t Sq = p + NP + 2 * D * D;
+        bhip_after(Sq, v[D - 1]);
+        matvec_streamed<D, bhip_cptr_t>(Sq, v, o);
+    }
+};
+)";
+    s += "template __global__ void " + rtc_kernel_name(gk, mo, noise, fl, 0, false) + "(const KArgs);\n}\n";
+    return s;
+}
+
 inline std::string rtc_source(const UserModel &um, int gk, int mo, int noise, int fl, int npair = 0)
 {
+    if (um.components) return rtc_source_components(um, gk, mo, noise, fl);
     std::string s = RTC_PREFIX;
     s += "\nnamespace bhip {\nstruct MUser {\n";
     s += "    static constexpr int D = " + std::to_string(um.d) + ", MP = " + std::to_string(um.mp) + ", NP = " + std::to_string(um.npar) + ", ID = 1000;\n";

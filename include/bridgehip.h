@@ -147,13 +147,14 @@ int bhip_model_define(bhip_ctx *ctx, int d, int mp, int npar, const char *drift_
  * branches are undefined (they name unbound variables), those calls return BHIP_EUNSUPPORTED. */
 int bhip_model_define_sigma(bhip_ctx *ctx, int d, int mp, int npar, const char *drift_src, const char *sigma_src, int *model_id);
 
-/* The same extension point at LARGE state dimension (even 4 <= d <= 32, m' = d, constant dense sigma): the drift runs on the
- * fp64-MFMA tile kernel, where a lane holds only part of a path's state, so the method body is given COMPONENT-WISE:
+/* The same extension point at LARGE state dimension (4 <= d <= 32, odd d too; m' = d, constant dense sigma): at d >= 9 the drift
+ * runs on the fp64-MFMA tile kernel, where a lane holds only part of a path's state, so the method body is given COMPONENT-WISE
+ * (dimensions 4..8 compile the same text into the path-per-lane kernels, as for LinPro targets: BHIP_OPT_MID_VALU):
  *     inputs  int k (component, 0-based), int d, double t, const double* x (d), const double* par (npar <= 16);  output double o, e.g.
  *     Lorenz-96:  "o = (x[(k+1)%d] - x[(k+d-2)%d])*x[(k+d-1)%d] - x[k] + par[0];"
  * Proposals on the returned model id take par = [npar drift parameters, sigma (d x d, column-major)].  Runs everything the
  * built-in LinPro target runs at large d: plain Euler-Maruyama, GuidedBridge / (nu,H) / PartialBridge guides with a
- * time-constant auxiliary, fused and stand-alone llikelihood, pCN chains. */
+ * time-constant auxiliary, fused and stand-alone llikelihood, pCN chains (and innovations! at d <= 8). */
 int bhip_model_define_components(bhip_ctx *ctx, int d, int npar, const char *component_src, int *model_id);
 
 /* ------------------------------------------------------------------ proposal  ("Po")

@@ -88,3 +88,59 @@ def test_plain_euler_maruyama_with_a_user_drift_at_d16():
     for p in (0, 32):
         Xr = o.solve_em(o.MODEL_LORENZ96, d, d, par, tt, x0, Wh[p])
         assert np.abs(Xh[p] - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [4, 5, 8])
+def test_component_drift_at_4_to_8_runs_one_path_per_lane(d):
+    """round 3: a component-wise user drift of dimension 4..8 runs on the path-per-lane kernel family like a LinPro target of that
+    dimension (k_paths<MUser>, hipRTC; the drift parameters, sigma, a and inv(sigma) streamed through the scalar unit) instead of
+    zero padded on the 16-row MFMA tile: against the oracle's Lorenz-96 stand-in, and against the tile kernel (BHIP_OPT_MID_VALU = 0)
+    -- proposals, stored-ensemble llikelihood, plain Euler-Maruyama, innovations!, pCN chains (slots)."""
+    ctx = bh.default_context(0)
+    tt, x0, v, sig, Baux, F = problem(d)
+    P = bh.UserProcessComponents(d, L96, [F], sig, ctx=ctx)
+    Pt = bh.LinPro(Baux, F * np.ones(d), sig)
+    Po = bh.GuidedBridge(tt, P, Pt, v, ctx=ctx)
+    par = np.concatenate([[F], o.cm(sig)])
+    apar = o.linpro_par(Baux, F * np.ones(d), sig)
+    ref = o.proposal_hv(tt, d, d, o.MODEL_LORENZ96, par, o.AUX_LINPRO, apar, Po.Hd, Po.V)
+    n = 150
+    X, W, ll = bh.sample_solve(x0, Po, n, seed=3, store_W=True)
+    Xh, Wh, llh = X.paths(), W.paths(), ll.cpu().numpy()
+    for p in (0, 63, 64, n - 1):
+        assert np.array_equal(Wh[p], o.wiener_sample(tt, d, 3, p, 0))
+        Xr = o.solve_guided(ref, x0, Wh[p])
+        assert np.abs(Xh[p] - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max()), (d, p, np.abs(Xh[p] - Xr).max())
+        llr = o.llikelihood(ref, Xr)
+        assert abs(llh[p] - llr) <= 1e-8 * (1 + abs(llr))
+    assert np.array_equal(Xh[:, -1, :], np.tile(v, (n, 1)))
+    ll2 = bh.llikelihood(bh.LeftRule(), X, Po).cpu().numpy()
+    assert np.all(np.abs(ll2 - llh) <= 1e-9 * (1 + np.abs(llh)))
+    ctx.set_option(bh.OPT_MID_VALU, 0)                       # the zero-padded tile kernel: same W, paths / ll to its tolerance
+    try:
+        Xt, Wt, llt = bh.sample_solve(x0, Po, n, seed=3, store_W=True)
+        cht = bh.Chains(Po, x0, 64, seed=9)
+        cht.step(0.9, 4)
+        acct, llct = cht.acc(), cht.ll()
+    finally:
+        ctx.set_option(bh.OPT_MID_VALU, 1)
+    assert np.array_equal(Wt.paths(), Wh)
+    assert np.abs(Xt.paths() - Xh).max() <= 1e-9 * (1 + np.abs(Xh).max()) and np.abs(llt.cpu().numpy() - llh).max() <= 1e-8 * (1 + np.abs(llh).max())
+    # plain Euler-Maruyama and its inverse map
+    proc = bh.PlainProcess(tt, P, ctx=ctx)
+    Xem = bh.solve(bh.EulerMaruyama(), x0, W, proc)
+    Xr = o.solve_em(o.MODEL_LORENZ96, d, d, par, tt, x0, Wh[7])
+    assert np.abs(Xem.paths()[7] - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max())
+    Wi = bh.innovations(bh.EulerMaruyama(), Xem, proc).paths()
+    assert np.abs(Wi - Wh).max() <= 1e-8 * (1 + np.abs(Wh).max())
+    # pCN chains on the slots: the oracle's decisions, the tile kernel's decisions
+    ch = bh.Chains(Po, x0, 64, seed=9)
+    ch.step(0.9, 4)
+    acc, llc = ch.acc(), ch.ll()
+    Xc, Wc = ch.paths(0, 64)
+    for p in (0, 17, 63):
+        r = o.mcmc(ref, x0, 0.9, 4, 9, p)
+        assert acc[p] == r["acc"] and np.array_equal(Wc[p], r["W"]), (d, p)
+        assert np.abs(Xc[p] - r["X"]).max() <= 1e-9 * (1 + np.abs(r["X"]).max()) and abs(llc[p] - r["ll"]) <= 1e-8 * (1 + abs(r["ll"]))
+    assert np.array_equal(acc, acct) and np.abs(llc - llct).max() <= 1e-8 * (1 + np.abs(llc).max())
