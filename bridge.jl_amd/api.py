@@ -293,7 +293,8 @@ class UserProcess(ContinuousTimeProcess):
 class UserProcessComponents(ContinuousTimeProcess):
     """A user-defined target at LARGE state dimension (4 <= d <= 32, dense constant sigma [d, d]): the body of
     `Bridge.b(t, x, P)` given COMPONENT-WISE as HIP C++ text -- it sees `int k` (component), `int d`, `double t`,
-    `const double* x`, `const double* par` and writes `double o` -- compiled into the fp64-MFMA tile kernel with hipRTC:
+    `const double* x`, `const double* par` and writes `double o` -- compiled with hipRTC into the fp64-MFMA tile kernel (d >= 9) or the
+    path-per-lane kernels (d = 4..8: `k` is then a constant per unrolled component):
 
         P = UserProcessComponents(16, "o = (x[(k+1)%d] - x[(k+d-2)%d])*x[(k+d-1)%d] - x[k] + par[0];", par=[8.0], sigma=0.5*np.eye(16))"""
 
