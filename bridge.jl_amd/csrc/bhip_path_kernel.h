@@ -255,6 +255,9 @@ BHIP_DEV void guide_terms(const M &model, double t, GP g, const double *x, doubl
 // depth of the prefetch window of the pCN kernel (a 16-byte slot per step in flight).  Measured on the bench
 // workload: 1, 2, 3 and 4 steps ahead run within 2 % of each other; 2 keeps the kernel at 118 VGPRs, 3 and 4 sit
 // on the 128-register cap of 4 waves per SIMD and spill a few loop-invariant values to scratch.
+#ifndef BHIP_PATHS_BLOCK
+#define BHIP_PATHS_BLOCK 256   // threads per workgroup of k_paths (<= 256: its launch bound)
+#endif
 #ifndef BHIP_PATHS_UNR_MULT
 #define BHIP_PATHS_UNR_MULT 1   // (2: twice the steps per loop iteration in the noise-drawing d <= 3 kernels -- measured, no gain)
 #endif
@@ -684,7 +687,7 @@ hipError_t launch_pc(const KArgs &a, hipStream_t st);            // bhip_pc_kern
 template <class M, int GK, int MO, int NOISE, int FL, bool PPR = false>
 hipError_t launch_paths(const KArgs &a, hipStream_t st)
 {
-    const int block = 256;
+    const int block = BHIP_PATHS_BLOCK;
     const long grid = (a.P + block - 1) / block;
     hipLaunchKernelGGL((k_paths<M, GK, MO, NOISE, FL, PPR>), dim3((unsigned)grid), dim3(block), 0, st, a);
     return hipGetLastError();
