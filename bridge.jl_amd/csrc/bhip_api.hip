@@ -1059,7 +1059,7 @@ static int fill_common(const bhip_proposal *po, KArgs &a, const double *x0, cons
     const int d = po->mh.d;
     std::memset(&a, 0, sizeof(a));
     NEED_DEVICE(ctx);
-    if (d > 3 && !po->mid) return fail(ctx, BHIP_EUNSUPPORTED, "path-per-lane kernel covers d <= 3 (LinPro targets: d <= 8)");
+    if (d > 3 && !po->mid) return fail(ctx, BHIP_EUNSUPPORTED, "path-per-lane kernel covers d <= 3 (LinPro targets and component-wise user drifts: d <= 8)");
     if (!po->d_rows) return fail(ctx, BHIP_ESTATE, "proposal has no coefficient rows (compute a guide first)");
     if (npaths < 1) return fail(ctx, BHIP_EINVAL, "npaths must be positive");
     if (skip < 0) return fail(ctx, BHIP_EINVAL, "skip must be >= 0");
