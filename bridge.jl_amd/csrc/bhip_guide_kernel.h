@@ -266,12 +266,15 @@ __global__ void k_seg_pi0(long n, long ld, const double *__restrict__ carry, dou
     for (int k = 0; k < D; k++) mu[(size_t)k * ld + p] = carry[(size_t)(D * D + k) * ld + p];
 }
 
+#ifndef BHIP_GUIDE_N32
+#define BHIP_GUIDE_N32 24576   // from this many chains on: 32 chains per wave (below: 16)
+#endif
 typedef hipError_t (*guide_launch_fn)(const GArgs &, hipStream_t);
 template <class M, int MO>
 hipError_t launch_seg_guide(const GArgs &g, hipStream_t st)
 {
     GArgs a = g;
-    a.lane_shift = g.n >= 65536 ? 0 : g.n >= 24576 ? 1 : 2;   // 64, 32 or 16 chains per wave: >= ~1024 waves where the ensemble allows
+    a.lane_shift = g.n >= 65536 ? 0 : g.n >= BHIP_GUIDE_N32 ? 1 : 2;   // 64, 32 or 16 chains per wave: >= ~1024 waves where the ensemble allows
     const long per = 64 >> a.lane_shift;
     hipLaunchKernelGGL((k_seg_guide<M, MO>), dim3((unsigned)((g.n + per - 1) / per)), dim3(64), 0, st, a);
     return hipGetLastError();
