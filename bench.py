@@ -389,8 +389,14 @@ def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
             "iteration_shared_guides_means_only": {"ms": ms_mo, "path_steps_per_s": ps / ms_mo * 1e3, "algorithmic_bytes_per_path_step": b_sh - 144,
                                                    "hbm_frac": ps * (b_sh - 144) / ms_mo / 1e6 / HBM_PEAK_GBS,
                                                    "note": "BHIP_SEGCHAINS_MCNEXT_MEAN: the per-chain running means only (all the adaptation reads); mcnext! proper keeps the 3 x 3 second moments too"},
+            # one call = the per-chain guide builder (k_seg_guide: 24 B of running mean read + the 120-byte compact row written per
+            # chain and grid point) AND the re-evaluation of every chain's current log-likelihood under its new guide (the script
+            # evaluates both llikelihoods afresh every iteration; here the current one is cached and re-done on adaptation:
+            # 24 B of X + the 120-byte row read per path-step).  profiles/r3_smoothing_trace.txt has the two kernels apart.
             "adapt_device": {"ms": ms_ad, "guide_segments_per_s": n * m / ms_ad * 1e3,
-                             "algorithmic_bytes": n * m * (M + 1) * 144, "hbm_frac": n * m * (M + 1) * 144 / ms_ad / 1e6 / HBM_PEAK_GBS},
+                             "algorithmic_bytes": n * m * ((M + 1) * 144 + M * 144),
+                             "algorithmic_bytes_guide_builder": n * m * (M + 1) * 144, "algorithmic_bytes_ll_reevaluation": n * m * M * 144,
+                             "hbm_frac": n * m * ((M + 1) * 144 + M * 144) / ms_ad / 1e6 / HBM_PEAK_GBS},
             "iteration_per_chain_guides": {"ms": ms_pc, "path_steps_per_s": ps / ms_pc * 1e3, "algorithmic_bytes_per_path_step": b_pc,
                                            "hbm_frac": ps * b_pc / ms_pc / 1e6 / HBM_PEAK_GBS}}
 
