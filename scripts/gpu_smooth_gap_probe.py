@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 import bench, bridgehip as bh
-ctx = bh.Context(0)
+side = torch.cuda.Stream() if os.environ.get('PROBE_SIDE_STREAM') else None
+ctx = bh.Context(0, stream=side.cuda_stream) if side else bh.Context(0)
 m, M, n = 4, 250, 32768
 P = bh.Lorenz((10.0, 20.0, 8 / 3), (3.0, 3.0, 3.0))
 tgrid = np.linspace(0.0, 0.002 * m * M, m * M + 1)
@@ -26,10 +27,10 @@ wo, wn = 0.9, math.sqrt(1 - 0.81)
 K = 20
 sc.step(wo, wn, 3); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record(); sc.step(np.full(K, wo), np.full(K, wn)); e1.record(); torch.cuda.synchronize()
+e0.record(side); sc.step(np.full(K, wo), np.full(K, wn)); e1.record(side); torch.cuda.synchronize()
 print("one call of %d iterations: %.3f ms per iteration" % (K, e0.elapsed_time(e1) / K))
-e0.record()
+e0.record(side)
 for _ in range(K):
     sc.step(wo, wn, 1)
-e1.record(); torch.cuda.synchronize()
+e1.record(side); torch.cuda.synchronize()
 print("%d calls of one iteration: %.3f ms per iteration" % (K, e0.elapsed_time(e1) / K))
