@@ -581,6 +581,8 @@ def main_per_rank(args, world):
         # record says so: a scaling run is never lost to the handshake.
         ok = 1
         try:
+            if os.environ.get("BENCH_FORCE_COMM_FAILURE") == "1":   # test hook: exercise the fall-back below
+                raise RuntimeError("forced by BENCH_FORCE_COMM_FAILURE")
             comm = bdist.Comm.from_torch_dist(ctx)
             bdist.allgather_stats(stats, world, comm)
         except Exception as e:   # noqa: BLE001 -- anything here is reported, not fatal
@@ -761,7 +763,7 @@ def main():
     # started by a launcher (torch.distributed.run sets WORLD_SIZE / RANK / LOCAL_RANK): one process per GPU.
     # started bare (`python bench.py --gpus N`): this process drives all N devices itself.
     world = int(os.environ.get("WORLD_SIZE", "0") or 0)
-    if world > 1:
+    if world > 1 or (world == 1 and os.environ.get("BENCH_PER_RANK") == "1"):   # (BENCH_PER_RANK: the launcher's code path at one rank, for tests)
         main_per_rank(args, world)
     else:
         main_local(args)

@@ -108,6 +108,25 @@ def test_bench_single_process_path_runs_the_collective_at_one_gpu():
     assert j["per_gpu_ms_per_step"][0] <= j["ms_per_step"] * 1.0001
 
 
+def test_bench_under_the_launcher_at_one_rank_and_its_fallback():
+    """the driver's N > 1 form (`python -m torch.distributed.run ... bench.py --gpus N`) at one rank (BENCH_PER_RANK=1 keeps it on the
+    one-process-per-GPU code path; bare, a world of one takes the launcher-less path): RCCL through torch for the handshake,
+    bhip_comm_init_rank + bhip_comm_allgather_stats for the data; and the fall-back -- should the product's communicator fail on any
+    rank the statistics are gathered by torch.distributed and the record says so: same numbers"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29573",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--chains", "4096", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-other-modes"]
+    out = []
+    for force in ("0", "1"):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, BENCH_FORCE_COMM_FAILURE=force, BENCH_PER_RANK="1"))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        out.append(json.loads(lines[0]))
+    assert "bhip_comm_init_rank" in out[0]["config"]["launch"]
+    assert "torch.distributed" in out[1]["config"]["launch"] and "forced by BENCH_FORCE_COMM_FAILURE" in out[1]["config"]["launch"]
+    assert out[0]["config"]["acceptance_rate"] == out[1]["config"]["acceptance_rate"] and out[0]["config"]["chains_total"] == 4096
+
+
 def test_bench_refuses_more_gpus_than_visible():
     """`python bench.py --gpus N` beyond the visible devices: rc != 0, a clear message, no JSON line (and no launcher message)"""
     n = torch.cuda.device_count() + 1
