@@ -606,12 +606,21 @@ def main_per_rank(args, world):
     stats.zero_()
     bdist.allgather_stats(stats, world, comm)
     elapsed, kern_ms, gathered = timed_region(w, args.steps, world, ctx, stats, comm)
+    # every rank's own device time over the timed steps (HIP events), so that a straggler shows in the record
+    mine = torch.tensor([float(sum(kern_ms))], dtype=torch.float64, device=ctx.device)
+    allms = torch.empty(world, dtype=torch.float64, device=ctx.device)
+    if world > 1:
+        dist.all_gather_into_tensor(allms, mine)
+    else:
+        allms.copy_(mine)
+    per_gpu_ms = [float(x) for x in allms.cpu()]
 
     out = None
     if rank == 0:
         how = ("bhip_comm_init_rank + bhip_comm_allgather_stats" if comm is not None else
                "statistics all-gather by torch.distributed" + (f" (product communicator: {comm_note})" if comm_note else " (gloo test double)"))
         out = base_record(args, world, w, elapsed, kern_ms, "one process per GPU (torch.distributed.run); " + how)
+        out["per_gpu_ms_per_step"] = [t / args.steps for t in per_gpu_ms]
         if w.chains is not None:
             add_chain_summary(out, gathered, w)
     if args.mode == "mcmc" and args.chains == 0:

@@ -116,3 +116,4 @@ def test_bench_two_ranks_equal_one_rank_with_twice_the_chains(tmp_path):
     assert j2["config"]["acceptance_rate"] == j1["config"]["acceptance_rate"]
     assert abs(j2["config"]["mean_ll"] - j1["config"]["mean_ll"]) <= 1e-12 * abs(j1["config"]["mean_ll"])
     assert j2["scaling"] == "weak" and j2["config"]["path_steps_per_step"] == 8192 * 1000
+    assert len(j2["per_gpu_ms_per_step"]) == 2 and all(0 < t <= j2["ms_per_step"] * 1.0001 for t in j2["per_gpu_ms_per_step"])   # every rank's device time

@@ -125,6 +125,7 @@ def test_bench_under_the_launcher_at_one_rank_and_its_fallback():
     assert "bhip_comm_init_rank" in out[0]["config"]["launch"]
     assert "torch.distributed" in out[1]["config"]["launch"] and "forced by BENCH_FORCE_COMM_FAILURE" in out[1]["config"]["launch"]
     assert out[0]["config"]["acceptance_rate"] == out[1]["config"]["acceptance_rate"] and out[0]["config"]["chains_total"] == 4096
+    assert len(out[0]["per_gpu_ms_per_step"]) == 1 and 0 < out[0]["per_gpu_ms_per_step"][0] <= out[0]["ms_per_step"] * 1.0001
 
 
 def test_bench_refuses_more_gpus_than_visible():
