@@ -117,12 +117,13 @@ def cpu_baseline(seconds_budget=20.0):
     return {"value": ratec, "unit": "path-steps/s", "cores": best_t, "kind": "port",
             "value_1thread": rate1, "host_cpus": os.cpu_count(), "affinity_cpus": ncpu, "cgroup_cpu_quota": quota,
             "probed_threads": {str(k): v for k, v in probed.items()},
-            "sample": f"{nchc} chains x {iters + 1} pCN iterations x {N_GRID - 1} steps of the bench workload "
-                      f"(OpenMP over chains, {best_t} threads = the fastest of the probed counts, {usable} usable hardware threads); "
-                      f"1-thread figure on {nch1} chains; "
-                      "C restatement of Bridge.jl's four-pass loop (no Julia on this box), not Bridge.jl itself"}
+            "sample": f"{nchc} chains x {iters + 1} pCN iterations x {N_GRID - 1} steps of the bench workload, OpenMP over chains, "
+                      f"{best_t} threads (fastest probed; {usable} usable); 1-thread figure on {nch1} chains; C restatement of "
+                      "Bridge.jl's four-pass loop, not Bridge.jl (no Julia here)"}
 
 
+NOISE_SPEC = ("bhip-philox-v3: Philox4x32-10, four normals per call = two Box-Muller pairs of 40 bits of radius + 24 bits of angle "
+              "(|z| <= 7.45; DESIGN 4); the reference's randn is a 52-bit ziggurat")
 PROFILE_TAG = "r3"   # profiles/<PROFILE_TAG>_<mode>_{trace,fetch,write}.txt, written by scripts/gpu_profile.sh this round
 
 
@@ -149,6 +150,51 @@ def profiled_traffic(mode, kernel_name):
             return None, msg
     return (2.0 * vals["fetch"] + vals["write"]) * 1024.0, (f"profiles/{PROFILE_TAG}_{mode}_fetch.txt (x2, gfx950 correction) + "
                                                            f"profiles/{PROFILE_TAG}_{mode}_write.txt")
+
+
+def live_traffic(mode, kernel_name, steps=6):
+    """HBM bytes per launch of the dominant kernel measured ON THIS BOX, now: two rocprofv3 runs of `bench.py --mode <mode>` (one
+    --pmc pass each: FETCH_SIZE and WRITE_SIZE cannot share a pass, MI355X_MICROARCH.md PMC slots; never combined with other trace
+    domains), read back from the rocpd databases.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide
+    coalesced read stream (same guide, HBM section), hence the factor 2.  Returns (bytes, source) or (None, reason)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="bhip_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "t", "--", sys.executable, os.path.abspath(__file__), "--mode", mode,
+                   "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-other-modes", "--no-live-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp) for f in fs if f.endswith(".db")]
+            if not dbs:
+                return None, f"rocprofv3 --pmc {counter}: no database (rc {r.returncode}): {r.stderr[-200:]}"
+            cur = sqlite3.connect(dbs[0]).cursor()
+            cols = [d[0] for d in cur.execute("select * from counters_collection limit 1").description]
+            namecol = "kernel_name" if "kernel_name" in cols else "name"
+            idcol = "dispatch_id" if "dispatch_id" in cols else None
+            rows = list(cur.execute(f"select {idcol or namecol}, value from counters_collection where {namecol} = ? and counter_name = ?", (kernel_name, counter)))
+            if not rows:
+                return None, f"rocprofv3 --pmc {counter}: no row for '{kernel_name}'"
+            if idcol:   # one value per dispatch = the sum over the counter's instances
+                per = {}
+                for did, v in rows:
+                    per[did] = per.get(did, 0.0) + v
+                vals[counter] = float(np.mean(list(per.values())))
+            else:
+                vals[counter] = float(np.mean([v for _, v in rows]))
+        except Exception as e:   # noqa: BLE001 -- the record is context, never a reason to fail the bench
+            return None, f"rocprofv3 --pmc {counter}: {type(e).__name__}: {e}"
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, ("measured on this box in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE (x2, gfx950 "
+                                                                       "correction) and --pmc WRITE_SIZE, separate passes of `bench.py --mode " + mode + "`")
 
 
 def profiled_valu(mode, kernel_name, paths):
@@ -269,6 +315,7 @@ class Workload:
         self.chains = None
         if is_chains:
             self.chains = bh.Chains(self.Po, np.array(x0), self.P, seed=4, path0=self.path0, store_X=True)
+            self.rho = rho
             self.step = lambda: self.chains.step(rho, 1)
             self.bytes_per_pathstep = 8 * d + 16 * mp    # write Xo (8d) + read W, write Wo (16 m')   SURVEY 8(d) mode M
         else:
@@ -305,6 +352,7 @@ class Workload:
         if tr is not None and self.P != MODES[self.mode][4]:
             tr, src = None, "profiled at the mode's default size only"
         r["traffic"], r["traffic_source"] = tr, src
+        r["traffic_box"] = "another box (committed rocprofv3 summaries under profiles/, looked up by kernel name)" if tr is not None else None
         r["valu"] = profiled_valu(self.mode, self.kernel, self.P) if (self.P == MODES[self.mode][4] and not self.fused) else None
         v = r["valu"]
         if v and r["bound"] == "hbm" and v["busy_frac"] > 0.6 and r["frac"] / v["busy_frac"] < 0.9:
@@ -338,6 +386,9 @@ def kernel_times(w, steps, warmup, min_ms=0.0):
     evs[steps].record()
     torch.cuda.synchronize()
     return [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
+
+
+SMOOTH_MOVED_BYTES = 64 + 24 + 48 + 192   # what the implementation moves per path-step (padded W lines, Xo store, Xo -> Xc commit copy, mcnext! state)
 
 
 def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
@@ -380,11 +431,18 @@ def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
     ms_mo = t(lambda: sm.step(wo, wn, 1), reps)
     del sm
     torch.cuda.empty_cache()
-    b_sh = 64 + 24 + 48 + 192      # W lines r+w (m' = 3 padded to 4: 32 + 32), Xo store, commit Xo -> Xc, mcnext! state r+w
+    # ALGORITHMIC bytes per path-step = what the reference's loop must move (smoothing.jl:160-213 swaps references on accept, it
+    # copies nothing): W read + Wo written 48 (m' = 3), Xo written 24, mcnext! reads X 24 and reads + writes its state
+    # (mean 3 + m2 9 doubles) 192 = 288.  The implementation MOVES more -- the lines pad m' = 3 to 4 (+16) and the accepted
+    # proposal is copied Xo -> Xc (+24 read; the write is the 24 counted above only if the commit replaced the store) -- reported
+    # beside it as `moved_bytes_per_path_step`; the fractions are computed on the algorithmic count.
+    b_sh = 48 + 24 + 24 + 192
+    b_moved = SMOOTH_MOVED_BYTES
     b_pc = b_sh + 120              # + the chain's compact guide row per step: Hd (9), V (3), linearisation point (3)
     return {"workload": f"Lorenz smoothing: {m} GuidedBridge(LinearAppr) segments x {M} steps, {n} chains, joint MH + pCN start + mcnext! per iteration",
             "path_steps_per_iteration": ps, "finite": ok,
             "iteration_shared_guides": {"ms": ms_sh, "path_steps_per_s": ps / ms_sh * 1e3, "algorithmic_bytes_per_path_step": b_sh,
+                                        "moved_bytes_per_path_step": b_moved,
                                         "hbm_frac": ps * b_sh / ms_sh / 1e6 / HBM_PEAK_GBS},
             "iteration_shared_guides_means_only": {"ms": ms_mo, "path_steps_per_s": ps / ms_mo * 1e3, "algorithmic_bytes_per_path_step": b_sh - 144,
                                                    "hbm_frac": ps * (b_sh - 144) / ms_mo / 1e6 / HBM_PEAK_GBS,
@@ -470,24 +528,35 @@ def timed_region_local(ws, steps, stats, group):
     round-robin (launches are asynchronous: one host thread keeps all devices busy), the per-device statistics reductions and
     the ONE grouped all-gather (bhip_comm_allgather_group), synchronize every device.  The wall clock around it is by
     construction the max over the devices.  Returns (elapsed s, per-launch ms of every device, gathered blocks,
-    per-device ms for the K steps, ms of the gather on device 0)."""
+    per-device ms for the K steps, ms of the gather on device 0, host microseconds per iteration inside the group step call)."""
     devs = [w.ctx.device for w in ws]
     streams = [torch.cuda.default_stream(d) for d in devs]
     n = len(ws)
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] for _ in range(n)]
     g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # chain ensembles: ONE C-ABI call per iteration steps every device (bhip_chains_step_group), one reduces every device's
+    # statistics (bhip_chains_stats_group); host_issue = host time inside those step calls, per iteration
+    grp = bdist.ChainsGroup([w.chains for w in ws]) if all(w.chains is not None for w in ws) else None
+    host_issue = 0.0
     for d in devs:
         torch.cuda.synchronize(d)
     t0 = time.perf_counter()
     for k in range(steps):
         for r in range(n):
             evs[r][k].record(streams[r])
-            ws[r].step()
+        if grp is not None:
+            ti = time.perf_counter()
+            grp.step(ws[0].rho, 1)
+            host_issue += time.perf_counter() - ti
+        else:
+            for r in range(n):
+                ws[r].step()
     for r in range(n):
         evs[r][steps].record(streams[r])
-        if ws[r].chains is not None:
-            ws[r].chains.stats(stats[r])
-        else:
+    if grp is not None:
+        grp.stats(stats)
+    else:
+        for r in range(n):
             with torch.cuda.device(devs[r]):
                 stats[r].zero_()
     g0.record(streams[0])
@@ -497,7 +566,8 @@ def timed_region_local(ws, steps, stats, group):
         torch.cuda.synchronize(d)
     elapsed = time.perf_counter() - t0
     kern = [[evs[r][k].elapsed_time(evs[r][k + 1]) for k in range(steps)] for r in range(n)]
-    return elapsed, kern, gathered[0], [evs[r][0].elapsed_time(evs[r][steps]) for r in range(n)], g0.elapsed_time(g1)
+    return (elapsed, kern, gathered[0], [evs[r][0].elapsed_time(evs[r][steps]) for r in range(n)], g0.elapsed_time(g1),
+            host_issue / steps * 1e6 if grp is not None else None)
 
 
 class _HostGather:
@@ -532,6 +602,7 @@ def base_record(args, world, w, elapsed, kern_ms, launch):
         "data": "synthetic",
         "config": {"workload": w.workload, "mode": args.mode, "paths_per_gpu": w.P, "grid_points": N_GRID,
                    "path_steps_per_step": w.P * steps_per_unit * world,
+                   "noise_spec": NOISE_SPEC,
                    "parallelism": f"chains sharded over {world} GPU(s) by contiguous global id, no data-path collective, one RCCL all-gather "
                                   "of the 64-byte statistics block inside libbridgehip.so",
                    "launch": launch},
@@ -676,12 +747,14 @@ def main_local(args):
             with torch.cuda.device(c.device):
                 stats[k].zero_()
         group.allgather(stats)
-    elapsed, kern, gathered, per_gpu_ms, gather_ms = timed_region_local(ws, args.steps, stats, group)
+    elapsed, kern, gathered, per_gpu_ms, gather_ms, issue_us = timed_region_local(ws, args.steps, stats, group)
     kern_ms = kern[0] if n == 1 else [float(np.mean([kern[r][k] for r in range(n)])) for k in range(args.steps)]
     out = base_record(args, n, w, elapsed, kern_ms,
                       "one process, one context per device; bhip_comm_init_all + bhip_comm_allgather_group" + (f" [{comm_note}]" if comm_note else ""))
     out["per_gpu_ms_per_step"] = [t / args.steps for t in per_gpu_ms]
     out["allgather_ms"] = gather_ms
+    if issue_us is not None:   # host time inside bhip_chains_step_group per iteration (all n devices' launches: one FFI crossing)
+        out["host_issue_us_per_step"] = issue_us
     if w.chains is not None:
         add_chain_summary(out, gathered, w)
     ctx = ctxs[0]
@@ -712,6 +785,15 @@ def main_local(args):
         out["other_modes"] = others
         out["smoothing"] = smoothing_record(ctx)
         out["box"] = box_calibration(ctx.device)
+        if not args.no_live_traffic:
+            # HBM bytes of the headline kernel from THIS box's counters (two rocprofv3 child runs, outside every timed region);
+            # the committed look-up stays as the fall-back and says which box it came from
+            tr, src = live_traffic("mcmc", out["roofline"]["kernel"])
+            if tr is not None:
+                out["roofline"].update({"traffic": tr, "traffic_source": src, "traffic_box": "this box, this run",
+                                        "traffic_over_algorithmic": tr / (out["roofline"]["algorithmic_bytes_per_path_step"] * out["roofline"]["path_steps_per_launch"])})
+            else:
+                out["roofline"]["traffic_live_failed"] = src
     elif n > 1 and default_run:
         # SURVEY 8(d) C4 quotes 32 768 chains per GPU: the same protocol at that shard size, next to the headline
         del w, ws
@@ -722,16 +804,32 @@ def main_local(args):
         for _ in range(args.warmup):
             for x in wcs:
                 x.step()
-        el_c, kern_c, _, pg_c, _ = timed_region_local(wcs, args.steps, stats, group)
+        el_c, kern_c, _, pg_c, _, issue_c = timed_region_local(wcs, args.steps, stats, group)
         tp = float(n) * wcs[0].P * steps_per_unit * args.steps
         out["survey_c4"] = {"chains_per_gpu": wcs[0].P, "value": tp / el_c, "unit": "path-steps/s", "ms_per_step": el_c / args.steps * 1e3,
                             "scaling": "weak", "per_gpu_ms_per_step": [t / args.steps for t in pg_c],
                             "roofline": wcs[0].roofline([float(np.mean([kern_c[r][k] for r in range(n)])) for k in range(args.steps)]),
-                            "note": "one host thread issues the launches of all devices: at 0.2 ms per launch and 8 devices the single-process "
-                                    "form is close to launch-bound; the launcher form (one process per GPU) is not"}
+                            "host_issue_us_per_step": issue_c,
+                            "note": "one host thread issues the launches of all devices through ONE bhip_chains_step_group call per iteration; "
+                                    "host_issue_us_per_step against ms_per_step says how far from launch-bound it is"}
         del wcs
     if n == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+    if "other_modes" in out:
+        # the whole record once more, compact and LAST on the line (a 2 000-character tail of it still holds every mode):
+        # mode -> [ms per launch, fraction of its roofline (8 TB/s; fp64 matrix peak for linpro32*), what binds it]
+        r = out["roofline"]
+        modes = {"mcmc": [round(r["kernel_avg_ms"], 4), round(r["frac"], 3), r["bound"]],
+                 "mcmc_sustained": [round(out["sustained"]["ms_per_step"], 4), round(out["sustained"]["hbm_frac"], 3), "hbm"]}
+        for o in out["other_modes"]:
+            ro = o["roofline"]
+            modes[o["mode"]] = [round(ro["kernel_avg_ms"], 4), round(ro["frac"], 3), ro["bound"]]
+        sm = out.get("smoothing") or {}
+        for key, short in (("iteration_shared_guides", "smooth_shared"), ("iteration_shared_guides_means_only", "smooth_means"),
+                           ("adapt_device", "smooth_adapt"), ("iteration_per_chain_guides", "smooth_perchain")):
+            if key in sm:
+                modes[short] = [round(sm[key]["ms"], 4), round(sm[key]["hbm_frac"], 3), "hbm"]
+        out["modes"] = modes
     emit_json(out)
     if group is not None:
         group.destroy()
@@ -767,6 +865,7 @@ def main():
     ap.add_argument("--mode", choices=sorted(MODES) + sorted(m + "_fused" for m in MODES if MODES[m][1] <= 3), default="mcmc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 child runs that measure the headline kernel's HBM bytes on this box")
     args = ap.parse_args()
     claim_stdout()
     # started by a launcher (torch.distributed.run sets WORLD_SIZE / RANK / LOCAL_RANK): one process per GPU.

@@ -59,6 +59,8 @@ SIGNATURES = {
     "bhip_chains_destroy": (None, [vp]),
     "bhip_chains_init": (C.c_int, [vp, dp, C.c_int]),
     "bhip_chains_step": (C.c_int, [vp, C.c_double, C.c_int, C.c_int]),
+    "bhip_chains_step_group": (C.c_int, [C.c_int, C.POINTER(vp), C.c_double, C.c_int, C.c_int]),
+    "bhip_chains_stats_group": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(vp)]),
     "bhip_chains_placement_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "bhip_chains_stats": (C.c_int, [vp, vp]),
     "bhip_chains_get": (C.c_int, [vp, dp, C.POINTER(C.c_int64)]),

@@ -101,6 +101,23 @@ bhip::launch_fn get_launch_wiener3(int, int, int, int);
 #define PC_FRESH_MAX_PATHS 98304
 #endif
 
+// one device allocation of a chain ensemble (hipMalloc, or reserved / created / mapped through the virtual-memory API)
+struct Arena {
+    void *base = nullptr;
+    size_t bytes = 0;
+    bool vmm = false;
+    size_t va_bytes = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::vector<size_t> hsizes;
+};
+struct PlaceSpec {
+    bool vmm = false;
+    size_t va_align = 0;   // alignment of the reserved virtual range (0: the runtime's)
+    size_t chunk = 0;      // physical memory created in pieces of this size (0: one piece)
+    size_t xo_gap = 0;     // extra bytes between the end of W and Xo (experiments)
+};
+static void arena_free(Arena &ar);
+
 struct bhip_ctx {
     int device = 0;
     bool host_only = false;   // device == -1: guide pre-computation only, every launch is refused
@@ -112,6 +129,7 @@ struct bhip_ctx {
     bool mid_valu = true;           // BHIP_OPT_MID_VALU: LinPro targets of dimension 4..8 one path per lane (0: zero padded on the MFMA tile kernel)
     bool fused = false;             // BHIP_OPT_FUSED_ARITHMETIC: the d <= 3 kernels built with a*b + c contracted (tolerance parity)
     bool tune_placement = true;     // BHIP_OPT_TUNE_PLACEMENT: large chain ensembles try a few allocations and keep the fastest (bhip_chains_init)
+    PlaceSpec place;                // how chain ensembles get their memory (chains_alloc_state)
     // lifetime: every proposal / chain ensemble / communicator holds a reference.  bhip_ctx_destroy with live children only
     // closes the context (garbage collectors -- Python at interpreter exit, Julia finalizers -- destroy handles in any order);
     // the last child releases it.  A closed context's stream is no longer synchronised (it was borrowed and may be gone).
@@ -174,7 +192,8 @@ struct bhip_chains {
     bool lines = false;     // d <= 3 (noise dimension <= 3): W in the line layout of bhip_chain_kernel.h, else 16-byte slots
     bool tile = false;      // d > 3 on the MFMA tile kernel (tile-line layout); LinPro targets of dimension 4..8 stay on the path-per-lane kernel (slots)
     int nch = 0;            // lines per chain and parity half = ceil(N / 16)
-    double *Wc = nullptr;   // W slots [N][mp][ld][2]  |  lines [2][nch][ld][16]
+    Arena arena;            // the allocation behind Wc / Xo
+    double *Wc = nullptr;   // W slots [N][mp][ld][2]  |  lines [nch][ld][2][16]
     double *Xo = nullptr;   // proposal paths [N][d][ld] (BHIP_CHAINS_STORE_X); lives behind Wc in the same allocation
     size_t wbytes = 0, xbytes = 0;
     // placement tuning (bhip_chains_init): allocations tried, ms per pCN iteration of the first and of the chosen one
@@ -911,9 +930,16 @@ static int finish_guide(bhip_proposal *po)
         HIPCHK(ctx, hipMemcpy(po->d_mpar, po->mh.dpar.data(), sizeof(double) * po->mh.dpar.size(), hipMemcpyHostToDevice));
     } else
     pack_rows(po->tt, po->mh, po->has_aux ? &po->aux : nullptr, po->g, rows, rs);
-    if (po->g.kind == BHIP_GUIDE_HV) {
-        // the kernels divide by Hd_i (d = 1) / det(Hd_i) (d = 2, 3) through the row's reciprocal (bhip_smallmat.h sm_div_by): the
-        // bits of `/` as long as the hardware division would not pre-scale its operands
+    if (po->g.kind == BHIP_GUIDE_HV && po->mid) {
+        // 4 <= d <= 8: the rows above hold inv(Hdiamond_i) (the (nu, H) form); what has to hold is that the inverse exists
+        for (int i = 0; i < N - 1; i++) {
+            const double c = std::fabs(det(po->g.Hd[i]));
+            if (!(c > 0.0 && std::isfinite(c)))
+                return fail(ctx, BHIP_EUNSUPPORTED, "GuidedBridge: Hdiamond[" + std::to_string(i) + "] is singular or not finite");
+        }
+    } else if (po->g.kind == BHIP_GUIDE_HV) {
+        // d <= 3 (the GUIDE_HV row layout): the kernels divide by Hd_i (d = 1) / det(Hd_i) (d = 2, 3) through the row's reciprocal
+        // (bhip_smallmat.h sm_div_by): the bits of `/` as long as the hardware division would not pre-scale its operands
         const int c_at = 3 + d * d + d + (d == 1 ? 0 : d == 2 ? 4 : 9);
         for (int i = 0; i < N - 1; i++) {
             const double c = std::fabs(rows[(size_t)i * rs + c_at]);
@@ -1053,6 +1079,24 @@ static int ensure_plain_rows(bhip_proposal *po)
     return finish_guide(po);
 }
 
+#ifdef PC_STAMP   /* measurement builds only: the waves' cycle stamps (bhip_pc_kernel.h), 12 words per wave */
+constexpr size_t PC_STAMP_WORDS = (size_t)12 << 16;
+static unsigned long long *pc_stamp_buffer()
+{
+    static unsigned long long *buf = nullptr;
+    if (!buf && hipMalloc((void **)&buf, PC_STAMP_WORDS * 8) == hipSuccess) (void)hipMemset(buf, 0, PC_STAMP_WORDS * 8);
+    return buf;
+}
+extern "C" int bhip_debug_stamps(unsigned long long *out, size_t words)
+{
+    unsigned long long *b = pc_stamp_buffer();
+    if (!b || !out) return BHIP_EINVAL;
+    if (hipDeviceSynchronize() != hipSuccess) return BHIP_EHIP;
+    if (hipMemcpy(out, b, std::min(words, PC_STAMP_WORDS) * 8, hipMemcpyDeviceToHost) != hipSuccess) return BHIP_EHIP;
+    (void)hipMemset(b, 0, PC_STAMP_WORDS * 8);
+    return BHIP_OK;
+}
+#endif
 static int fill_common(const bhip_proposal *po, KArgs &a, const double *x0, const double *x0_dev, long npaths, int skip)
 {
     bhip_ctx *ctx = po->ctx;
@@ -1075,6 +1119,9 @@ static int fill_common(const bhip_proposal *po, KArgs &a, const double *x0, cons
         a.vend[k] = po->vend[k];
         a.mu_aux[k] = aux_linpro ? po->aux.mu()[k] : 0.0;
     }
+#ifdef PC_STAMP
+    a.stamp = pc_stamp_buffer();
+#endif
     if (po->mid) a.mpar_dev = po->d_mpar;   // the parameter block of a LinPro<4..8> target stays in device memory
     else {
         if ((int)po->mh.dpar.size() > 40) return fail(ctx, BHIP_EINVAL, "model parameter block too large");
@@ -1362,15 +1409,91 @@ int bhip_gpupdate(int d, int m, const double *Hd, const double *V, const double 
 }
 
 /* ------------------------------------------------------------------ chains */
-// ONE allocation for the chain state W and the proposal paths Xo (Xo behind W, 2 MiB aligned)
-static hipError_t chains_alloc_state(const bhip_chains *ch, double **Wc, double **Xo)
+// Chain-state arenas.  ONE allocation holds the chain state W and the proposal paths Xo (Xo behind W, 2 MiB aligned).  Two ways
+// to get it: hipMalloc, or the virtual-memory API -- hipMemAddressReserve with a chosen alignment of the VIRTUAL range,
+// hipMemCreate of the physical memory in chunks of a chosen size, hipMemMap -- which is what lets the library say something
+// about where an ensemble lands (profiles/r4_placement_*.txt).
+static PlaceSpec place_spec_env()
+{
+    // BHIP_PLACE=vmm:<va_align MiB>:<chunk MiB>[:<xo gap KiB>]   (measurement hook; the product default is set in bhip_ctx)
+    PlaceSpec ps;
+    const char *e = getenv("BHIP_PLACE");
+    if (!e || strncmp(e, "vmm", 3) != 0) return ps;
+    ps.vmm = true;
+    unsigned long a = 0, c = 0, g = 0;
+    if (sscanf(e, "vmm:%lu:%lu:%lu", &a, &c, &g) >= 1) { ps.va_align = (size_t)a << 20; ps.chunk = (size_t)c << 20; ps.xo_gap = (size_t)g << 10; }
+    return ps;
+}
+static hipError_t arena_alloc(int device, size_t bytes, const PlaceSpec &ps, Arena &ar)
+{
+    ar = Arena();
+    if (!ps.vmm) {
+        const hipError_t e = hipMalloc(&ar.base, bytes);
+        if (e == hipSuccess) ar.bytes = bytes;
+        return e;
+    }
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+    if (e != hipSuccess) return e;
+    if (gran == 0) gran = (size_t)2 << 20;
+    const size_t piece = ps.chunk ? (ps.chunk + gran - 1) / gran * gran : 0;
+    const size_t unit = piece ? piece : gran;
+    const size_t total = (bytes + unit - 1) / unit * unit;
+    void *va = nullptr;
+    e = hipMemAddressReserve(&va, total, ps.va_align, nullptr, 0);
+    if (e != hipSuccess) return e;
+    ar.vmm = true; ar.base = va; ar.va_bytes = total; ar.bytes = bytes;
+    for (size_t off = 0; off < total && e == hipSuccess;) {
+        const size_t sz = piece ? piece : total;
+        hipMemGenericAllocationHandle_t h;
+        e = hipMemCreate(&h, sz, &prop, 0);
+        if (e != hipSuccess) break;
+        e = hipMemMap((char *)va + off, sz, 0, h, 0);
+        if (e != hipSuccess) { (void)hipMemRelease(h); break; }
+        ar.handles.push_back(h); ar.hsizes.push_back(sz);
+        off += sz;
+    }
+    if (e == hipSuccess) {
+        hipMemAccessDesc desc = {};
+        desc.location = prop.location;
+        desc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(va, total, &desc, 1);
+    }
+    if (e != hipSuccess) arena_free(ar);
+    return e;
+}
+static void arena_free(Arena &ar)
+{
+    if (!ar.base) return;
+    if (!ar.vmm) (void)hipFree(ar.base);
+    else {
+        size_t off = 0;
+        for (size_t k = 0; k < ar.handles.size(); k++) {
+            (void)hipMemUnmap((char *)ar.base + off, ar.hsizes[k]);
+            (void)hipMemRelease(ar.handles[k]);
+            off += ar.hsizes[k];
+        }
+        (void)hipMemAddressFree(ar.base, ar.va_bytes);
+    }
+    ar = Arena();
+}
+static hipError_t chains_alloc_state(const bhip_chains *ch, Arena &ar, double **Wc, double **Xo)
 {
     const size_t MB2 = (size_t)2 << 20;
-    const size_t wspan = (ch->wbytes + MB2 - 1) / MB2 * MB2;
+    PlaceSpec ps = ch->ctx->place;
+    const PlaceSpec pe = place_spec_env();
+    if (pe.vmm) ps = pe;
+    const size_t wspan = (ch->wbytes + MB2 - 1) / MB2 * MB2 + ps.xo_gap;
     const bool want_x = (ch->flags & BHIP_CHAINS_STORE_X) != 0;
     *Wc = nullptr; *Xo = nullptr;
-    const hipError_t e = hipMalloc((void **)Wc, want_x ? wspan + ch->xbytes : ch->wbytes);
-    if (e == hipSuccess && want_x) *Xo = (double *)((char *)*Wc + wspan);
+    const hipError_t e = arena_alloc(ch->ctx->device, want_x ? wspan + ch->xbytes : ch->wbytes, ps, ar);
+    if (e != hipSuccess) return e;
+    *Wc = (double *)ar.base;
+    if (want_x) *Xo = (double *)((char *)ar.base + wspan);
     return e;
 }
 
@@ -1403,7 +1526,7 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
                                        : sizeof(double) * 2 * N * po->mh.mp * ch->ld;
     const size_t xbytes = sizeof(double) * N * po->mh.d * ch->ld;
     ch->wbytes = wbytes; ch->xbytes = xbytes;
-    hipError_t e = chains_alloc_state(ch, &ch->Wc, &ch->Xo);
+    hipError_t e = chains_alloc_state(ch, ch->arena, &ch->Wc, &ch->Xo);
     if (e == hipSuccess) e = hipMalloc((void **)&ch->cur, ch->ld);
     if (e == hipSuccess) e = hipMalloc((void **)&ch->llcur, sizeof(double) * ch->ld);
     if (e == hipSuccess) e = hipMalloc((void **)&ch->acc, sizeof(unsigned int) * ch->ld);
@@ -1418,7 +1541,7 @@ void bhip_chains_destroy(bhip_chains *ch)
     if (!ch) return;
     bhip_ctx *ctx = ch->ctx;
     ctx_quiesce(ctx);
-    if (ch->Wc) (void)hipFree(ch->Wc);
+    arena_free(ch->arena);
     if (ch->cur && !ch->shares_state) (void)hipFree(ch->cur);
     if (ch->llcur && !ch->shares_state) (void)hipFree(ch->llcur);
     if (ch->acc && !ch->shares_state) (void)hipFree(ch->acc);
@@ -1518,9 +1641,9 @@ int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
     bhip_ctx *ctx = ch->ctx;
     const bool big = ch->wbytes + ch->xbytes >= ((size_t)1 << 30);
     if (rc || !ctx->tune_placement || !big || !ch->lines || !ch->Xo || ch->shares_state || ch->place_tries > 0) return rc;
-    struct Cand { double *Wc, *Xo; float ms; };
+    struct Cand { Arena ar; double *Wc, *Xo; float ms; };
     std::vector<Cand> cands;
-    Cand cur{ch->Wc, ch->Xo, 0.f};
+    Cand cur{ch->arena, ch->Wc, ch->Xo, 0.f};
     rc = chains_time_iterations(ch, skip, &cur.ms);
     if (rc) return rc;
     cands.push_back(cur);
@@ -1529,22 +1652,25 @@ int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
     while ((int)cands.size() < max_tries && best > 0.93f * worst) {   // the two populations lie ~10 % apart
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * (ch->wbytes + ch->xbytes)) break;
-        Cand c{nullptr, nullptr, 0.f};
-        if (chains_alloc_state(ch, &c.Wc, &c.Xo) != hipSuccess) { (void)hipGetLastError(); break; }
-        ch->Wc = c.Wc; ch->Xo = c.Xo;
-        rc = chains_init_impl(ch, x0, nullptr, 0, skip, 0u);
-        if (!rc) rc = chains_time_iterations(ch, skip, &c.ms);
+        Cand c{Arena(), nullptr, nullptr, 0.f};
+        if (chains_alloc_state(ch, c.ar, &c.Wc, &c.Xo) != hipSuccess) { (void)hipGetLastError(); break; }
+        ch->arena = c.ar; ch->Wc = c.Wc; ch->Xo = c.Xo;
+        const int rcc = chains_init_impl(ch, x0, nullptr, 0, skip, 0u);
+        const int rct = rcc ? rcc : chains_time_iterations(ch, skip, &c.ms);
+        if (rct) {   // a candidate that cannot be initialised or timed is dropped, not reported: the ensemble keeps what it has
+            (void)hipStreamSynchronize(ctx->stream);
+            arena_free(c.ar);
+            break;
+        }
         cands.push_back(c);
-        if (rc) break;
         worst = std::max(worst, c.ms); best = std::min(best, c.ms);
     }
     size_t ib = 0;
     for (size_t k = 1; k < cands.size(); k++) if (cands[k].ms > 0.f && cands[k].ms < cands[ib].ms) ib = k;
     (void)hipStreamSynchronize(ctx->stream);
-    for (size_t k = 0; k < cands.size(); k++) if (k != ib) (void)hipFree(cands[k].Wc);
-    ch->Wc = cands[ib].Wc; ch->Xo = cands[ib].Xo;
+    for (size_t k = 0; k < cands.size(); k++) if (k != ib) arena_free(cands[k].ar);
+    ch->arena = cands[ib].ar; ch->Wc = cands[ib].Wc; ch->Xo = cands[ib].Xo;
     ch->place_tries = (int)cands.size(); ch->place_ms_first = cands[0].ms; ch->place_ms_best = cands[ib].ms;
-    if (rc) return rc;
     return chains_init_impl(ch, x0, nullptr, 0, skip, 0u);   // the state of iteration 0, whatever the timing runs did to it
 }
 
@@ -1602,42 +1728,71 @@ static int chains_llikelihood_ppr(bhip_chains *ch, const double *X_dev, long ldX
     return launch_ppr(ch, NOISE_LLONLY, a);
 }
 
-int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip)
+// argument checks of bhip_chains_step / bhip_chains_step_group for one ensemble; resolves BHIP_SKIP_OF_INIT
+static int chains_step_check(bhip_chains *ch, double rho, int iters, int &skip)
 {
-    if (!ch) return BHIP_EINVAL;
     bhip_ctx *ctx = ch->ctx;
     if (!ch->inited) return fail(ctx, BHIP_ESTATE, "bhip_chains_step: call bhip_chains_init first");
     if (iters < 0) return fail(ctx, BHIP_EINVAL, "iters must be >= 0");
     if (!(rho >= -1.0 && rho <= 1.0)) return fail(ctx, BHIP_EINVAL, "rho must lie in [-1, 1] (sqrt(1 - rho^2) is the weight of the fresh noise)");
     if (skip == BHIP_SKIP_OF_INIT) skip = ch->skip0;   // llo and ll then always sum the same terms
+    if (skip < 0) return fail(ctx, BHIP_EINVAL, "skip must be >= 0");
+    // the line kernels read cur[] and the W lines of whole 64-chain groups: ld is padded to 64 and those arrays are sized by ld
+    if (ch->lines && (ch->ld % 64 != 0 || ch->ld < ch->n)) return fail(ctx, BHIP_ESTATE, "chain storage: leading dimension must be a multiple of 64 covering all chains");
+    return BHIP_OK;
+}
+// ONE pCN iteration of one ensemble, launched on its context's stream.  The proposal buffer Xo is overwritten by every
+// iteration, so within one call only the LAST iteration's store can ever be observed: the earlier ones (store_x = false) run
+// the instantiation without the store.
+static int chains_step_once(bhip_chains *ch, double rho, int skip, bool store_x)
+{
     const bhip_proposal *po = ch->po;
     if (ch->tile) {
-        if (skip < 0) return fail(ctx, BHIP_EINVAL, "skip must be >= 0");
-        for (int it = 0; it < iters; it++) {
-            ++ch->iter;
-            double *Xo = it == iters - 1 ? ch->Xo : nullptr;   // see below
-            int rct = launch_tile_path(po, ch->x0.data(), nullptr, 0, nullptr, 0, Xo, ch->ld, nullptr, skip, ch->n, 2, ch->seed, ch->iter, ch->path0, 1, ch, rho);
-            if (rct) return rct;
-        }
-        return BHIP_OK;
+        ++ch->iter;
+        return launch_tile_path(po, ch->x0.data(), nullptr, 0, nullptr, 0, store_x ? ch->Xo : nullptr, ch->ld, nullptr, skip, ch->n, 2, ch->seed, ch->iter, ch->path0, 1, ch, rho);
     }
     KArgs a;
-    int rc = fill_common(po, a, ch->x0.data(), nullptr, ch->n, skip);
+    int rc = fill_common(po, a, ch->x0.data(), nullptr, ch->n, skip);   // (makes the context's device current)
     if (rc) return rc;
-    a.Wc = ch->Wc; a.Xo = ch->Xo; a.ldC = ch->ld;
+    ++ch->iter;
+    a.Wc = ch->Wc; a.Xo = store_x ? ch->Xo : nullptr; a.ldC = ch->ld;
     a.cur = ch->cur; a.llcur = ch->llcur; a.acc = ch->acc;
     a.rho = rho; a.srho = std::sqrt(1 - rho * rho);
     a.k0 = (uint32_t)ch->seed; a.k1 = (uint32_t)(ch->seed >> 32); a.path0 = ch->path0;
-    // The proposal buffer Xo is overwritten by every iteration, so within one call only the LAST iteration's
-    // store can ever be observed: the earlier iterations run the instantiation without the store.
-    // the line kernels read cur[] and the W lines of whole 64-chain groups: ld is padded to 64 and those arrays are sized by ld
-    if (ch->lines && (ch->ld % 64 != 0 || ch->ld < ch->n)) return fail(ctx, BHIP_ESTATE, "chain storage: leading dimension must be a multiple of 64 covering all chains");
-    for (int it = 0; it < iters; it++) {
-        a.iter = ++ch->iter;
-        a.Xo = it == iters - 1 ? ch->Xo : nullptr;
-        rc = do_launch(po, ch->lines ? NOISE_PCN_LINES : NOISE_PCN, a);
+    a.iter = ch->iter;
+    return do_launch(po, ch->lines ? NOISE_PCN_LINES : NOISE_PCN, a);
+}
+
+int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip)
+{
+    if (!ch) return BHIP_EINVAL;
+    int rc = chains_step_check(ch, rho, iters, skip);
+    for (int it = 0; it < iters && !rc; it++) rc = chains_step_once(ch, rho, skip, it == iters - 1);
+    return rc;
+}
+
+// The same for n ensembles -- one per device of a node, each on its own context -- in ONE call: iteration by iteration the
+// launches go out round-robin, each on its context's stream (asynchronous: a single host thread, e.g. a Julia ccall host,
+// keeps every device busy and crosses the FFI once per call instead of once per device and iteration).  Results are those of
+// stepping every ensemble by itself (tests/test_gpu_group.py).
+int bhip_chains_step_group(int n, bhip_chains *const *chs, double rho, int iters, int skip)
+{
+    if (n < 1 || !chs) return BHIP_EINVAL;
+    constexpr int MAXG = 64;
+    if (n > MAXG) return BHIP_EINVAL;
+    int skips[MAXG];
+    for (int k = 0; k < n; k++) {
+        if (!chs[k]) return BHIP_EINVAL;
+        for (int j = 0; j < k; j++) if (chs[j] == chs[k]) return fail(chs[k]->ctx, BHIP_EINVAL, "bhip_chains_step_group: the same ensemble twice");
+        skips[k] = skip;
+        const int rc = chains_step_check(chs[k], rho, iters, skips[k]);
         if (rc) return rc;
     }
+    for (int it = 0; it < iters; it++)
+        for (int k = 0; k < n; k++) {
+            const int rc = chains_step_once(chs[k], rho, skips[k], it == iters - 1);
+            if (rc) return rc;
+        }
     return BHIP_OK;
 }
 
@@ -1652,6 +1807,18 @@ int bhip_chains_stats(bhip_chains *ch, double *stats_dev)
     HIPCHK(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_chain_stats_final, dim3(1), dim3(256), 0, ctx->stream, ch->statpart, nparts, ch->n, (double)ch->iter, stats_dev);
     HIPCHK(ctx, hipGetLastError());
+    return BHIP_OK;
+}
+
+// bhip_chains_stats of n ensembles (one per device), each reduction on its own context's stream, in one call
+int bhip_chains_stats_group(int n, bhip_chains *const *chs, double *const *stats_dev)
+{
+    if (n < 1 || !chs || !stats_dev) return BHIP_EINVAL;
+    for (int k = 0; k < n; k++) {
+        if (!chs[k] || !stats_dev[k]) return BHIP_EINVAL;
+        const int rc = bhip_chains_stats(chs[k], stats_dev[k]);
+        if (rc) return rc;
+    }
     return BHIP_OK;
 }
 
@@ -1810,8 +1977,9 @@ int bhip_chains_load(bhip_chains *ch, const void *host_buf)
     const char *in = static_cast<const char *>(host_buf);
     std::memcpy(&h, in, sizeof(h));
     if (h.magic != CHAIN_MAGIC) return fail(ctx, BHIP_EINVAL, "bhip_chains_load: not a chain state buffer");
-    if (h.rng_spec != RNG_SPEC_VERSION)   // 0: saved before the field existed (bhip-philox-v1 builds)
-        return fail(ctx, BHIP_EINVAL, "bhip_chains_load: the state was saved under another noise specification (bhip-philox-v" + std::to_string(h.rng_spec ? h.rng_spec : 1) +
+    if (h.rng_spec != RNG_SPEC_VERSION)   // 0: saved before the field existed (bhip-philox-v1 AND -v2 builds wrote 0 there)
+        return fail(ctx, BHIP_EINVAL, "bhip_chains_load: the state was saved under another noise specification (" +
+                                      (h.rng_spec ? "bhip-philox-v" + std::to_string(h.rng_spec) : std::string("bhip-philox-v1 or -v2: before the field existed")) +
                                       "); a resumed run would not reproduce the uninterrupted one");
     if (h.n != ch->n || h.N != (int64_t)N || h.mp != po->mh.mp || h.d != po->mh.d)
         return fail(ctx, BHIP_EINVAL, "bhip_chains_load: the state was saved for another ensemble shape (chains, grid, dimensions)");

@@ -90,6 +90,9 @@ struct KArgs {
     int lna;                      // the per-chain rows carry LinearNoiseAppr data (slope) instead of the linearisation point
     const double *vend_pc;        // [D][ldr]
     const unsigned char *uv_pc;   // [ldr]
+#ifdef PC_STAMP   /* measurement builds only (scripts/gpu_stamp_probe.py): per-wave cycle budget of the producer / consumer waves */
+    unsigned long long *stamp;
+#endif
 };
 
 typedef const __attribute__((address_space(4))) double *cptr_t;
@@ -272,7 +275,28 @@ struct LaneState {
     double ll;
     double wprev[MP], w2prev[MP];
     double zq[3];   // normals 1..3 of the current Philox call (four normals per call, bhip_rng.h)
+#ifdef PC_STAMP
+    unsigned long long tacc[6], tlast;
+#endif
 };
+
+#if defined(PC_STAMP) && PC_STAMP >= 2
+// s_memtime stamps INSIDE the step (level 2): every mark closes a phase -- waits for the wave's LDS / scalar loads, reads the
+// clock, adds the cycles since the previous mark to phase k.  Scheduling barriers on both sides keep the phases apart: this is a
+// budget of the raw, un-overlapped costs (the production schedule batches the LDS reads of eight steps), not a timing of it.
+template <class ST> BHIP_DEV void pc_mark(ST &st, int k)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    st.tacc[k] += t - st.tlast;
+    st.tlast = t;
+    __builtin_amdgcn_sched_barrier(0);
+}
+#define PSTAMP(k) do { if constexpr (NOISE == NOISE_EXT) pc_mark(st, k); } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
 
 // One Euler step of one path, branch-free (a single basic block so that the scheduler can interleave
 // the state-independent work -- Philox, Box-Muller, address arithmetic -- with the dependent chain).
@@ -297,6 +321,7 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int n
 #pragma unroll
     for (int q = 0; q < (STR ? 3 : RL::LEN); q++) rw[q] = row[q];
     const double t = rw[RL::T], dt = rw[RL::DT];
+    PSTAMP(0);   // phase 0: everything since the previous step's last mark + the row in registers (LDS / scalar-load latency)
 
     if constexpr (NOISE == NOISE_LLONLY) {
 #pragma unroll
@@ -372,6 +397,7 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int n
 #pragma unroll
         for (int k = 0; k < D; k++) st_stream(xout + ((size_t)i * D + k) * ldx + xl, st.y[k]);
     }
+    PSTAMP(1);   // phase 1: dw + the issue of the X stores (back-pressure shows here)
 
     double bT[D];
     model.b(t, st.y, bT);
@@ -453,6 +479,15 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int n
         for (int k = 0; k < D; k++)   // src/euler.jl:264; a structurally zero sigma row contributes an exact "+ 0.0"
             st.y[k] = M::noisy(k) ? st.y[k] + bT[k] * dt + s[k] : st.y[k] + bT[k] * dt;
     }
+    PSTAMP(2);   // phase 2: the step's arithmetic (issue; the last result is still in the pipeline)
+#if defined(PC_STAMP) && PC_STAMP >= 2
+    if constexpr (NOISE == NOISE_EXT) {   // phase 3: wait for the state itself (a dependent move), phase 4: an empty phase = the cost of a mark
+        asm volatile("v_mov_b64 %0, %0" : "+v"(st.y[0]));
+        asm volatile("s_nop 0" ::: "memory");
+    }
+#endif
+    PSTAMP(3);
+    PSTAMP(4);
 }
 
 // Minimum waves per SIMD the register allocator must allow.  The BASELINE workloads launch

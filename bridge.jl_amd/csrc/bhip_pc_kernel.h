@@ -47,6 +47,11 @@ enum { NOISE_FRESH_PC = 6, NOISE_PCN_LINES_PC = 7 };
 #ifndef PC_WPE
 #define PC_WPE 4            // minimum waves per SIMD the register allocation must allow (8 workgroups per CU by LDS)
 #endif
+#if defined(PC_STAMP) && PC_STAMP >= 2
+#define PC_CONS_UNROLL 1
+#else
+#define PC_CONS_UNROLL (RLDS ? PC_CONS_UNROLL_SMALL : 2)
+#endif
 constexpr int PC_TILE = 64 * LINE_ROW;                          // doubles per hand-over tile
 constexpr size_t PC_LDS = sizeof(double) * (RNG_TAB_DOUBLES + 2 * PC_TILE);   // 19 984 bytes: 8 workgroups per CU
 typedef const __attribute__((address_space(3))) double *ldsrow_t;
@@ -56,6 +61,26 @@ typedef const __attribute__((address_space(3))) double *ldsrow_t;
 // producer's line stores) to be acknowledged by the L2, once per chunk, which the waves of a small ensemble (one or two per
 // SIMD) cannot hide.  Nothing but LDS is handed over between the waves of a pair.
 __device__ __forceinline__ void pc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifdef PC_STAMP
+// level 1: two stamps per chunk and wave -- cycles working, cycles waiting at the hand-over barrier
+struct PcStamp {
+    unsigned long long t0, work = 0, bar = 0, tot0;
+    __device__ __forceinline__ static unsigned long long now() { __builtin_amdgcn_sched_barrier(0); const unsigned long long t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); return t; }
+    __device__ __forceinline__ void begin() { tot0 = t0 = now(); }
+    __device__ __forceinline__ void before_barrier() { const unsigned long long t = now(); work += t - t0; t0 = t; }
+    __device__ __forceinline__ void after_barrier() { const unsigned long long t = now(); bar += t - t0; t0 = t; }
+    __device__ __forceinline__ void write(unsigned long long *buf, int slot, int role, const unsigned long long *ph) const
+    {
+        if ((threadIdx.x & 63) != 0 || !buf) return;
+        unsigned long long *o = buf + (size_t)slot * 12;
+        o[0] = 1 + role; o[1] = now() - tot0; o[2] = work; o[3] = bar;
+        for (int k = 0; k < 6; k++) o[4 + k] = ph ? ph[k] : 0ull;
+    }
+};
+#define PC_ST(x) x
+#else
+#define PC_ST(x)
+#endif
 
 // KArgs::rdtp (device): rdtp[j] = sqrt(tt[j] - tt[j-1]) for 1 <= j <= N-1, rdtp[0] = 0, zero padded to a multiple of 16:
 // the Wiener increment INTO grid point j, so that a chunk reads 16/m' consecutive, aligned values and grid point 0
@@ -155,6 +180,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
             }
         };
         if constexpr (RLDS) fetch_rows(0);
+        PC_ST(PcStamp ps; ps.begin();)
 
         for (int k = 0; k <= nch; k++) {
             if (k < nch) {
@@ -246,8 +272,11 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
                     }
                 }
             }
+            PC_ST(ps.before_barrier();)
             pc_barrier();   // chunk k is complete; the consumer has finished chunk k-1 (the tile written next)
+            PC_ST(ps.after_barrier();)
         }
+        PC_ST(ps.write(a.stamp, blockIdx.x * (2 * NPAIR) + wave, 0, nullptr);)
         return;
     }
 
@@ -303,6 +332,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
         }
     };
     fetch_row(0, rcur);
+    PC_ST(PcStamp ps; ps.begin(); for (int q = 0; q < 6; q++) st.tacc[q] = 0ull; st.tlast = ps.t0;)
     for (int k = 0; k <= nch; k++) {
         if (k > 0) {
             const int kc = k - 1;
@@ -311,7 +341,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
             const int j0 = kc * SPC;
             if (kc > 0 && j0 + SPC <= N) {
                 // interior chunk: SPC steps  i = j - 1
-#pragma unroll (RLDS ? PC_CONS_UNROLL_SMALL : 2)
+#pragma unroll PC_CONS_UNROLL
                 for (int s = 0; s < SPC; s++) {
                     double wn[MP];
 #pragma unroll
@@ -340,8 +370,11 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
                 }
             }
         }
+        PC_ST(ps.before_barrier();)
         pc_barrier();
+        PC_ST(ps.after_barrier(); st.tlast = ps.t0;)
     }
+    PC_ST(ps.write(a.stamp, blockIdx.x * (2 * NPAIR) + wave, 1, st.tacc);)
 
     if constexpr (PPR) {
         if (a.uv_pc[p]) {

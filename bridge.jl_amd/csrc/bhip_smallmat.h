@@ -69,8 +69,12 @@ BHIP_DEV void sm_inv(const double *a, double *R)   // StaticArrays inv.jl
 // path.  The correctly rounded fp64 division the compiler emits is: reciprocal seed, two Newton steps (divisor only), then
 // q0 = a*y, rem = fma(-c, q0, a), q = fma(rem, y, q0).  The divisor-only part is done once per row -- on the host for shared
 // rows (1.0/c, the correctly rounded reciprocal the Newton steps converge to), here for per-chain rows -- and the step keeps
-// the three operations that depend on the path: the same bits as `a / c` (what the oracle computes) for 2^-200 < |c| < 2^200,
-// checked on the host for shared rows (UniformDivisor in bhip_models.h is the same construction for model constants).
+// the three operations that depend on the path: the same bits as `a / c` (what the oracle computes) for 2^-200 < |c| < 2^200
+// (checked on the host for shared rows; UniformDivisor in bhip_models.h is the same construction for model constants) AND a
+// numerator whose quotient and remainder stay normal: 2^-700 < |a| < 2^700 is ample (q0 = a*y then lies within 2^+-900 and the
+// remainder, ~2^-53 |a|, above 2^-753).  Outside that numerator range -- a path that has left every physical scale -- the
+// hardware's pre-scaled division and these three operations may differ in the last bit or in how they overflow; the parity
+// contract is stated for states inside it (the path kernels never produce such numerators from finite, moderate inputs).
 BHIP_DEV double sm_recip(double c)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

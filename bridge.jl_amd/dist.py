@@ -137,6 +137,37 @@ class CommGroup:
             pass
 
 
+class ChainsGroup:
+    """The chain ensembles of ONE process driving several devices (one `Chains` per device): `step` is ONE C-ABI call that
+    issues every device's launches round-robin (bhip_chains_step_group), `stats` one call for all the per-device reductions
+    (bhip_chains_stats_group).  A single-threaded ccall host then pays one FFI crossing per call, not one per device and iteration."""
+
+    def __init__(self, chains):
+        import ctypes as C
+        self.chains = list(chains)
+        self.n = len(self.chains)
+        self._hs = (C.c_void_p * self.n)(*[c.h.value if hasattr(c.h, "value") else c.h for c in self.chains])
+        self.lib = self.chains[0].ctx.lib
+
+    def step(self, rho, iters=1, skip=-1):
+        rc = self.lib.bhip_chains_step_group(self.n, self._hs, float(rho), int(iters), int(skip))
+        if rc:
+            for c in self.chains:   # the failing ensemble's context holds the message
+                msg = c.ctx.lib.bhip_last_error(c.ctx.h)
+                if msg:
+                    raise RuntimeError(f"bhip_chains_step_group: rc {rc}: {msg.decode()}")
+            raise RuntimeError(f"bhip_chains_step_group: rc {rc}")
+        for c in self.chains:
+            c.iterations += iters
+
+    def stats(self, outs):
+        """outs[k]: float64 tensor [STATS_LEN] on the device of chains[k]"""
+        import ctypes as C
+        ps = (C.c_void_p * self.n)(*[o.data_ptr() for o in outs])
+        self.chains[0].ctx.check(self.lib.bhip_chains_stats_group(self.n, self._hs, ps))
+        return outs
+
+
 def allgather_stats(stats, world=None, comm=None):
     """ONE all-gather of the per-rank statistics block -> tensor [world, STATS_LEN] on every rank.
     comm: a Comm (the product's RCCL communicator); without it the torch.distributed group is used (gloo in the CPU tests)"""

@@ -285,11 +285,18 @@ int bhip_chains_placement_info(const bhip_chains *ch, int *tries, float *ms_firs
  * skip to the initial ll only -- with sk = 0 there; any other combination is the caller's explicit choice). */
 #define BHIP_SKIP_OF_INIT (-1)
 int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip);
+/* The loop of partialbridge_fitzhugh.jl:143-176 for n ensembles -- one per device of a node, each created on its own context --
+ * in ONE call: iteration by iteration the n launches go out round-robin, each on its context's stream (asynchronous), so a
+ * single host thread (a Julia `ccall` host) keeps every device busy with one FFI crossing per call instead of one per device
+ * and iteration.  Same results as bhip_chains_step on every ensemble by itself.  n <= 64, no ensemble twice. */
+int bhip_chains_step_group(int n, bhip_chains *const *chs, double rho, int iters, int skip);
 /* device-side reduction of the ensemble statistics into stats_dev[8] =
  *   {nchains, iterations done, sum acc, sum ll, sum ll^2, min ll, max ll, sum acc^2}
  * (the block that is all-gathered over RCCL in the multi-GPU run) */
 #define BHIP_STATS_LEN 8
 int bhip_chains_stats(bhip_chains *ch, double *stats_dev);
+/* bhip_chains_stats for the n ensembles of bhip_chains_step_group (stats_dev[k] on the device of chs[k]), one call */
+int bhip_chains_stats_group(int n, bhip_chains *const *chs, double *const *stats_dev);
 /* per-chain outputs (host pointers, any may be NULL): current ll, acceptance counts */
 int bhip_chains_get(bhip_chains *ch, double *ll, int64_t *acc);
 /* current state of chains p0..p0+np as AoS host arrays: X [np][N][d], W [np][N][mp] */
