@@ -97,6 +97,7 @@ SIGNATURES = {
     "bhip_comm_destroy": (None, [vp]),
     "bhip_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "bhip_normals_host": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, dp]),
+    "bhip_normals_host_spec": (None, [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, dp]),
 }
 
 AUX_FN = C.CFUNCTYPE(None, C.c_double, dp, dp, dp, vp)

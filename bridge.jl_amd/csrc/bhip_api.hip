@@ -130,6 +130,8 @@ struct bhip_ctx {
     bool fused = false;             // BHIP_OPT_FUSED_ARITHMETIC: the d <= 3 kernels built with a*b + c contracted (tolerance parity)
     bool tune_placement = true;     // BHIP_OPT_TUNE_PLACEMENT: large chain ensembles try a few allocations and keep the fastest (bhip_chains_init)
     PlaceSpec place;                // how chain ensembles get their memory (chains_alloc_state)
+    int xcd_map = 0;                // workgroup -> chain-group mapping of the d <= 3 kernels (bhip_path_kernel.h xcd_block)
+    int noise_spec = 3;             // BHIP_OPT_NOISE_SPEC: 3 = bhip-philox-v3 (default), 2 = bhip-philox-v2, the full-resolution stream (bhip_rng.h)
     // lifetime: every proposal / chain ensemble / communicator holds a reference.  bhip_ctx_destroy with live children only
     // closes the context (garbage collectors -- Python at interpreter exit, Julia finalizers -- destroy handles in any order);
     // the last child releases it.  A closed context's stream is no longer synchronised (it was borrowed and may be gone).
@@ -209,6 +211,7 @@ struct bhip_chains {
     const double *prows = nullptr, *vend_pc = nullptr;
     const unsigned char *uv_pc = nullptr;
     int lna = 0;                  // the per-chain rows carry LinearNoiseAppr slopes instead of linearisation points
+    int noise_spec = 3;           // the noise specification the ensemble was created under (the context's BHIP_OPT_NOISE_SPEC then); fixed for its life
 };
 
 static int fail(bhip_ctx *ctx, int code, const std::string &msg)
@@ -365,6 +368,11 @@ int bhip_ctx_set_option(bhip_ctx *ctx, int option, int value)
     if (option == BHIP_OPT_TUNE_PLACEMENT) { ctx->tune_placement = value != 0; return BHIP_OK; }
     if (option == BHIP_OPT_MID_VALU) { ctx->mid_valu = value != 0; return BHIP_OK; }
     if (option == BHIP_OPT_FUSED_ARITHMETIC) { ctx->fused = value != 0; return BHIP_OK; }
+    if (option == BHIP_OPT_NOISE_SPEC) {
+        if (value != 2 && value != 3) return fail(ctx, BHIP_EINVAL, "BHIP_OPT_NOISE_SPEC: 3 (bhip-philox-v3, the default) or 2 (bhip-philox-v2, full resolution)");
+        ctx->noise_spec = value;
+        return BHIP_OK;
+    }
     return fail(ctx, BHIP_EINVAL, "bhip_ctx_set_option: unknown option");
 }
 
@@ -843,6 +851,7 @@ static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const d
     a.Win = W_in; a.ldWin = ldWin; a.Wout = W_out; a.ldWout = ldWout; a.X = X; a.ldX = ldX; a.ll = ll;
     a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.iter = iter; a.path0 = path0;
     a.wstride = wstride;
+    a.noise_spec = ctx->noise_spec;
     if (noise == 2) {   // pCN chain step
         a.Wc = ch->Wc; a.ldC = ch->ld; a.cur = ch->cur; a.llcur = ch->llcur; a.acc = ch->acc;
         a.rho = rho; a.srho = w_new >= 0.0 ? w_new : std::sqrt(1 - rho * rho);
@@ -1112,6 +1121,8 @@ static int fill_common(const bhip_proposal *po, KArgs &a, const double *x0, cons
     a.rdtp = po->d_rdtp;
     a.P = npaths;
     a.wstride = 1;
+    a.noise_spec = ctx->noise_spec;
+    { const char *e = getenv("BHIP_XCD_MAP"); a.xcd_map = e ? atoi(e) : ctx->xcd_map; }   // (the environment: measurement hook)
     const bool aux_linpro = po->has_aux && po->aux.linpro_form();   // b~ = B(x - mu~); else b~ = B x + beta~ (mu~ = 0)
     a.use_vend = po->use_vend;
     for (int k = 0; k < d; k++) {
@@ -1250,12 +1261,12 @@ int bhip_wiener_sample(bhip_ctx *ctx, const double *tt, int N, int mp, double *W
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // rdt is a stack-lifetime host buffer
     const dim3 grid((unsigned)((npaths + 255) / 256)), block(256);
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    if (mp == 1) hipLaunchKernelGGL(k_wiener<1>, grid, block, 0, ctx->stream, ctx->scratch, N, W_dev, ld, npaths, k0, k1, iter, path0);
-    else if (mp == 2) hipLaunchKernelGGL(k_wiener<2>, grid, block, 0, ctx->stream, ctx->scratch, N, W_dev, ld, npaths, k0, k1, iter, path0);
-    else if (mp == 3) hipLaunchKernelGGL(k_wiener<3>, grid, block, 0, ctx->stream, ctx->scratch, N, W_dev, ld, npaths, k0, k1, iter, path0);
-    else if (mp == 4) hipLaunchKernelGGL(k_wiener<4>, grid, block, 0, ctx->stream, ctx->scratch, N, W_dev, ld, npaths, k0, k1, iter, path0);
+    if (mp == 1) hipLaunchKernelGGL(k_wiener<1>, grid, block, 0, ctx->stream, ctx->scratch, N, W_dev, ld, npaths, k0, k1, iter, path0, ctx->noise_spec);
+    else if (mp == 2) hipLaunchKernelGGL(k_wiener<2>, grid, block, 0, ctx->stream, ctx->scratch, N, W_dev, ld, npaths, k0, k1, iter, path0, ctx->noise_spec);
+    else if (mp == 3) hipLaunchKernelGGL(k_wiener<3>, grid, block, 0, ctx->stream, ctx->scratch, N, W_dev, ld, npaths, k0, k1, iter, path0, ctx->noise_spec);
+    else if (mp == 4) hipLaunchKernelGGL(k_wiener<4>, grid, block, 0, ctx->stream, ctx->scratch, N, W_dev, ld, npaths, k0, k1, iter, path0, ctx->noise_spec);
     else
-        hipLaunchKernelGGL(k_wiener_big, grid, block, 0, ctx->stream, ctx->scratch, N, mp, W_dev, ld, npaths, (uint32_t)seed, (uint32_t)(seed >> 32), iter, path0);
+        hipLaunchKernelGGL(k_wiener_big, grid, block, 0, ctx->stream, ctx->scratch, N, mp, W_dev, ld, npaths, (uint32_t)seed, (uint32_t)(seed >> 32), iter, path0, ctx->noise_spec);
     HIPCHK(ctx, hipGetLastError());
     return BHIP_OK;
 }
@@ -1511,7 +1522,7 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     if (!ch) return fail(ctx, BHIP_EHIP, "out of host memory");
     ch->ctx = ctx; ch->po = po; ch->n = nchains; ch->ld = (nchains + 63) / 64 * 64;
     ctx_retain(ctx);
-    ch->path0 = path0; ch->seed = seed; ch->flags = flags;
+    ch->path0 = path0; ch->seed = seed; ch->flags = flags; ch->noise_spec = ctx->noise_spec;
     const size_t N = po->tt.size();
     ch->tile = po->mh.d > 3 && !(po->mid && ctx->mid_valu);
     ch->lines = po->mh.d <= 3 && po->mh.mp <= 3;
@@ -1558,6 +1569,7 @@ static int chains_init_impl(bhip_chains *ch, const double *x0, const double *x0_
     const bhip_proposal *po = ch->po;
     NEED_DEVICE(ctx);
     if (skip < 0) return fail(ctx, BHIP_EINVAL, "skip must be >= 0");
+    if (ch->noise_spec != ctx->noise_spec) return fail(ctx, BHIP_ESTATE, "the context's noise specification changed after the ensemble was created");
     ch->x0.assign(x0, x0 + po->mh.d);
     if (!ch->shares_state) {
         HIPCHK(ctx, hipMemsetAsync(ch->cur, 0, ch->ld, ctx->stream));
@@ -1733,6 +1745,7 @@ static int chains_step_check(bhip_chains *ch, double rho, int iters, int &skip)
 {
     bhip_ctx *ctx = ch->ctx;
     if (!ch->inited) return fail(ctx, BHIP_ESTATE, "bhip_chains_step: call bhip_chains_init first");
+    if (ch->noise_spec != ctx->noise_spec) return fail(ctx, BHIP_ESTATE, "the context's noise specification changed after the ensemble was created");
     if (iters < 0) return fail(ctx, BHIP_EINVAL, "iters must be >= 0");
     if (!(rho >= -1.0 && rho <= 1.0)) return fail(ctx, BHIP_EINVAL, "rho must lie in [-1, 1] (sqrt(1 - rho^2) is the weight of the fresh noise)");
     if (skip == BHIP_SKIP_OF_INIT) skip = ch->skip0;   // llo and ll then always sum the same terms
@@ -1927,7 +1940,6 @@ struct ChainStateHeader {
     uint32_t path0, iter;
     int32_t skip0, rng_spec;   // rng_spec: version of the noise specification the chains were driven with (bhip-philox-v<rng_spec>)
 };
-constexpr int32_t RNG_SPEC_VERSION = 3;   // bhip_rng.h: bhip-philox-v3
 constexpr uint64_t CHAIN_MAGIC = 0x314E484350494842ULL;   // "BHIPCHN1" little endian
 }  // namespace
 
@@ -1948,7 +1960,7 @@ int bhip_chains_save(bhip_chains *ch, void *host_buf)
     const size_t N = ch->po->tt.size(), nW = N * ch->po->mh.mp * ch->n;
     ChainStateHeader h{};
     h.magic = CHAIN_MAGIC; h.n = ch->n; h.N = (int64_t)N; h.mp = ch->po->mh.mp; h.d = ch->po->mh.d;
-    h.seed = ch->seed; h.path0 = ch->path0; h.iter = ch->iter; h.skip0 = ch->skip0; h.rng_spec = RNG_SPEC_VERSION;
+    h.seed = ch->seed; h.path0 = ch->path0; h.iter = ch->iter; h.skip0 = ch->skip0; h.rng_spec = ch->noise_spec;
     char *out = static_cast<char *>(host_buf);
     std::memcpy(out, &h, sizeof(h));
     double *tmp = nullptr;
@@ -1977,7 +1989,7 @@ int bhip_chains_load(bhip_chains *ch, const void *host_buf)
     const char *in = static_cast<const char *>(host_buf);
     std::memcpy(&h, in, sizeof(h));
     if (h.magic != CHAIN_MAGIC) return fail(ctx, BHIP_EINVAL, "bhip_chains_load: not a chain state buffer");
-    if (h.rng_spec != RNG_SPEC_VERSION)   // 0: saved before the field existed (bhip-philox-v1 AND -v2 builds wrote 0 there)
+    if (h.rng_spec != ch->noise_spec)   // 0: saved before the field existed (bhip-philox-v1 and the round-2 -v2 builds wrote 0 there)
         return fail(ctx, BHIP_EINVAL, "bhip_chains_load: the state was saved under another noise specification (" +
                                       (h.rng_spec ? "bhip-philox-v" + std::to_string(h.rng_spec) : std::string("bhip-philox-v1 or -v2: before the field existed")) +
                                       "); a resumed run would not reproduce the uninterrupted one");
@@ -2214,6 +2226,16 @@ void bhip_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
 {
     const u32x4 r = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
     out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+void bhip_normals_host_spec(int spec, uint64_t seed, uint32_t path, uint32_t iter, int n0, int n, double *z)
+{
+    double z0 = 0, z1 = 0; long have = -1;
+    for (int j = 0; j < n; j++) {
+        const int idx = n0 + j;
+        if ((idx >> 1) != have) { normal_pair_spec(spec, TabConst(), (uint32_t)seed, (uint32_t)(seed >> 32), path, iter, (uint32_t)(idx >> 1), z0, z1); have = idx >> 1; }
+        z[j] = (idx & 1) ? z1 : z0;
+    }
 }
 
 void bhip_normals_host(uint64_t seed, uint32_t path, uint32_t iter, int n0, int n, double *z)

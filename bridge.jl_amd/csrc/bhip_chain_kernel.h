@@ -93,70 +93,77 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
     };
     if (BHIP_LINES_STAGE) fetch(0);
 
-    // one Euler step i (grid point j = i + 1 = SPC*k + s): the chain's current W[j] comes from the tile, the proposal goes back
-    auto step = [&](int i, int s, int i4 = -1 /* i & 3 where static */) {
-        double wc[MP];
+    // the chunk loop, generic in the table accessor whose TYPE carries the noise specification (bhip_rng.h): the kernel holds it
+    // twice and one wave-uniform branch per launch picks the copy
+    auto run_chunks = [&](const auto &tb) {
+        using TB = typename bhip_unref<decltype(tb)>::type;
+        // one Euler step i (grid point j = i + 1 = SPC*k + s): the chain's current W[j] comes from the tile, the proposal goes back
+        auto step = [&](int i, int s, int i4 = -1 /* i & 3 where static */) {
+            double wc[MP];
 #pragma unroll
-        for (int cc = 0; cc < MP; cc++) wc[cc] = mine[s * MPP + cc];
-        if constexpr (PPR) {
-            constexpr int NPP = pp_row_len<D>();
-            double cr[NPP];
-            const double *src = a.prows + (size_t)i * NPP * a.ldr + p;
+            for (int cc = 0; cc < MP; cc++) wc[cc] = mine[s * MPP + cc];
+            if constexpr (PPR) {
+                constexpr int NPP = pp_row_len<D>();
+                double cr[NPP];
+                const double *src = a.prows + (size_t)i * NPP * a.ldr + p;
 #pragma unroll
-            for (int q = 0; q < NPP; q++) cr[q] = src[(size_t)q * a.ldr];
-            ExpRow<RL::LEN - 3> x;
-            x.sh = rows + (size_t)i * RL::RS;
-            expand_pp_row<M>(model, a.lna, cr, x.e);
-            path_step<M, GK, MO, NOISE_PCN, FL, ExpRow<RL::LEN - 3>>(model, a, x, i, nll, path, wc, nullptr, 0, xout, ldx, st, TabConst(), 0u, i4);
-        } else
-            path_step<M, GK, MO, NOISE_PCN, FL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wc, nullptr, 0, xout, ldx, st, TabConst(), 0u, i4);
+                for (int q = 0; q < NPP; q++) cr[q] = src[(size_t)q * a.ldr];
+                ExpRow<RL::LEN - 3> x;
+                x.sh = rows + (size_t)i * RL::RS;
+                expand_pp_row<M>(model, a.lna, cr, x.e);
+                path_step<M, GK, MO, NOISE_PCN, FL, ExpRow<RL::LEN - 3>, TB>(model, a, x, i, nll, path, wc, nullptr, 0, xout, ldx, st, tb, 0u, i4);
+            } else
+                path_step<M, GK, MO, NOISE_PCN, FL, cptr_t, TB>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wc, nullptr, 0, xout, ldx, st, tb, 0u, i4);
 #pragma unroll
-        for (int cc = 0; cc < MP; cc++) mine[s * MPP + cc] = st.wprev[cc];
-    };
+            for (int cc = 0; cc < MP; cc++) mine[s * MPP + cc] = st.wprev[cc];
+        };
 
-    for (int k = 0; k < nch; k++) {
-        if (!BHIP_LINES_STAGE) fetch(k);
+        for (int k = 0; k < nch; k++) {
+            if (!BHIP_LINES_STAGE) fetch(k);
 #pragma unroll
-        for (int q = 0; q < 8; q++) {   // staged lines -> tile
-            double *d = tile + (8 * q + sub) * LINE_ROW + part;
-            d[0] = stage[q].x; d[1] = stage[q].y;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (BHIP_LINES_STAGE && k + 1 < nch) fetch(k + 1);   // in flight while this chunk is computed
-        const int j0 = k * SPC;
-        if (k > 0 && j0 + SPC <= N) {
-            // interior chunk: SPC valid steps, four at a time (j0 is a multiple of 4) so that the position of a step's normals
-            // inside their Philox call is static
+            for (int q = 0; q < 8; q++) {   // staged lines -> tile
+                double *d = tile + (8 * q + sub) * LINE_ROW + part;
+                d[0] = stage[q].x; d[1] = stage[q].y;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (BHIP_LINES_STAGE && k + 1 < nch) fetch(k + 1);   // in flight while this chunk is computed
+            const int j0 = k * SPC;
+            if (k > 0 && j0 + SPC <= N) {
+                // interior chunk: SPC valid steps, four at a time (j0 is a multiple of 4) so that the position of a step's normals
+                // inside their Philox call is static
 #ifndef BHIP_LINES_UNROLL
 #define BHIP_LINES_UNROLL 1
 #endif
 #pragma unroll BHIP_LINES_UNROLL
-            for (int s = 0; s < SPC; s += 4) {
-                step(j0 + s - 1, s, 3);
-                step(j0 + s, s + 1, 0);
-                step(j0 + s + 1, s + 2, 1);
-                step(j0 + s + 2, s + 3, 2);
-            }
-        } else {
-            // first chunk (grid point 0 is W[0] = Wo[0] = 0, no step) and the ragged last chunk
+                for (int s = 0; s < SPC; s += 4) {
+                    step(j0 + s - 1, s, 3);
+                    step(j0 + s, s + 1, 0);
+                    step(j0 + s + 1, s + 2, 1);
+                    step(j0 + s + 2, s + 3, 2);
+                }
+            } else {
+                // first chunk (grid point 0 is W[0] = Wo[0] = 0, no step) and the ragged last chunk
 #pragma unroll 1
-            for (int s = 0; s < SPC; s += 2) {
-                const int i0 = j0 + s - 1;
-                if (i0 < 0) {
+                for (int s = 0; s < SPC; s += 2) {
+                    const int i0 = j0 + s - 1;
+                    if (i0 < 0) {
 #pragma unroll
-                    for (int cc = 0; cc < MP; cc++) mine[cc] = 0.0;
-                } else if (i0 < nsteps) step(i0, s);
-                if (i0 + 1 < nsteps) step(i0 + 1, s + 1);
+                        for (int cc = 0; cc < MP; cc++) mine[cc] = 0.0;
+                    } else if (i0 < nsteps) step(i0, s);
+                    if (i0 + 1 < nsteps) step(i0 + 1, s + 1);
+                }
             }
-        }
-        __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int q = 0; q < 8; q++) {   // tile -> the lines of the other halves
-            const double *d = tile + (8 * q + sub) * LINE_ROW + part;
-            st_stream((d2v *)(a.Wc + line_index(par[q] ^ 1, k, c0 + 8 * q + sub, nch, a.ldC) + part), d2v{d[0], d[1]});
+            for (int q = 0; q < 8; q++) {   // tile -> the lines of the other halves
+                const double *d = tile + (8 * q + sub) * LINE_ROW + part;
+                st_stream((d2v *)(a.Wc + line_index(par[q] ^ 1, k, c0 + 8 * q + sub, nch, a.ldC) + part), d2v{d[0], d[1]});
+            }
+            __builtin_amdgcn_wave_barrier();   // the tile is overwritten by the next chunk only after these reads
         }
-        __builtin_amdgcn_wave_barrier();   // the tile is overwritten by the next chunk only after these reads
-    }
+    };
+    if (a.noise_spec == 2) run_chunks(FullRes<TabConst>(TabConst()));
+    else run_chunks(TabConst());
 
     if constexpr (PPR) {
         if (a.uv_pc[p]) {

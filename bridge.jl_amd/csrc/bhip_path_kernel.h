@@ -27,6 +27,10 @@ namespace bhip {
 enum { NOISE_EXT = 0, NOISE_FRESH = 1, NOISE_PCN = 2, NOISE_LLONLY = 3, NOISE_INNOV = 4,
        NOISE_PCN_LINES = 5 /* pCN step on the line layout, k_chain_lines in bhip_chain_kernel.h (m' <= 3) */ };
 
+template <class T> struct bhip_unref { typedef T type; };
+template <class T> struct bhip_unref<T &> { typedef T type; };
+template <class T> struct bhip_unref<const T &> { typedef T type; };
+template <class T> struct bhip_unref<const T> { typedef T type; };
 template <bool C, class A, class B> struct bhip_cond { typedef A type; };   // (no <type_traits> under hipRTC)
 template <class A, class B> struct bhip_cond<false, A, B> { typedef B type; };
 
@@ -78,6 +82,8 @@ struct KArgs {
     uint32_t k0, k1, iter, path0;
     uint32_t blk0;        // offset of the Philox block index (multi-segment chains: segment << 24; 0 otherwise)
     int defer_accept;     // pCN modes: do not decide -- only report llo in `ll` (joint accept over segments, bhip_segchains_*)
+    int noise_spec;       // 2: the full-resolution stream bhip-philox-v2 (BHIP_OPT_NOISE_SPEC); anything else: bhip-philox-v3 (bhip_rng.h)
+    int xcd_map;          // workgroup -> chain-group mapping (xcd_block below): 0 identity, 1 rotated, 2 contiguous per XCD
     double x0[BHIP_MAXD_LANE];       // d <= 3 for every process; LinPro targets of dimension 4..8 run one path per lane too
     double vend[BHIP_MAXD_LANE];
     double mu_aux[BHIP_MAXD_LANE];
@@ -96,6 +102,21 @@ struct KArgs {
 };
 
 typedef const __attribute__((address_space(4))) double *cptr_t;
+
+// Which 64-chain group (256-path block) a workgroup works on.  The hardware deals workgroup b to XCD b % 8, and every XCD has its own
+// L2 with 16 address-interleaved channels: with the identity mapping XCD x touches only the groups g = x (mod 8), i.e. a fixed
+// residue of the address bits that select among them (512-byte pieces of every 4 KiB of a path row, 16 KiB of every 128 KiB of
+// the chain lines) -- a fraction of its channels.  mode 1 rotates the residue with the row of eight (every XCD sees every
+// residue), mode 2 gives XCD x the contiguous eighth [x nb/8, (x+1) nb/8) of the groups.  Whole rows of eight only; the ragged
+// tail keeps the identity.
+__device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb, int mode)
+{
+    const unsigned full = nb & ~7u;
+    if (mode == 0 || b >= full) return b;
+    const unsigned x = b & 7u, q = b >> 3;
+    if (mode == 1) return (q << 3) | ((x + q) & 7u);
+    return x * (full >> 3) + q;
+}
 
 // a coefficient row whose time entries are shared (scalar loads) and whose other entries belong to the lane's chain
 struct PerPathRow {
@@ -511,7 +532,7 @@ __global__ __launch_bounds__(256, (PPR || M::D > 4 || (M::D > 3 && NOISE == NOIS
     }
     using TabT = typename bhip_cond<DRAWS, TabLDS, TabConst>::type;
     const TabT tab = [&]() { if constexpr (DRAWS) return TabLDS(rng_tab); else return TabConst(); }();
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long p = (long)xcd_block(blockIdx.x, gridDim.x, a.xcd_map) * blockDim.x + threadIdx.x;
     if (p >= a.P) return;
     // the model functor: built once from the kernel arguments, or (STREAMED) re-opened from the device copy at every step
     auto make_model = [&]() {
@@ -648,29 +669,38 @@ __global__ __launch_bounds__(256, (PPR || M::D > 4 || (M::D > 3 && NOISE == NOIS
                 st_stream(&wslot[((size_t)(i + 1) * MP + k) * a.ldC], c ? d2v{st.wprev[k], slot[k].y} : d2v{slot[k].x, st.wprev[k]});
         }
     };
-    // unrolled so that the position of a step's normals inside their Philox call (four normals per call) and the register row
+    // unrolled so that the position of a step's normals inside their quad (four normals per quad) and the register row
     // of the per-chain coefficients are static: four steps per iteration where normals are drawn (two for m' = 2), else two
     constexpr int UNR = (DRAWS ? ((MP == 2 || MP % 4 == 0) ? 2 : 4) : 2) * ((DRAWS && !PPR && M::D <= 3) ? BHIP_PATHS_UNR_MULT : 1);
-    int i = 0;
-    for (; i + UNR - 1 < nsteps; i += UNR) {
+    // the time loop, generic in the table accessor: its TYPE carries the noise specification (bhip_rng.h), so the kernels that draw
+    // hold the loop twice and ONE wave-uniform branch per launch picks the copy -- the default copy is the loop it always was
+    auto time_loop = [&](const auto &tb) {
+        using TB = typename bhip_unref<decltype(tb)>::type;
+        int i = 0;
+        for (; i + UNR - 1 < nsteps; i += UNR) {
 #pragma unroll
-        for (int u = 0; u < UNR; u++) {   // i is a multiple of UNR: u is the step's static phase
-            double cur[NIN];
-            advance(i + u, cur);
-            fetch_row(i + u + 1, rr[(u + 1) & 1]);
-            path_step<M, GK, MO, NOISE, FL, RowT, TabT>(is_streamed<M>::value ? make_model() : model, a, rowat(i + u, rr[u & 1]), i + u, nll, path, cur, wout, ldwo, xout, ldx, st, tab, 0u, u);
-            commit(i + u);
+            for (int u = 0; u < UNR; u++) {   // i is a multiple of UNR: u is the step's static phase
+                double cur[NIN];
+                advance(i + u, cur);
+                fetch_row(i + u + 1, rr[(u + 1) & 1]);
+                path_step<M, GK, MO, NOISE, FL, RowT, TB>(is_streamed<M>::value ? make_model() : model, a, rowat(i + u, rr[u & 1]), i + u, nll, path, cur, wout, ldwo, xout, ldx, st, tb, 0u, u);
+                commit(i + u);
+            }
         }
-    }
 #pragma unroll 1
-    for (; i < nsteps; i++) {   // ragged tail (< UNR steps): dynamic phase, the current per-chain row always in rr[0]
-        double cur[NIN];
-        advance(i, cur);
-        fetch_row(i + 1, rr[1]);
-        path_step<M, GK, MO, NOISE, FL, RowT, TabT>(is_streamed<M>::value ? make_model() : model, a, rowat(i, rr[0]), i, nll, path, cur, wout, ldwo, xout, ldx, st, tab);
-        commit(i);
-        rr[0] = rr[1];
-    }
+        for (; i < nsteps; i++) {   // ragged tail (< UNR steps): dynamic phase, the current per-chain row always in rr[0]
+            double cur[NIN];
+            advance(i, cur);
+            fetch_row(i + 1, rr[1]);
+            path_step<M, GK, MO, NOISE, FL, RowT, TB>(is_streamed<M>::value ? make_model() : model, a, rowat(i, rr[0]), i, nll, path, cur, wout, ldwo, xout, ldx, st, tb);
+            commit(i);
+            rr[0] = rr[1];
+        }
+    };
+    if constexpr (DRAWS) {
+        if (a.noise_spec == 2) time_loop(FullRes<TabT>(tab));
+        else time_loop(tab);
+    } else time_loop(tab);
 
     if constexpr (NOISE == NOISE_INNOV) {
 #pragma unroll

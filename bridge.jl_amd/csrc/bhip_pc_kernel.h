@@ -114,7 +114,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    long c0 = ((long)blockIdx.x * NPAIR + pair) * 64;
+    long c0 = ((long)xcd_block(blockIdx.x, gridDim.x, a.xcd_map) * NPAIR + pair) * 64;
     // a second pair without chains (odd number of 64-chain groups) re-runs the last group -- identical values to
     // identical addresses -- so that it takes part in every barrier; it commits nothing (no lane is live)
     const bool dup = c0 >= a.P;
@@ -234,34 +234,40 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
                     }
                 };
                 const uint32_t q0 = (uint32_t)(NQ * k) + (a.blk0 >> 1);   // blk0 counts pairs (two per call) and is even
-                auto draw = [&](int i, double (&z)[4]) {
+                // the chunk's draws, generic in the table accessor whose TYPE carries the noise specification (bhip_rng.h): both copies
+                // are straight-line code, one wave-uniform branch per chunk picks one
+                auto draws = [&](const auto &tb) {
+                    auto draw = [&](int i, double (&z)[4]) {
 #ifdef PC_KNOCKOUT_NOISE   /* measurement only: what the consumer alone costs */
-                    z[0] = 0.25; z[1] = -0.5; z[2] = 0.125; z[3] = -0.75;
+                        z[0] = 0.25; z[1] = -0.5; z[2] = 0.125; z[3] = -0.75;
 #else
-                    normal_quad(rtab, a.k0, a.k1, path, a.iter, q0 + (uint32_t)i, z[0], z[1], z[2], z[3]);
+                        normal_quad(tb, a.k0, a.k1, path, a.iter, q0 + (uint32_t)i, z[0], z[1], z[2], z[3]);
 #endif
-                };
+                    };
 #pragma unroll
-                for (int c = 0; c < MP; c++) value(c, carry[c]);
-                // every call but the last: all four normals are values of this chunk (component index static for m' = 1, 2 at any
-                // unrolling; m' = 3 -- three calls -- is unrolled fully)
-                constexpr int QU = (RLDS || MP == 3) ? NQ : PC_QUAD_UNROLL;
+                    for (int c = 0; c < MP; c++) value(c, carry[c]);
+                    // every call but the last: all four normals are values of this chunk (component index static for m' = 1, 2 at any
+                    // unrolling; m' = 3 -- three calls -- is unrolled fully)
+                    constexpr int QU = (RLDS || MP == 3) ? NQ : PC_QUAD_UNROLL;
 #pragma unroll QU
-                for (int i = 0; i < NQ - 1; i++) {
-                    double z[4];
-                    draw(i, z);
+                    for (int i = 0; i < NQ - 1; i++) {
+                        double z[4];
+                        draw(i, z);
 #pragma unroll
-                    for (int u = 0; u < 4; u++) value(4 * i + u + MP, z[u]);
-                }
-                {
-                    double z[4];
-                    draw(NQ - 1, z);
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (u < 4 - MP) value(NV - 4 + u + MP, z[u]);
-                        else carry[u - (4 - MP)] = z[u];
+                        for (int u = 0; u < 4; u++) value(4 * i + u + MP, z[u]);
                     }
-                }
+                    {
+                        double z[4];
+                        draw(NQ - 1, z);
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (u < 4 - MP) value(NV - 4 + u + MP, z[u]);
+                            else carry[u - (4 - MP)] = z[u];
+                        }
+                    }
+                };
+                if (a.noise_spec == 2) draws(FullRes<TabLDS>(rtab));
+                else draws(rtab);
                 if constexpr (PCN) {
                     __builtin_amdgcn_wave_barrier();
                     double *kb = chunk_base(k);

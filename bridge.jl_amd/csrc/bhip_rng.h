@@ -1,4 +1,4 @@
-// bhip_rng.h -- RNG specification "bhip-philox-v3" (host + device).
+// bhip_rng.h -- RNG specifications "bhip-philox-v3" (the default) and "bhip-philox-v2" (full resolution, selectable), host + device.
 //
 // Replaces the reference's global randn() (src/wiener.jl:31,44,55), which is not reproducible
 // outside Julia, with a counter-based generator whose output depends only on
@@ -250,14 +250,48 @@ BHIP_HD void box_muller_40_24(const Tab &tab, uint32_t a, uint32_t b, double &z0
     z1 = rad * s;
 }
 
-// Philox call `q` of stream 0 -> normals 4q .. 4q+3
+// ---- the FULL-RESOLUTION specification "bhip-philox-v2" (selectable: BHIP_OPT_NOISE_SPEC = 2).  All 128 bits of a Philox call
+// go into ONE Box-Muller pair -- 53 bits of radius (|z| <= 8.57), 53 bits of angle -- as the round-2 library drew them: call h
+// gives pair h (normals 2h, 2h+1), u1 = (bits53(r0, r1) + 1) 2^-53, u2 = bits53(r2, r3) 2^-53.  Same log / sqrt / sin / cos.
+// Twice the Philox calls per normal of v3; golden vectors guided_paths_v2 / _v3.npz are this stream.
+template <class Tab>
+BHIP_HD void box_muller_53_53(const Tab &tab, const u32x4 &r, double &z0, double &z1)
+{
+    const double u1 = u53_open0(r.x, r.y);
+    const double u2 = u53_open1(r.z, r.w);
+    const double rad = sqrt_fixed_range(det_m2log(u1, tab));
+    double s, c;
+    det_sincos2pi(u2, r.w, tab, s, c);
+    z0 = rad * c;
+    z1 = rad * s;
+}
+// The specification travels in the TYPE of the table accessor: FullRes<Tab> reads the tables like Tab and makes normal_quad /
+// normal_pair draw the v2 stream.  A kernel holds both code paths and picks one per launch with a wave-uniform branch hoisted out
+// of its loops (KArgs::noise_spec), so the default path's schedule is the one it had.
+template <class Tab>
+struct FullRes : Tab {
+    static constexpr int NOISE_SPEC = 2;
+    BHIP_HD explicit FullRes(const Tab &t) : Tab(t) {}
+};
+template <class...> using rng_void_t = void;
+template <class Tab, class = void> struct noise_spec_of { static constexpr int value = 3; };
+template <class Tab> struct noise_spec_of<Tab, rng_void_t<decltype(Tab::NOISE_SPEC)>> { static constexpr int value = Tab::NOISE_SPEC; };
+
+// normals 4q .. 4q+3 of stream 0: v3 -- Philox call q, two 40 + 24-bit pairs;  v2 -- calls 2q and 2q+1, one 53 + 53-bit pair each
 template <class Tab>
 BHIP_HD void normal_quad(const Tab &tab, uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t q, double &z0, double &z1, double &z2,
                          double &z3, uint32_t stream = 0u)
 {
-    const u32x4 r = philox4x32_10(path, stream, iter, q, k0, k1);
-    box_muller_40_24(tab, r.x, r.y, z0, z1);
-    box_muller_40_24(tab, r.z, r.w, z2, z3);
+    if constexpr (noise_spec_of<Tab>::value == 2) {
+        const u32x4 ra = philox4x32_10(path, stream, iter, 2u * q, k0, k1);
+        const u32x4 rb = philox4x32_10(path, stream, iter, 2u * q + 1u, k0, k1);
+        box_muller_53_53(tab, ra, z0, z1);
+        box_muller_53_53(tab, rb, z2, z3);
+    } else {
+        const u32x4 r = philox4x32_10(path, stream, iter, q, k0, k1);
+        box_muller_40_24(tab, r.x, r.y, z0, z1);
+        box_muller_40_24(tab, r.z, r.w, z2, z3);
+    }
 }
 
 // pair `h` of stream 0 -> normals 2h (z0) and 2h+1 (z1): half h & 1 of Philox call h >> 1.  The generic form (host, the
@@ -266,9 +300,22 @@ template <class Tab>
 BHIP_HD void normal_pair(const Tab &tab, uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t h, double &z0, double &z1,
                          uint32_t stream = 0u)
 {
-    const u32x4 r = philox4x32_10(path, stream, iter, h >> 1, k0, k1);
-    const bool second = (h & 1u) != 0u;
-    box_muller_40_24(tab, second ? r.z : r.x, second ? r.w : r.y, z0, z1);
+    if constexpr (noise_spec_of<Tab>::value == 2) {
+        box_muller_53_53(tab, philox4x32_10(path, stream, iter, h, k0, k1), z0, z1);
+    } else {
+        const u32x4 r = philox4x32_10(path, stream, iter, h >> 1, k0, k1);
+        const bool second = (h & 1u) != 0u;
+        box_muller_40_24(tab, second ? r.z : r.x, second ? r.w : r.y, z0, z1);
+    }
+}
+// the same with the specification chosen at run time (2: full resolution; anything else: v3) -- host code and the kernels that
+// draw a handful of normals per launch
+template <class Tab>
+BHIP_HD void normal_pair_spec(int spec, const Tab &tab, uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t h, double &z0, double &z1,
+                              uint32_t stream = 0u)
+{
+    if (spec == 2) normal_pair(FullRes<Tab>(tab), k0, k1, path, iter, h, z0, z1, stream);
+    else normal_pair(tab, k0, k1, path, iter, h, z0, z1, stream);
 }
 BHIP_HD void normal_pair(uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t blk, double &z0, double &z1)
 {

@@ -69,6 +69,7 @@ struct TArgs {
     long ldx0;
     uint32_t blk0;          // offset of the noise stream in pairs (multi-segment chains: segment << 24), as KArgs::blk0
     int defer_accept;       // pCN: do not decide -- only report llo in `ll` (joint accept over segments, bhip_segchains_*)
+    int noise_spec;         // 2: the full-resolution stream bhip-philox-v2; anything else: bhip-philox-v3 (bhip_rng.h), as KArgs::noise_spec
 };
 // The target drift of the built-in instantiations is LinPro's B(x - mu), one of the five MFMA products.  A hipRTC user process
 // supplies its drift COMPONENT-WISE instead: UD::bk(k, t, x, par) = b_k(t, x, P), where x points to the path's whole state
@@ -368,34 +369,39 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
             // draws the fifth.
             double mine[4 * T];   // statically indexed
             double *zb = zb_lds + (size_t)wave * TILE_ZB + j * 18;
+            // (generic in the table accessor whose TYPE carries the noise specification, bhip_rng.h: one wave-uniform branch per step)
+            auto draw_rows = [&](const auto &tb) {
 #pragma unroll
-            for (int t = 0; t < T; t++) {
-                const uint32_t nb = (uint32_t)i * (uint32_t)dtr + 16u * (uint32_t)t;
-                double z[4];
-                if constexpr ((BHIP_TILE_EXP & 2) != 0) { z[0] = 1e-3 * (double)(lane + t); z[1] = -z[0]; z[2] = 0.5 * z[0]; z[3] = -z[2]; }
-                else normal_quad(rtab, a.k0, a.k1, path, a.iter, (nb >> 2) + (uint32_t)kq + (a.blk0 >> 1), z[0], z[1], z[2], z[3]);
-                if constexpr (!PAD) {
-                    *(tile_d2v *)(zb + 4 * kq) = tile_d2v{z[0], z[1]};
-                    *(tile_d2v *)(zb + 4 * kq + 2) = tile_d2v{z[2], z[3]};
-                } else {
-                    const int off = (int)(nb & 3u);
+                for (int t = 0; t < T; t++) {
+                    const uint32_t nb = (uint32_t)i * (uint32_t)dtr + 16u * (uint32_t)t;
+                    double z[4];
+                    if constexpr ((BHIP_TILE_EXP & 2) != 0) { z[0] = 1e-3 * (double)(lane + t); z[1] = -z[0]; z[2] = 0.5 * z[0]; z[3] = -z[2]; }
+                    else normal_quad(tb, a.k0, a.k1, path, a.iter, (nb >> 2) + (uint32_t)kq + (a.blk0 >> 1), z[0], z[1], z[2], z[3]);
+                    if constexpr (!PAD) {
+                        *(tile_d2v *)(zb + 4 * kq) = tile_d2v{z[0], z[1]};
+                        *(tile_d2v *)(zb + 4 * kq + 2) = tile_d2v{z[2], z[3]};
+                    } else {
+                        const int off = (int)(nb & 3u);
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int pos = 4 * kq + u - off;
-                        if (pos >= 0) zb[pos] = z[u];          // (pos <= 15 always)
+                        for (int u = 0; u < 4; u++) {
+                            const int pos = 4 * kq + u - off;
+                            if (pos >= 0) zb[pos] = z[u];          // (pos <= 15 always)
+                        }
+                        if (off != 0 && kq == 0) {                 // wave-uniform `off`: the window's last entries come from a fifth call
+                            normal_quad(tb, a.k0, a.k1, path, a.iter, (nb >> 2) + 4u + (a.blk0 >> 1), z[0], z[1], z[2], z[3]);
+#pragma unroll
+                            for (int u = 0; u < 3; u++)
+                                if (u < off) zb[16 + u - off] = z[u];
+                        }
                     }
-                    if (off != 0 && kq == 0) {                 // wave-uniform `off`: the window's last entries come from a fifth call
-                        normal_quad(rtab, a.k0, a.k1, path, a.iter, (nb >> 2) + 4u + (a.blk0 >> 1), z[0], z[1], z[2], z[3]);
+                    __builtin_amdgcn_wave_barrier();   // one wave's LDS operations execute in order: the writes precede the reads
 #pragma unroll
-                        for (int u = 0; u < 3; u++)
-                            if (u < off) zb[16 + u - off] = z[u];
-                    }
+                    for (int r = 0; r < 4; r++) mine[4 * t + r] = zb[4 * r + kq];
+                    __builtin_amdgcn_wave_barrier();   // ... and the reads precede the next pass's writes
                 }
-                __builtin_amdgcn_wave_barrier();   // one wave's LDS operations execute in order: the writes precede the reads
-#pragma unroll
-                for (int r = 0; r < 4; r++) mine[4 * t + r] = zb[4 * r + kq];
-                __builtin_amdgcn_wave_barrier();   // ... and the reads precede the next pass's writes
-            }
+            };
+            if (a.noise_spec == 2) draw_rows(FullRes<TabLDS>(rtab));
+            else draw_rows(rtab);
             if constexpr (BHIP_TILE_DMA_LATE) issue_dmas();   // the reads of wb are long done; the DMAs still have the products' time
             land_stage();
             double *qo = wop;

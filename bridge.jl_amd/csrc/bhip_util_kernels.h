@@ -70,48 +70,53 @@ __global__ void k_soa_to_tlines(const double *__restrict__ soa, double *__restri
 // component-minor normals, src/wiener.jl:24-35; test/with_srand.jl)
 template <int MP>
 __global__ __launch_bounds__(256) void k_wiener(const double *__restrict__ rootdt, int N, double *__restrict__ W, long ld, long P,
-                                                uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0)
+                                                uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0, int noise_spec)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const uint32_t path = path0 + (uint32_t)p;
-    double w[MP];
-    double *out = W + p;
+    // the noise specification (bhip_rng.h) travels in the table accessor's type; one wave-uniform branch per launch picks the body
+    auto run = [&](const auto &tab) {
+        double w[MP];
+        double *out = W + p;
 #pragma unroll
-    for (int k = 0; k < MP; k++) { w[k] = 0.0; out[(size_t)k * ld] = 0.0; }
-    out += (size_t)MP * ld;
-    // four grid steps per iteration = 4*MP normals = MP whole Philox calls (bhip_rng.h: four normals per call): normal n = i*MP + k is
-    // number n & 3 of call n >> 2, so a call is drawn once (through normal_pair every call was computed twice, once per half)
-    int i = 0;
-    for (; i + 3 < N - 1; i += 4) {
-        double z[4 * MP];
+        for (int k = 0; k < MP; k++) { w[k] = 0.0; out[(size_t)k * ld] = 0.0; }
+        out += (size_t)MP * ld;
+        // four grid steps per iteration = 4*MP normals = MP whole quads (bhip_rng.h: normals 4q .. 4q+3): normal n = i*MP + k is
+        // number n & 3 of quad n >> 2, so a quad is drawn once
+        int i = 0;
+        for (; i + 3 < N - 1; i += 4) {
+            double z[4 * MP];
 #pragma unroll
-        for (int b = 0; b < MP; b++)
-            normal_quad(TabConst(), k0, k1, path, iter, (uint32_t)(i / 4 * MP + b), z[4 * b], z[4 * b + 1], z[4 * b + 2], z[4 * b + 3]);
+            for (int b = 0; b < MP; b++)
+                normal_quad(tab, k0, k1, path, iter, (uint32_t)(i / 4 * MP + b), z[4 * b], z[4 * b + 1], z[4 * b + 2], z[4 * b + 3]);
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const double rdt = rootdt[i + s];
+            for (int s = 0; s < 4; s++) {
+                const double rdt = rootdt[i + s];
 #pragma unroll
-            for (int k = 0; k < MP; k++) { w[k] = w[k] + rdt * z[s * MP + k]; __builtin_nontemporal_store(w[k], out + (size_t)k * ld); }
+                for (int k = 0; k < MP; k++) { w[k] = w[k] + rdt * z[s * MP + k]; __builtin_nontemporal_store(w[k], out + (size_t)k * ld); }
+                out += (size_t)MP * ld;
+            }
+        }
+        for (; i < N - 1; i++) {   // the last steps (fewer than four): single normals, the pair that holds them
+            const double rdt0 = rootdt[i];
+#pragma unroll
+            for (int k = 0; k < MP; k++) {
+                const int n = i * MP + k;
+                double z0, z1;
+                normal_pair(tab, k0, k1, path, iter, (uint32_t)(n >> 1), z0, z1);
+                w[k] = w[k] + rdt0 * ((n & 1) ? z1 : z0);
+                out[(size_t)k * ld] = w[k];
+            }
             out += (size_t)MP * ld;
         }
-    }
-    for (; i < N - 1; i++) {   // the last steps (fewer than four): single normals, the half of the call that holds them
-        const double rdt0 = rootdt[i];
-#pragma unroll
-        for (int k = 0; k < MP; k++) {
-            const int n = i * MP + k;
-            double z0, z1;
-            normal_pair(k0, k1, path, iter, (uint32_t)(n >> 1), z0, z1);
-            w[k] = w[k] + rdt0 * ((n & 1) ? z1 : z0);
-            out[(size_t)k * ld] = w[k];
-        }
-        out += (size_t)MP * ld;
-    }
+    };
+    if (noise_spec == 2) run(FullRes<TabConst>(TabConst()));
+    else run(TabConst());
 }
 // mp > 4 (large-d Wiener): state kept in memory instead of registers
 __global__ __launch_bounds__(256) void k_wiener_big(const double *__restrict__ rootdt, int N, int mp, double *__restrict__ W, long ld, long P,
-                                                    uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0)
+                                                    uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0, int noise_spec)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256) void k_wiener_big(const double *__restrict__ r
         for (int k = 0; k < mp; k++) {
             const int n = i * mp + k;
             double z;
-            if ((n & 1) == 0) normal_pair(k0, k1, path, iter, (uint32_t)(n >> 1), z, zc);
+            if ((n & 1) == 0) normal_pair_spec(noise_spec, TabConst(), k0, k1, path, iter, (uint32_t)(n >> 1), z, zc);
             else z = zc;
             W[((size_t)(i + 1) * mp + k) * ld + p] = W[((size_t)i * mp + k) * ld + p] + rdt * z;
         }
@@ -260,7 +265,7 @@ __global__ void k_seg_y0(long n, long ld, double w_old, double w_new, const doub
 #pragma unroll
     for (int k = 0; k < D * D; k++) ch[k] = chol_pc ? chol_pc[(size_t)k * ld + p] : geo.mpar[k];
 #pragma unroll
-    for (int k = 0; k < D; k += 2) normal_pair(TabConst(), k0, k1, path0 + (uint32_t)p, iter, (uint32_t)(k >> 1), xi[k], xi[k + 1], 2u);
+    for (int k = 0; k < D; k += 2) normal_pair_spec(geo.noise_spec, TabConst(), k0, k1, path0 + (uint32_t)p, iter, (uint32_t)(k >> 1), xi[k], xi[k + 1], 2u);
 #pragma unroll
     for (int r = 0; r < D; r++) {
         double cz = ch[r] * xi[0];
@@ -274,7 +279,7 @@ __global__ void k_seg_y0(long n, long ld, double w_old, double w_new, const doub
 // the same at any state dimension (d > 3: the MFMA tile kernel's chains): mu [d], chol [d*d] (column-major) in device memory
 static __global__ void k_seg_y0_big(long n, long ld, int d, double w_old, double w_new, const double *__restrict__ y0, double *__restrict__ y0o,
                                     uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0, const double *__restrict__ mu,
-                                    const double *__restrict__ chol, const unsigned char *__restrict__ newblock)
+                                    const double *__restrict__ chol, const unsigned char *__restrict__ newblock, int noise_spec)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -283,7 +288,7 @@ static __global__ void k_seg_y0_big(long n, long ld, int d, double w_old, double
         return;
     }
     double xi[34];   // d <= 32
-    for (int k = 0; k < d; k += 2) normal_pair(TabConst(), k0, k1, path0 + (uint32_t)p, iter, (uint32_t)(k >> 1), xi[k], xi[k + 1], 2u);
+    for (int k = 0; k < d; k += 2) normal_pair_spec(noise_spec, TabConst(), k0, k1, path0 + (uint32_t)p, iter, (uint32_t)(k >> 1), xi[k], xi[k + 1], 2u);
     for (int r = 0; r < d; r++) {
         double cz = chol[r] * xi[0];
         for (int c = 1; c < d; c++) cz += chol[r + d * c] * xi[c];

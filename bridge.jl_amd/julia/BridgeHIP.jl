@@ -322,6 +322,25 @@ function mcmc(Po::HIPProposal, x0, iterations; ρ = 0.9, nchains = 1, seed = 0, 
     acc, ll, ch, stats
 end
 
+"""
+    step_group!(chs::Vector{Chains}, ρ, iterations; skip = -1)
+    stats_group!(chs::Vector{Chains}, stats_dev::Vector{Ptr{Cvoid}})
+
+ONE `ccall` that runs `iterations` pCN iterations on every ensemble of `chs` -- one per device of the node, each created on its own
+`Context` -- issuing the launches round-robin on the contexts' streams (`bhip_chains_step_group`): a single-threaded session keeps
+all GPUs busy with one crossing per call.  `skip = -1`: the skip every ensemble was initialised with.
+"""
+function step_group!(chs::Vector{Chains}, ρ, iterations; skip = -1)
+    hs = Ptr{Cvoid}[ch.h for ch in chs]
+    check(chs[1].ctx, ccall((:bhip_chains_step_group, lib), Cint, (Cint, Ptr{Ptr{Cvoid}}, Cdouble, Cint, Cint), length(hs), hs, ρ, iterations, skip))
+    chs
+end
+function stats_group!(chs::Vector{Chains}, stats_dev::Vector{Ptr{Cvoid}})
+    hs = Ptr{Cvoid}[ch.h for ch in chs]
+    check(chs[1].ctx, ccall((:bhip_chains_stats_group, lib), Cint, (Cint, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}), length(hs), hs, stats_dev))
+    stats_dev
+end
+
 # ---------------------------------------------------------------- the smoothing loop (supplements/smoothing/smoothing.jl:99-213)
 """
     SegChains(Po::Vector{<:HIPProposal}, π0μ, π0C, nchains; seed, path0, skip, mcnext)

@@ -69,10 +69,10 @@ int main(int argc, char **argv)
     }
     CHECK(ctx[0], bhip_comm_init_all(ndev, ctx, comm));
 
-    /* asynchronous launches, round-robin over the devices */
-    for (int it = 0; it < iterations; it++)
-        for (int k = 0; k < ndev; k++) CHECK(ctx[k], bhip_chains_step(ch[k], rho, 1, 0));
-    for (int k = 0; k < ndev; k++) CHECK(ctx[k], bhip_chains_stats(ch[k], stats_dev[k]));
+    /* ONE call steps every device: iteration by iteration the launches go out round-robin, each on its context's stream
+     * (asynchronous), and one more reduces every device's statistics -- two crossings of the ABI for the whole loop */
+    CHECK(ctx[0], bhip_chains_step_group(ndev, ch, rho, iterations, 0));
+    CHECK(ctx[0], bhip_chains_stats_group(ndev, ch, stats_dev));
     /* the one collective: every device receives every device's block */
     CHECK(ctx[0], bhip_comm_allgather_group(ndev, comm, (const double *const *)stats_dev, all_dev, BHIP_STATS_LEN));
     /* the ungrouped per-communicator call is refused on a multi-rank single-process communicator (it would deadlock) */

@@ -116,6 +116,16 @@ int bhip_ctx_sync(bhip_ctx *ctx);
  * fp64 tolerance -- and issues ~15 % fewer vector instructions in the instruction-bound modes.  Noise is unaffected up to the
  * last bit of the Wiener cumulation W[i] + sqrt(dt)*xi.  Per-chain device-built guides and hipRTC user processes ignore it. */
 #define BHIP_OPT_FUSED_ARITHMETIC 4
+/* BHIP_OPT_NOISE_SPEC (default 3): which stream of standard normals replaces the reference's randn (src/wiener.jl:31,44,55).
+ *   3  bhip-philox-v3: one Philox4x32-10 call gives FOUR normals (two Box-Muller pairs, 40 bits of radius + 24 bits of angle each:
+ *      |z| <= 7.45, the angle on a 2^24 grid) -- the faster generator, the one every figure in BENCH / profiles is quoted on;
+ *   2  bhip-philox-v2: one call gives TWO normals (one pair, 53 + 53 bits: |z| <= 8.57) -- the full-resolution stream, for callers
+ *      who want nothing between them and the reference's 52-bit ziggurat but the Box-Muller map; twice the Philox calls.
+ * Both are bit-identical on host and device and keyed by (seed, global path id, iteration, normal index).  Takes effect for
+ * everything drawn afterwards on the context (bhip_wiener_sample, bhip_sample_solve, chain and multi-segment ensembles); an
+ * ensemble keeps the specification it was created under (its saved state carries it) and refuses to run under another
+ * (BHIP_ESTATE). */
+#define BHIP_OPT_NOISE_SPEC 5
 int bhip_ctx_set_option(bhip_ctx *ctx, int option, int value);
 const char *bhip_last_error(const bhip_ctx *ctx);
 /* device memory helpers for callers without their own allocator */
@@ -418,10 +428,12 @@ int bhip_comm_allgather_group(int n, bhip_comm *const *comms, const double *cons
 void bhip_comm_destroy(bhip_comm *comm);
 
 /* ------------------------------------------------------------------ RNG specification helpers (host)
- * bhip-philox-v2: Philox4x32-10, key=(seed lo,hi), counter=(path, stream, iter, block); block j of
- * stream 0 yields the normals 2j, 2j+1 (Box-Muller with the library's deterministic, table-driven log/sincos). */
+ * Philox4x32-10, key = (seed lo, hi), counter = (path, stream, iter, call).  bhip_normals_host: normals n0 .. n0+n-1 of stream 0
+ * under the default specification bhip-philox-v3 (call q -> normals 4q .. 4q+3); bhip_normals_host_spec: under `spec` = 3 or 2
+ * (bhip-philox-v2: call h -> normals 2h, 2h+1; BHIP_OPT_NOISE_SPEC) -- the very values the kernels draw, bit for bit. */
 void bhip_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void bhip_normals_host(uint64_t seed, uint32_t path, uint32_t iter, int n0, int n, double *z);
+void bhip_normals_host_spec(int spec, uint64_t seed, uint32_t path, uint32_t iter, int n0, int n, double *z);
 
 #ifdef __cplusplus
 }

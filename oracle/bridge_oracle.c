@@ -329,8 +329,28 @@ BO_CLONES void bo_sincos2pi_k24(uint32_t k24, double *sn, double *cs)
  * key = (seed_lo, seed_hi); stream 0 = Wiener normals, 1 = accept uniforms, 2 = pCN move of the start.
  * Pair h (normals 2h, 2h+1) = half h & 1 of call h >> 1: words a = r[2s], b = r[2s+1];
  *   u1 = (K40 + 1) 2^-40 in (0,1], K40 = (b >> 24) 2^32 + a;   u2 = K24 2^-24, K24 = b & 0xffffff. */
+/* Specification v2 (selectable in the product: BHIP_OPT_NOISE_SPEC = 2; here: bo_set_noise_spec(2)) -- the full-resolution stream the
+ * round-2 library drew and tests/golden/guided_paths_v2 / _v3.npz hold: Philox call h -> pair h (normals 2h, 2h+1) with all 128 bits,
+ *   u1 = (bits53(r0, r1) + 1) 2^-53 in (0,1],   u2 = bits53(r2, r3) 2^-53 in [0,1)   (bits53(lo, hi) = ((hi << 32 | lo) >> 11)). */
+static int bo_noise_spec = 3;
+void bo_set_noise_spec(int spec) { bo_noise_spec = spec == 2 ? 2 : 3; }
+int bo_get_noise_spec(void) { return bo_noise_spec; }
+static void bo_normal_pair_v2(uint64_t seed, uint32_t path, uint32_t stream, uint32_t iter, uint32_t h, double z[2])
+{
+    uint32_t ctr[4] = {path, stream, iter, h}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, r[4];
+    bo_philox4x32_10(ctr, key, r);
+    uint64_t a = ((uint64_t)r[1] << 32) | r[0], b = ((uint64_t)r[3] << 32) | r[2];
+    double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;    /* (0,1] */
+    double u2 = (double)(b >> 11) * 0x1.0p-53;          /* [0,1) */
+    double rad = sqrt(bo_m2log(u1));
+    double s, c;
+    bo_sincos2pi(u2, r[3], &s, &c);
+    z[0] = rad * c;
+    z[1] = rad * s;
+}
 BO_CLONES void bo_normal_pair_stream(uint64_t seed, uint32_t path, uint32_t stream, uint32_t iter, uint32_t h, double z[2])
 {
+    if (bo_noise_spec == 2) { bo_normal_pair_v2(seed, path, stream, iter, h, z); return; }
     uint32_t ctr[4] = {path, stream, iter, h >> 1}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, r[4];
     bo_philox4x32_10(ctr, key, r);
     uint32_t a = r[2 * (h & 1u)], b = r[2 * (h & 1u) + 1];

@@ -103,6 +103,23 @@ def sincos2pi(u):
     return s.value, c.value
 
 
+class noise_spec:
+    """`with o.noise_spec(2): ...` -- the oracle draws the full-resolution stream bhip-philox-v2 (bo_set_noise_spec) inside the block,
+    the default bhip-philox-v3 outside.  The twin of the product's BHIP_OPT_NOISE_SPEC."""
+
+    def __init__(self, spec):
+        self.spec = spec
+
+    def __enter__(self):
+        self.old = lib().bo_get_noise_spec()
+        lib().bo_set_noise_spec(C.c_int(self.spec))
+        return self
+
+    def __exit__(self, *exc):
+        lib().bo_set_noise_spec(C.c_int(self.old))
+        return False
+
+
 def normals(seed, path, it, n0, n):
     z = np.empty(n)
     lib().bo_normals(C.c_uint64(seed), C.c_uint32(path), C.c_uint32(it), C.c_int(n0), C.c_int(n), z.ctypes.data_as(dp))

@@ -330,3 +330,35 @@ def test_one_path_per_lane_short_grids_and_loop_remainders(ctx, d, N):
         r = o.mcmc(ref, c.x0, 0.8, 4, 4, 2 + p, skip=skip)
         assert acc[p] == r["acc"] and np.array_equal(Wc[p], r["W"]), (d, N, p)
         _close(Xc[p], r["X"], np.array([llc[p]]), np.array([r["ll"]]))
+
+
+@pytest.mark.parametrize("d", [4, 5, 6, 7])
+def test_mid_dimension_guidedbridge_with_diagonal_hdiamond(ctx, d):
+    """Advisor r3 (high): with sigma = c*I and B~ = -I every Hdiamond_i -- and its inverse -- is exactly diagonal.  finish_guide's
+    range check used to read the (nu, H) rows of the 4..8 family with the d <= 3 GUIDE_HV offsets, landed on an off-diagonal
+    (exactly zero) entry of inv(Hdiamond) and refused a valid GuidedBridge with "Hdiamond singular".  Every other GPU test
+    uses a dense sigma.  src/guip.jl:165-193."""
+    B = -np.eye(d) + 0.1 * np.diag(np.arange(d) / d)       # diagonal target drift too
+    sig = 0.5 * np.eye(d)
+    par = o.linpro_par(B, np.zeros(d), sig)
+    apar = o.linpro_par(-np.eye(d), np.zeros(d), sig)
+    c = problems.Case(f"linpro{d}_isotropic", np.linspace(0, 1.0, 61), np.zeros(d), o.MODEL_LINPRO, par, o.AUX_LINPRO, apar,
+                      o.GUIDE_HV, d, d, v=0.5 * np.ones(d), exact=False)
+    ref = c.oracle_proposal()
+    for mid in (1, 0):                                     # one path per lane, and the zero-padded tile kernel
+        ctx.set_option(bh.OPT_MID_VALU, mid)
+        try:
+            Po = c.bh_proposal(bh, ctx)                    # used to raise BHIP_EUNSUPPORTED here
+            X, W, ll = bh.sample_solve(c.x0, Po, 70, seed=3, iter=1, store_W=True)
+        finally:
+            ctx.set_option(bh.OPT_MID_VALU, 1)
+        Xh, Wh, llh = X.paths(), W.paths(), ll.cpu().numpy()
+        for p in (0, 33, 69):
+            Xr = o.solve_guided(ref, c.x0, Wh[p])
+            _close(Xh[p], Xr, llh[p:p + 1], np.array([o.llikelihood(ref, Xr)]))
+    # a genuinely singular Hdiamond is still refused, with the message that names it
+    sing = problems.Case(f"linpro{d}_singular", np.linspace(0, 1.0, 21), np.zeros(d), o.MODEL_LINPRO,
+                         o.linpro_par(B, np.zeros(d), np.zeros((d, d))), o.AUX_LINPRO, o.linpro_par(-np.eye(d), np.zeros(d), np.zeros((d, d))),
+                         o.GUIDE_HV, d, d, v=0.5 * np.ones(d), exact=False)
+    with pytest.raises(Exception, match="singular"):
+        sing.bh_proposal(bh, ctx)

@@ -67,6 +67,12 @@ def test_rng_spec_matches_oracle_bitwise():
         z = np.empty(n)
         lib.bhip_normals_host(seed, path, it, n0, n, bh.api._dptr(z))
         assert np.array_equal(z, o.normals(seed, path, it, n0, n))
+        for spec in (3, 2):       # BHIP_OPT_NOISE_SPEC: the product's host form of both streams against the oracle's
+            zs = np.empty(n)
+            lib.bhip_normals_host_spec(spec, seed, path, it, n0, n, bh.api._dptr(zs))
+            with o.noise_spec(spec):
+                assert np.array_equal(zs, o.normals(seed, path, it, n0, n)), spec
+            assert np.array_equal(zs, z) == (spec == 3)
 
 
 @pytest.mark.parametrize("case", problems.cases(101), ids=lambda c: c.name)

@@ -450,6 +450,26 @@ def test_oracle_reproduces_committed_golden_vectors():
     _check_given_W(np.load(os.path.join(GOLD, "guided_paths_v4.npz")), True)
 
 
+def test_full_resolution_noise_spec_reproduces_golden_v3_from_its_seeds():
+    """bhip-philox-v2, the full-resolution stream (one Box-Muller pair of 53 + 53 bits per Philox call), is selectable again
+    (product: BHIP_OPT_NOISE_SPEC = 2; oracle: bo_set_noise_spec): tests/golden/guided_paths_v3.npz was written by the round-2
+    library's oracle under that specification, so with it selected the oracle must reproduce the file FROM ITS SEEDS -- Wiener
+    paths, guided paths, log-likelihoods and the pCN chains (decisions included) -- bit for bit; and the default specification
+    must not (the two streams differ)."""
+    g = np.load(os.path.join(GOLD, "guided_paths_v3.npz"))
+    with o.noise_spec(2):
+        _check_given_W(g, True)
+        z2 = o.normals(7, 3, 1, 0, 64)
+    z3 = o.normals(7, 3, 1, 0, 64)
+    assert not np.array_equal(z2, z3)
+    import problems
+    c = problems.cases(int(g["meta"][0]))[0]
+    assert not np.array_equal(o.wiener_sample(c.tt, c.mp, int(g["meta"][2]), 0, 0), g[c.name + "/W"][0])
+    # v2's radius reaches further than v3's sqrt(80 ln 2) = 7.45 and both stay finite at the extreme uniforms
+    with o.noise_spec(2):
+        assert np.isfinite(o.normals(2 ** 63 + 5, 2 ** 32 - 1, 2 ** 31, 0, 4096)).all()
+
+
 def test_oracle_reproduces_earlier_golden_vectors_given_their_wiener_paths():
     """guided_paths_v2.npz / _v3.npz were written under the noise specification v2 (round 2): their Wiener paths are no longer
     what the generator draws, but the guided paths and log-likelihoods GIVEN those stored paths do not involve it and must
