@@ -179,7 +179,8 @@ def live_traffic(mode, kernel_name, steps=6):
             cols = [d[0] for d in cur.execute("select * from counters_collection limit 1").description]
             namecol = "kernel_name" if "kernel_name" in cols else "name"
             idcol = "dispatch_id" if "dispatch_id" in cols else None
-            rows = list(cur.execute(f"select {idcol or namecol}, value from counters_collection where {namecol} = ? and counter_name = ?", (kernel_name, counter)))
+            rows = list(cur.execute(f"select {idcol or namecol}, value from counters_collection where {namecol} like ? and counter_name = ?",
+                                    ("%" + kernel_name + "%", counter)))   # (the database's names read `void bhip::k_pc<...>(bhip::KArgs)`)
             if not rows:
                 return None, f"rocprofv3 --pmc {counter}: no row for '{kernel_name}'"
             if idcol:   # one value per dispatch = the sum over the counter's instances
@@ -304,12 +305,18 @@ class Workload:
             mode = mode[:-len("_fused")]
             ctx = bh.Context(ctx.device.index)
             ctx.set_option(bh.OPT_FUSED_ARITHMETIC, 1)
+        self.v2noise = mode.endswith("_v2noise")
+        if self.v2noise:   # the same workload under the full-resolution noise specification bhip-philox-v2 (BHIP_OPT_NOISE_SPEC = 2)
+            mode = mode[:-len("_v2noise")]
+            ctx = bh.Context(ctx.device.index)
+            ctx.set_option(bh.OPT_NOISE_SPEC, 2)
         build, d, mp, x0, default_P, is_chains, rho, text, kname = MODES[mode]
         self.mode, self.ctx = mode, ctx
         self.P = chains if chains else default_P
         self.path0 = rank * self.P                   # contiguous shard of the global ids; the RNG is keyed by the global id
         self.Po = build(ctx)
-        self.workload = text + (" [BHIP_OPT_FUSED_ARITHMETIC: tolerance parity 1e-9 / 1e-8]" if self.fused else "")
+        self.workload = text + (" [BHIP_OPT_FUSED_ARITHMETIC: tolerance parity 1e-9 / 1e-8]" if self.fused else "") + \
+            (" [BHIP_OPT_NOISE_SPEC = 2: bhip-philox-v2, one Box-Muller pair of 53 + 53 bits per Philox call]" if self.v2noise else "")
         self.kernel = kname(self.P).replace("bhip::", "bhip_fused::") if self.fused else kname(self.P)
         self.flops_per_pathstep = 5 * 2 * d * d if d > 8 else None   # d = 32: five d x d mat-vecs per path-step on the matrix cores
         self.chains = None
@@ -348,12 +355,12 @@ class Workload:
             tf = per_launch * self.flops_per_pathstep / avg_s / 1e12
             r.update({"bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TF,
                       "algorithmic_flops_per_path_step": self.flops_per_pathstep, "hbm_algorithmic_GBs": gbs})
-        tr, src = (None, "not profiled (fused build)") if self.fused else profiled_traffic(self.mode, self.kernel)
+        tr, src = (None, "not profiled (fused build / v2 noise)") if (self.fused or self.v2noise) else profiled_traffic(self.mode, self.kernel)
         if tr is not None and self.P != MODES[self.mode][4]:
             tr, src = None, "profiled at the mode's default size only"
         r["traffic"], r["traffic_source"] = tr, src
         r["traffic_box"] = "another box (committed rocprofv3 summaries under profiles/, looked up by kernel name)" if tr is not None else None
-        r["valu"] = profiled_valu(self.mode, self.kernel, self.P) if (self.P == MODES[self.mode][4] and not self.fused) else None
+        r["valu"] = profiled_valu(self.mode, self.kernel, self.P) if (self.P == MODES[self.mode][4] and not self.fused and not self.v2noise) else None
         v = r["valu"]
         if v and r["bound"] == "hbm" and v["busy_frac"] > 0.6 and r["frac"] / v["busy_frac"] < 0.9:
             # the kernel's SIMDs spend most of its duration ISSUING vector instructions: what binds it is the instruction count
@@ -775,10 +782,11 @@ def main_local(args):
         others = []
         del w, ws
         torch.cuda.empty_cache()
-        for mode in ("c4shard", "c2", "proposals", "nclar", "nclar_mcmc", "linpro4", "linpro32", "linpro32_mcmc", "c2_fused", "proposals_fused", "nclar_fused"):
+        for mode in ("c4shard", "c2", "proposals", "nclar", "nclar_mcmc", "linpro4", "linpro32", "linpro32_mcmc", "c2_fused", "proposals_fused", "nclar_fused",
+                     "mcmc_v2noise", "proposals_v2noise", "c2_v2noise"):
             wo = Workload(mode, ctx, 0, 0)
             ms = kernel_times(wo, args.steps, args.warmup, min_ms=100.0)
-            others.append({"mode": mode + ("_fused" if wo.fused and not mode.endswith("_fused") else ""), "workload": wo.workload, "paths": wo.P,
+            others.append({"mode": mode, "workload": wo.workload, "paths": wo.P,
                            "path_steps_per_s": wo.P * steps_per_unit / (float(np.mean(ms)) * 1e-3), "roofline": wo.roofline(ms)})
             del wo
             torch.cuda.empty_cache()
@@ -862,7 +870,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chains", type=int, default=0, help="chains (paths) per GPU; 0 = the mode's named size")
-    ap.add_argument("--mode", choices=sorted(MODES) + sorted(m + "_fused" for m in MODES if MODES[m][1] <= 3), default="mcmc")
+    ap.add_argument("--mode", choices=sorted(MODES) + sorted(m + "_fused" for m in MODES if MODES[m][1] <= 3) + sorted(m + "_v2noise" for m in MODES),
+                    default="mcmc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 child runs that measure the headline kernel's HBM bytes on this box")

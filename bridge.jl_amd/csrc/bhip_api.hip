@@ -100,10 +100,18 @@ bhip::launch_fn get_launch_wiener3(int, int, int, int);
 #ifndef PC_FRESH_MAX_PATHS
 #define PC_FRESH_MAX_PATHS 98304
 #endif
+// fresh proposals: up to how many paths the wave-specialised kernel is chosen over the one-lane kernel (BHIP_PC_FRESH_MAX in the
+// environment: measurement hook for the A/B of the two, scripts/gpu_fresh_ab.py)
+static long pc_fresh_max_paths()
+{
+    const char *e = getenv("BHIP_PC_FRESH_MAX");
+    return e ? atol(e) : (long)PC_FRESH_MAX_PATHS;
+}
 
 // one device allocation of a chain ensemble (hipMalloc, or reserved / created / mapped through the virtual-memory API)
 struct Arena {
     void *base = nullptr;
+    void *base2 = nullptr;   // the proposal paths when they are an allocation of their own (rank-separated placement)
     size_t bytes = 0;
     bool vmm = false;
     size_t va_bytes = 0;
@@ -111,10 +119,15 @@ struct Arena {
     std::vector<size_t> hsizes;
 };
 struct PlaceSpec {
+    bool contig = false;   // hipExtMallocWithFlags(hipDeviceMallocContiguous): ONE physically contiguous block
     bool vmm = false;
     size_t va_align = 0;   // alignment of the reserved virtual range (0: the runtime's)
     size_t chunk = 0;      // physical memory created in pieces of this size (0: one piece)
     size_t xo_gap = 0;     // extra bytes between the end of W and Xo (experiments)
+    size_t w_off = 0, x_off = 0;   // contig2: explicit offsets of W and Xo inside the block (experiments)
+    bool offsets = false;
+    size_t arena_bytes = 0;        // arena: the process-wide contiguous block the offsets refer to (experiments; never freed)
+    size_t spacer = 0;             // W and Xo as two allocations with a transient spacer of this size allocated between them
 };
 static void arena_free(Arena &ar);
 
@@ -1123,6 +1136,7 @@ static int fill_common(const bhip_proposal *po, KArgs &a, const double *x0, cons
     a.wstride = 1;
     a.noise_spec = ctx->noise_spec;
     { const char *e = getenv("BHIP_XCD_MAP"); a.xcd_map = e ? atoi(e) : ctx->xcd_map; }   // (the environment: measurement hook)
+    { const char *e = getenv("BHIP_TUNE"); a.tune = e ? atoi(e) : 0; }
     const bool aux_linpro = po->has_aux && po->aux.linpro_form();   // b~ = B(x - mu~); else b~ = B x + beta~ (mu~ = 0)
     a.use_vend = po->use_vend;
     for (int k = 0; k < d; k++) {
@@ -1204,7 +1218,7 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         int npair = 0, knoise = noise;
         const long groups = (a.P + 63) / 64;
         if (ctx->wave_specialised && a.rdtp && po->mh.mp <= 3 && a.wstride == 1) {
-            if (noise == NOISE_FRESH && a.P <= PC_FRESH_MAX_PATHS) knoise = NOISE_FRESH_PC;
+            if (noise == NOISE_FRESH && a.P <= pc_fresh_max_paths()) knoise = NOISE_FRESH_PC;
             else if (noise == NOISE_PCN_LINES) knoise = NOISE_PCN_LINES_PC;
             if (knoise != noise) npair = groups <= PC_MAX_GROUPS_2PAIR ? 2 : groups <= PC_MAX_GROUPS_4PAIR ? 4 : 1;
         }
@@ -1239,7 +1253,7 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         // producer/consumer waves (bhip_pc_kernel.h): same results, the kernel of choice wherever it is instantiated
         // Fresh proposals: with 4 waves per SIMD the one-lane-does-everything kernel already issues at ~85 % of the VALU
         // rate and the hand-over only costs; the split pays below that (profiles/r2_small_configs.txt).
-        if (noise == NOISE_FRESH && a.P <= PC_FRESH_MAX_PATHS) f = find_launch(po->mh, gk_dispatch, mo, NOISE_FRESH_PC, fl, ctx->fused);
+        if (noise == NOISE_FRESH && a.P <= pc_fresh_max_paths()) f = find_launch(po->mh, gk_dispatch, mo, NOISE_FRESH_PC, fl, ctx->fused);
         else if (noise == NOISE_PCN_LINES) f = find_launch(po->mh, gk_dispatch, mo, NOISE_PCN_LINES_PC, fl, ctx->fused);
     }
     if (!f) f = find_launch(po->mh, gk_dispatch, mo, noise, fl, ctx->fused);
@@ -1429,6 +1443,27 @@ static PlaceSpec place_spec_env()
     // BHIP_PLACE=vmm:<va_align MiB>:<chunk MiB>[:<xo gap KiB>]   (measurement hook; the product default is set in bhip_ctx)
     PlaceSpec ps;
     const char *e = getenv("BHIP_PLACE");
+    if (e && strncmp(e, "spacer", 6) == 0) {   // spacer:<GiB>[:contig]
+        unsigned long g = 0;
+        if (sscanf(e, "spacer:%lu", &g) == 1) { ps.spacer = (size_t)g << 30; ps.contig = strstr(e, ":contig") != nullptr; }
+        return ps;
+    }
+    if (e && strncmp(e, "arena", 5) == 0) {   // arena:<size GiB>:<W offset MiB>:<Xo offset MiB>  -- ONE contiguous block per process, kept
+        unsigned long sz = 0, a = 0, b = 0;
+        if (sscanf(e, "arena:%lu:%lu:%lu", &sz, &a, &b) == 3) { ps.contig = true; ps.offsets = true; ps.arena_bytes = (size_t)sz << 30; ps.w_off = (size_t)a << 20; ps.x_off = (size_t)b << 20; }
+        return ps;
+    }
+    if (e && strncmp(e, "contig2", 7) == 0) {   // contig2:<W offset MiB>:<Xo offset MiB>
+        unsigned long a = 0, b = 0;
+        if (sscanf(e, "contig2:%lu:%lu", &a, &b) == 2) { ps.contig = true; ps.offsets = true; ps.w_off = (size_t)a << 20; ps.x_off = (size_t)b << 20; }
+        return ps;
+    }
+    if (e && strncmp(e, "contig", 6) == 0) {   // contig[:<xo gap KiB>]
+        ps.contig = true;
+        unsigned long g = 0;
+        if (sscanf(e, "contig:%lu", &g) == 1) ps.xo_gap = (size_t)g << 10;
+        return ps;
+    }
     if (!e || strncmp(e, "vmm", 3) != 0) return ps;
     ps.vmm = true;
     unsigned long a = 0, c = 0, g = 0;
@@ -1438,6 +1473,11 @@ static PlaceSpec place_spec_env()
 static hipError_t arena_alloc(int device, size_t bytes, const PlaceSpec &ps, Arena &ar)
 {
     ar = Arena();
+    if (ps.contig) {
+        const hipError_t e = hipExtMallocWithFlags(&ar.base, bytes, hipDeviceMallocContiguous);
+        if (e == hipSuccess) ar.bytes = bytes;
+        return e;
+    }
     if (!ps.vmm) {
         const hipError_t e = hipMalloc(&ar.base, bytes);
         if (e == hipSuccess) ar.bytes = bytes;
@@ -1480,6 +1520,7 @@ static hipError_t arena_alloc(int device, size_t bytes, const PlaceSpec &ps, Are
 static void arena_free(Arena &ar)
 {
     if (!ar.base) return;
+    if (ar.base2) (void)hipFree(ar.base2);
     if (!ar.vmm) (void)hipFree(ar.base);
     else {
         size_t off = 0;
@@ -1497,10 +1538,46 @@ static hipError_t chains_alloc_state(const bhip_chains *ch, Arena &ar, double **
     const size_t MB2 = (size_t)2 << 20;
     PlaceSpec ps = ch->ctx->place;
     const PlaceSpec pe = place_spec_env();
-    if (pe.vmm) ps = pe;
+    if (pe.vmm || pe.contig || pe.spacer) ps = pe;
     const size_t wspan = (ch->wbytes + MB2 - 1) / MB2 * MB2 + ps.xo_gap;
     const bool want_x = (ch->flags & BHIP_CHAINS_STORE_X) != 0;
     *Wc = nullptr; *Xo = nullptr;
+    if (ps.spacer && want_x) {   // W, [spacer], Xo: two allocations that the spacer pushes into different regions of the physical memory
+        ar = Arena();
+        auto alloc = [&](void **q, size_t bytes) { return ps.contig ? hipExtMallocWithFlags(q, bytes, hipDeviceMallocContiguous) : hipMalloc(q, bytes); };
+        hipError_t es = alloc(&ar.base, ch->wbytes);
+        if (es != hipSuccess) return es;
+        void *sp = nullptr;
+        const hipError_t e1 = hipMalloc(&sp, ps.spacer);   // (failure: the device has no room for it -- the proposal paths land where they land)
+        if (e1 != hipSuccess) { (void)hipGetLastError(); sp = nullptr; }
+        es = alloc(&ar.base2, ch->xbytes);
+        if (sp) (void)hipFree(sp);
+        if (es != hipSuccess) { (void)hipFree(ar.base); ar = Arena(); return es; }
+        ar.bytes = ch->wbytes;
+        *Wc = (double *)ar.base; *Xo = (double *)ar.base2;
+        return hipSuccess;
+    }
+    if (ps.offsets && want_x && ps.arena_bytes) {   // (experiments) explicit offsets inside ONE process-wide contiguous block
+        static void *big = nullptr;
+        static size_t big_bytes = 0;
+        if (!big) {
+            const hipError_t eb = hipExtMallocWithFlags(&big, ps.arena_bytes, hipDeviceMallocContiguous);
+            if (eb != hipSuccess) return eb;
+            big_bytes = ps.arena_bytes;
+        }
+        if (std::max(ps.w_off + ch->wbytes, ps.x_off + ch->xbytes) > big_bytes) return hipErrorOutOfMemory;
+        ar = Arena();   // not owned: arena_free does nothing
+        *Wc = (double *)((char *)big + ps.w_off);
+        *Xo = (double *)((char *)big + ps.x_off);
+        return hipSuccess;
+    }
+    if (ps.offsets && want_x) {   // (experiments) W and Xo at explicit offsets of one contiguous block
+        const hipError_t eo = arena_alloc(ch->ctx->device, std::max(ps.w_off + ch->wbytes, ps.x_off + ch->xbytes), ps, ar);
+        if (eo != hipSuccess) return eo;
+        *Wc = (double *)((char *)ar.base + ps.w_off);
+        *Xo = (double *)((char *)ar.base + ps.x_off);
+        return eo;
+    }
     const hipError_t e = arena_alloc(ch->ctx->device, want_x ? wspan + ch->xbytes : ch->wbytes, ps, ar);
     if (e != hipSuccess) return e;
     *Wc = (double *)ar.base;
@@ -1521,6 +1598,7 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     bhip_chains *ch = new (std::nothrow) bhip_chains();
     if (!ch) return fail(ctx, BHIP_EHIP, "out of host memory");
     ch->ctx = ctx; ch->po = po; ch->n = nchains; ch->ld = (nchains + 63) / 64 * 64;
+    { const char *e = getenv("BHIP_LD_PAD"); if (e) ch->ld += atol(e) / 64 * 64; }   // (measurement hook: leading dimension off the power of two)
     ctx_retain(ctx);
     ch->path0 = path0; ch->seed = seed; ch->flags = flags; ch->noise_spec = ctx->noise_spec;
     const size_t N = po->tt.size();

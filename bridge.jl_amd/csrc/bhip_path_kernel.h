@@ -84,6 +84,7 @@ struct KArgs {
     int defer_accept;     // pCN modes: do not decide -- only report llo in `ll` (joint accept over segments, bhip_segchains_*)
     int noise_spec;       // 2: the full-resolution stream bhip-philox-v2 (BHIP_OPT_NOISE_SPEC); anything else: bhip-philox-v3 (bhip_rng.h)
     int xcd_map;          // workgroup -> chain-group mapping (xcd_block below): 0 identity, 1 rotated, 2 contiguous per XCD
+    int tune;             // measurement switches (BHIP_TUNE in the environment): bit 0 no consumer priority, bit 1 producer priority
     double x0[BHIP_MAXD_LANE];       // d <= 3 for every process; LinPro targets of dimension 4..8 run one path per lane too
     double vend[BHIP_MAXD_LANE];
     double mu_aux[BHIP_MAXD_LANE];

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
 
     if (role == 0) {
         // ------------------------------------------------------------------ producer
+        if constexpr (RLDS) { if (a.tune & 2) __builtin_amdgcn_s_setprio(3); }   // (measurement: BHIP_TUNE bit 1)
         const TabLDS rtab(tab);
         const cptr_t rdtp = (cptr_t)(uintptr_t)a.rdtp;
         double wprev[MP], w2prev[MP];
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
 #ifdef PC_CONS_PRIO_ALL
     __builtin_amdgcn_s_setprio(PC_CONS_PRIO);
 #else
-    if constexpr (RLDS) __builtin_amdgcn_s_setprio(PC_CONS_PRIO);
+    if constexpr (RLDS) { if (!(a.tune & 1)) __builtin_amdgcn_s_setprio(PC_CONS_PRIO); }
 #endif
     const M model(a.mpar);
     const int nll = N - 1 - a.skip;

@@ -17,7 +17,15 @@ ctx = bh.default_context(0)
 ctx.set_option(bh.OPT_TUNE_PLACEMENT, 0)
 nens = int(os.environ.get("PMC_NENS", "5"))
 launches = int(os.environ.get("PMC_LAUNCHES", "6"))
-ws = [bench.Workload(os.environ.get("PROBE_MODE", "mcmc"), ctx, 0, 0) for _ in range(nens)]
+places = os.environ.get("PMC_PLACES", "").split()     # per ensemble: malloc | contig | vmm:... (BHIP_PLACE); default: hipMalloc for all
+ws = []
+for k in range(nens):
+    pl = places[k] if k < len(places) else "malloc"
+    if pl == "malloc":
+        os.environ.pop("BHIP_PLACE", None)
+    else:
+        os.environ["BHIP_PLACE"] = pl
+    ws.append(bench.Workload(os.environ.get("PROBE_MODE", "mcmc"), ctx, 0, 0))
 for k, w in enumerate(ws):
     ms = bench.kernel_times(w, launches, 1)
     print(f"ensemble {k}: mean {np.mean(ms):.4f} ms  min {np.min(ms):.4f}", flush=True)
