@@ -619,7 +619,7 @@ def base_record(args, world, w, elapsed, kern_ms, launch):
 
 def add_chain_summary(out, gathered, w=None):
     if w is not None and w.chains is not None:
-        # BHIP_OPT_TUNE_PLACEMENT (setup, before any timing): allocations tried, ms per iteration on the first and the chosen one
+        # BHIP_OPT_TUNE_PLACEMENT (setup, before any timing): Xo allocations timed, ms per iteration of the same-piece reference and of the kept pair
         out["config"]["placement"] = w.chains.placement()
     summary = bdist.combine_stats(gathered)
     out["config"]["acceptance_rate"] = summary["acceptance_rate"]

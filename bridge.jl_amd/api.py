@@ -848,11 +848,11 @@ class Chains:
         self.iterations += iters
 
     def placement(self):
-        """what the placement tuning did (bhip_chains_placement_info): allocations tried (0 = not tuned), ms per iteration on the
-        first and on the chosen allocation"""
+        """what the placement did (bhip_chains_placement_info): allocations of Xo that were timed (0 = not placed), ms per iteration
+        with W and Xo in ONE contiguous block (the same-piece reference), ms per iteration on the pair that was kept"""
         n, a, b = C.c_int(), C.c_float(), C.c_float()
         self.ctx.check(self.ctx.lib.bhip_chains_placement_info(self.h, C.byref(n), C.byref(a), C.byref(b)))
-        return {"tries": n.value, "ms_first": a.value, "ms_best": b.value}
+        return {"tries": n.value, "ms_first": a.value, "ms_best": b.value, "ms_same_piece_reference": a.value, "ms_kept": b.value}
 
     def stats(self, out=None):
         """device tensor [8]: {nchains, iterations, sum acc, sum ll, sum ll^2, min ll, max ll, sum acc^2}"""

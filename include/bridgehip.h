@@ -97,10 +97,14 @@ int bhip_ctx_sync(bhip_ctx *ctx);
  * Euler recurrence and the log-likelihood; 0 selects the one-lane-does-everything kernels.  Results are bit-identical;
  * the switch exists for A/B measurements and for the test that proves the identity. */
 #define BHIP_OPT_WAVE_SPECIALISED 1
-/* BHIP_OPT_TUNE_PLACEMENT (default 1): chain ensembles of 1 GiB or more measure where their memory landed -- on MI355X the
- * pCN iteration (three streams: read W, write Wo, write Xo) runs up to 15 % slower on some allocations than on others, for the
- * life of the allocation.  bhip_chains_init then times a few iterations on up to six allocations, keeps the fastest and
- * re-initialises (see bhip_chains_placement_info); 0 keeps the first allocation.  Results do not depend on it. */
+/* BHIP_OPT_TUNE_PLACEMENT (default 1): placement of large chain ensembles.  On MI355X the pCN iteration (three streams: read W,
+ * write Wo, write Xo) runs 14-16 % faster when the chain state W and the proposal paths Xo lie in DIFFERENT 96-GiB pieces of the
+ * device's physical memory (each piece has its own DRAM banks; three streams inside one piece close each other's rows:
+ * profiles/r4_placement_regions.txt).  HIP neither reports nor accepts physical addresses, so ensembles of 1 GiB or more keep W and
+ * Xo in two physically contiguous allocations and bhip_chains_init MEASURES whether they share a piece: a few iterations on one
+ * contiguous block holding both (the same-piece reference, freed again), a few on the ensemble's own pair, and -- only if that is
+ * not 7 % faster -- on up to three more allocations for Xo, of which the fastest is kept (bhip_chains_placement_info; ~10 ms per
+ * step, once per ensemble).  0 keeps the first pair.  Results do not depend on it. */
 #define BHIP_OPT_TUNE_PLACEMENT 2
 /* BHIP_OPT_MID_VALU (default 1): LinPro targets of dimension 4 <= d <= 8 run one path per lane like the d <= 3 processes (the
  * d x d products as scalar FMAs, coefficients through the scalar unit) in bhip_sample_solve, bhip_solve, bhip_llikelihood,
@@ -286,8 +290,8 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
 void bhip_chains_destroy(bhip_chains *ch);
 /* iteration 0: W = sample(tt, Wiener()); solve!(X, x0, W, Po); ll = llikelihood(X, Po; skip) */
 int bhip_chains_init(bhip_chains *ch, const double *x0, int skip);
-/* what BHIP_OPT_TUNE_PLACEMENT did for this ensemble: allocations tried (0: not tuned), ms per pCN iteration on the first
- * and on the chosen one */
+/* what BHIP_OPT_TUNE_PLACEMENT did for this ensemble: allocations of Xo that were timed (0: not placed), ms per pCN iteration with W
+ * and Xo in ONE contiguous block (the same-piece reference; without one: on the first pair), and on the pair that was kept */
 int bhip_chains_placement_info(const bhip_chains *ch, int *tries, float *ms_first, float *ms_best);
 /* `iters` pCN iterations: sample!(W2); Wo = rho*W + sqrt(1-rho^2)*W2; solve!; llo; accept iff
  * log(U) <= llo - ll.  skip applies to llo like partialbridge_nclar.jl:121; pass BHIP_SKIP_OF_INIT to use the skip the

@@ -122,15 +122,17 @@ def test_no_store_variants_and_per_path_starts(ctx):
 
 
 def test_placement_tuning_changes_nothing_but_the_allocation(ctx):
-    """BHIP_OPT_TUNE_PLACEMENT: an ensemble of 1 GiB or more times a few pCN iterations on up to four allocations and keeps the
-    fastest; the state is initialised afresh afterwards, so chains, paths and statistics are those of an untuned ensemble"""
+    """BHIP_OPT_TUNE_PLACEMENT: an ensemble of 1 GiB or more keeps W and Xo in two contiguous allocations and measures whether they
+    share a 96-GiB piece of the device memory (a reference block holding both, then the pair, then up to three more Xo); the state is
+    initialised afresh afterwards, so chains, paths and statistics are those of an ensemble that was not placed"""
     import torch
     case = [c for c in problems.cases(1001) if c.name == "fhn_partialbridge_extreme"][0]
     Po = case.bh_proposal(bh, ctx)
     n = 36000                                            # x 32 KB of state per chain > 1 GiB
     a = bh.Chains(Po, case.x0, n, seed=9)
     info = a.placement()
-    assert 1 <= info["tries"] <= 6 and 0 < info["ms_best"] <= info["ms_first"]
+    assert 1 <= info["tries"] <= 4 and info["ms_best"] > 0 and info["ms_first"] > 0
+    assert info["ms_best"] <= 1.05 * info["ms_first"]      # the pair that was kept is never slower than the same-piece reference
     a.step(0.9, 3)
     ctx.set_option(bh.OPT_TUNE_PLACEMENT, 0)
     try:
