@@ -42,6 +42,10 @@ launch_fn get_launch_mid5(int, int, int);
 launch_fn get_launch_mid6(int, int, int);
 launch_fn get_launch_mid7(int, int, int);
 launch_fn get_launch_mid8(int, int, int);
+launch_fn get_launch_mid9(int, int, int);
+launch_fn get_launch_mid10(int, int, int);
+launch_fn get_launch_mid11(int, int, int);
+launch_fn get_launch_mid12(int, int, int);
 launch_fn get_launch_ppr_pendulum(int, int);
 guide_launch_fn get_guide_launch_lorenz(int);
 guide_launch_fn get_guide_launch_pendulum(int);
@@ -97,6 +101,12 @@ bhip::launch_fn get_launch_wiener2(int, int, int, int);
 bhip::launch_fn get_launch_wiener3(int, int, int, int);
 }  // namespace bhip_fused
 
+#ifndef BHIP_MID_MAX_DEFAULT
+#define BHIP_MID_MAX_DEFAULT 10   // largest dimension that runs one path per lane by default: 11 and 12 are instantiated but lose to the padded tile (profiles/r4_mid_dims.txt)
+#endif
+#ifndef BHIP_MID_MAX_CHAINS
+#define BHIP_MID_MAX_CHAINS 8     // ... and the largest whose pCN chains do (16-byte slots)
+#endif
 #ifndef PC_FRESH_MAX_PATHS
 #define PC_FRESH_MAX_PATHS 98304
 #endif
@@ -129,10 +139,9 @@ struct bhip_ctx {
     double *scratch = nullptr;
     size_t scratch_bytes = 0;
     bool wave_specialised = true;   // BHIP_OPT_WAVE_SPECIALISED: producer/consumer kernels (bhip_pc_kernel.h) where they exist
-    bool mid_valu = true;           // BHIP_OPT_MID_VALU: LinPro targets of dimension 4..8 one path per lane (0: zero padded on the MFMA tile kernel)
+    int mid_max = BHIP_MID_MAX_DEFAULT;   // BHIP_OPT_MID_VALU: LinPro targets / component-wise drifts of dimension 4..mid_max one path per lane (0: all of them on the MFMA tile kernel)
     bool fused = false;             // BHIP_OPT_FUSED_ARITHMETIC: the d <= 3 kernels built with a*b + c contracted (tolerance parity)
     bool tune_placement = true;     // BHIP_OPT_TUNE_PLACEMENT: large chain ensembles try a few allocations and keep the fastest (bhip_chains_init)
-    int xcd_map = 0;                // workgroup -> chain-group mapping of the d <= 3 kernels (bhip_path_kernel.h xcd_block)
     int noise_spec = 3;             // BHIP_OPT_NOISE_SPEC: 3 = bhip-philox-v3 (default), 2 = bhip-philox-v2, the full-resolution stream (bhip_rng.h)
     // lifetime: every proposal / chain ensemble / communicator holds a reference.  bhip_ctx_destroy with live children only
     // closes the context (garbage collectors -- Python at interpreter exit, Julia finalizers -- destroy handles in any order);
@@ -174,7 +183,7 @@ struct bhip_proposal {
     int rs = 0;
     double *d_rdtp = nullptr;   // rdtp[j] = sqrt(tt[j] - tt[j-1]), rdtp[0] = 0, zero padded to a multiple of 16 (bhip_pc_kernel.h)
     bool use_vend = false;
-    double vend[BHIP_MAXD_LANE] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double vend[BHIP_MAXD_LANE] = {0};
     // LinPro target of dimension 4..8: d_rows holds the coefficient rows in the (nu, H) form for the path-per-lane kernel (the
     // tile data serve its chains)
     bool mid = false;
@@ -368,7 +377,11 @@ int bhip_ctx_set_option(bhip_ctx *ctx, int option, int value)
     if (!ctx) return BHIP_EINVAL;
     if (option == BHIP_OPT_WAVE_SPECIALISED) { ctx->wave_specialised = value != 0; return BHIP_OK; }
     if (option == BHIP_OPT_TUNE_PLACEMENT) { ctx->tune_placement = value != 0; return BHIP_OK; }
-    if (option == BHIP_OPT_MID_VALU) { ctx->mid_valu = value != 0; return BHIP_OK; }
+    if (option == BHIP_OPT_MID_VALU) {   // 0: off; 1: the default cut; 4..12: one path per lane up to that dimension
+        if (value != 0 && value != 1 && (value < 4 || value > BHIP_MAXD_LANE)) return fail(ctx, BHIP_EINVAL, "BHIP_OPT_MID_VALU: 0, 1 (default) or the largest dimension 4..12 that runs one path per lane");
+        ctx->mid_max = value == 0 ? 0 : value == 1 ? BHIP_MID_MAX_DEFAULT : value;
+        return BHIP_OK;
+    }
     if (option == BHIP_OPT_FUSED_ARITHMETIC) { ctx->fused = value != 0; return BHIP_OK; }
     if (option == BHIP_OPT_NOISE_SPEC) {
         if (value != 2 && value != 3) return fail(ctx, BHIP_EINVAL, "BHIP_OPT_NOISE_SPEC: 3 (bhip-philox-v3, the default) or 2 (bhip-philox-v2, full resolution)");
@@ -1124,8 +1137,6 @@ static int fill_common(const bhip_proposal *po, KArgs &a, const double *x0, cons
     a.P = npaths;
     a.wstride = 1;
     a.noise_spec = ctx->noise_spec;
-    { const char *e = getenv("BHIP_XCD_MAP"); a.xcd_map = e ? atoi(e) : ctx->xcd_map; }   // (the environment: measurement hook)
-    { const char *e = getenv("BHIP_TUNE"); a.tune = e ? atoi(e) : 0; }
     const bool aux_linpro = po->has_aux && po->aux.linpro_form();   // b~ = B(x - mu~); else b~ = B x + beta~ (mu~ = 0)
     a.use_vend = po->use_vend;
     for (int k = 0; k < d; k++) {
@@ -1152,13 +1163,21 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
     int fl = 0;
     if (noise == NOISE_PCN || noise == NOISE_PCN_LINES) fl = a.Xo ? 1 : 0;
     else fl = (a.X ? 1 : 0) | (a.Wout ? 2 : 0);
-    if (po->mid) {   // LinPro, d = 4..8: rows in the (nu, H) form, one kernel family
+    // BHIP_OPT_NOISE_SPEC = 2: the register-tight kernels hold the default stream only (bhip_path_kernel.h k_paths, bhip_chain_kernel.h):
+    // the pCN step on the 16-byte slots is refused (chains at d > 3 were created on the tile kernel under this specification,
+    // bhip_chains_create; at d <= 3 the slots only serve grids too long for the line layout), the one-lane line kernel gives way to
+    // the wave-specialised one
+    const bool v2 = a.noise_spec == 2;
+    if (v2 && noise == NOISE_PCN)
+        return fail(ctx, BHIP_EUNSUPPORTED, "BHIP_OPT_NOISE_SPEC = 2: the pCN step on the 16-byte slots draws the default noise stream only");
+    const bool wave_spec = ctx->wave_specialised || v2;
+    if (po->mid) {   // LinPro, d = 4..12: rows in the (nu, H) form, one kernel family
         const int gkm = po->g.kind == BHIP_GUIDE_NONE ? BHIP_GUIDE_NONE : BHIP_GUIDE_NUH;
         if (a.rs != row_stride(gkm, po->mh.d, 1, true)) return fail(ctx, BHIP_ESTATE, "row stride mismatch");
         if (po->mh.id >= USER_MODEL_BASE) {   // component-wise user drift: k_paths<MUser (streamed), gk, 1, noise, fl> through hipRTC
             if (!(noise == NOISE_EXT || noise == NOISE_FRESH || noise == NOISE_PCN || noise == NOISE_LLONLY || noise == NOISE_INNOV) ||
                 (gkm == BHIP_GUIDE_NONE && (noise == NOISE_PCN || noise == NOISE_LLONLY)))
-                return fail(ctx, BHIP_EUNSUPPORTED, "no path-per-lane kernel for this mode at 4 <= d <= 8");
+                return fail(ctx, BHIP_EUNSUPPORTED, "no path-per-lane kernel for this mode at 4 <= d <= 12");
             const int flk = noise == NOISE_INNOV ? 2 : fl;
             hipFunction_t fn = nullptr;
             {
@@ -1185,8 +1204,12 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         case 6: fm = get_launch_mid6(gkm, noise, fl); break;
         case 7: fm = get_launch_mid7(gkm, noise, fl); break;
         case 8: fm = get_launch_mid8(gkm, noise, fl); break;
+        case 9: fm = get_launch_mid9(gkm, noise, fl); break;
+        case 10: fm = get_launch_mid10(gkm, noise, fl); break;
+        case 11: fm = get_launch_mid11(gkm, noise, fl); break;
+        case 12: fm = get_launch_mid12(gkm, noise, fl); break;
         }
-        if (!fm) return fail(ctx, BHIP_EUNSUPPORTED, "no path-per-lane kernel for this mode at 4 <= d <= 8");
+        if (!fm) return fail(ctx, BHIP_EUNSUPPORTED, "no path-per-lane kernel for this mode at 4 <= d <= 12");
         HIPCHK(ctx, fm(a, ctx->stream));
         return BHIP_OK;
     }
@@ -1206,7 +1229,7 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         // full 160 KB of dynamic LDS on gfx950 without an opt-in: probed, 48 ... 160 KB)
         int npair = 0, knoise = noise;
         const long groups = (a.P + 63) / 64;
-        if (ctx->wave_specialised && a.rdtp && po->mh.mp <= 3 && a.wstride == 1) {
+        if (wave_spec && a.rdtp && po->mh.mp <= 3 && a.wstride == 1) {
             if (noise == NOISE_FRESH && a.P <= pc_fresh_max_paths()) knoise = NOISE_FRESH_PC;
             else if (noise == NOISE_PCN_LINES) knoise = NOISE_PCN_LINES_PC;
             if (knoise != noise) npair = groups <= PC_MAX_GROUPS_2PAIR ? 2 : groups <= PC_MAX_GROUPS_4PAIR ? 4 : 1;
@@ -1238,7 +1261,7 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         return BHIP_OK;
     }
     launch_fn f = nullptr;
-    if (ctx->wave_specialised && a.rdtp && po->mh.mp <= 3 && a.wstride == 1) {
+    if (wave_spec && a.rdtp && po->mh.mp <= 3 && a.wstride == 1) {
         // producer/consumer waves (bhip_pc_kernel.h): same results, the kernel of choice wherever it is instantiated
         // Fresh proposals: with 4 waves per SIMD the one-lane-does-everything kernel already issues at ~85 % of the VALU
         // rate and the hand-over only costs; the split pays below that (profiles/r2_small_configs.txt).
@@ -1287,7 +1310,7 @@ int bhip_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, const d
     }
     if (ldW < npaths || (X_dev && ldX < npaths)) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
     if (x0_dev && ldX < npaths) return fail(ctx, BHIP_ELENGTH, "per-path starting points x0_dev are laid out [d][ldX]: ldX must be >= npaths");
-    if (po->mh.d > 3 && !(po->mid && ctx->mid_valu))
+    if (po->mh.d > 3 && !(po->mid && po->mh.d <= ctx->mid_max))
         return launch_tile_path(po, x0, W_dev, ldW, nullptr, 0, X_dev, ldX, ll_dev, skip, npaths, 0, 0, 0, 0, 1, nullptr, 0.0, x0_dev, ldX);
     KArgs a;
     int rc = fill_common(po, a, x0, x0_dev, npaths, skip);
@@ -1310,7 +1333,7 @@ int bhip_sample_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, 
     if ((W_dev && ldW < npaths) || (X_dev && ldX < npaths)) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
     if (x0_dev && ldX < npaths) return fail(ctx, BHIP_ELENGTH, "per-path starting points x0_dev are laid out [d][ldX]: ldX must be >= npaths");
     PATH_RANGE(ctx, path0, npaths > 0 ? npaths : 0);
-    if (po->mh.d > 3 && !(po->mid && ctx->mid_valu))
+    if (po->mh.d > 3 && !(po->mid && po->mh.d <= ctx->mid_max))
         return launch_tile_path(po, x0, nullptr, 0, W_dev, ldW, X_dev, ldX, ll_dev, skip, npaths, 1, seed, iter, path0, 1, nullptr, 0.0, x0_dev, ldX);
     KArgs a;
     int rc = fill_common(po, a, x0, x0_dev, npaths, skip);
@@ -1326,13 +1349,13 @@ int bhip_llikelihood(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev
     if (!ctx || !po || !X_dev || !ll_dev) return BHIP_EINVAL;
     SAME_CTX(ctx, po);
     if (po->g.kind == BHIP_GUIDE_NONE) return fail(ctx, BHIP_EINVAL, "bhip_llikelihood: needs a guided proposal");
-    if (po->mh.d > 3 && !(po->mid && ctx->mid_valu)) {
+    if (po->mh.d > 3 && !(po->mid && po->mh.d <= ctx->mid_max)) {
         if (ldX < npaths) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
         const std::vector<double> zero(po->mh.d, 0.0);
         return launch_tile_path(po, zero.data(), X_dev, ldX, nullptr, 0, nullptr, 0, ll_dev, skip, npaths, 3, 0, 0, 0);
     }
     KArgs a;
-    const double zero[BHIP_MAXD_LANE] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double zero[BHIP_MAXD_LANE] = {0};
     int rc = fill_common(po, a, zero, nullptr, npaths, skip);
     if (rc) return rc;
     if (ldX < npaths) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths");
@@ -1345,7 +1368,7 @@ int bhip_innovations(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev
     if (!ctx || !po || !X_dev || !W_dev) return BHIP_EINVAL;
     SAME_CTX(ctx, po);
     if (po->mh.d != po->mh.mp) return fail(ctx, BHIP_EINVAL, "bhip_innovations: needs a square, invertible sigma (d == m')");
-    if (po->mh.d > 3 && !(po->mid && ctx->mid_valu))
+    if (po->mh.d > 3 && !(po->mid && po->mh.d <= ctx->mid_max))
         return fail(ctx, BHIP_EUNSUPPORTED, "innovations: d <= 3, or a LinPro target of dimension 4..8 (the path-per-lane kernels)");
     if (po->g.kind == BHIP_GUIDE_NONE) {
         int rc = ensure_plain_rows(const_cast<bhip_proposal *>(po));
@@ -1505,7 +1528,9 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     ctx_retain(ctx);
     ch->path0 = path0; ch->seed = seed; ch->flags = flags; ch->noise_spec = ctx->noise_spec;
     const size_t N = po->tt.size();
-    ch->tile = po->mh.d > 3 && !(po->mid && ctx->mid_valu);
+    // d > 3: one path per lane (slots) up to the chains' cut -- lower than the proposals' (the slots' traffic and registers: 8.5 vs 5.6 ms at
+    // d = 9) --, and never under the full-resolution noise specification (the slot kernel draws the default stream only)
+    ch->tile = po->mh.d > 3 && !(po->mid && po->mh.d <= std::min(ctx->mid_max, (int)BHIP_MID_MAX_CHAINS) && ctx->noise_spec != 2);
     ch->lines = po->mh.d <= 3 && po->mh.mp <= 3;
     const size_t spc = LINE_DOUBLES / (ch->lines ? line_mpp(po->mh.mp) : 1);   // grid points per line (m' = 3: padded to 4 components)
     ch->nch = (int)((N + spc - 1) / spc);
@@ -1709,7 +1734,8 @@ static int launch_ppr(bhip_chains *ch, int noise, KArgs &a)
     a.prows = ch->prows; a.ldr = ch->ld; a.vend_pc = ch->vend_pc; a.uv_pc = ch->uv_pc; a.lna = ch->lna;
     const int fl = (noise == NOISE_PCN || noise == NOISE_PCN_LINES) ? (a.Xo ? 1 : 0) : 0;
     // (bit 1 of the selector: the monolithic line kernel instead of the wave-specialised one)
-    launch_fn f = find_launch_ppr(po->mh, noise, fl | ((noise == NOISE_PCN_LINES && !(ctx->wave_specialised && a.rdtp)) ? 2 : 0));
+    if (a.noise_spec == 2 && noise == NOISE_PCN) return fail(ctx, BHIP_EUNSUPPORTED, "BHIP_OPT_NOISE_SPEC = 2: the pCN step on the 16-byte slots draws the default noise stream only");
+    launch_fn f = find_launch_ppr(po->mh, noise, fl | ((noise == NOISE_PCN_LINES && !((ctx->wave_specialised || a.noise_spec == 2) && a.rdtp)) ? 2 : 0));
     if (!f) return fail(ctx, BHIP_EUNSUPPORTED, "no per-chain-guide kernel for this model");
     HIPCHK(ctx, f(a, ctx->stream));
     return BHIP_OK;

@@ -93,8 +93,7 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
     };
     if (BHIP_LINES_STAGE) fetch(0);
 
-    // the chunk loop, generic in the table accessor whose TYPE carries the noise specification (bhip_rng.h): the kernel holds it
-    // twice and one wave-uniform branch per launch picks the copy
+    // the chunk loop, generic in the table accessor that carries the noise specification (bhip_rng.h)
     auto run_chunks = [&](const auto &tb) {
         using TB = typename bhip_unref<decltype(tb)>::type;
         // one Euler step i (grid point j = i + 1 = SPC*k + s): the chain's current W[j] comes from the tile, the proposal goes back
@@ -162,8 +161,7 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
             __builtin_amdgcn_wave_barrier();   // the tile is overwritten by the next chunk only after these reads
         }
     };
-    if (a.noise_spec == 2) run_chunks(FullRes<TabConst>(TabConst()));
-    else run_chunks(TabConst());
+    run_chunks(TabConst());   // (the default stream only: under BHIP_OPT_NOISE_SPEC = 2 the host launches the wave-specialised kernel, do_launch)
 
     if constexpr (PPR) {
         if (a.uv_pc[p]) {

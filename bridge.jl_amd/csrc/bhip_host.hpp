@@ -497,8 +497,8 @@ inline int model_setup(int id, int d_hint, const double *par, int npar, ModelHos
     case BHIP_MODEL_OU: mh.dpar.push_back(mh.a.a[0]); mh.dpar.push_back(1.0 / par[1]); break;
     case BHIP_MODEL_LINPRO: {
         mh.dpar.insert(mh.dpar.end(), mh.a.a.begin(), mh.a.a.end());
-        // (d <= 3: closed forms; 4 <= d <= 8, the path-per-lane kernels' range: LU.  The tile kernel builds its own constants.)
-        if (d <= 8) { const Mat Si = det(S) != 0.0 ? inv(S) : Mat(d, d); mh.dpar.insert(mh.dpar.end(), Si.a.begin(), Si.a.end()); }
+        // (d <= 3: closed forms; 4 <= d <= 12, the path-per-lane kernels' range: LU.  The tile kernel builds its own constants.)
+        if (d <= 12) { const Mat Si = det(S) != 0.0 ? inv(S) : Mat(d, d); mh.dpar.insert(mh.dpar.end(), Si.a.begin(), Si.a.end()); }
         break; }
     case BHIP_MODEL_FHN: case BHIP_MODEL_INTDIFF: case BHIP_MODEL_PENDULUM: mh.dpar.push_back(mh.a(1, 1)); break;
     case BHIP_MODEL_NCLAR: mh.dpar.push_back(mh.a(2, 2)); break;

@@ -95,7 +95,15 @@ launch_fn get_launch_mid6(int gk, int noise, int fl) { return get_launch_mid<MLi
 launch_fn get_launch_mid7(int gk, int noise, int fl) { return get_launch_mid<MLinPro<7, bhip_cptr_t>>(gk, noise, fl); }
 #elif BHIP_INST == 15
 launch_fn get_launch_mid8(int gk, int noise, int fl) { return get_launch_mid<MLinPro<8, bhip_cptr_t>>(gk, noise, fl); }
+#elif BHIP_INST == 16
+launch_fn get_launch_mid9(int gk, int noise, int fl) { return get_launch_mid<MLinPro<9, bhip_cptr_t>>(gk, noise, fl); }
+#elif BHIP_INST == 17
+launch_fn get_launch_mid10(int gk, int noise, int fl) { return get_launch_mid<MLinPro<10, bhip_cptr_t>>(gk, noise, fl); }
+#elif BHIP_INST == 18
+launch_fn get_launch_mid11(int gk, int noise, int fl) { return get_launch_mid<MLinPro<11, bhip_cptr_t>>(gk, noise, fl); }
+#elif BHIP_INST == 19
+launch_fn get_launch_mid12(int gk, int noise, int fl) { return get_launch_mid<MLinPro<12, bhip_cptr_t>>(gk, noise, fl); }
 #else
-#error "BHIP_INST must be 0..15"
+#error "BHIP_INST must be 0..19"
 #endif
 }  // namespace bhip

@@ -44,7 +44,7 @@ template <class M> struct has_sinv<M, bhip_void_t<decltype(&M::sinv_mul)>> { sta
 template <class M, class = void> struct is_constdiff { static constexpr bool value = true; };
 template <class M> struct is_constdiff<M, bhip_void_t<decltype(M::STATE_SIGMA)>> { static constexpr bool value = !M::STATE_SIGMA; };
 
-constexpr int BHIP_MAXD_LANE = 8;
+constexpr int BHIP_MAXD_LANE = 12;   // one path per lane up to here (4..8 since round 3, 9..12 since round 4); beyond: the MFMA tile kernel
 
 // processes whose parameter block is re-opened from device memory at every step (MLinPro<4..8, bhip_cptr_t>)
 template <class M, class = void> struct is_streamed { static constexpr bool value = false; };
@@ -83,9 +83,7 @@ struct KArgs {
     uint32_t blk0;        // offset of the Philox block index (multi-segment chains: segment << 24; 0 otherwise)
     int defer_accept;     // pCN modes: do not decide -- only report llo in `ll` (joint accept over segments, bhip_segchains_*)
     int noise_spec;       // 2: the full-resolution stream bhip-philox-v2 (BHIP_OPT_NOISE_SPEC); anything else: bhip-philox-v3 (bhip_rng.h)
-    int xcd_map;          // workgroup -> chain-group mapping (xcd_block below): 0 identity, 1 rotated, 2 contiguous per XCD
-    int tune;             // measurement switches (BHIP_TUNE in the environment): bit 0 no consumer priority, bit 1 producer priority
-    double x0[BHIP_MAXD_LANE];       // d <= 3 for every process; LinPro targets of dimension 4..8 run one path per lane too
+    double x0[BHIP_MAXD_LANE];       // d <= 3 for every process; LinPro targets of dimension 4..12 run one path per lane too
     double vend[BHIP_MAXD_LANE];
     double mu_aux[BHIP_MAXD_LANE];
     double mpar[40];
@@ -103,21 +101,6 @@ struct KArgs {
 };
 
 typedef const __attribute__((address_space(4))) double *cptr_t;
-
-// Which 64-chain group (256-path block) a workgroup works on.  The hardware deals workgroup b to XCD b % 8, and every XCD has its own
-// L2 with 16 address-interleaved channels: with the identity mapping XCD x touches only the groups g = x (mod 8), i.e. a fixed
-// residue of the address bits that select among them (512-byte pieces of every 4 KiB of a path row, 16 KiB of every 128 KiB of
-// the chain lines) -- a fraction of its channels.  mode 1 rotates the residue with the row of eight (every XCD sees every
-// residue), mode 2 gives XCD x the contiguous eighth [x nb/8, (x+1) nb/8) of the groups.  Whole rows of eight only; the ragged
-// tail keeps the identity.
-__device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb, int mode)
-{
-    const unsigned full = nb & ~7u;
-    if (mode == 0 || b >= full) return b;
-    const unsigned x = b & 7u, q = b >> 3;
-    if (mode == 1) return (q << 3) | ((x + q) & 7u);
-    return x * (full >> 3) + q;
-}
 
 // a coefficient row whose time entries are shared (scalar loads) and whose other entries belong to the lane's chain
 struct PerPathRow {
@@ -330,7 +313,7 @@ template <class ST> BHIP_DEV void pc_mark(ST &st, int k)
 template <class M, int GK, int MO, int NOISE, int FL, class RowPtr = cptr_t, class Tab = TabConst>
 BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int nll, uint32_t path, const double *win_k,
                         double *wout, long ldwo, double *xout, long ldx, LaneState<M::D, M::MP> &st, const Tab &tab = Tab(),
-                        uint32_t xl = 0u /* lane offset when xout is the wave-uniform base: address = scalar base + 32-bit lane offset */,
+                        uint32_t xl = 0u /* the lane's BYTE offset when xout is the wave-uniform base: address = scalar base + 32-bit lane offset */,
                         int i4 = -1 /* i & 3 where the caller knows it statically (unrolled time loops); -1: taken from i */)
 {
     constexpr int D = M::D, MP = M::MP;
@@ -417,7 +400,8 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int n
     // ---- LOOP B: yy[i] = y (stored BEFORE the update, src/euler.jl:263)
     if constexpr (NOISE != NOISE_LLONLY && (FL & 1) != 0) {
 #pragma unroll
-        for (int k = 0; k < D; k++) st_stream(xout + ((size_t)i * D + k) * ldx + xl, st.y[k]);
+        for (int k = 0; k < D; k++)   // (uniform row base) + (the lane's 32-bit BYTE offset): the store takes its base from scalar registers
+            st_stream((double *)((char *)(xout + ((size_t)i * D + k) * ldx) + xl), st.y[k]);
     }
     PSTAMP(1);   // phase 1: dw + the issue of the X stores (back-pressure shows here)
 
@@ -533,7 +517,7 @@ __global__ __launch_bounds__(256, (PPR || M::D > 4 || (M::D > 3 && NOISE == NOIS
     }
     using TabT = typename bhip_cond<DRAWS, TabLDS, TabConst>::type;
     const TabT tab = [&]() { if constexpr (DRAWS) return TabLDS(rng_tab); else return TabConst(); }();
-    const long p = (long)xcd_block(blockIdx.x, gridDim.x, a.xcd_map) * blockDim.x + threadIdx.x;
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.P) return;
     // the model functor: built once from the kernel arguments, or (STREAMED) re-opened from the device copy at every step
     auto make_model = [&]() {
@@ -698,7 +682,12 @@ __global__ __launch_bounds__(256, (PPR || M::D > 4 || (M::D > 3 && NOISE == NOIS
             rr[0] = rr[1];
         }
     };
-    if constexpr (DRAWS) {
+    // Fresh proposals hold the loop twice (every copy one basic block per step: the scheduler interleaves the generator with the
+    // recurrence; a branch at the draw instead cost the 4..8-dimensional kernels 40 %).  The pCN step on the slots has no registers
+    // for two copies (they spilled) and stays on the default stream: under BHIP_OPT_NOISE_SPEC = 2 the host sends chains to the
+    // wave-specialised kernel (d <= 3) or the tile kernel (d > 3) and refuses what only this kernel could run (do_launch).
+    constexpr bool TWO_COPIES = DRAWS && NOISE == NOISE_FRESH;
+    if constexpr (TWO_COPIES) {
         if (a.noise_spec == 2) time_loop(FullRes<TabT>(tab));
         else time_loop(tab);
     } else time_loop(tab);

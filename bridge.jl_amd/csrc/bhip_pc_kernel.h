@@ -114,7 +114,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    long c0 = ((long)xcd_block(blockIdx.x, gridDim.x, a.xcd_map) * NPAIR + pair) * 64;
+    long c0 = ((long)blockIdx.x * NPAIR + pair) * 64;
     // a second pair without chains (odd number of 64-chain groups) re-runs the last group -- identical values to
     // identical addresses -- so that it takes part in every barrier; it commits nothing (no lane is live)
     const bool dup = c0 >= a.P;
@@ -130,7 +130,6 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
 
     if (role == 0) {
         // ------------------------------------------------------------------ producer
-        if constexpr (RLDS) { if (a.tune & 2) __builtin_amdgcn_s_setprio(3); }   // (measurement: BHIP_TUNE bit 1)
         const TabLDS rtab(tab);
         const cptr_t rdtp = (cptr_t)(uintptr_t)a.rdtp;
         double wprev[MP], w2prev[MP];
@@ -294,7 +293,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
 #ifdef PC_CONS_PRIO_ALL
     __builtin_amdgcn_s_setprio(PC_CONS_PRIO);
 #else
-    if constexpr (RLDS) { if (!(a.tune & 1)) __builtin_amdgcn_s_setprio(PC_CONS_PRIO); }
+    if constexpr (RLDS) __builtin_amdgcn_s_setprio(PC_CONS_PRIO);
 #endif
     const M model(a.mpar);
     const int nll = N - 1 - a.skip;
@@ -334,7 +333,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
             x.sh = rows + (size_t)i * RL::RS;
             expand_pp_row<M>(model, a.lna, rcur.v, x.e);
             fetch_row(i + 1, rnxt);
-            path_step<M, GK, MO, NOISE_EXT, CFL, ExpRow<NE>>(model, a, x, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p);
+            path_step<M, GK, MO, NOISE_EXT, CFL, ExpRow<NE>>(model, a, x, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p * 8u);
             rcur = rnxt;
         }
     };
@@ -358,8 +357,8 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
                     st.ll += wn[0];
 #else
                     if constexpr (PPR) ppr_step(i, wn);
-                    else if constexpr (RLDS) path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, lrows + s * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p);
-                    else path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p);
+                    else if constexpr (RLDS) path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, lrows + s * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p * 8u);
+                    else path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p * 8u);
 #endif
                 }
             } else {
@@ -372,8 +371,8 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
 #pragma unroll
                     for (int c = 0; c < MP; c++) wn[c] = mine[s * MPP + c];
                     if constexpr (PPR) ppr_step(i, wn);
-                    else if constexpr (RLDS) path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, lrows + s * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p);
-                    else path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p);
+                    else if constexpr (RLDS) path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, lrows + s * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p * 8u);
+                    else path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p * 8u);
                 }
             }
         }

@@ -99,6 +99,9 @@ typedef const __attribute__((address_space(4))) double *tile_cptr_t;   // consta
 #ifndef BHIP_TILE_SPREAD_EVERY
 #define BHIP_TILE_SPREAD_EVERY 2
 #endif
+#ifndef BHIP_TL_PAIR
+#define BHIP_TL_PAIR 0      // tile lines: 1 = the parity halves of a chain's line as a 256-byte pair (what the d <= 3 lines gained 3-4 % from): measured at d = 32, 16.47-16.54 vs 16.40 ms -- not kept
+#endif
 #ifndef BHIP_TILE_LDSDMA
 #define BHIP_TILE_LDSDMA 1
 #endif
@@ -180,7 +183,11 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     // A lane reads its 8 values of the chain's CURRENT half and writes the proposal to the OTHER half (the accept flips the
     // chain's parity bit), so that whole lines travel: 8 m' B read + 8 m' B written per path-step -- the algorithmic bytes
     // (the 16-byte slots of round 1 moved the unchanged half too: 1280 instead of 768 B per path-step at d = 32).
-    const size_t tl_grid = (size_t)T * a.ldC * 16, tl_half = (size_t)N * tl_grid;   // doubles per grid point / per half
+    // BHIP_TL_PAIR (round 4): the two parity halves of a chain's line are NEIGHBOURS, Wl[((((i*T + t)*ld + p)*2 + h)*16 + ..] -- a 256-byte
+    // pair, as the d <= 3 line layout has had since round 3: the read of the current half and the write of the other fall into the
+    // same DRAM row (0: the halves 17 GB apart, Wl[(((h*N + i)*T + t)*ld + p)*16 + ..])
+    constexpr size_t TL_LINE = BHIP_TL_PAIR ? 32 : 16;                                // doubles from a chain's line to the next chain's
+    const size_t tl_grid = (size_t)T * a.ldC * TL_LINE, tl_half = BHIP_TL_PAIR ? (size_t)16 : (size_t)N * tl_grid;   // doubles per grid point / between the halves
     const double *wrd = nullptr;
     double *wwr = nullptr, *wst = nullptr;   // wst: where the step in flight stores its proposal line (BHIP_TILE_SPREAD)
 
@@ -207,14 +214,14 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     int cpar = 0;
     if constexpr (NOISE == 2) {
         cpar = a.cur[p];
-        wrd = a.Wc + (size_t)cpar * tl_half + (size_t)p * 16 + 2 * kq;
-        wwr = a.Wc + (size_t)(cpar ^ 1) * tl_half + (size_t)p * 16 + 2 * kq;
+        wrd = a.Wc + (size_t)cpar * tl_half + (size_t)p * TL_LINE + 2 * kq;
+        wwr = a.Wc + (size_t)(cpar ^ 1) * tl_half + (size_t)p * TL_LINE + 2 * kq;
 #pragma unroll
         for (int t = 0; t < T; t++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) w2prev[t][r] = 0.0;
 #pragma unroll
-            for (int jj = 0; jj < 2; jj++) *(tile_d2v *)(wwr + (size_t)t * a.ldC * 16 + 8 * jj) = tile_d2v{0.0, 0.0};   // Wo[0] = 0 (W[0] = 0 is already in the current half)
+            for (int jj = 0; jj < 2; jj++) *(tile_d2v *)(wwr + (size_t)t * a.ldC * TL_LINE + 8 * jj) = tile_d2v{0.0, 0.0};   // Wo[0] = 0 (W[0] = 0 is already in the current half)
         }
         wrd += tl_grid; wwr += tl_grid;      // -> grid point 1
     }
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
             for (int t = 0; t < T; t++)
 #pragma unroll
                 for (int jj = 0; jj < 2; jj++)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wrd + (size_t)t * a.ldC * 16 + 8 * jj),
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wrd + (size_t)t * a.ldC * TL_LINE + 8 * jj),
                                                      (__attribute__((address_space(3))) void *)(wb + (t * 2 + jj) * 128), 16, 0, 0);
         }
     };
@@ -357,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 for (int t = 0; t < T; t++)
 #pragma unroll
                     for (int jj = 0; jj < 2; jj++) {
-                        const tile_d2v v = (BHIP_TILE_EXP & 8) ? tile_d2v{1e-3 * (double)lane, 2e-3} : tile_ld((const tile_d2v *)(wrd + (size_t)t * a.ldC * 16 + 8 * jj));
+                        const tile_d2v v = (BHIP_TILE_EXP & 8) ? tile_d2v{1e-3 * (double)lane, 2e-3} : tile_ld((const tile_d2v *)(wrd + (size_t)t * a.ldC * TL_LINE + 8 * jj));
                         wcur[t][2 * jj] = v.x; wcur[t][2 * jj + 1] = v.y;
                     }
             }
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                         w2prev[t][r] = w2;
                         wprev[t][r] = wo;
                         if constexpr ((BHIP_TILE_EXP & 16) == 0 && !BHIP_TILE_SPREAD) {   // (zero-padded rows carry exact zeros)
-                            if ((r & 1) == 1) tile_st((tile_d2v *)(wwr + (size_t)t * a.ldC * 16 + 8 * (r >> 1)), tile_d2v{wprev[t][r - 1], wo});
+                            if ((r & 1) == 1) tile_st((tile_d2v *)(wwr + (size_t)t * a.ldC * TL_LINE + 8 * (r >> 1)), tile_d2v{wprev[t][r - 1], wo});
                         }
                     } else {
                         const double wn = wprev[t][r] + rdt * mine[4 * t + r];   // sample!: W[i+1] = W[i] + sqrt(dt)*xi
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
         auto store_w = [&](int t) {
             if constexpr (NOISE == 2 && BHIP_TILE_SPREAD == 1 && (BHIP_TILE_EXP & 16) == 0) {
 #pragma unroll
-                for (int jj = 0; jj < 2; jj++) tile_st((tile_d2v *)(wst + (size_t)t * a.ldC * 16 + 8 * jj), tile_d2v{wprev[t][2 * jj], wprev[t][2 * jj + 1]});
+                for (int jj = 0; jj < 2; jj++) tile_st((tile_d2v *)(wst + (size_t)t * a.ldC * TL_LINE + 8 * jj), tile_d2v{wprev[t][2 * jj], wprev[t][2 * jj + 1]});
             }
         };
         auto store_x = [&](int t) {
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
             if (k < 2 * T) {
                 if constexpr (NOISE == 2 && (BHIP_TILE_EXP & 16) == 0) {
                     const int t = k >> 1, jj = k & 1;
-                    tile_st((tile_d2v *)(wst + (size_t)t * a.ldC * 16 + 8 * jj), tile_d2v{wprev[t][2 * jj], wprev[t][2 * jj + 1]});
+                    tile_st((tile_d2v *)(wst + (size_t)t * a.ldC * TL_LINE + 8 * jj), tile_d2v{wprev[t][2 * jj], wprev[t][2 * jj + 1]});
                 }
             } else if (k < 6 * T) {
                 if constexpr (NOISE != 3 && HASX) {

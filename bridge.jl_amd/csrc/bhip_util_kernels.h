@@ -46,7 +46,19 @@ __global__ void k_soa_to_slots(const double *__restrict__ soa, double *__restric
 //   k_tlines_to_soa: the CURRENT halves of chains p0..p0+np -> plain SoA [N][d][np]  (rows d..16T-1 are padding, not copied)
 //   k_soa_to_tlines: plain SoA [N][d][np] -> half 0 of all np = n chains, padding rows zeroed
 // position of component q = 4r + kq of a row group inside its 128-byte tile line (bhip_tile_kernel.h)
+#ifndef BHIP_TL_PAIR
+#define BHIP_TL_PAIR 0      // (as in bhip_tile_kernel.h)
+#endif
 __device__ __forceinline__ int tl_pos(int q) { const int r = q >> 2, kq = q & 3; return 8 * (r >> 1) + 2 * kq + (r & 1); }
+// offset of the line (half h, grid point i, row group t, chain p) of the tile-line layout
+__device__ __forceinline__ size_t tl_line(int h, int i, int t, long p, int N, int T, long ld)
+{
+#if BHIP_TL_PAIR
+    return ((((size_t)i * T + t) * ld + p) * 2 + h) * 16;
+#else
+    return ((((size_t)h * N + i) * T + t) * ld + p) * 16;
+#endif
+}
 __global__ void k_tlines_to_soa(const double *__restrict__ Wl, const unsigned char *__restrict__ cur, double *__restrict__ soa,
                                 int N, int d, int T, long ld, long p0, long np)
 {
@@ -54,8 +66,7 @@ __global__ void k_tlines_to_soa(const double *__restrict__ Wl, const unsigned ch
     if (idx >= (long)N * d * np) return;
     const long p = idx % np, e = idx / np;
     const int i = (int)(e / d), row = (int)(e % d);
-    const size_t half = (size_t)N * T * ld * 16;
-    soa[e * np + p] = Wl[(size_t)cur[p0 + p] * half + ((((size_t)i * T + row / 16) * ld + p0 + p) * 16) + tl_pos(row % 16)];
+    soa[e * np + p] = Wl[tl_line(cur[p0 + p], i, row / 16, p0 + p, N, T, ld) + tl_pos(row % 16)];
 }
 __global__ void k_soa_to_tlines(const double *__restrict__ soa, double *__restrict__ Wl, int N, int d, int T, long ld, long np)
 {
@@ -63,7 +74,7 @@ __global__ void k_soa_to_tlines(const double *__restrict__ soa, double *__restri
     if (idx >= (long)N * 16 * T * np) return;
     const long p = idx % np, e = idx / np;
     const int i = (int)(e / (16 * T)), row = (int)(e % (16 * T));
-    Wl[(((size_t)i * T + row / 16) * ld + p) * 16 + tl_pos(row % 16)] = row < d ? soa[((size_t)i * d + row) * np + p] : 0.0;
+    Wl[tl_line(0, i, row / 16, p, N, T, ld) + tl_pos(row % 16)] = row < d ? soa[((size_t)i * d + row) * np + p] : 0.0;
 }
 
 // sample!(W, Wiener{SVector{mp}}()):  W[0] = 0; W[i+1] = W[i] + rootdt[i]*xi   (time-major,

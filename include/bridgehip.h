@@ -106,12 +106,17 @@ int bhip_ctx_sync(bhip_ctx *ctx);
  * not 7 % faster -- on up to three more allocations for Xo, of which the fastest is kept (bhip_chains_placement_info; ~10 ms per
  * step, once per ensemble).  0 keeps the first pair.  Results do not depend on it. */
 #define BHIP_OPT_TUNE_PLACEMENT 2
-/* BHIP_OPT_MID_VALU (default 1): LinPro targets of dimension 4 <= d <= 8 run one path per lane like the d <= 3 processes (the
- * d x d products as scalar FMAs, coefficients through the scalar unit) in bhip_sample_solve, bhip_solve, bhip_llikelihood,
- * bhip_innovations and bhip_chains_* / bhip_segchains_* (read when the ensemble is created); 0 runs them zero padded on the 16-row
- * MFMA tile kernel (no innovations there).  On MI355X the fp64 matrix cores have no rate advantage over fp64 FMAs, and a 16x16x4
- * instruction cannot skip padding: d = 4 is 5.7x faster for proposals, 3.2x for chains.  Same results to the tile kernel's
- * tolerance (the guide solve is a product with the pre-inverted matrix in both), identical accept decisions and Wiener states. */
+/* BHIP_OPT_MID_VALU (default 1): LinPro targets and component-wise user drifts of "middle" dimension run one path per lane like the
+ * d <= 3 processes (the d x d products as scalar FMAs, coefficients through the scalar unit) in bhip_sample_solve, bhip_solve,
+ * bhip_llikelihood, bhip_innovations and bhip_chains_* / bhip_segchains_* (read when the ensemble is created) instead of zero padded on
+ * the 16-row MFMA tile kernel (no innovations there).  On MI355X the fp64 matrix cores have no rate advantage over fp64 FMAs, and a
+ * 16x16x4 instruction cannot skip padding: d = 4 is 5.7x faster for proposals, 3.2x for chains; d = 9 1.9x for proposals.
+ *   1        the default cuts: proposals / solve / llikelihood / innovations up to the dimension where the lanes stop winning
+ *            (profiles/r4_mid_dims.txt), pCN chains (16-byte slots) up to d = 8;
+ *   4 .. 12  one path per lane up to that dimension (chains: up to min(that, 8));
+ *   0        off: every d > 3 on the tile kernel.
+ * Same results to the tile kernel's tolerance (the guide solve is a product with the pre-inverted matrix in both), identical accept
+ * decisions and Wiener states.  Under BHIP_OPT_NOISE_SPEC = 2 chains at d > 3 always run on the tile kernel. */
 #define BHIP_OPT_MID_VALU 3
 /* BHIP_OPT_FUSED_ARITHMETIC (default 0): 1 runs the d <= 3 path kernels (built-in processes; ensembles and chains with a guide
  * shared by the ensemble) from a second build of the same source in which the compiler may contract a*b + c into one fused
@@ -163,12 +168,12 @@ int bhip_model_define_sigma(bhip_ctx *ctx, int d, int mp, int npar, const char *
 
 /* The same extension point at LARGE state dimension (4 <= d <= 32, odd d too; m' = d, constant dense sigma): at d >= 9 the drift
  * runs on the fp64-MFMA tile kernel, where a lane holds only part of a path's state, so the method body is given COMPONENT-WISE
- * (dimensions 4..8 compile the same text into the path-per-lane kernels, as for LinPro targets: BHIP_OPT_MID_VALU):
+ * (dimensions 4..12 compile the same text into the path-per-lane kernels, as for LinPro targets: BHIP_OPT_MID_VALU):
  *     inputs  int k (component, 0-based), int d, double t, const double* x (d), const double* par (npar <= 16);  output double o, e.g.
  *     Lorenz-96:  "o = (x[(k+1)%d] - x[(k+d-2)%d])*x[(k+d-1)%d] - x[k] + par[0];"
  * Proposals on the returned model id take par = [npar drift parameters, sigma (d x d, column-major)].  Runs everything the
  * built-in LinPro target runs at large d: plain Euler-Maruyama, GuidedBridge / (nu,H) / PartialBridge guides with a
- * time-constant auxiliary, fused and stand-alone llikelihood, pCN chains (and innovations! at d <= 8). */
+ * time-constant auxiliary, fused and stand-alone llikelihood, pCN chains (and innovations! at d <= 12). */
 int bhip_model_define_components(bhip_ctx *ctx, int d, int npar, const char *component_src, int *model_id);
 
 /* ------------------------------------------------------------------ proposal  ("Po")

@@ -8,7 +8,7 @@ import numpy as np, torch
 import bridgehip as bh
 ctx = bh.default_context(0)
 N, P = 1001, 262144
-for d in (4, 5, 6, 8):
+for d in [int(x) for x in os.environ.get("PROBE_DIMS", "4 5 6 8").split()]:
     rng = np.random.default_rng(5)
     G = rng.standard_normal((d, d)) / np.sqrt(d); G2 = rng.standard_normal((d, d)) / np.sqrt(d)
     sig = 0.5 * np.eye(d) + 0.05 * G2
@@ -17,7 +17,7 @@ for d in (4, 5, 6, 8):
     def step(it=[0]):
         it[0] += 1
         ctx.check(ctx.lib.bhip_sample_solve(ctx.h, Po.h, bh.api._dptr(x0), None, None, P, X.ptr(), P, bh.api.vp(ll.data_ptr()), 0, P, 4, it[0], 0))
-    for valu in (1, 0):
+    for valu in (12, 0):
         ctx.set_option(bh.OPT_MID_VALU, valu)
         step(); step(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -17,11 +17,11 @@ def t(ch, k=8):
     e0.record(); ch.step(0.9, k); e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / k
 
-for d in (4, 5, 6, 8):
+for d in [int(x) for x in os.environ.get("PROBE_DIMS", "4 5 6 8").split()]:
     c = problems.linpro_big_case(d, 1001)
     Po = c.bh_proposal(bh, ctx)
     out = []
-    for opt in (1, 0):
+    for opt in (12, 0):
         ctx.set_option(bh.OPT_MID_VALU, opt)
         ch = bh.Chains(Po, c.x0, n, seed=1)
         out.append(t(ch))

@@ -159,11 +159,21 @@ def test_tile_kernel_pcn_chains(ctx, d, kind):
     assert np.abs(m2[40] - (Xall[:, 40] - mean[40]).T @ (Xall[:, 40] - mean[40])).max() < 1e-10
 
 
-@pytest.mark.parametrize("d", [4, 5, 6, 7, 10, 15, 17, 24, 30, 31])
-def test_tile_kernel_other_dimensions_run_zero_padded(ctx, d):
+@pytest.fixture
+def padded_tile(ctx):
+    """BHIP_OPT_MID_VALU = 0 for the duration of a test: dimensions 4..12 on the zero-padded MFMA tile kernel instead of one path per lane"""
+    ctx.set_option(bh.OPT_MID_VALU, 0)
+    yield ctx
+    ctx.set_option(bh.OPT_MID_VALU, 1)
+
+
+@pytest.mark.parametrize("d", [4, 5, 6, 7, 10, 12, 15, 17, 24, 30, 31])
+def test_tile_kernel_other_dimensions_run_zero_padded(padded_tile, d):
     """LinPro targets of any dimension 4..31 -- odd ones too since round 3 -- run on the 16- or 32-component instantiation with
     zero padding: the noise keeps the d-component counter layout (normal i*d + row of Philox call (i*d + row) >> 2: Wiener paths
-    bit-exact), the ensembles hold d rows, results agree with the oracle to the MFMA tolerance."""
+    bit-exact), the ensembles hold d rows, results agree with the oracle to the MFMA tolerance.  (Dimensions 4..12 run one path per
+    lane by default -- test_dimensions_4_to_12_run_one_path_per_lane -- and are sent to the tile kernel here by BHIP_OPT_MID_VALU = 0.)"""
+    ctx = padded_tile
     c = problems.linpro_big_case(d, 81)
     P = 40
     Po, ref = c.bh_proposal(bh, ctx), c.oracle_proposal()
@@ -217,9 +227,9 @@ def test_tile_kernel_per_path_starting_points(ctx):
         assert np.array_equal(Xh[p, 0], starts[p])
 
 
-@pytest.mark.parametrize("d", [4, 5, 6, 7, 8])
-def test_dimensions_4_to_8_run_one_path_per_lane(ctx, d):
-    """LinPro targets of dimension 4..8 (round 3): bhip_sample_solve / bhip_solve / bhip_llikelihood run them on the path-per-lane
+@pytest.mark.parametrize("d", [4, 5, 6, 7, 8, 9, 10, 12])
+def test_dimensions_4_to_12_run_one_path_per_lane(ctx, d):
+    """LinPro targets of dimension 4..8 (round 3) and 9..12 (round 4): bhip_sample_solve / bhip_solve / bhip_llikelihood run them on the path-per-lane
     kernel (k_paths<MLinPro<d>, (nu,H) form>: scalar FMAs, coefficients through the scalar unit) instead of zero padded on the
     16-row MFMA tile.  Wiener paths bit-exact vs the oracle, paths / ll at the large-d tolerance (pre-inverted guide matrix),
     agreement with the tile kernel (BHIP_OPT_MID_VALU = 0), ragged ensemble sizes, plain Euler-Maruyama, per-path starts, innovations!, pCN chains
