@@ -124,7 +124,7 @@ def cpu_baseline(seconds_budget=20.0):
 
 NOISE_SPEC = ("bhip-philox-v3: Philox4x32-10, four normals per call = two Box-Muller pairs of 40 bits of radius + 24 bits of angle "
               "(|z| <= 7.45; DESIGN 4); the reference's randn is a 52-bit ziggurat")
-PROFILE_TAG = "r3"   # profiles/<PROFILE_TAG>_<mode>_{trace,fetch,write}.txt, written by scripts/gpu_profile.sh this round
+PROFILE_TAG = "r4"   # profiles/<PROFILE_TAG>_<mode>_{trace,fetch,write}.txt, written by scripts/gpu_profile_all.sh this round
 
 
 def profiled_traffic(mode, kernel_name):

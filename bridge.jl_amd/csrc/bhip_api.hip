@@ -1650,8 +1650,9 @@ static int chains_time_iterations(bhip_chains *ch, int skip, float *ms, int reps
 //   1. the reference: ONE contiguous block holding W and Xo together -- one piece by construction (unless it straddles a cut) -- timed
 //      for a few iterations and freed: what this kernel takes when the streams share a piece;
 //   2. the ensemble's own W and Xo: timed; 7 % under the reference (the two cases lie 14-16 % apart) means different pieces: done;
-//   3. otherwise another Xo is allocated while the first one stays held (so that it lands elsewhere), up to four in all; the fastest
-//      is kept, the others are freed.  Each candidate costs one 8d-bytes-per-path-step allocation and ~4 launches.
+//   3. otherwise further allocations are made while the earlier ones stay held (so that they land elsewhere) -- Xo, Xo, then W and Xo in
+//      turn, six pairs at most --, each timed with the partner of the best pair so far; the fastest pair is kept, the rest is freed.
+//      Each candidate costs one allocation and ~4 launches (a new W also its set-up).
 // Results are those of an ensemble placed anywhere (the state of iteration 0 is set up afresh at the end; tests/test_gpu_pc.py).
 static int chains_place(bhip_chains *ch, const double *x0, int skip)
 {
@@ -1671,39 +1672,45 @@ static int chains_place(bhip_chains *ch, const double *x0, int skip)
             if (rc) t_ref = 0.f;   // no reference: the candidates are compared with each other
         } else (void)hipGetLastError();
     }
-    struct Cand { void *xo; float ms; };
+    // the pairs tried: every new allocation -- Xo, Xo, then W and Xo in turn -- is timed with the partner of the best pair so far.  All the
+    // buffers that came out "same piece" lie in ONE piece, so a buffer from another piece is fast with any of them; re-rolling W as well
+    // matters when the allocator keeps handing out runs of W's piece while the earlier candidates are held (two of six ensembles of
+    // one process found no second piece with Xo alone).
+    struct Cand { void *w, *xo; float ms; };
     std::vector<Cand> cands;
+    std::vector<void *> held;   // every allocation made here or at create time, freed below unless kept
     int rc = chains_init_impl(ch, x0, nullptr, 0, skip, 0u);   // (the reference run used other memory)
     if (rc) return rc;
-    Cand cur{ch->arena.base2, 0.f};
+    Cand cur{ch->arena.base, ch->arena.base2, 0.f};
     rc = chains_time_iterations(ch, skip, &cur.ms);
     if (rc) return rc;
     cands.push_back(cur);
-    const int max_tries = 4;
-    auto good = [&](float ms) {
-        float slow = t_ref;
-        for (const Cand &c : cands) slow = std::max(slow, c.ms);
-        return ms < 0.93f * slow;
-    };
-    while ((int)cands.size() < max_tries && !good(cands.back().ms)) {
+    held.push_back(cur.w); held.push_back(cur.xo);
+    const int max_tries = 6;
+    auto slowest = [&]() { float s = t_ref; for (const Cand &c : cands) s = std::max(s, c.ms); return s; };
+    auto best = [&]() { size_t ib = 0; for (size_t k = 1; k < cands.size(); k++) if (cands[k].ms < cands[ib].ms) ib = k; return ib; };
+    while ((int)cands.size() < max_tries && !(cands[best()].ms < 0.93f * slowest())) {
+        const bool roll_w = cands.size() >= 3 && cands.size() % 2 == 1;   // tries 1, 2: Xo; then W, Xo, W
+        const size_t bytes = roll_w ? ch->wbytes : ch->xbytes;
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * ch->xbytes) break;
-        Cand c{nullptr, 0.f};
-        if (alloc_run(&c.xo, ch->xbytes) != hipSuccess) { (void)hipGetLastError(); break; }
-        ch->Xo = (double *)c.xo;
-        if (chains_time_iterations(ch, skip, &c.ms)) {   // a candidate that cannot be timed is dropped, not reported
-            (void)hipStreamSynchronize(ctx->stream);
-            (void)hipFree(c.xo);
-            break;
-        }
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bytes) break;
+        void *q = nullptr;
+        if (alloc_run(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        held.push_back(q);
+        Cand c = cands[best()];
+        if (roll_w) c.w = q; else c.xo = q;
+        ch->Wc = (double *)c.w; ch->Xo = (double *)c.xo;
+        int rct = roll_w ? chains_init_impl(ch, x0, nullptr, 0, skip, 0u) : BHIP_OK;   // a new W needs its state
+        if (!rct) rct = chains_time_iterations(ch, skip, &c.ms);
+        if (rct) break;   // a candidate that cannot be set up or timed is dropped, not reported (freed below)
         cands.push_back(c);
     }
-    size_t ib = 0;
-    for (size_t k = 1; k < cands.size(); k++) if (cands[k].ms < cands[ib].ms) ib = k;
+    const Cand keep = cands[best()];
     (void)hipStreamSynchronize(ctx->stream);
-    for (size_t k = 0; k < cands.size(); k++) if (k != ib) (void)hipFree(cands[k].xo);
-    ch->arena.base2 = cands[ib].xo; ch->Xo = (double *)cands[ib].xo;
-    ch->place_tries = (int)cands.size(); ch->place_ms_first = t_ref > 0.f ? t_ref : cands[0].ms; ch->place_ms_best = cands[ib].ms;
+    for (void *q : held) if (q != keep.w && q != keep.xo) (void)hipFree(q);
+    ch->arena.base = keep.w; ch->arena.base2 = keep.xo;
+    ch->Wc = (double *)keep.w; ch->Xo = (double *)keep.xo;
+    ch->place_tries = (int)cands.size(); ch->place_ms_first = t_ref > 0.f ? t_ref : cands[0].ms; ch->place_ms_best = keep.ms;
     return chains_init_impl(ch, x0, nullptr, 0, skip, 0u);   // the state of iteration 0, whatever the timing runs did to it
 }
 

@@ -103,8 +103,8 @@ int bhip_ctx_sync(bhip_ctx *ctx);
  * profiles/r4_placement_regions.txt).  HIP neither reports nor accepts physical addresses, so ensembles of 1 GiB or more keep W and
  * Xo in two physically contiguous allocations and bhip_chains_init MEASURES whether they share a piece: a few iterations on one
  * contiguous block holding both (the same-piece reference, freed again), a few on the ensemble's own pair, and -- only if that is
- * not 7 % faster -- on up to three more allocations for Xo, of which the fastest is kept (bhip_chains_placement_info; ~10 ms per
- * step, once per ensemble).  0 keeps the first pair.  Results do not depend on it. */
+ * not 7 % faster -- on further allocations (Xo, Xo, then W and Xo in turn: six pairs at most), of which the fastest pair is kept
+ * (bhip_chains_placement_info; ~10 ms per step, once per ensemble).  0 keeps the first pair.  Results do not depend on it. */
 #define BHIP_OPT_TUNE_PLACEMENT 2
 /* BHIP_OPT_MID_VALU (default 1): LinPro targets and component-wise user drifts of "middle" dimension run one path per lane like the
  * d <= 3 processes (the d x d products as scalar FMAs, coefficients through the scalar unit) in bhip_sample_solve, bhip_solve,
@@ -295,7 +295,7 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
 void bhip_chains_destroy(bhip_chains *ch);
 /* iteration 0: W = sample(tt, Wiener()); solve!(X, x0, W, Po); ll = llikelihood(X, Po; skip) */
 int bhip_chains_init(bhip_chains *ch, const double *x0, int skip);
-/* what BHIP_OPT_TUNE_PLACEMENT did for this ensemble: allocations of Xo that were timed (0: not placed), ms per pCN iteration with W
+/* what BHIP_OPT_TUNE_PLACEMENT did for this ensemble: (W, Xo) pairs that were timed (0: not placed), ms per pCN iteration with W
  * and Xo in ONE contiguous block (the same-piece reference; without one: on the first pair), and on the pair that was kept */
 int bhip_chains_placement_info(const bhip_chains *ch, int *tries, float *ms_first, float *ms_best);
 /* `iters` pCN iterations: sample!(W2); Wo = rho*W + sqrt(1-rho^2)*W2; solve!; llo; accept iff

@@ -23,10 +23,14 @@ def main():
                 "max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(scratch_size), max(lds_size), "
                 "max(grid_x), max(workgroup_x) from kernels group by name order by sum(duration) desc"))
             tot = sum(r[5] for r in rows) or 1.0
-            print(f"{'kernel':<100} {'calls':>5} {'avg_us':>10} {'min_us':>10} {'max_us':>10} {'%':>6} {'vgpr':>5} {'agpr':>5} {'sgpr':>5} "
+            med = {}
+            for (nm,) in cur.execute("select distinct name from kernels"):
+                d = sorted(x[0] for x in db.cursor().execute("select duration from kernels where name = ?", (nm,)))
+                med[nm] = d[len(d) // 2] if d else 0.0
+            print(f"{'kernel':<100} {'calls':>5} {'avg_us':>10} {'median_us':>10} {'min_us':>10} {'max_us':>10} {'%':>6} {'vgpr':>5} {'agpr':>5} {'sgpr':>5} "
                   f"{'scratch':>7} {'lds':>6} {'grid':>10} {'wg':>4}")
             for r in rows:
-                print(f"{r[0][:100]:<100} {r[1]:>5} {r[2] / 1e3:>10.1f} {r[3] / 1e3:>10.1f} {r[4] / 1e3:>10.1f} {100 * r[5] / tot:>6.1f} "
+                print(f"{r[0][:100]:<100} {r[1]:>5} {r[2] / 1e3:>10.1f} {med.get(r[0], 0.0) / 1e3:>10.1f} {r[3] / 1e3:>10.1f} {r[4] / 1e3:>10.1f} {100 * r[5] / tot:>6.1f} "
                       f"{r[6]:>5} {r[7]:>5} {r[8]:>5} {r[9]:>7} {r[10]:>6} {r[11]:>10} {r[12]:>4}")
         except sqlite3.Error as e:
             print("  (no kernel table)", e)

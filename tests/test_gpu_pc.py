@@ -131,7 +131,7 @@ def test_placement_tuning_changes_nothing_but_the_allocation(ctx):
     n = 36000                                            # x 32 KB of state per chain > 1 GiB
     a = bh.Chains(Po, case.x0, n, seed=9)
     info = a.placement()
-    assert 1 <= info["tries"] <= 4 and info["ms_best"] > 0 and info["ms_first"] > 0
+    assert 1 <= info["tries"] <= 6 and info["ms_best"] > 0 and info["ms_first"] > 0
     assert info["ms_best"] <= 1.05 * info["ms_first"]      # the pair that was kept is never slower than the same-piece reference
     a.step(0.9, 3)
     ctx.set_option(bh.OPT_TUNE_PLACEMENT, 0)
