@@ -260,3 +260,33 @@ def test_bench_without_launcher_refuses_more_gpus_than_visible():
     assert r.returncode == 2, r.stderr[-1500:]
     assert f"--gpus {n} but only {n - 1} device(s) visible" in r.stderr and "torch.distributed.run" not in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_context_options_are_validated():
+    """bhip_ctx_set_option on a host-only context: the value ranges of the round-4 options (BHIP_OPT_NOISE_SPEC: 3 | 2;
+    BHIP_OPT_MID_VALU: 0, 1 or the largest dimension 4..12 that runs one path per lane), unknown options refused with a message"""
+    c = bh.Context(-1)
+    lib = c.lib
+    for v in (3, 2, 3):
+        assert lib.bhip_ctx_set_option(c.h, bh.OPT_NOISE_SPEC, v) == 0
+    for v in (0, 1, 4, -2):
+        assert lib.bhip_ctx_set_option(c.h, bh.OPT_NOISE_SPEC, v) == -1
+        assert b"NOISE_SPEC" in lib.bhip_last_error(c.h)
+    for v in (0, 1, 4, 8, 10, 12, 1):
+        assert lib.bhip_ctx_set_option(c.h, bh.OPT_MID_VALU, v) == 0
+    for v in (2, 3, 13, -1):
+        assert lib.bhip_ctx_set_option(c.h, bh.OPT_MID_VALU, v) == -1
+    for opt in (bh.OPT_WAVE_SPECIALISED, bh.OPT_TUNE_PLACEMENT, bh.OPT_FUSED_ARITHMETIC):
+        assert lib.bhip_ctx_set_option(c.h, opt, 0) == 0 and lib.bhip_ctx_set_option(c.h, opt, 1) == 0
+    assert lib.bhip_ctx_set_option(c.h, 99, 1) == -1 and b"unknown option" in lib.bhip_last_error(c.h)
+    assert lib.bhip_ctx_set_option(None, bh.OPT_NOISE_SPEC, 2) == -1
+
+
+def test_group_entry_points_reject_bad_arguments_without_a_device():
+    lib = bh._lib.load()
+    assert lib.bhip_chains_step_group(0, None, 0.9, 1, 0) == -1
+    assert lib.bhip_chains_step_group(2, None, 0.9, 1, 0) == -1
+    assert lib.bhip_chains_stats_group(1, None, None) == -1
+    hs = (C.c_void_p * 2)(None, None)
+    assert lib.bhip_chains_step_group(2, hs, 0.9, 1, 0) == -1
+    assert lib.bhip_chains_step_group(65, hs, 0.9, 1, 0) == -1
