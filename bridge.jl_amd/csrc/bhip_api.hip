@@ -1369,7 +1369,7 @@ int bhip_innovations(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev
     SAME_CTX(ctx, po);
     if (po->mh.d != po->mh.mp) return fail(ctx, BHIP_EINVAL, "bhip_innovations: needs a square, invertible sigma (d == m')");
     if (po->mh.d > 3 && !(po->mid && po->mh.d <= ctx->mid_max))
-        return fail(ctx, BHIP_EUNSUPPORTED, "innovations: d <= 3, or a LinPro target of dimension 4..8 (the path-per-lane kernels)");
+        return fail(ctx, BHIP_EUNSUPPORTED, "innovations: d <= 3, or a LinPro target of a dimension that runs one path per lane (4..10 by default, up to 12 with BHIP_OPT_MID_VALU)");
     if (po->g.kind == BHIP_GUIDE_NONE) {
         int rc = ensure_plain_rows(const_cast<bhip_proposal *>(po));
         if (rc) return rc;

@@ -235,6 +235,16 @@ def test_dimensions_4_to_12_run_one_path_per_lane(ctx, d):
     agreement with the tile kernel (BHIP_OPT_MID_VALU = 0), ragged ensemble sizes, plain Euler-Maruyama, per-path starts, innovations!, pCN chains
     (slots) against the oracle, a saved state and the tile kernel's chains."""
     c = problems.linpro_big_case(d, 81)
+    if d > 10:
+        ctx.set_option(bh.OPT_MID_VALU, d)      # 11 and 12 are instantiated but lie beyond the default cut (10)
+    try:
+        _lanes_at_dimension(ctx, c, d)
+    finally:
+        ctx.set_option(bh.OPT_MID_VALU, 1)
+
+
+def _lanes_at_dimension(ctx, c, d):
+    mid = d if d > 10 else 1
     Po, ref = c.bh_proposal(bh, ctx), c.oracle_proposal()
     for P in (150, 256 + 17):
         X, W, ll = bh.sample_solve(c.x0, Po, P, seed=6, iter=2, path0=100, store_W=True)
@@ -254,7 +264,7 @@ def test_dimensions_4_to_12_run_one_path_per_lane(ctx, d):
         try:
             Xp, Wp, llp = bh.sample_solve(c.x0, Po, P, seed=6, iter=2, path0=100, store_W=True)
         finally:
-            ctx.set_option(bh.OPT_MID_VALU, 1)
+            ctx.set_option(bh.OPT_MID_VALU, mid)
         assert torch.equal(Wp.data, W.data)
         assert float((Xp.data - X.data).abs().max()) <= 1e-9 * (1 + float(X.data.abs().max()))
         assert float((llp - ll).abs().max()) <= 1e-8 * (1 + float(ll.abs().max()))
@@ -311,7 +321,7 @@ def test_dimensions_4_to_12_run_one_path_per_lane(ctx, d):
         Xt, Wt = cht.paths(0, n)
         acct, llt = cht.acc(), cht.ll()
     finally:
-        ctx.set_option(bh.OPT_MID_VALU, 1)
+        ctx.set_option(bh.OPT_MID_VALU, mid)
     assert np.array_equal(acct, acc) and np.array_equal(Wt, Wc)
     assert np.abs(Xt - Xc).max() <= 1e-9 * (1 + np.abs(Xc).max()) and np.abs(llt - llc).max() <= 1e-8 * (1 + np.abs(llc).max())
 
