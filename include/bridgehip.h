@@ -364,6 +364,8 @@ int bhip_segchains_init(bhip_segchains *sc, const double *mu, const double *chol
 /* `iters` iterations; w_old[it], w_new[it] host arrays of length iters */
 int bhip_segchains_step(bhip_segchains *sc, const double *w_old, const double *w_new, int iters);
 /* host outputs (any may be NULL): ll [m][nchains] (current, per segment), acc [nchains], y0 [nchains][d] */
+/* bhip_chains_placement_info of segment `segment` (large segments are placed at bhip_segchains_init: BHIP_OPT_TUNE_PLACEMENT) */
+int bhip_segchains_placement_info(const bhip_segchains *sc, int segment, int *tries, float *ms_first, float *ms_best);
 int bhip_segchains_get(bhip_segchains *sc, double *ll, int64_t *acc, double *y0);
 /* current paths of chains p0..p0+np of one segment as AoS host arrays: X [np][N][d], W [np][N][mp] */
 int bhip_segchains_get_paths(bhip_segchains *sc, int segment, long p0, long np, double *X_aos, double *W_aos);

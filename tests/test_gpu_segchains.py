@@ -190,3 +190,38 @@ def test_joint_mh_over_segments_at_large_dimension(ctx, d):
         Xa, _ = sc.paths(i, 0, n)
         Xb, _ = sc.paths(i + 1, 0, n)
         assert np.array_equal(Xa[:, -1, :], Xb[:, 0, :])
+
+
+def test_large_segments_are_placed_and_results_do_not_depend_on_it(ctx):
+    """Segments of 1 GiB or more keep W and Xo in two contiguous allocations (bhip_api.hip chains_alloc_state); bhip_segchains_init
+    places every such pair (different 96-GiB pieces of the device memory, measured: chains_place) before the ensemble's state is set
+    up.  Decisions, log-likelihoods, starts and paths are those of the ensemble that was not placed (BHIP_OPT_TUNE_PLACEMENT = 0)."""
+    import ctypes as C
+    import torch
+    segs, refs, mu, chol, d = build_segments(ctx, "linpro2", m=2, M=512)     # 2 x 513 grid points, d = m' = 2
+    n = 72000                                                                # x (2 x 33 lines x 128 B + 513 x 2 x 8 B) = 1.2 GB per segment
+    w_old, w_new = np.sqrt(1 - 0.8) * np.ones(3), np.sqrt(0.8) * np.ones(3)
+    outs = []
+    for tune in (1, 0):
+        ctx.set_option(bh.OPT_TUNE_PLACEMENT, tune)
+        try:
+            sc = bh.SegChains(segs, mu, chol, n, seed=3, mcnext=False)
+            info = []
+            for i in range(2):
+                t, a, b = C.c_int(), C.c_float(), C.c_float()
+                ctx.check(ctx.lib.bhip_segchains_placement_info(sc.h, i, C.byref(t), C.byref(a), C.byref(b)))
+                info.append(t.value)
+            sc.step(w_old, w_new)
+            ll, acc, y0 = sc.state()
+            X = sc.paths(1, n - 2, 2)[0]
+            outs.append((ll, acc, y0, X, info))
+            del sc
+            torch.cuda.empty_cache()
+        finally:
+            ctx.set_option(bh.OPT_TUNE_PLACEMENT, 1)
+    (lla, acca, y0a, Xa, ia), (llb, accb, y0b, Xb, ib) = outs
+    assert np.array_equal(lla, llb) and np.array_equal(acca, accb) and np.array_equal(y0a, y0b) and np.array_equal(Xa, Xb)
+    assert acca.sum() > 0
+    assert all(1 <= t <= 6 for t in ia) and all(t == 0 for t in ib)
+    r = o.smooth_mcmc(refs, mu, chol, w_old, w_new, 3, n - 1)
+    assert acca[n - 1] == r["acc"] and np.array_equal(Xa[1], r["X"][1])
