@@ -395,7 +395,9 @@ def kernel_times(w, steps, warmup, min_ms=0.0):
     return [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
 
 
-SMOOTH_MOVED_BYTES = 64 + 24 + 48 + 192   # what the implementation moves per path-step (padded W lines, Xo store, Xo -> Xc commit copy, mcnext! state)
+# what the implementation moves per path-step: padded W lines read + written 64, Xo store 24, the commit's 72 (with one lane per chain
+# and random decisions every 128-byte line of Xo AND of Xc is read, and the lines of Xc are written back), mcnext! state 192
+SMOOTH_MOVED_BYTES = 64 + 24 + 72 + 192
 
 
 def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
@@ -427,15 +429,25 @@ def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
             ev[j].record(); fn()
         ev[k].record(); torch.cuda.synchronize()
         return float(np.mean([ev[j].elapsed_time(ev[j + 1]) for j in range(k)]))
+    def t_iters(s, k, rounds=3):
+        # `k` iterations in ONE call (the library runs the commit + mcnext! of an iteration on its own stream beside the next
+        # iteration's proposals and joins the streams before the call returns: the join is inside the timed region)
+        s.step(wo, wn, 2); torch.cuda.synchronize()
+        out = []
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); s.step(wo, wn, k); e1.record(); torch.cuda.synchronize()
+            out.append(e0.elapsed_time(e1) / k)
+        return float(np.median(out))
     ps = n * m * M
-    ms_sh = t(lambda: sc.step(wo, wn, 1), reps)
+    ms_sh = t_iters(sc, 2 * reps)
     ms_ad = t(lambda: sc.adapt_device(L, Sig, obs[:m], HT, vT), max(2, reps // 2))
-    ms_pc = t(lambda: sc.step(wo, wn, 1), reps)
+    ms_pc = t_iters(sc, 2 * reps)
     ok = bool(np.isfinite(sc.state()[0]).all())
     del sc
     torch.cuda.empty_cache()
     sm = bh.SegChains(segs, v, bh.cholupper_t(H), n, seed=1, mcnext_mean_only=True)   # the economy option: running means only
-    ms_mo = t(lambda: sm.step(wo, wn, 1), reps)
+    ms_mo = t_iters(sm, 2 * reps)
     del sm
     torch.cuda.empty_cache()
     # ALGORITHMIC bytes per path-step = what the reference's loop must move (smoothing.jl:160-213 swaps references on accept, it

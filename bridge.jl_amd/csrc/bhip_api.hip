@@ -208,6 +208,9 @@ struct bhip_chains {
     Arena arena;            // the allocation behind Wc / Xo
     double *Wc = nullptr;   // W slots [N][mp][ld][2]  |  lines [nch][ld][2][16]
     double *Xo = nullptr;   // proposal paths [N][d][ld] (BHIP_CHAINS_STORE_X); lives behind Wc in the same allocation
+    // multi-segment chains with time-blocked paths (bhip_segchains.inc owns the memory): deferred proposals go there instead of Xo
+    double *Xtb = nullptr, *xend = nullptr;
+    long xtb_half = 0;
     size_t wbytes = 0, xbytes = 0;
     // placement tuning (bhip_chains_init): allocations tried, ms per pCN iteration of the first and of the chosen one
     int place_tries = 0;
@@ -1170,7 +1173,8 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
     const bool v2 = a.noise_spec == 2;
     if (v2 && noise == NOISE_PCN)
         return fail(ctx, BHIP_EUNSUPPORTED, "BHIP_OPT_NOISE_SPEC = 2: the pCN step on the 16-byte slots draws the default noise stream only");
-    const bool wave_spec = ctx->wave_specialised || v2;
+    const bool wave_spec = ctx->wave_specialised || v2 || a.Xtb;   // (time-blocked path stores exist in the wave-specialised kernel only)
+    if (a.Xtb && !(noise == NOISE_PCN_LINES && a.rdtp && po->mh.mp <= 3 && a.wstride == 1 && !po->mid)) return fail(ctx, BHIP_ESTATE, "time-blocked paths need the line layout");
     if (po->mid) {   // LinPro, d = 4..12: rows in the (nu, H) form, one kernel family
         const int gkm = po->g.kind == BHIP_GUIDE_NONE ? BHIP_GUIDE_NONE : BHIP_GUIDE_NUH;
         if (a.rs != row_stride(gkm, po->mh.d, 1, true)) return fail(ctx, BHIP_ESTATE, "row stride mismatch");
@@ -1251,7 +1255,8 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         void *params[] = {&args};
         if (npair > 0) {
             const int spc = LINE_DOUBLES / line_mpp(po->mh.mp);
-            const unsigned lds = npair == 1 ? (unsigned)PC_LDS : (unsigned)(sizeof(double) * (RNG_TAB_DOUBLES + npair * (2 * PC_TILE + 2 * spc * a.rs)));
+            const unsigned lds = (npair == 1 ? (unsigned)PC_LDS : (unsigned)(sizeof(double) * (RNG_TAB_DOUBLES + npair * (2 * PC_TILE + 2 * spc * a.rs)))) +
+                                 (a.Xtb ? (unsigned)pc_xs_bytes(po->mh.d, npair) : 0u);
             HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)((groups + npair - 1) / npair), 1, 1, 128 * npair, 1, 1, lds, ctx->stream, params, nullptr));
             return BHIP_OK;
         }
@@ -1743,7 +1748,8 @@ static int launch_ppr(bhip_chains *ch, int noise, KArgs &a)
     const int fl = (noise == NOISE_PCN || noise == NOISE_PCN_LINES) ? (a.Xo ? 1 : 0) : 0;
     // (bit 1 of the selector: the monolithic line kernel instead of the wave-specialised one)
     if (a.noise_spec == 2 && noise == NOISE_PCN) return fail(ctx, BHIP_EUNSUPPORTED, "BHIP_OPT_NOISE_SPEC = 2: the pCN step on the 16-byte slots draws the default noise stream only");
-    launch_fn f = find_launch_ppr(po->mh, noise, fl | ((noise == NOISE_PCN_LINES && !((ctx->wave_specialised || a.noise_spec == 2) && a.rdtp)) ? 2 : 0));
+    if (a.Xtb && !(noise == NOISE_PCN_LINES && a.rdtp)) return fail(ctx, BHIP_ESTATE, "time-blocked paths need the line layout");
+    launch_fn f = find_launch_ppr(po->mh, noise, fl | ((noise == NOISE_PCN_LINES && !((ctx->wave_specialised || a.noise_spec == 2 || a.Xtb) && a.rdtp)) ? 2 : 0));
     if (!f) return fail(ctx, BHIP_EUNSUPPORTED, "no per-chain-guide kernel for this model");
     HIPCHK(ctx, f(a, ctx->stream));
     return BHIP_OK;
@@ -1761,6 +1767,7 @@ static int chains_propose_deferred(bhip_chains *ch, double w_old, double w_new, 
     if (rc) return rc;
     a.x0_dev = x0_dev; a.ldx0 = ldx0; a.blk0 = blk0; a.defer_accept = 1; a.ll = llo_dev;
     a.Wc = ch->Wc; a.Xo = ch->Xo; a.ldC = ch->ld;
+    if (ch->Xtb) { a.Xo = nullptr; a.Xtb = ch->Xtb; a.xtb_half = ch->xtb_half; a.xend = ch->xend; }   // (the instantiation without the plain X store)
     a.cur = ch->cur; a.llcur = ch->llcur; a.acc = ch->acc;
     a.rho = w_old; a.srho = w_new;
     a.k0 = (uint32_t)ch->seed; a.k1 = (uint32_t)(ch->seed >> 32); a.path0 = ch->path0; a.iter = iter;

@@ -54,6 +54,10 @@ enum { NOISE_FRESH_PC = 6, NOISE_PCN_LINES_PC = 7 };
 #endif
 constexpr int PC_TILE = 64 * LINE_ROW;                          // doubles per hand-over tile
 constexpr size_t PC_LDS = sizeof(double) * (RNG_TAB_DOUBLES + 2 * PC_TILE);   // 19 984 bytes: 8 workgroups per CU
+// time-blocked path stores (KArgs::Xtb): a consumer lane collects eight grid points of its chain in LDS -- [k][8] + 2 doubles of padding
+// per lane -- and writes them as 64 contiguous bytes per component
+constexpr int pc_xs_row(int d) { return 8 * d + 2; }
+constexpr size_t pc_xs_bytes(int d, int npair) { return sizeof(double) * 64 * pc_xs_row(d) * npair; }
 typedef const __attribute__((address_space(3))) double *ldsrow_t;
 
 // The hand-over barrier of a chunk: the wave's LDS operations are done, the workgroup meets.  NOT __syncthreads: its
@@ -110,6 +114,8 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
     const int wave = threadIdx.x >> 6, pair = wave % NPAIR, role = wave / NPAIR;   // waves 0..NPAIR-1 produce, the others consume
     double *pc_lds = pc_lds_all + RNG_TAB_DOUBLES + pair * (2 * PC_TILE + (RLDS ? 2 * CROW : 0));   // [2][PC_TILE] then (RLDS) [2][CROW]
     double *crow = pc_lds + 2 * PC_TILE;
+    // (time-blocked path stores: the consumers' staging rows lie behind the pairs' tiles -- allocated by the launch only when a.Xtb is set)
+    double *xs_all = pc_lds_all + RNG_TAB_DOUBLES + NPAIR * (2 * PC_TILE + (RLDS ? 2 * CROW : 0));
     TabLDS::load(tab, threadIdx.x, 128 * NPAIR);
     __syncthreads();
 
@@ -301,6 +307,37 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
     LaneState<D, MP> st;
 #pragma unroll
     for (int k = 0; k < D; k++) st.y[k] = a.x0_dev ? a.x0_dev[k * a.ldx0 + p] : a.x0[k];
+    // time-blocked path stores (multi-segment chains): yy[i] = y is collected per lane in LDS and leaves as 64 contiguous bytes per
+    // component when a block of eight grid points is complete, into the half of the chain's pair that is NOT its current path
+    constexpr bool TBX = PCN && (FL & 1) == 0;
+    constexpr int XSR = pc_xs_row(D);
+    double *xs = nullptr;
+    char *xlane = nullptr;
+    bool xtb = false;
+    if constexpr (TBX) {
+        xtb = a.Xtb != nullptr;
+        if (xtb) {
+            xs = xs_all + pair * (64 * XSR) + lane * XSR;
+            xlane = (char *)(a.Xtb + (size_t)((a.cur[p] & 1) ^ 1) * a.xtb_half) + (size_t)p * 64;
+        }
+    }
+    auto flush_x = [&](int blk) {
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            d2v *dst = (d2v *)(xlane + ((size_t)blk * D + k) * (size_t)a.ldC * 64);
+#pragma unroll
+            for (int q = 0; q < 4; q++) st_stream(dst + q, *(const d2v *)(xs + k * 8 + 2 * q));
+        }
+    };
+    auto stage_x = [&](int i) {   // yy[i] = y, BEFORE the update (src/euler.jl:263)
+        if constexpr (TBX) {
+            if (xtb) {
+#pragma unroll
+                for (int k = 0; k < D; k++) xs[k * 8 + (i & 7)] = st.y[k];
+                if ((i & 7) == 7) flush_x(i >> 3);
+            }
+        }
+    };
     // The per-chain start is the consumer's only vector load.  Left to itself the compiler defers the wait for it to the first use
     // of the state it can find on every path -- the join block at the end of a chunk, INSIDE the chunk loop: an s_waitcnt vmcnt(0)
     // per chunk, i.e. a wait for the acknowledgement of every path store the wave has issued, once per chunk.  Waiting here,
@@ -353,6 +390,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
 #pragma unroll
                     for (int c = 0; c < MP; c++) wn[c] = mine[s * MPP + c];
                     const int i = j0 + s - 1;
+                    stage_x(i);
 #ifdef PC_KNOCKOUT_STEP   /* measurement only: what the producer alone costs */
                     st.ll += wn[0];
 #else
@@ -367,6 +405,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
                 for (int s = 0; s < SPC; s++) {
                     const int i = j0 + s - 1;
                     if (i < 0 || i >= nsteps) continue;
+                    stage_x(i);
                     double wn[MP];
 #pragma unroll
                     for (int c = 0; c < MP; c++) wn[c] = mine[s * MPP + c];
@@ -394,6 +433,17 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
     if constexpr ((FL & 1) != 0) {
 #pragma unroll
         for (int k = 0; k < D; k++) st_stream(&xout[((size_t)(N - 1) * D + k) * ldx + p], st.y[k]);
+    }
+    if constexpr (TBX) {
+        if (xtb) {   // the end point closes the last block (its tail beyond N - 1 is padding)
+#pragma unroll
+            for (int k = 0; k < D; k++) xs[k * 8 + ((N - 1) & 7)] = st.y[k];
+            flush_x((N - 1) >> 3);
+            if (a.xend) {
+#pragma unroll
+                for (int k = 0; k < D; k++) a.xend[(size_t)k * a.ldC + p] = st.y[k];
+            }
+        }
     }
     if constexpr (PCN) {
         // if log(rand()) <= llo - ll: W <- Wo (parity flip), ll <- llo, acc += 1      partialbridge_fitzhugh.jl:160-167
@@ -428,7 +478,8 @@ template <class M, int GK, int MO, int MODE, int FL, int NPAIR, bool PPR = false
 void launch_pc_n(const KArgs &a, hipStream_t st, long groups)
 {
     using RL = RowLayout<GK, M::D, MO, is_constdiff<M>::value>;
-    const size_t lds = NPAIR == 1 ? PC_LDS : sizeof(double) * (RNG_TAB_DOUBLES + NPAIR * (2 * PC_TILE + 2 * (LINE_DOUBLES / line_mpp(M::MP)) * RL::RS));
+    const size_t lds = (NPAIR == 1 ? PC_LDS : sizeof(double) * (RNG_TAB_DOUBLES + NPAIR * (2 * PC_TILE + 2 * (LINE_DOUBLES / line_mpp(M::MP)) * RL::RS))) +
+                       (a.Xtb ? pc_xs_bytes(M::D, NPAIR) : 0);
     // more than the default 64 KB of dynamic LDS: opt in -- per device and cheap, so on every launch (a process may drive several devices)
     if (lds > 65536) (void)hipFuncSetAttribute((const void *)k_pc<M, GK, MO, MODE, FL, NPAIR, PPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_pc<M, GK, MO, MODE, FL, NPAIR, PPR>), dim3((unsigned)((groups + NPAIR - 1) / NPAIR)), dim3(128 * NPAIR), lds, st, a);

@@ -309,13 +309,13 @@ static __global__ void k_seg_y0_big(long n, long ld, int d, double w_old, double
 }
 
 // commit (+ the running means of mcnext!) at any state dimension: blockIdx.y = grid point, blockIdx.z = segment
-static __global__ void k_seg_commit_big(long n, long ld, int N, int m, int d, double *const *__restrict__ tab, const unsigned char *__restrict__ accflag,
-                                        int want_stats, double count)
+static __global__ void k_seg_commit_big(long n, long ld, int N, int m, int d, double *const *__restrict__ tab, int xo /* 0 or 4m: this iteration's Xo */,
+                                        const unsigned char *__restrict__ accflag, int want_stats, double count)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y, sg = blockIdx.z;
     if (p >= n) return;
-    const double *__restrict__ Xo = tab[sg];
+    const double *__restrict__ Xo = tab[xo + sg];
     double *__restrict__ Xc = tab[m + sg];
     double *__restrict__ mean = want_stats ? tab[2 * m + sg] : nullptr;
     const bool a = accflag[p] != 0;
@@ -330,14 +330,14 @@ static __global__ void k_seg_commit_big(long n, long ld, int N, int m, int d, do
 // the same with the full per-chain mcnext! state (mean, m2) at any state dimension d <= 32: 64 chains per workgroup; a chain's
 // delta = x - m and x - m_new (src/mclog.jl:50-54) wait in LDS ([k][lane]: conflict free) while the d*d entries of m2 stream
 // through -- 16 d*d bytes per chain and grid point and iteration, the pass is as long as that state is large.
-static __global__ void __launch_bounds__(64) k_seg_commit_big_m2(long n, long ld, int N, int m, int d, double *const *__restrict__ tab,
+static __global__ void __launch_bounds__(64) k_seg_commit_big_m2(long n, long ld, int N, int m, int d, double *const *__restrict__ tab, int xo,
                                                                  const unsigned char *__restrict__ accflag, double count)
 {
     __shared__ double sh_delta[32 * 64], sh_xm[32 * 64];
     const long p = (long)blockIdx.x * 64 + threadIdx.x;
     const int i = blockIdx.y, sg = blockIdx.z, t = threadIdx.x;
     if (p >= n) return;
-    const double *__restrict__ Xo = tab[sg];
+    const double *__restrict__ Xo = tab[xo + sg];
     double *__restrict__ Xc = tab[m + sg];
     double *__restrict__ mean = tab[2 * m + sg];
     double *__restrict__ m2 = tab[3 * m + sg];
@@ -366,7 +366,8 @@ static __global__ void __launch_bounds__(64) k_seg_commit_big_m2(long n, long ld
 static __global__ void k_seg_accept(long n, long ld, int m, int d, const double *__restrict__ llo, double *__restrict__ ll,
                                     unsigned char *__restrict__ cur, unsigned int *__restrict__ acc, unsigned char *__restrict__ accflag,
                                     double *__restrict__ y0, const double *__restrict__ y0o, uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0,
-                                    unsigned char *__restrict__ newblock, int doaccept /* smoothing.jl:156-158,193: the first adaptive proposal is accepted */)
+                                    unsigned char *__restrict__ newblock, int doaccept /* smoothing.jl:156-158,193: the first adaptive proposal is accepted */,
+                                    unsigned char *__restrict__ cursnap /* time-blocked paths: the parities AFTER this decision, for the commit on the second stream */)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -375,6 +376,7 @@ static __global__ void k_seg_accept(long n, long ld, int m, int d, const double 
     const double u = accept_uniform(k0, k1, path0 + (uint32_t)p, iter);
     const bool ok = doaccept || det_log(u) <= lls;
     accflag[p] = ok ? 1 : 0;
+    if (cursnap) cursnap[p] = (unsigned char)(cur[p] ^ (ok ? 1 : 0));
     if (ok) {
         if (newblock) newblock[p] = 0;
         cur[p] ^= 1;
@@ -387,14 +389,14 @@ static __global__ void k_seg_accept(long n, long ld, int m, int d, const double 
 // accepted chains: Xc <- Xo;  then (optionally) mcnext! of every chain with its current path:
 //   delta = x - m; m += delta/(n+1); m2 += outer(delta, x - m)        src/mclog.jl:48-56
 // (all m segments in ONE launch: blockIdx.z = segment, the per-segment arrays come from a device table
-//  tab[0..m) = Xo, tab[m..2m) = Xc, tab[2m..3m) = mean, tab[3m..4m) = m2)
+//  tab[0..m) = Xo of the even iterations, tab[m..2m) = Xc, tab[2m..3m) = mean, tab[3m..4m) = m2, tab[4m..5m) = Xo of the odd ones)
 template <int D>
-__global__ void k_seg_commit(long n, long ld, int N, int m, double *const *__restrict__ tab, const unsigned char *__restrict__ accflag, int want_stats, double count)
+__global__ void k_seg_commit(long n, long ld, int N, int m, double *const *__restrict__ tab, int xo, const unsigned char *__restrict__ accflag, int want_stats, double count)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y, sg = blockIdx.z;
     if (p >= n) return;
-    const double *__restrict__ Xo = tab[sg];
+    const double *__restrict__ Xo = tab[xo + sg];
     double *__restrict__ Xc = tab[m + sg];
     double *__restrict__ mean = want_stats ? tab[2 * m + sg] : nullptr;
     double *__restrict__ m2 = want_stats ? tab[3 * m + sg] : nullptr;   // null: the means only (BHIP_SEGCHAINS_MCNEXT_MEAN)
@@ -427,6 +429,82 @@ __global__ void k_seg_commit(long n, long ld, int N, int m, double *const *__res
                 }
         }
     }
+}
+
+// ---- the same loop on TIME-BLOCKED paths (KArgs::Xtb, bhip_path_kernel.h): eight grid points of one chain are 64 contiguous bytes and the
+// chain's current path is the half its parity names -- an accept copies nothing and mcnext! reads exactly the current paths (with plain
+// SoA paths and one lane per chain every line of the proposal AND of the current paths is fetched, and the lines of the accepted ones
+// written back: 72 bytes per grid point at d = 3 where 24 are needed).
+// mcnext! of every chain with its current path, all segments in one launch: blockIdx.y = block of eight grid points, blockIdx.z = segment;
+// tab[0..m) = Xtb, tab[2m..3m) = mean, tab[3m..4m) = m2 (plain SoA [N][D(*D)][ld], as in k_seg_commit)
+template <int D>
+__global__ void k_seg_mcnext_tb(long n, long ld, int N, int m, double *const *__restrict__ tab, long half, const unsigned char *__restrict__ cursnap, double count)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int blk = blockIdx.y, sg = blockIdx.z;
+    if (p >= n) return;
+    const double *__restrict__ X = tab[sg] + (size_t)(cursnap[p] & 1) * half;
+    double *__restrict__ mean = tab[2 * m + sg];
+    double *__restrict__ m2 = tab[3 * m + sg];   // null: the means only (BHIP_SEGCHAINS_MCNEXT_MEAN)
+    double x[D][8];
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        const d2v *src = (const d2v *)(X + (((size_t)blk * D + k) * ld + p) * 8);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const d2v v = ld_stream(src + q); x[k][2 * q] = v.x; x[k][2 * q + 1] = v.y; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int i = blk * 8 + j;
+        if (i < N) {
+            double delta[D], xm[D];
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+                const size_t e = ((size_t)i * D + k) * ld + p;
+                const double mk = mean[e];
+                delta[k] = x[k][j] - mk;
+                const double mn = mk + delta[k] / (count + 1.0);
+                mean[e] = mn;
+                xm[k] = x[k][j] - mn;
+            }
+            if (m2) {
+#pragma unroll
+                for (int c = 0; c < D; c++)
+#pragma unroll
+                    for (int r = 0; r < D; r++) {
+                        const size_t e = ((size_t)i * D * D + r + D * c) * ld + p;
+                        m2[e] = m2[e] + delta[r] * xm[c];
+                    }
+            }
+        }
+    }
+}
+
+// time-blocked half `h` (per chain: cur[p] ^ flip, or 0 without cur) <-> plain SoA [N][d][ld]: the chains' current paths for whoever reads
+// them in the library's common layout (getters, llikelihood under new proposals), and the initial paths the other way
+static __global__ void k_tb_to_soa(long n, long ld, int N, int d, const double *__restrict__ Xtb, long half, const unsigned char *__restrict__ cur, double *__restrict__ Xs)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int blk = blockIdx.y;
+    if (p >= n) return;
+    const double *X = Xtb + (size_t)(cur ? (cur[p] & 1) : 0) * half;
+    for (int k = 0; k < d; k++)
+        for (int j = 0; j < 8; j++) {
+            const int i = blk * 8 + j;
+            if (i < N) Xs[((size_t)i * d + k) * ld + p] = X[(((size_t)blk * d + k) * ld + p) * 8 + j];
+        }
+}
+static __global__ void k_soa_to_tb(long n, long ld, int N, int d, const double *__restrict__ Xs, double *__restrict__ Xtb, long half, const unsigned char *__restrict__ cur)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int blk = blockIdx.y;
+    if (p >= n) return;
+    double *X = Xtb + (size_t)(cur ? (cur[p] & 1) : 0) * half;
+    for (int k = 0; k < d; k++)
+        for (int j = 0; j < 8; j++) {
+            const int i = blk * 8 + j;
+            X[(((size_t)blk * d + k) * ld + p) * 8 + j] = i < N ? Xs[((size_t)i * d + k) * ld + p] : 0.0;
+        }
 }
 
 

@@ -87,6 +87,80 @@ def test_joint_mh_over_segments_equals_oracle(ctx, kind):
         assert np.array_equal(Xa[:, -1, :], Xb[:, 0, :])
 
 
+@pytest.mark.parametrize("kind,pooled", [("lorenz", True), ("linpro2", True), ("lorenz", False), ("linpro2", False), ("ou1", False)])
+def test_commit_stream_overlap_changes_nothing(ctx, kind, pooled):
+    """The commit + mcnext! of iteration t runs on the library's second stream beside the proposals of iteration t + 1
+    (bhip_segchains.inc): nine iterations in ONE call -- commits overlapped, buffer reuse waited for -- leave exactly the state
+    that nine single-iteration calls (each joined before it returns) leave, at a size where the kernels really run side by
+    side.  pooled: plain SoA paths, two proposal buffers, commit copy, the pooled kernels behind the commit on the second
+    stream; otherwise (d <= 3): time-blocked paths in parity halves, mcnext! alone on the second stream."""
+    segs, refs, mu, chol, d = build_segments(ctx, kind, m=3, M=64)
+    n, iters = 20000, 9
+    rng = np.random.default_rng(3)
+    rho_ = np.exp(-0.5 * rng.exponential(size=iters))
+    w_new, w_old = np.sqrt(rho_), np.sqrt(1 - rho_)
+    a = bh.SegChains(segs, mu, chol, n, seed=23, mcnext=True, pooled=pooled)
+    b = bh.SegChains(segs, mu, chol, n, seed=23, mcnext=True, pooled=pooled)
+    a.step(w_old, w_new)
+    for it in range(iters):
+        b.step(w_old[it:it + 1], w_new[it:it + 1])
+    for x, y in zip(a.state(), b.state()):
+        assert np.array_equal(x, y)
+    assert 0 < a.state()[1].sum() < n * iters
+    for i in range(len(segs)):
+        Xa, Wa = a.paths(i, 0, n)
+        Xb, Wb = b.paths(i, 0, n)
+        assert np.array_equal(Xa, Xb) and np.array_equal(Wa, Wb)
+        for p in (0, 777, n - 1):
+            for u, v in zip(a.mcstats(i, p), b.mcstats(i, p)):
+                assert np.array_equal(u, v)
+        if pooled:
+            for u, v in zip(a.pooled_stats(i), b.pooled_stats(i)):
+                assert np.array_equal(u, v)
+    # and against the oracle for one chain
+    r = o.smooth_mcmc(refs, mu, chol, w_old, w_new, 23, 777, stats=True)
+    for i in range(len(segs)):
+        assert np.array_equal(a.paths(i, 777, 1)[0][0], r["X"][i])
+        mean, m2, cnt = a.mcstats(i, 777)
+        assert cnt == iters and np.array_equal(mean, r["mean"][i]) and np.array_equal(m2, r["m2"][i])
+
+
+@pytest.mark.parametrize("kind", ["lorenz", "linpro2", "ou1"])
+def test_time_blocked_paths_equal_plain_paths(ctx, kind, monkeypatch):
+    """d <= 3 without pooled statistics keeps the segments' paths time-blocked in parity halves (accept = parity flip, mcnext!
+    reads the current halves); BHIP_SEG_PLAIN_X=1 at creation keeps the plain SoA paths with the commit copy.  Same chains,
+    bit for bit, also with a grid whose length is not a multiple of the block (N = 51) and a chain count that is no multiple
+    of 64; the means-only statistics and no statistics at all take the same route."""
+    segs, refs, mu, chol, d = build_segments(ctx, kind, m=3, M=50)
+    n, iters = 333, 8
+    rng = np.random.default_rng(11)
+    rho_ = np.exp(-0.5 * rng.exponential(size=iters))
+    w_new, w_old = np.sqrt(rho_), np.sqrt(1 - rho_)
+    for kw in ({"mcnext": True}, {"mcnext_mean_only": True}, {}):
+        tb = bh.SegChains(segs, mu, chol, n, seed=3, path0=7, **kw)
+        monkeypatch.setenv("BHIP_SEG_PLAIN_X", "1")
+        pl = bh.SegChains(segs, mu, chol, n, seed=3, path0=7, **kw)
+        monkeypatch.delenv("BHIP_SEG_PLAIN_X")
+        for c in (tb, pl):
+            c.step(w_old[:5], w_new[:5])
+        X_mid = [tb.paths(i, 0, n)[0] for i in range(3)]          # (materialises the plain-layout current paths in between)
+        for i in range(3):
+            assert np.array_equal(X_mid[i], pl.paths(i, 0, n)[0])
+        for c in (tb, pl):
+            c.step(w_old[5:], w_new[5:])
+        for x, y in zip(tb.state(), pl.state()):
+            assert np.array_equal(x, y)
+        for i in range(3):
+            Xa, Wa = tb.paths(i, 0, n)
+            Xb, Wb = pl.paths(i, 0, n)
+            assert np.array_equal(Xa, Xb) and np.array_equal(Wa, Wb)
+            assert not np.array_equal(Xa, X_mid[i])
+            if kw:
+                for p in (0, 64, n - 1):
+                    for u, v in zip(tb.mcstats(i, p), pl.mcstats(i, p)):
+                        assert (u is None and v is None) or np.array_equal(u, v)
+
+
 def test_segchains_argument_checks(ctx):
     segs, refs, mu, chol, d = build_segments(ctx, "ou1", m=2)
     other = bh.GuidedBridge(np.linspace(0, 1, 11), bh.LinPro([[-0.8]], [0.0], [[0.8]]), bh.LinPro([[-0.8]], [0.2], [[0.8]]), [0.1], ctx=ctx)
