@@ -395,9 +395,10 @@ def kernel_times(w, steps, warmup, min_ms=0.0):
     return [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
 
 
-# what the implementation moves per path-step: padded W lines read + written 64, Xo store 24, the commit's 72 (with one lane per chain
-# and random decisions every 128-byte line of Xo AND of Xc is read, and the lines of Xc are written back), mcnext! state 192
-SMOOTH_MOVED_BYTES = 64 + 24 + 72 + 192
+# what the implementation moves per path-step: padded W lines read + written 64, the proposal path into the other parity half 24, mcnext!
+# reads the current half 24 and reads + writes its state 192 (rocprofv3 FETCH + WRITE of the loop's kernels: profiles/r4_smoothing_*.txt;
+# round 3's plain SoA paths with the commit copy moved 64 + 24 + 66 + 192: every line of Xo AND of Xc read, the lines of Xc written back)
+SMOOTH_MOVED_BYTES = 64 + 24 + 24 + 192
 
 
 def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
@@ -452,9 +453,8 @@ def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
     torch.cuda.empty_cache()
     # ALGORITHMIC bytes per path-step = what the reference's loop must move (smoothing.jl:160-213 swaps references on accept, it
     # copies nothing): W read + Wo written 48 (m' = 3), Xo written 24, mcnext! reads X 24 and reads + writes its state
-    # (mean 3 + m2 9 doubles) 192 = 288.  The implementation MOVES more -- the lines pad m' = 3 to 4 (+16) and the accepted
-    # proposal is copied Xo -> Xc (+24 read; the write is the 24 counted above only if the commit replaced the store) -- reported
-    # beside it as `moved_bytes_per_path_step`; the fractions are computed on the algorithmic count.
+    # (mean 3 + m2 9 doubles) 192 = 288.  The implementation MOVES 16 more -- the W lines pad m' = 3 to 4 -- reported beside it as
+    # `moved_bytes_per_path_step`; the fractions are computed on the algorithmic count.
     b_sh = 48 + 24 + 24 + 192
     b_moved = SMOOTH_MOVED_BYTES
     b_pc = b_sh + 120              # + the chain's compact guide row per step: Hd (9), V (3), linearisation point (3)

@@ -96,9 +96,9 @@ struct KArgs {
     const double *vend_pc;        // [D][ldr]
     const unsigned char *uv_pc;   // [ldr]
     // multi-segment chains on the line layout (bhip_segchains.inc; wave-specialised kernel, instantiation without the plain X store): the
-    // paths in the TIME-BLOCKED layout -- eight grid points of ONE chain side by side, 64 bytes, so that whoever reads the current
-    // paths of chains with different parities fetches nothing else: Xtb[h*xtb_half + (((i >> 3)*D + k)*ldC + p)*8 + (i & 7)]; half
-    // cur[p] holds the chain's current path, half cur[p] ^ 1 receives the proposal (like W: accept = parity flip, no copy);
+    // paths in the TIME-BLOCKED layout -- sixteen grid points of ONE chain side by side, one 128-byte line, so that whoever reads the
+    // current paths of chains with different parities fetches nothing else: Xtb[h*xtb_half + (((i >> 4)*D + k)*ldC + p)*16 + (i & 15)];
+    // half cur[p] holds the chain's current path, half cur[p] ^ 1 receives the proposal (like W: accept = parity flip, no copy);
     // xend [D][ldC]: the proposal's end point, the start of the next segment
     double *Xtb;
     long xtb_half;

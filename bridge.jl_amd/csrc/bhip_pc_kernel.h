@@ -54,9 +54,9 @@ enum { NOISE_FRESH_PC = 6, NOISE_PCN_LINES_PC = 7 };
 #endif
 constexpr int PC_TILE = 64 * LINE_ROW;                          // doubles per hand-over tile
 constexpr size_t PC_LDS = sizeof(double) * (RNG_TAB_DOUBLES + 2 * PC_TILE);   // 19 984 bytes: 8 workgroups per CU
-// time-blocked path stores (KArgs::Xtb): a consumer lane collects eight grid points of its chain in LDS -- [k][8] + 2 doubles of padding
-// per lane -- and writes them as 64 contiguous bytes per component
-constexpr int pc_xs_row(int d) { return 8 * d + 2; }
+// time-blocked path stores (KArgs::Xtb): a consumer lane collects sixteen grid points of its chain in LDS -- [k][16] + 1 double of padding
+// per lane: conflict-free 8-byte accesses -- and the wave writes them out as whole 128-byte lines, eight lanes per line
+constexpr int pc_xs_row(int d) { return 16 * d + 1; }
 constexpr size_t pc_xs_bytes(int d, int npair) { return sizeof(double) * 64 * pc_xs_row(d) * npair; }
 typedef const __attribute__((address_space(3))) double *ldsrow_t;
 
@@ -307,34 +307,47 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
     LaneState<D, MP> st;
 #pragma unroll
     for (int k = 0; k < D; k++) st.y[k] = a.x0_dev ? a.x0_dev[k * a.ldx0 + p] : a.x0[k];
-    // time-blocked path stores (multi-segment chains): yy[i] = y is collected per lane in LDS and leaves as 64 contiguous bytes per
-    // component when a block of eight grid points is complete, into the half of the chain's pair that is NOT its current path
+    // time-blocked path stores (multi-segment chains): yy[i] = y is collected per lane in LDS; when a block of sixteen grid points is
+    // complete the wave moves it out like the producer moves the W lines -- instruction q writes the lines of chains c0 + 8q + lane/8,
+    // lane%8 selects 16 bytes: whole 128-byte lines per instruction -- into the half of each chain's pair that is NOT its current path
     constexpr bool TBX = PCN && (FL & 1) == 0;
     constexpr int XSR = pc_xs_row(D);
-    double *xs = nullptr;
+    double *xs = nullptr, *xsw = nullptr;
     char *xlane = nullptr;
+    uint32_t xhb = 0u;
     bool xtb = false;
     if constexpr (TBX) {
         xtb = a.Xtb != nullptr;
         if (xtb) {
-            xs = xs_all + pair * (64 * XSR) + lane * XSR;
-            xlane = (char *)(a.Xtb + (size_t)((a.cur[p] & 1) ^ 1) * a.xtb_half) + (size_t)p * 64;
+            xsw = xs_all + pair * (64 * XSR);
+            xs = xsw + lane * XSR;
+            const int sub = lane >> 3, part = 2 * (lane & 7);
+            xlane = (char *)(a.Xtb + ((size_t)c0 + sub) * 16 + part);
+#pragma unroll
+            for (int q = 0; q < 8; q++)   // cur[] is allocated (and zeroed) up to ld; the proposal goes to the other half
+                xhb |= (uint32_t)((a.cur[c0 + 8 * q + sub] & 1) ^ 1) << q;
         }
     }
     auto flush_x = [&](int blk) {
+        __builtin_amdgcn_wave_barrier();
+        const int sub = lane >> 3, part = 2 * (lane & 7);
 #pragma unroll
         for (int k = 0; k < D; k++) {
-            d2v *dst = (d2v *)(xlane + ((size_t)blk * D + k) * (size_t)a.ldC * 64);
+            char *kb = xlane + ((size_t)blk * D + k) * (size_t)a.ldC * 128;
 #pragma unroll
-            for (int q = 0; q < 4; q++) st_stream(dst + q, *(const d2v *)(xs + k * 8 + 2 * q));
+            for (int q = 0; q < 8; q++) {
+                const double *src = xsw + (8 * q + sub) * XSR + k * 16 + part;
+                st_stream((d2v *)(kb + (size_t)q * (8 * 128) + (size_t)((xhb >> q) & 1u) * ((size_t)a.xtb_half * 8)), d2v{src[0], src[1]});
+            }
         }
+        __builtin_amdgcn_wave_barrier();
     };
     auto stage_x = [&](int i) {   // yy[i] = y, BEFORE the update (src/euler.jl:263)
         if constexpr (TBX) {
             if (xtb) {
 #pragma unroll
-                for (int k = 0; k < D; k++) xs[k * 8 + (i & 7)] = st.y[k];
-                if ((i & 7) == 7) flush_x(i >> 3);
+                for (int k = 0; k < D; k++) xs[k * 16 + (i & 15)] = st.y[k];
+                if ((i & 15) == 15) flush_x(i >> 4);
             }
         }
     };
@@ -437,8 +450,8 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
     if constexpr (TBX) {
         if (xtb) {   // the end point closes the last block (its tail beyond N - 1 is padding)
 #pragma unroll
-            for (int k = 0; k < D; k++) xs[k * 8 + ((N - 1) & 7)] = st.y[k];
-            flush_x((N - 1) >> 3);
+            for (int k = 0; k < D; k++) xs[k * 16 + ((N - 1) & 15)] = st.y[k];
+            flush_x((N - 1) >> 4);
             if (a.xend) {
 #pragma unroll
                 for (int k = 0; k < D; k++) a.xend[(size_t)k * a.ldC + p] = st.y[k];

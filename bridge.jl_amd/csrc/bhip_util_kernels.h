@@ -431,56 +431,97 @@ __global__ void k_seg_commit(long n, long ld, int N, int m, double *const *__res
     }
 }
 
-// ---- the same loop on TIME-BLOCKED paths (KArgs::Xtb, bhip_path_kernel.h): eight grid points of one chain are 64 contiguous bytes and the
+// ---- the same loop on TIME-BLOCKED paths (KArgs::Xtb, bhip_path_kernel.h): sixteen grid points of one chain are one 128-byte line and the
 // chain's current path is the half its parity names -- an accept copies nothing and mcnext! reads exactly the current paths (with plain
 // SoA paths and one lane per chain every line of the proposal AND of the current paths is fetched, and the lines of the accepted ones
 // written back: 72 bytes per grid point at d = 3 where 24 are needed).
-// mcnext! of every chain with its current path, all segments in one launch: blockIdx.y = block of eight grid points, blockIdx.z = segment;
-// tab[0..m) = Xtb, tab[2m..3m) = mean, tab[3m..4m) = m2 (plain SoA [N][D(*D)][ld], as in k_seg_commit)
+// mcnext! of every chain with its current path, all segments in one launch.  A work item = 64 chains x one block of sixteen grid points
+// of one segment; the grid is a fixed number of workgroups that walk the items (gridDim.x apart): beside the wave-specialised proposal
+// kernels, whose workgroups need most of a CU's LDS, only as many workgroups as fit next to them may be resident -- a grid of one
+// workgroup per item would keep every CU's LDS in small pieces and the proposals waiting for the whole pass.  The 64 x D lines of an
+// item come in whole -- eight lanes per line, fetched one item ahead -- into an LDS tile; then thread (c, jq) updates grid points
+// 4jq .. 4jq+3 of chain c, all loads of the state (plain SoA [N][D(*D)][ld], contiguous across the 64 chains) before the first use.
+// tab[0..m) = Xtb, tab[2m..3m) = mean, tab[3m..4m) = m2
 template <int D>
-__global__ void k_seg_mcnext_tb(long n, long ld, int N, int m, double *const *__restrict__ tab, long half, const unsigned char *__restrict__ cursnap, double count)
+__global__ __launch_bounds__(256) void k_seg_mcnext_tb(long n, long ld, int N, int m, double *const *__restrict__ tab, long half,
+                                                       const unsigned char *__restrict__ cursnap, double count, long ngroups, int nblk)
 {
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int blk = blockIdx.y, sg = blockIdx.z;
-    if (p >= n) return;
-    const double *__restrict__ X = tab[sg] + (size_t)(cursnap[p] & 1) * half;
-    double *__restrict__ mean = tab[2 * m + sg];
-    double *__restrict__ m2 = tab[3 * m + sg];   // null: the means only (BHIP_SEGCHAINS_MCNEXT_MEAN)
-    double x[D][8];
+    constexpr int ROW = 16 * D + 1;   // odd: conflict-free 8-byte accesses
+    __shared__ double tile[64 * ROW];
+    const int t = threadIdx.x;
+    const int sub = t >> 3, part = 2 * (t & 7);   // 32 lines per instruction: chains sub, sub + 32 of component k
+    const long items = ngroups * nblk * m;
+    d2v nx[D][2];
+    auto fetch = [&](long w) {
+        const long g = w % ngroups;
+        const int blk = (int)((w / ngroups) % nblk), sg = (int)(w / (ngroups * nblk));
+        const double *X = tab[sg];
 #pragma unroll
-    for (int k = 0; k < D; k++) {
-        const d2v *src = (const d2v *)(X + (((size_t)blk * D + k) * ld + p) * 8);
+        for (int k = 0; k < D; k++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const d2v v = ld_stream(src + q); x[k][2 * q] = v.x; x[k][2 * q + 1] = v.y; }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int i = blk * 8 + j;
-        if (i < N) {
-            double delta[D], xm[D];
-#pragma unroll
-            for (int k = 0; k < D; k++) {
-                const size_t e = ((size_t)i * D + k) * ld + p;
-                const double mk = mean[e];
-                delta[k] = x[k][j] - mk;
-                const double mn = mk + delta[k] / (count + 1.0);
-                mean[e] = mn;
-                xm[k] = x[k][j] - mn;
+            for (int q = 0; q < 2; q++) {
+                const long p = g * 64 + 32 * q + sub;   // (cursnap and the lines are allocated up to ld, a multiple of 64)
+                nx[k][q] = ld_stream((const d2v *)(X + (size_t)(cursnap[p] & 1) * half + (((size_t)blk * D + k) * ld + p) * 16 + part));
             }
-            if (m2) {
+    };
+    long w = blockIdx.x;
+    if (w < items) fetch(w);
+    for (; w < items; w += gridDim.x) {
+        const long g = w % ngroups;
+        const int blk = (int)((w / ngroups) % nblk), sg = (int)(w / (ngroups * nblk));
 #pragma unroll
-                for (int c = 0; c < D; c++)
+        for (int k = 0; k < D; k++)
 #pragma unroll
-                    for (int r = 0; r < D; r++) {
-                        const size_t e = ((size_t)i * D * D + r + D * c) * ld + p;
-                        m2[e] = m2[e] + delta[r] * xm[c];
+            for (int q = 0; q < 2; q++) {
+                double *d = tile + (32 * q + sub) * ROW + k * 16 + part;
+                d[0] = nx[k][q].x; d[1] = nx[k][q].y;
+            }
+        __syncthreads();
+        if (w + gridDim.x < items) fetch(w + gridDim.x);
+        const int c = t & 63, jq = t >> 6;
+        const long p = g * 64 + c;
+        if (p < n) {
+            double *__restrict__ mean = tab[2 * m + sg];
+            double *__restrict__ m2 = tab[3 * m + sg];   // null: the means only (BHIP_SEGCHAINS_MCNEXT_MEAN)
+            double mk[4][D], q2[4][D * D];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = min(blk * 16 + 4 * jq + u, N - 1);
+#pragma unroll
+                for (int k = 0; k < D; k++) mk[u][k] = mean[((size_t)i * D + k) * ld + p];
+                if (m2) {
+#pragma unroll
+                    for (int e = 0; e < D * D; e++) q2[u][e] = m2[((size_t)i * D * D + e) * ld + p];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = 4 * jq + u, i = blk * 16 + j;
+                if (i < N) {
+                    double x[D], delta[D], xm[D];
+#pragma unroll
+                    for (int k = 0; k < D; k++) x[k] = tile[c * ROW + k * 16 + j];
+#pragma unroll
+                    for (int k = 0; k < D; k++) {
+                        delta[k] = x[k] - mk[u][k];
+                        const double mn = mk[u][k] + delta[k] / (count + 1.0);
+                        mean[((size_t)i * D + k) * ld + p] = mn;
+                        xm[k] = x[k] - mn;
                     }
+                    if (m2) {
+#pragma unroll
+                        for (int cc = 0; cc < D; cc++)
+#pragma unroll
+                            for (int r = 0; r < D; r++) m2[((size_t)i * D * D + r + D * cc) * ld + p] = q2[u][r + D * cc] + delta[r] * xm[cc];
+                    }
+                }
             }
         }
+        __syncthreads();   // the tile is rewritten next
     }
 }
 
-// time-blocked half `h` (per chain: cur[p] ^ flip, or 0 without cur) <-> plain SoA [N][d][ld]: the chains' current paths for whoever reads
+// time-blocked half `h` (per chain: cur[p], or 0 without cur) <-> plain SoA [N][d][ld]: the chains' current paths for whoever reads
 // them in the library's common layout (getters, llikelihood under new proposals), and the initial paths the other way
 static __global__ void k_tb_to_soa(long n, long ld, int N, int d, const double *__restrict__ Xtb, long half, const unsigned char *__restrict__ cur, double *__restrict__ Xs)
 {
@@ -489,9 +530,9 @@ static __global__ void k_tb_to_soa(long n, long ld, int N, int d, const double *
     if (p >= n) return;
     const double *X = Xtb + (size_t)(cur ? (cur[p] & 1) : 0) * half;
     for (int k = 0; k < d; k++)
-        for (int j = 0; j < 8; j++) {
-            const int i = blk * 8 + j;
-            if (i < N) Xs[((size_t)i * d + k) * ld + p] = X[(((size_t)blk * d + k) * ld + p) * 8 + j];
+        for (int j = 0; j < 16; j++) {
+            const int i = blk * 16 + j;
+            if (i < N) Xs[((size_t)i * d + k) * ld + p] = X[(((size_t)blk * d + k) * ld + p) * 16 + j];
         }
 }
 static __global__ void k_soa_to_tb(long n, long ld, int N, int d, const double *__restrict__ Xs, double *__restrict__ Xtb, long half, const unsigned char *__restrict__ cur)
@@ -501,11 +542,10 @@ static __global__ void k_soa_to_tb(long n, long ld, int N, int d, const double *
     if (p >= n) return;
     double *X = Xtb + (size_t)(cur ? (cur[p] & 1) : 0) * half;
     for (int k = 0; k < d; k++)
-        for (int j = 0; j < 8; j++) {
-            const int i = blk * 8 + j;
-            X[(((size_t)blk * d + k) * ld + p) * 8 + j] = i < N ? Xs[((size_t)i * d + k) * ld + p] : 0.0;
+        for (int j = 0; j < 16; j++) {
+            const int i = blk * 16 + j;
+            X[(((size_t)blk * d + k) * ld + p) * 16 + j] = i < N ? Xs[((size_t)i * d + k) * ld + p] : 0.0;
         }
 }
-
 
 }  // namespace bhip

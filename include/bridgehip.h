@@ -361,15 +361,22 @@ void bhip_segchains_destroy(bhip_segchains *sc);
 /* mu (d), chol = C (d*d, column-major, lower): pi0 = N(mu, C C').  Initial state: y0 = mu; per segment fresh W,
  * X = bridge!(...) chained, ll (skip applies to every llikelihood).                               smoothing.jl:99-106 */
 int bhip_segchains_init(bhip_segchains *sc, const double *mu, const double *chol, int skip);
-/* `iters` iterations; w_old[it], w_new[it] host arrays of length iters */
+/* `iters` iterations; w_old[it], w_new[it] host arrays of length iters.  Within a call the mcnext! (and, where paths are copied on
+ * accept, the commit) of an iteration runs on a second stream of the library beside the next iteration's proposals; the two
+ * streams are joined before the call returns -- whatever follows on the context's stream sees the state after `iters` iterations.
+ * Several iterations per call is the fast way to run the loop. */
 int bhip_segchains_step(bhip_segchains *sc, const double *w_old, const double *w_new, int iters);
-/* host outputs (any may be NULL): ll [m][nchains] (current, per segment), acc [nchains], y0 [nchains][d] */
-/* bhip_chains_placement_info of segment `segment` (large segments are placed at bhip_segchains_init: BHIP_OPT_TUNE_PLACEMENT) */
+/* bhip_chains_placement_info of segment `segment` (large segments whose proposals go to plain path buffers -- d > 3 or pooled
+ * statistics -- are placed at bhip_segchains_init: BHIP_OPT_TUNE_PLACEMENT; with d <= 3 and no pooled statistics the paths live
+ * in parity halves like W and nothing is placed: tries = 0) */
 int bhip_segchains_placement_info(const bhip_segchains *sc, int segment, int *tries, float *ms_first, float *ms_best);
+/* host outputs (any may be NULL): ll [m][nchains] (current, per segment), acc [nchains], y0 [nchains][d] */
 int bhip_segchains_get(bhip_segchains *sc, double *ll, int64_t *acc, double *y0);
 /* current paths of chains p0..p0+np of one segment as AoS host arrays: X [np][N][d], W [np][N][mp] */
 int bhip_segchains_get_paths(bhip_segchains *sc, int segment, long p0, long np, double *X_aos, double *W_aos);
-/* the device-resident current paths of one segment, SoA [N][d][*ld] */
+/* the device-resident current paths of one segment, SoA [N][d][*ld]; valid until the next bhip_segchains_step (d <= 3 without
+ * pooled statistics: the ensemble keeps its paths in parity halves, sixteen grid points of a chain per 128-byte line, and this
+ * array is gathered from them on the context's stream when asked for) */
 int bhip_segchains_current_X(bhip_segchains *sc, int segment, double **Xc_dev, long *ld);
 /* the mcnext! state of ONE chain of one segment (src/mclog.jl:48-56): mean [N][d], m2 [N][d*d] (column-major), count */
 int bhip_segchains_mcstats(bhip_segchains *sc, int segment, long chain, double *mean, double *m2, int64_t *count);

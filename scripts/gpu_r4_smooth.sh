@@ -1,3 +1,4 @@
 mkdir -p gpurun_out/r4s
-python -m pytest tests/test_gpu_segchains.py tests/test_gpu_adapt_device.py tests/test_c_example.py tests/test_linearappr.py tests/test_gpu_fullsize.py -x -q -m gpu 2>&1 | tail -15 > gpurun_out/r4s/tests.txt
-python scripts/gpu_smooth_ab.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r4s/ab.txt
+for w in 128 192 256 320 384 256; do echo "two streams, mcnext workgroups $w"; BHIP_SEG_MCNEXT_WGS=$w python scripts/gpu_smooth_ab.py one "tb"; done 2>&1 | grep -v amdgpu.ids > gpurun_out/r4s/wgs.txt
+BHIP_SEG_PLAIN_X=1 python scripts/gpu_smooth_ab.py one "plain two streams" 2>&1 | grep -v amdgpu.ids >> gpurun_out/r4s/wgs.txt
+BHIP_SEG_PLAIN_X=1 BHIP_SEG_ONE_STREAM=1 python scripts/gpu_smooth_ab.py one "plain one stream" 2>&1 | grep -v amdgpu.ids >> gpurun_out/r4s/wgs.txt

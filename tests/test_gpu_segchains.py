@@ -269,7 +269,9 @@ def test_joint_mh_over_segments_at_large_dimension(ctx, d):
 def test_large_segments_are_placed_and_results_do_not_depend_on_it(ctx):
     """Segments of 1 GiB or more keep W and Xo in two contiguous allocations (bhip_api.hip chains_alloc_state); bhip_segchains_init
     places every such pair (different 96-GiB pieces of the device memory, measured: chains_place) before the ensemble's state is set
-    up.  Decisions, log-likelihoods, starts and paths are those of the ensemble that was not placed (BHIP_OPT_TUNE_PLACEMENT = 0)."""
+    up.  Decisions, log-likelihoods, starts and paths are those of the ensemble that was not placed (BHIP_OPT_TUNE_PLACEMENT = 0).
+    (Pooled statistics: the ensembles whose proposals go to the plain Xo buffers -- with time-blocked paths the hot loop does not touch
+    Xo and nothing is placed.)"""
     import ctypes as C
     import torch
     segs, refs, mu, chol, d = build_segments(ctx, "linpro2", m=2, M=512)     # 2 x 513 grid points, d = m' = 2
@@ -279,7 +281,7 @@ def test_large_segments_are_placed_and_results_do_not_depend_on_it(ctx):
     for tune in (1, 0):
         ctx.set_option(bh.OPT_TUNE_PLACEMENT, tune)
         try:
-            sc = bh.SegChains(segs, mu, chol, n, seed=3, mcnext=False)
+            sc = bh.SegChains(segs, mu, chol, n, seed=3, mcnext=False, pooled=True)
             info = []
             for i in range(2):
                 t, a, b = C.c_int(), C.c_float(), C.c_float()
