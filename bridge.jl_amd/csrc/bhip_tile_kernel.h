@@ -109,8 +109,11 @@ template <class V> __device__ __forceinline__ void tile_st(V *p, V v) { if const
 template <class V> __device__ __forceinline__ V tile_ld(const V *p) { if constexpr (BHIP_TILE_NT) return __builtin_nontemporal_load(p); else return *p; }
 
 struct TileNoHook { __device__ __forceinline__ void operator()(int) const {} };
-template <int T, class HOOK = TileNoHook>
-__device__ __forceinline__ void tile_mv(const double *__restrict__ Mf, const double (&v)[T][4], double (&out)[T][4], int lane, HOOK hook = HOOK())
+// PADK (zero-padded processes, template PAD of k_tile): K-slices nks .. 4T-1 hold nothing but the zero padding of the operand and of the
+// matrix's columns -- their products add +0.0 and are skipped behind a wave-uniform branch (d = 9..12 on the 16-row tile: three k-steps
+// instead of four)
+template <int T, class HOOK = TileNoHook, bool PADK = false>
+__device__ __forceinline__ void tile_mv(const double *__restrict__ Mf, const double (&v)[T][4], double (&out)[T][4], int lane, HOOK hook = HOOK(), int nks = 4 * T)
 {
     if constexpr ((BHIP_TILE_EXP & 4) != 0) {
 #pragma unroll
@@ -124,9 +127,11 @@ __device__ __forceinline__ void tile_mv(const double *__restrict__ Mf, const dou
     for (int tp = 0; tp < T; tp++) acc[tp] = double4v{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int ks = 0; ks < 4 * T; ks++) {
+        if (!PADK || ks < nks) {
 #pragma unroll
-        for (int tp = 0; tp < T; tp++)
-            acc[tp] = __builtin_amdgcn_mfma_f64_16x16x4f64(Mf[(tp * 4 * T + ks) * 64 + lane], v[ks >> 2][ks & 3], acc[tp], 0, 0, 0);
+            for (int tp = 0; tp < T; tp++)
+                acc[tp] = __builtin_amdgcn_mfma_f64_16x16x4f64(Mf[(tp * 4 * T + ks) * 64 + lane], v[ks >> 2][ks & 3], acc[tp], 0, 0, 0);
+        }
         hook(ks);   // (statically unrolled: ks is a constant in the hook)
     }
 #pragma unroll
@@ -158,6 +163,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     // dtr..D-1 are zero padding of every matrix and vector, hold no data in the ensembles and are never loaded or stored
     const int dtr = PAD ? a.dtrue : D;
     auto ok = [&](int t, int r) { return !PAD || 16 * t + 4 * r + kq < dtr; };
+    const int nks = PAD ? (dtr + 3) >> 2 : 4 * T;   // live K-slices of the matrix products (tile_mv)
 
     for (int c = tid; c < 4 * DD + 5 * D; c += 256) cm[c] = a.cst[c];
     for (int c = tid; c < STEP; c += 256) hb[c] = a.steps[c];
@@ -519,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
             }
         double rr[T][4], bT[T][4], bA[T][4], g[T][4], s[T][4];
         spread(0);
-        tile_mv<T>(hm, w, rr, lane, hook_at(0));
+        tile_mv<T, decltype(hook_at(0)), PAD>(hm, w, rr, lane, hook_at(0), nks);
         spread(1);
         if constexpr (UD::ON) {
             // gather the path's state (its components sit in 4 lanes x 8 registers) and evaluate b_k for this lane's rows
@@ -538,13 +544,13 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                     const int row = 16 * t + 4 * r + kq;
                     bT[t][r] = (!PAD || row < dtr) ? UD::bk(row, ti, xv, a.upar) : 0.0;
                 }
-        } else tile_mv<T>(Bf, xm, bT, lane, hook_at(1));
+        } else tile_mv<T, decltype(hook_at(1)), PAD>(Bf, xm, bT, lane, hook_at(1), nks);
         spread(2);
-        tile_mv<T>(Btf, xa, bA, lane, hook_at(UD::ON ? 1 : 2));
+        tile_mv<T, decltype(hook_at(0)), PAD>(Btf, xa, bA, lane, hook_at(UD::ON ? 1 : 2), nks);
         spread(3);
         if constexpr (NOISE != 3) {
-            tile_mv<T>(Af, rr, g, lane, hook_at(UD::ON ? 2 : 3));
-            tile_mv<T>(Sf, dw, s, lane, hook_at(UD::ON ? 3 : 4));
+            tile_mv<T, decltype(hook_at(0)), PAD>(Af, rr, g, lane, hook_at(UD::ON ? 2 : 3), nks);
+            tile_mv<T, decltype(hook_at(0)), PAD>(Sf, dw, s, lane, hook_at(UD::ON ? 3 : 4), nks);
         }
 
         // ---- llikelihood: som += dot(b - b~, r)*dt, reduced over the path's 4 row groups
