@@ -125,6 +125,100 @@ def test_commit_stream_overlap_changes_nothing(ctx, kind, pooled):
         assert cnt == iters and np.array_equal(mean, r["mean"][i]) and np.array_equal(m2, r["m2"][i])
 
 
+@pytest.mark.parametrize("M,n", [(1, 1), (3, 65), (14, 64), (15, 130), (16, 63), (17, 129), (31, 5), (32, 200)])
+def test_time_blocked_paths_at_block_edges(ctx, M, n):
+    """Grids of N = M + 1 points around the sixteen-point blocks of the time-blocked paths (a block that ends exactly at the end
+    point, one that holds the end point alone, a grid shorter than a block) and chain counts around the 64-chain groups: every
+    chain equals its oracle twin -- paths, W, statistics, decisions."""
+    segs, refs, mu, chol, d = build_segments(ctx, "lorenz", m=2, M=M)
+    iters = 5
+    rng = np.random.default_rng(M)
+    rho_ = np.exp(-0.5 * rng.exponential(size=iters))
+    w_new, w_old = np.sqrt(rho_), np.sqrt(1 - rho_)
+    sc = bh.SegChains(segs, mu, chol, n, seed=9, path0=3, mcnext=True)
+    sc.step(w_old, w_new)
+    ll, acc, y0 = sc.state()
+    for p in sorted({0, n // 2, n - 1}):
+        r = o.smooth_mcmc(refs, mu, chol, w_old, w_new, 9, 3 + p, stats=True)
+        assert acc[p] == r["acc"] and np.array_equal(ll[:, p], r["ll"]) and np.array_equal(y0[p], r["y0"])
+        for i in range(2):
+            X, W = sc.paths(i, p, 1)
+            assert np.array_equal(X[0], r["X"][i]) and np.array_equal(W[0], r["W"][i])
+            mean, m2, cnt = sc.mcstats(i, p)
+            assert cnt == iters and np.array_equal(mean, r["mean"][i]) and np.array_equal(m2, r["m2"][i])
+
+
+def test_time_blocked_paths_with_user_process_noise_spec_2_and_fused_build(ctx):
+    """The other routes into the wave-specialised kernel take the time-blocked path stores too: a hipRTC process (the same kernel
+    template, compiled at run time, its LDS sized by the launch code of that route) reproduces the built-in Lorenz bit for bit;
+    the full-resolution noise stream (BHIP_OPT_NOISE_SPEC = 2) equals its oracle twin; the fused-arithmetic build agrees to its
+    stated tolerance on the first proposal."""
+    import torch
+    m, M, n, iters = 2, 37, 150, 4
+    th, sg = (10.0, 20.0, 8 / 3), (3.0, 3.0, 3.0)
+    rng = np.random.default_rng(2)
+    tgrid = np.linspace(0, 0.05 * m, m * M + 1)
+    obs = np.array([1.5, -1.5, 25.0]) + rng.standard_normal((m + 1, 3))
+    rho_ = np.exp(-0.5 * rng.exponential(size=iters))
+    w_new, w_old = np.sqrt(rho_), np.sqrt(1 - rho_)
+
+    def build(c, P):
+        Pt = bh.LinPro(-np.eye(3), np.zeros(3), np.diag(sg))
+        H, v = bh.gpupdate(np.diag([np.inf] * 3), np.zeros(3), np.eye(3), 0.5 * np.eye(3), obs[m])
+        segs, refs = [None] * m, [None] * m
+        for i in range(m - 1, -1, -1):
+            tt = tgrid[i * M:(i + 1) * M + 1].copy()
+            segs[i] = bh.GuidedBridge(tt, P, Pt, v, H, ctx=c)
+            refs[i] = o.proposal_hv(tt, 3, 3, o.MODEL_LORENZ, [*th, *sg], o.AUX_LINPRO, o.linpro_par(-np.eye(3), np.zeros(3), np.diag(sg)), segs[i].Hd, segs[i].V)
+            H, v = bh.gpupdate(segs[i], np.eye(3), np.eye(3), obs[i])
+        return segs, refs, v, np.linalg.cholesky((H + H.T) / 2)
+
+    def run(c, P, its=iters):
+        segs, refs, mu, chol = build(c, P)
+        sc = bh.SegChains(segs, mu, chol, n, seed=4, path0=1, mcnext=True)
+        sc.step(w_old[:its], w_new[:its])
+        return sc, refs, mu, chol
+
+    src = "o[0] = par[0]*(x[1] - x[0]); o[1] = x[0]*(par[1] - x[2]) - x[1]; o[2] = x[0]*x[1] - par[2]*x[2];"
+    a, refs, mu, chol = run(ctx, bh.Lorenz(th, sg))
+    b, _, _, _ = run(ctx, bh.UserProcess(3, src, list(th), np.diag(sg), ctx=ctx))
+    for x, y in zip(a.state(), b.state()):
+        assert np.array_equal(x, y)
+    for i in range(m):
+        assert np.array_equal(a.paths(i, 0, n)[0], b.paths(i, 0, n)[0])
+        for u, v in zip(a.mcstats(i, n - 1), b.mcstats(i, n - 1)):
+            assert np.array_equal(u, v)
+    r = o.smooth_mcmc(refs, mu, chol, w_old, w_new, 4, 1 + 77, stats=True)
+    assert np.array_equal(a.paths(1, 77, 1)[0][0], r["X"][1]) and a.state()[1][77] == r["acc"]
+
+    c2 = bh.Context(0)
+    c2.set_option(bh.OPT_NOISE_SPEC, 2)
+    v2, refs2, mu2, chol2 = run(c2, bh.Lorenz(th, sg))
+    with o.noise_spec(2):
+        for p in (0, 64, n - 1):
+            r = o.smooth_mcmc(refs2, mu2, chol2, w_old, w_new, 4, 1 + p, stats=True)
+            for i in range(m):
+                X, W = v2.paths(i, p, 1)
+                assert np.array_equal(X[0], r["X"][i]) and np.array_equal(W[0], r["W"][i])
+                mean, m2, cnt = v2.mcstats(i, p)
+                assert np.array_equal(mean, r["mean"][i]) and np.array_equal(m2, r["m2"][i])
+            assert v2.state()[1][p] == r["acc"]
+    assert not np.array_equal(v2.paths(0, 0, 1)[1], a.paths(0, 0, 1)[1])
+
+    cf = bh.Context(0)
+    cf.set_option(bh.OPT_FUSED_ARITHMETIC, 1)
+    f1, _, _, _ = run(cf, bh.Lorenz(th, sg), its=1)
+    e1, _, _, _ = run(ctx, bh.Lorenz(th, sg), its=1)
+    same = f1.state()[1] == e1.state()[1]                    # chains that took the same first decision hold the same proposal (or none)
+    assert same.mean() > 0.95
+    for i in range(m):
+        Xf, Wf = f1.paths(i, 0, n)
+        Xe, We = e1.paths(i, 0, n)
+        assert np.abs(Wf[same] - We[same]).max() <= 1e-13                      # (the pCN mix rho*W + sqrt(1 - rho^2)*W2 is contracted too)
+        assert np.abs(Xf[same] - Xe[same]).max() <= 1e-9 * (1 + np.abs(Xe).max())
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("kind", ["lorenz", "linpro2", "ou1"])
 def test_time_blocked_paths_equal_plain_paths(ctx, kind, monkeypatch):
     """d <= 3 without pooled statistics keeps the segments' paths time-blocked in parity halves (accept = parity flip, mcnext!
