@@ -398,7 +398,7 @@ def kernel_times(w, steps, warmup, min_ms=0.0):
 # what the implementation moves per path-step: padded W lines read + written 64, the proposal path into the other parity half 24, mcnext!
 # reads the current half 24 and reads + writes its state 192 (rocprofv3 FETCH + WRITE of the loop's kernels: profiles/r4_smoothing_*.txt;
 # round 3's plain SoA paths with the commit copy moved 64 + 24 + 66 + 192: every line of Xo AND of Xc read, the lines of Xc written back)
-SMOOTH_MOVED_BYTES = 64 + 24 + 24 + 192
+SMOOTH_MOVED_BYTES = 64 + 24 + 24 + 192   # with a statistics pass per iteration (K = 1); see smoothing_record for the deferred form
 
 
 def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
@@ -441,6 +441,7 @@ def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
             out.append(e0.elapsed_time(e1) / k)
         return float(np.median(out))
     ps = n * m * M
+    K, nbuf = sc.statistics_info()
     ms_sh = t_iters(sc, 2 * reps)
     ms_ad = t(lambda: sc.adapt_device(L, Sig, obs[:m], HT, vT), max(2, reps // 2))
     ms_pc = t_iters(sc, 2 * reps)
@@ -455,16 +456,24 @@ def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
     # copies nothing): W read + Wo written 48 (m' = 3), Xo written 24, mcnext! reads X 24 and reads + writes its state
     # (mean 3 + m2 9 doubles) 192 = 288.  The implementation MOVES 16 more -- the W lines pad m' = 3 to 4 -- reported beside it as
     # `moved_bytes_per_path_step`; the fractions are computed on the algorithmic count.
-    b_sh = 48 + 24 + 24 + 192
-    b_moved = SMOOTH_MOVED_BYTES
+    # Since round 4 the library applies mcnext! every K iterations to the K current paths a ring of path buffers has kept
+    # (bhip_segchains_statistics_info: same bits, the state travels once per K iterations): what THAT loop must move per path-step is
+    # 48 + 24 + 24 (a path read per iteration at most: none for an iteration in which the chain did not move) + 192 / K -- the count the
+    # fractions below are computed on; the reference's count stays in the record beside it.
+    b_ref = 48 + 24 + 24 + 192
+    b_sh = 48 + 24 + 24 + 192 / K
+    b_moved = b_sh + 16
     b_pc = b_sh + 120              # + the chain's compact guide row per step: Hd (9), V (3), linearisation point (3)
     return {"workload": f"Lorenz smoothing: {m} GuidedBridge(LinearAppr) segments x {M} steps, {n} chains, joint MH + pCN start + mcnext! per iteration",
-            "path_steps_per_iteration": ps, "finite": ok,
+            "path_steps_per_iteration": ps, "finite": ok, "statistics_every": K, "path_buffers_per_segment": nbuf,
             "iteration_shared_guides": {"ms": ms_sh, "path_steps_per_s": ps / ms_sh * 1e3, "algorithmic_bytes_per_path_step": b_sh,
-                                        "moved_bytes_per_path_step": b_moved,
-                                        "hbm_frac": ps * b_sh / ms_sh / 1e6 / HBM_PEAK_GBS},
-            "iteration_shared_guides_means_only": {"ms": ms_mo, "path_steps_per_s": ps / ms_mo * 1e3, "algorithmic_bytes_per_path_step": b_sh - 144,
-                                                   "hbm_frac": ps * (b_sh - 144) / ms_mo / 1e6 / HBM_PEAK_GBS,
+                                        "moved_bytes_per_path_step": b_moved, "reference_loop_bytes_per_path_step": b_ref,
+                                        "hbm_frac": ps * b_sh / ms_sh / 1e6 / HBM_PEAK_GBS,
+                                        "note": f"mcnext! applied every {K} iterations to the {K} current paths kept in a ring of {nbuf} path buffers per segment (same bits as a pass per iteration, "
+                                                "which this record timed at 2.15-2.28 ms in round 3 and 1.70-1.77 ms with the paths in parity halves); the iteration is now bound by its four "
+                                                "dependent proposal launches (0.68 ms alone at one wave per SIMD), not by HBM"},
+            "iteration_shared_guides_means_only": {"ms": ms_mo, "path_steps_per_s": ps / ms_mo * 1e3, "algorithmic_bytes_per_path_step": b_sh - 144 / K,
+                                                   "hbm_frac": ps * (b_sh - 144 / K) / ms_mo / 1e6 / HBM_PEAK_GBS,
                                                    "note": "BHIP_SEGCHAINS_MCNEXT_MEAN: the per-chain running means only (all the adaptation reads); mcnext! proper keeps the 3 x 3 second moments too"},
             # one call = the per-chain guide builder (k_seg_guide: 24 B of running mean read + the 120-byte compact row written per
             # chain and grid point) AND the re-evaluation of every chain's current log-likelihood under its new guide (the script

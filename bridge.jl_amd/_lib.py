@@ -77,6 +77,7 @@ SIGNATURES = {
     "bhip_segchains_init": (C.c_int, [vp, dp, dp, C.c_int]),
     "bhip_segchains_step": (C.c_int, [vp, dp, dp, C.c_int]),
     "bhip_segchains_placement_info": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "bhip_segchains_statistics_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bhip_segchains_get": (C.c_int, [vp, dp, C.POINTER(C.c_int64), dp]),
     "bhip_segchains_get_paths": (C.c_int, [vp, C.c_int, C.c_long, C.c_long, dp, dp]),
     "bhip_segchains_current_X": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_long)]),

@@ -1038,6 +1038,12 @@ class SegChains:
         self.ctx.check(self.ctx.lib.bhip_segchains_pooled_stats(self.h, segment, _dptr(mean), _dptr(m2), C.byref(cnt)))
         return mean, _uncm(m2, self.d, self.d), cnt.value
 
+    def statistics_info(self):
+        """(K, buffers): iterations per mcnext! pass and path buffers per segment (bhip_segchains_statistics_info)"""
+        k, b = C.c_int(), C.c_int()
+        self.ctx.check(self.ctx.lib.bhip_segchains_statistics_info(self.h, C.byref(k), C.byref(b)))
+        return k.value, b.value
+
     def mcstats(self, segment, chain):
         """the mcnext! state of one chain: (mean [N, d], m2 [N, d, d], count)   src/mclog.jl:48-56"""
         mean, cnt = np.empty((self.N, self.d)), C.c_int64()

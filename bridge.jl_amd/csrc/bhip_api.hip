@@ -211,6 +211,7 @@ struct bhip_chains {
     // multi-segment chains with time-blocked paths (bhip_segchains.inc owns the memory): deferred proposals go there instead of Xo
     double *Xtb = nullptr, *xend = nullptr;
     long xtb_half = 0;
+    const unsigned char *xsel = nullptr;   // the buffer of the ring that receives each chain's proposal (null: the half that is not cur[p])
     size_t wbytes = 0, xbytes = 0;
     // placement tuning (bhip_chains_init): allocations tried, ms per pCN iteration of the first and of the chosen one
     int place_tries = 0;
@@ -1767,7 +1768,7 @@ static int chains_propose_deferred(bhip_chains *ch, double w_old, double w_new, 
     if (rc) return rc;
     a.x0_dev = x0_dev; a.ldx0 = ldx0; a.blk0 = blk0; a.defer_accept = 1; a.ll = llo_dev;
     a.Wc = ch->Wc; a.Xo = ch->Xo; a.ldC = ch->ld;
-    if (ch->Xtb) { a.Xo = nullptr; a.Xtb = ch->Xtb; a.xtb_half = ch->xtb_half; a.xend = ch->xend; }   // (the instantiation without the plain X store)
+    if (ch->Xtb) { a.Xo = nullptr; a.Xtb = ch->Xtb; a.xtb_half = ch->xtb_half; a.xend = ch->xend; a.xsel = ch->xsel; }   // (the instantiation without the plain X store)
     a.cur = ch->cur; a.llcur = ch->llcur; a.acc = ch->acc;
     a.rho = w_old; a.srho = w_new;
     a.k0 = (uint32_t)ch->seed; a.k1 = (uint32_t)(ch->seed >> 32); a.path0 = ch->path0; a.iter = iter;

@@ -99,10 +99,13 @@ struct KArgs {
     // paths in the TIME-BLOCKED layout -- sixteen grid points of ONE chain side by side, one 128-byte line, so that whoever reads the
     // current paths of chains with different parities fetches nothing else: Xtb[h*xtb_half + (((i >> 4)*D + k)*ldC + p)*16 + (i & 15)];
     // half cur[p] holds the chain's current path, half cur[p] ^ 1 receives the proposal (like W: accept = parity flip, no copy);
-    // xend [D][ldC]: the proposal's end point, the start of the next segment
+    // xsel (optional): the buffer h = xsel[p] that receives chain p's proposal, out of a ring of up to 16 (deferred mcnext!: the current
+    // paths of the last few iterations stay where they are until the statistics pass has read them); xend [D][ldC]: the proposal's end
+    // point, the start of the next segment
     double *Xtb;
     long xtb_half;
     double *xend;
+    const unsigned char *xsel;
 #ifdef PC_STAMP   /* measurement builds only (scripts/gpu_stamp_probe.py): per-wave cycle budget of the producer / consumer waves */
     unsigned long long *stamp;
 #endif

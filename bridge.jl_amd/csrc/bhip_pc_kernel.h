@@ -310,6 +310,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
     // time-blocked path stores (multi-segment chains): yy[i] = y is collected per lane in LDS; when a block of sixteen grid points is
     // complete the wave moves it out like the producer moves the W lines -- instruction q writes the lines of chains c0 + 8q + lane/8,
     // lane%8 selects 16 bytes: whole 128-byte lines per instruction -- into the half of each chain's pair that is NOT its current path
+    // (or the buffer a.xsel names: four bits per chain)
     constexpr bool TBX = PCN && (FL & 1) == 0;
     constexpr int XSR = pc_xs_row(D);
     double *xs = nullptr, *xsw = nullptr;
@@ -324,8 +325,10 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
             const int sub = lane >> 3, part = 2 * (lane & 7);
             xlane = (char *)(a.Xtb + ((size_t)c0 + sub) * 16 + part);
 #pragma unroll
-            for (int q = 0; q < 8; q++)   // cur[] is allocated (and zeroed) up to ld; the proposal goes to the other half
-                xhb |= (uint32_t)((a.cur[c0 + 8 * q + sub] & 1) ^ 1) << q;
+            for (int q = 0; q < 8; q++) {   // cur[] / xsel[] are allocated (and zeroed) up to ld; without xsel the proposal goes to the other half
+                const long c = c0 + 8 * q + sub;
+                xhb |= (uint32_t)(a.xsel ? (a.xsel[c] & 15) : ((a.cur[c] & 1) ^ 1)) << (4 * q);
+            }
         }
     }
     auto flush_x = [&](int blk) {
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const double *src = xsw + (8 * q + sub) * XSR + k * 16 + part;
-                st_stream((d2v *)(kb + (size_t)q * (8 * 128) + (size_t)((xhb >> q) & 1u) * ((size_t)a.xtb_half * 8)), d2v{src[0], src[1]});
+                st_stream((d2v *)(kb + (size_t)q * (8 * 128) + (size_t)((xhb >> (4 * q)) & 15u) * ((size_t)a.xtb_half * 8)), d2v{src[0], src[1]});
             }
         }
         __builtin_amdgcn_wave_barrier();

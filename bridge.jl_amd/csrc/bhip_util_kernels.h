@@ -367,7 +367,12 @@ static __global__ void k_seg_accept(long n, long ld, int m, int d, const double 
                                     unsigned char *__restrict__ cur, unsigned int *__restrict__ acc, unsigned char *__restrict__ accflag,
                                     double *__restrict__ y0, const double *__restrict__ y0o, uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0,
                                     unsigned char *__restrict__ newblock, int doaccept /* smoothing.jl:156-158,193: the first adaptive proposal is accepted */,
-                                    unsigned char *__restrict__ cursnap /* time-blocked paths: the parities AFTER this decision, for the commit on the second stream */)
+                                    // time-blocked paths in a ring of buffers (bhip_segchains.inc): xcur[p] = the buffer that holds chain p's current
+                                    // path, xtgt[p] = the one its proposal was written to; hist_cur [..][ld]: the current buffers after the iterations
+                                    // whose mcnext! is still pending (this one is entry j); hist_prev [K][ld]: those of the batch whose statistics
+                                    // pass may still be running (or null).  The next proposal goes to the lowest buffer none of them names.
+                                    unsigned char *__restrict__ xcur, unsigned char *__restrict__ xtgt, unsigned char *__restrict__ hist_cur,
+                                    const unsigned char *__restrict__ hist_prev, int j, int K)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -376,7 +381,16 @@ static __global__ void k_seg_accept(long n, long ld, int m, int d, const double 
     const double u = accept_uniform(k0, k1, path0 + (uint32_t)p, iter);
     const bool ok = doaccept || det_log(u) <= lls;
     accflag[p] = ok ? 1 : 0;
-    if (cursnap) cursnap[p] = (unsigned char)(cur[p] ^ (ok ? 1 : 0));
+    if (xcur) {
+        const unsigned b = ok ? xtgt[p] : xcur[p];
+        xcur[p] = (unsigned char)b;
+        hist_cur[(size_t)j * ld + p] = (unsigned char)b;
+        unsigned mask = 1u << b;
+        for (int u = 0; u < j; u++) mask |= 1u << hist_cur[(size_t)u * ld + p];
+        if (hist_prev)
+            for (int u = 0; u < K; u++) mask |= 1u << hist_prev[(size_t)u * ld + p];
+        xtgt[p] = (unsigned char)(__ffs((int)~mask) - 1);
+    }
     if (ok) {
         if (newblock) newblock[p] = 0;
         cur[p] ^= 1;
@@ -435,16 +449,20 @@ __global__ void k_seg_commit(long n, long ld, int N, int m, double *const *__res
 // chain's current path is the half its parity names -- an accept copies nothing and mcnext! reads exactly the current paths (with plain
 // SoA paths and one lane per chain every line of the proposal AND of the current paths is fetched, and the lines of the accepted ones
 // written back: 72 bytes per grid point at d = 3 where 24 are needed).
-// mcnext! of every chain with its current path, all segments in one launch.  A work item = 64 chains x one block of sixteen grid points
-// of one segment; the grid is a fixed number of workgroups that walk the items (gridDim.x apart): beside the wave-specialised proposal
-// kernels, whose workgroups need most of a CU's LDS, only as many workgroups as fit next to them may be resident -- a grid of one
-// workgroup per item would keep every CU's LDS in small pieces and the proposals waiting for the whole pass.  The 64 x D lines of an
-// item come in whole -- eight lanes per line, fetched one item ahead -- into an LDS tile; then thread (c, jq) updates grid points
-// 4jq .. 4jq+3 of chain c, all loads of the state (plain SoA [N][D(*D)][ld], contiguous across the 64 chains) before the first use.
-// tab[0..m) = Xtb, tab[2m..3m) = mean, tab[3m..4m) = m2
+// mcnext! of every chain with its current paths of the last kk iterations (kk <= K; hist [K][ld]: the buffer that held chain p's current
+// path after each of them), all segments in one launch -- DEFERRED statistics: the state of a grid point (mean, m2: 16 D (D + 1) bytes read
+// and written) travels once per kk iterations instead of once per iteration, and an iteration in which the chain did not move reads no
+// path (its line is still in the tile).  The updates are those of src/mclog.jl:48-56, one after the other in registers: same operations,
+// same order, same bits as a pass per iteration.
+// A work item = 64 chains x one block of sixteen grid points of one segment; the grid is a fixed number of workgroups that walk the items
+// (gridDim.x apart): beside the wave-specialised proposal kernels, whose workgroups need most of a CU's LDS, only as many workgroups as
+// fit next to them may be resident -- a grid of one workgroup per item would keep every CU's LDS in small pieces and the proposals waiting
+// for the whole pass.  The 64 x D lines of an item and history entry come in whole -- eight lanes per line, fetched one entry ahead --
+// into an LDS tile; thread (c, jq) updates grid points 4jq .. 4jq+3 of chain c, all loads of the state (plain SoA [N][D(*D)][ld],
+// contiguous across the 64 chains) before the first use.   tab[0..m) = Xtb (buffer b at + b*half), tab[2m..3m) = mean, tab[3m..4m) = m2
 template <int D>
 __global__ __launch_bounds__(256) void k_seg_mcnext_tb(long n, long ld, int N, int m, double *const *__restrict__ tab, long half,
-                                                       const unsigned char *__restrict__ cursnap, double count, long ngroups, int nblk)
+                                                       const unsigned char *__restrict__ hist, int kk, double count, long ngroups, int nblk)
 {
     constexpr int ROW = 16 * D + 1;   // odd: conflict-free 8-byte accesses
     __shared__ double tile[64 * ROW];
@@ -452,38 +470,33 @@ __global__ __launch_bounds__(256) void k_seg_mcnext_tb(long n, long ld, int N, i
     const int sub = t >> 3, part = 2 * (t & 7);   // 32 lines per instruction: chains sub, sub + 32 of component k
     const long items = ngroups * nblk * m;
     d2v nx[D][2];
-    auto fetch = [&](long w) {
+    unsigned skn = 0u;   // bit q: the fetch of nx[.][q] was skipped (the chain's buffer is that of the entry before: the tile row stays)
+    auto fetch = [&](long w, int u) {
         const long g = w % ngroups;
         const int blk = (int)((w / ngroups) % nblk), sg = (int)(w / (ngroups * nblk));
         const double *X = tab[sg];
+        skn = 0u;
 #pragma unroll
-        for (int k = 0; k < D; k++)
+        for (int q = 0; q < 2; q++) {
+            const long p = g * 64 + 32 * q + sub;   // (hist and the lines are allocated up to ld, a multiple of 64)
+            const unsigned b = hist[(size_t)u * ld + p];
+            if (u > 0 && hist[(size_t)(u - 1) * ld + p] == b) { skn |= 1u << q; continue; }
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const long p = g * 64 + 32 * q + sub;   // (cursnap and the lines are allocated up to ld, a multiple of 64)
-                nx[k][q] = ld_stream((const d2v *)(X + (size_t)(cursnap[p] & 1) * half + (((size_t)blk * D + k) * ld + p) * 16 + part));
-            }
+            for (int k = 0; k < D; k++) nx[k][q] = ld_stream((const d2v *)(X + (size_t)b * half + (((size_t)blk * D + k) * ld + p) * 16 + part));
+        }
     };
     long w = blockIdx.x;
-    if (w < items) fetch(w);
+    if (w < items) fetch(w, 0);
     for (; w < items; w += gridDim.x) {
         const long g = w % ngroups;
         const int blk = (int)((w / ngroups) % nblk), sg = (int)(w / (ngroups * nblk));
-#pragma unroll
-        for (int k = 0; k < D; k++)
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                double *d = tile + (32 * q + sub) * ROW + k * 16 + part;
-                d[0] = nx[k][q].x; d[1] = nx[k][q].y;
-            }
-        __syncthreads();
-        if (w + gridDim.x < items) fetch(w + gridDim.x);
         const int c = t & 63, jq = t >> 6;
         const long p = g * 64 + c;
-        if (p < n) {
-            double *__restrict__ mean = tab[2 * m + sg];
-            double *__restrict__ m2 = tab[3 * m + sg];   // null: the means only (BHIP_SEGCHAINS_MCNEXT_MEAN)
-            double mk[4][D], q2[4][D * D];
+        const bool mine = p < n;
+        double *__restrict__ mean = tab[2 * m + sg];
+        double *__restrict__ m2 = tab[3 * m + sg];   // null: the means only (BHIP_SEGCHAINS_MCNEXT_MEAN)
+        double mk[4][D], q2[4][D * D];
+        if (mine) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int i = min(blk * 16 + 4 * jq + u, N - 1);
@@ -494,41 +507,69 @@ __global__ __launch_bounds__(256) void k_seg_mcnext_tb(long n, long ld, int N, i
                     for (int e = 0; e < D * D; e++) q2[u][e] = m2[((size_t)i * D * D + e) * ld + p];
                 }
             }
+        }
+        for (int h = 0; h < kk; h++) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = 4 * jq + u, i = blk * 16 + j;
-                if (i < N) {
+            for (int q = 0; q < 2; q++) {
+                if (skn & (1u << q)) continue;
+#pragma unroll
+                for (int k = 0; k < D; k++) {
+                    double *d = tile + (32 * q + sub) * ROW + k * 16 + part;
+                    d[0] = nx[k][q].x; d[1] = nx[k][q].y;
+                }
+            }
+            __syncthreads();
+            if (h + 1 < kk) fetch(w, h + 1);
+            else if (w + gridDim.x < items) fetch(w + gridDim.x, 0);
+            if (mine) {
+                const double cnt = count + (double)h;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int j = 4 * jq + u;
                     double x[D], delta[D], xm[D];
 #pragma unroll
                     for (int k = 0; k < D; k++) x[k] = tile[c * ROW + k * 16 + j];
 #pragma unroll
                     for (int k = 0; k < D; k++) {
                         delta[k] = x[k] - mk[u][k];
-                        const double mn = mk[u][k] + delta[k] / (count + 1.0);
-                        mean[((size_t)i * D + k) * ld + p] = mn;
-                        xm[k] = x[k] - mn;
+                        mk[u][k] = mk[u][k] + delta[k] / (cnt + 1.0);
+                        xm[k] = x[k] - mk[u][k];
                     }
                     if (m2) {
 #pragma unroll
                         for (int cc = 0; cc < D; cc++)
 #pragma unroll
-                            for (int r = 0; r < D; r++) m2[((size_t)i * D * D + r + D * cc) * ld + p] = q2[u][r + D * cc] + delta[r] * xm[cc];
+                            for (int r = 0; r < D; r++) q2[u][r + D * cc] = q2[u][r + D * cc] + delta[r] * xm[cc];
+                    }
+                }
+            }
+            __syncthreads();   // the tile is rewritten next
+        }
+        if (mine) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = blk * 16 + 4 * jq + u;
+                if (i < N) {
+#pragma unroll
+                    for (int k = 0; k < D; k++) mean[((size_t)i * D + k) * ld + p] = mk[u][k];
+                    if (m2) {
+#pragma unroll
+                        for (int e = 0; e < D * D; e++) m2[((size_t)i * D * D + e) * ld + p] = q2[u][e];
                     }
                 }
             }
         }
-        __syncthreads();   // the tile is rewritten next
     }
 }
 
-// time-blocked half `h` (per chain: cur[p], or 0 without cur) <-> plain SoA [N][d][ld]: the chains' current paths for whoever reads
+// time-blocked buffer `h` (per chain: cur[p] -- a parity or a ring index --, or 0 without cur) <-> plain SoA [N][d][ld]: the chains' current paths for whoever reads
 // them in the library's common layout (getters, llikelihood under new proposals), and the initial paths the other way
 static __global__ void k_tb_to_soa(long n, long ld, int N, int d, const double *__restrict__ Xtb, long half, const unsigned char *__restrict__ cur, double *__restrict__ Xs)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int blk = blockIdx.y;
     if (p >= n) return;
-    const double *X = Xtb + (size_t)(cur ? (cur[p] & 1) : 0) * half;
+    const double *X = Xtb + (size_t)(cur ? cur[p] : 0) * half;
     for (int k = 0; k < d; k++)
         for (int j = 0; j < 16; j++) {
             const int i = blk * 16 + j;
@@ -540,7 +581,7 @@ static __global__ void k_soa_to_tb(long n, long ld, int N, int d, const double *
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int blk = blockIdx.y;
     if (p >= n) return;
-    double *X = Xtb + (size_t)(cur ? (cur[p] & 1) : 0) * half;
+    double *X = Xtb + (size_t)(cur ? cur[p] : 0) * half;
     for (int k = 0; k < d; k++)
         for (int j = 0; j < 16; j++) {
             const int i = blk * 16 + j;

@@ -370,6 +370,13 @@ int bhip_segchains_step(bhip_segchains *sc, const double *w_old, const double *w
  * statistics -- are placed at bhip_segchains_init: BHIP_OPT_TUNE_PLACEMENT; with d <= 3 and no pooled statistics the paths live
  * in parity halves like W and nothing is placed: tries = 0) */
 int bhip_segchains_placement_info(const bhip_segchains *sc, int segment, int *tries, float *ms_first, float *ms_best);
+/* how the ensemble keeps its mcnext! statistics (supplements/smoothing/smoothing.jl:211-213 updates them every iteration): *every = K,
+ * the number of iterations one statistics pass covers (1: a pass per iteration) -- with d <= 3 and BHIP_SEGCHAINS_MCNEXT[_MEAN] the
+ * segments' paths live in a ring of *buffers = K + L path buffers, the K current paths of a batch stay where they are until ONE pass has
+ * applied the K updates of src/mclog.jl:48-56 in order (same bits; the state travels once per K iterations), running beside the first
+ * L iterations of the next batch; every bhip_segchains_step call ends with a pass over what is pending.  K = 4, L = 4 unless the device
+ * lacks the memory for the buffers.  Any pointer may be NULL. */
+int bhip_segchains_statistics_info(const bhip_segchains *sc, int *every, int *buffers);
 /* host outputs (any may be NULL): ll [m][nchains] (current, per segment), acc [nchains], y0 [nchains][d] */
 int bhip_segchains_get(bhip_segchains *sc, double *ll, int64_t *acc, double *y0);
 /* current paths of chains p0..p0+np of one segment as AoS host arrays: X [np][N][d], W [np][N][mp] */

@@ -219,6 +219,35 @@ def test_time_blocked_paths_with_user_process_noise_spec_2_and_fused_build(ctx):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("defer", ["1 1", "2 1", "3 2", "4 4", "8 4", "5 5"])
+def test_deferred_statistics_equal_a_pass_per_iteration(ctx, defer, monkeypatch):
+    """mcnext! of the time-blocked paths is applied every K iterations to the K current paths a ring of K + L buffers has kept, the
+    pass running beside the first L iterations of the next batch (bhip_segchains.inc): whatever K and L (BHIP_SEG_DEFER at creation),
+    whatever the split of the iterations into calls (each call ends with a pass over what is pending), the chains and their
+    statistics are those of the oracle's loop, which updates every iteration -- bit for bit."""
+    segs, refs, mu, chol, d = build_segments(ctx, "lorenz", m=2, M=40)
+    n, iters = 9000, 23
+    rng = np.random.default_rng(8)
+    rho_ = np.exp(-0.5 * rng.exponential(size=iters))
+    w_new, w_old = np.sqrt(rho_), np.sqrt(1 - rho_)
+    monkeypatch.setenv("BHIP_SEG_DEFER", defer)
+    sc = bh.SegChains(segs, mu, chol, n, seed=31, path0=2, mcnext=True)
+    monkeypatch.delenv("BHIP_SEG_DEFER")
+    cuts = [0, 13, 14, 17, iters]                                  # 13 iterations in one call, then 1, 3 and 6
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        sc.step(w_old[a:b], w_new[a:b])
+        assert sc.mcstats(0, 0)[2] == b
+    ll, acc, y0 = sc.state()
+    assert 0 < acc.sum() < n * iters
+    for p in (0, 4444, n - 1):
+        r = o.smooth_mcmc(refs, mu, chol, w_old, w_new, 31, 2 + p, stats=True)
+        assert acc[p] == r["acc"] and np.array_equal(ll[:, p], r["ll"])
+        for i in range(2):
+            assert np.array_equal(sc.paths(i, p, 1)[0][0], r["X"][i])
+            mean, m2, cnt = sc.mcstats(i, p)
+            assert cnt == iters and np.array_equal(mean, r["mean"][i]) and np.array_equal(m2, r["m2"][i])
+
+
 @pytest.mark.parametrize("kind", ["lorenz", "linpro2", "ou1"])
 def test_time_blocked_paths_equal_plain_paths(ctx, kind, monkeypatch):
     """d <= 3 without pooled statistics keeps the segments' paths time-blocked in parity halves (accept = parity flip, mcnext!
