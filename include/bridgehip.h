@@ -368,7 +368,7 @@ int bhip_segchains_init(bhip_segchains *sc, const double *mu, const double *chol
 int bhip_segchains_step(bhip_segchains *sc, const double *w_old, const double *w_new, int iters);
 /* bhip_chains_placement_info of segment `segment` (large segments whose proposals go to plain path buffers -- d > 3 or pooled
  * statistics -- are placed at bhip_segchains_init: BHIP_OPT_TUNE_PLACEMENT; with d <= 3 and no pooled statistics the paths live
- * in parity halves like W and nothing is placed: tries = 0) */
+ * in a ring of time-blocked buffers and nothing is placed: tries = 0) */
 int bhip_segchains_placement_info(const bhip_segchains *sc, int segment, int *tries, float *ms_first, float *ms_best);
 /* how the ensemble keeps its mcnext! statistics (supplements/smoothing/smoothing.jl:211-213 updates them every iteration): *every = K,
  * the number of iterations one statistics pass covers (1: a pass per iteration) -- with d <= 3 and BHIP_SEGCHAINS_MCNEXT[_MEAN] the
@@ -382,7 +382,7 @@ int bhip_segchains_get(bhip_segchains *sc, double *ll, int64_t *acc, double *y0)
 /* current paths of chains p0..p0+np of one segment as AoS host arrays: X [np][N][d], W [np][N][mp] */
 int bhip_segchains_get_paths(bhip_segchains *sc, int segment, long p0, long np, double *X_aos, double *W_aos);
 /* the device-resident current paths of one segment, SoA [N][d][*ld]; valid until the next bhip_segchains_step (d <= 3 without
- * pooled statistics: the ensemble keeps its paths in parity halves, sixteen grid points of a chain per 128-byte line, and this
+ * pooled statistics: the ensemble keeps its paths in a ring of buffers, sixteen grid points of a chain per 128-byte line, and this
  * array is gathered from them on the context's stream when asked for) */
 int bhip_segchains_current_X(bhip_segchains *sc, int segment, double **Xc_dev, long *ld);
 /* the mcnext! state of ONE chain of one segment (src/mclog.jl:48-56): mean [N][d], m2 [N][d*d] (column-major), count */
