@@ -57,6 +57,11 @@ constexpr size_t PC_LDS = sizeof(double) * (RNG_TAB_DOUBLES + 2 * PC_TILE);   //
 // time-blocked path stores (KArgs::Xtb): a consumer lane collects sixteen grid points of its chain in LDS -- [k][16] + 1 double of padding
 // per lane: conflict-free 8-byte accesses -- and the wave writes them out as whole 128-byte lines, eight lanes per line
 constexpr int pc_xs_row(int d) { return 16 * d + 1; }
+#ifndef PC_TBX_UNROLL_PPR
+#define PC_TBX_UNROLL_PPR 2   // steps per iteration of the interior loop in the copy that stores time-blocked paths, per-chain guide rows
+#endif
+struct TabTrue { static constexpr bool value = true; };
+struct TabFalse { static constexpr bool value = false; };
 constexpr size_t pc_xs_bytes(int d, int npair) { return sizeof(double) * 64 * pc_xs_row(d) * npair; }
 typedef const __attribute__((address_space(3))) double *ldsrow_t;
 
@@ -345,13 +350,14 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
         }
         __builtin_amdgcn_wave_barrier();
     };
-    auto stage_x = [&](int i) {   // yy[i] = y, BEFORE the update (src/euler.jl:263)
-        if constexpr (TBX) {
-            if (xtb) {
+    // (a block can only be complete at the FIRST step of a chunk -- i = SPC*kc + s - 1 with SPC a divisor of 16 --: the interior loop's
+    // unrolled body holds the line moves once, not once per step; with them in every step the small-ensemble instantiations went from
+    // ~145 to 256 registers and spilled)
+    auto stage_x = [&](auto on, int i, bool first_of_chunk) {   // yy[i] = y, BEFORE the update (src/euler.jl:263)
+        if constexpr (decltype(on)::value) {
 #pragma unroll
-                for (int k = 0; k < D; k++) xs[k * 16 + (i & 15)] = st.y[k];
-                if ((i & 15) == 15) flush_x(i >> 4);
-            }
+            for (int k = 0; k < D; k++) xs[k * 16 + (i & 15)] = st.y[k];
+            if (first_of_chunk && (i & 15) == 15) flush_x(i >> 4);
         }
     };
     // The per-chain start is the consumer's only vector load.  Left to itself the compiler defers the wait for it to the first use
@@ -392,6 +398,9 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
     };
     fetch_row(0, rcur);
     PC_ST(PcStamp ps; ps.begin(); for (int q = 0; q < 6; q++) st.tacc[q] = 0ull; st.tlast = ps.t0;)
+    // the chunk loop, held twice by the instantiations that can store time-blocked paths: with the wave-uniform `if (xtb)` inside the
+    // unrolled step the small-ensemble kernels WITHOUT such stores went from ~145 registers to 256 and spilled up to 1 KB
+    auto chunk_loop = [&](auto tbx_on) {
     for (int k = 0; k <= nch; k++) {
         if (k > 0) {
             const int kc = k - 1;
@@ -400,13 +409,14 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
             const int j0 = kc * SPC;
             if (kc > 0 && j0 + SPC <= N) {
                 // interior chunk: SPC steps  i = j - 1
-#pragma unroll PC_CONS_UNROLL
+                constexpr int UNR = (decltype(tbx_on)::value && PPR) ? PC_TBX_UNROLL_PPR : PC_CONS_UNROLL;
+#pragma unroll UNR
                 for (int s = 0; s < SPC; s++) {
                     double wn[MP];
 #pragma unroll
                     for (int c = 0; c < MP; c++) wn[c] = mine[s * MPP + c];
                     const int i = j0 + s - 1;
-                    stage_x(i);
+                    stage_x(tbx_on, i, s == 0);
 #ifdef PC_KNOCKOUT_STEP   /* measurement only: what the producer alone costs */
                     st.ll += wn[0];
 #else
@@ -421,7 +431,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
                 for (int s = 0; s < SPC; s++) {
                     const int i = j0 + s - 1;
                     if (i < 0 || i >= nsteps) continue;
-                    stage_x(i);
+                    stage_x(tbx_on, i, true);
                     double wn[MP];
 #pragma unroll
                     for (int c = 0; c < MP; c++) wn[c] = mine[s * MPP + c];
@@ -435,6 +445,11 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
         pc_barrier();
         PC_ST(ps.after_barrier(); st.tlast = ps.t0;)
     }
+    };
+    if constexpr (TBX) {
+        if (xtb) chunk_loop(TabTrue());
+        else chunk_loop(TabFalse());
+    } else chunk_loop(TabFalse());
     PC_ST(ps.write(a.stamp, blockIdx.x * (2 * NPAIR) + wave, 1, st.tacc);)
 
     if constexpr (PPR) {
