@@ -248,6 +248,37 @@ def test_deferred_statistics_equal_a_pass_per_iteration(ctx, defer, monkeypatch)
             assert cnt == iters and np.array_equal(mean, r["mean"][i]) and np.array_equal(m2, r["m2"][i])
 
 
+@pytest.mark.parametrize("name", ["fhn_partialbridge_extreme", "fhn2_nuh_full", "nclar_firstcomponent", "ouproc_nuh", "linpro2_guidedbridge"])
+def test_joint_mh_over_partial_bridge_segments(ctx, name):
+    """The loop takes any guided proposals: PartialBridge (L, M, mu), PartialBridgeNuH, a sin-drift process (NCLAR, d = 3 with scalar
+    noise) -- every guide form of the wave-specialised kernel writes the time-blocked paths and hands the end point on.  Two segments on
+    the case's own grid (the second starts where the first ends), pi0 around the case's starting point, deferred statistics: == the oracle."""
+    import problems
+    c = [c for c in problems.cases(77) if c.name == name][0]
+    segs = [c.bh_proposal(bh, ctx), c.bh_proposal(bh, ctx)]
+    ref = c.oracle_proposal()
+    refs = [ref, ref]
+    mu, chol = c.x0, 0.05 * np.eye(c.d)
+    n, iters = 130, 6
+    rng = np.random.default_rng(1)
+    rho_ = np.exp(-0.5 * rng.exponential(size=iters))
+    w_new, w_old = np.sqrt(rho_), np.sqrt(1 - rho_)
+    sc = bh.SegChains(segs, mu, chol, n, seed=12, path0=9, mcnext=True)
+    sc.step(w_old[:5], w_new[:5])
+    sc.step(w_old[5:], w_new[5:])
+    ll, acc, y0 = sc.state()
+    for p in (0, 64, n - 1):
+        r = o.smooth_mcmc(refs, mu, chol, w_old, w_new, 12, 9 + p, stats=True)
+        assert acc[p] == r["acc"] and np.array_equal(y0[p], r["y0"]), (name, p)
+        for i in range(2):
+            X, W = sc.paths(i, p, 1)
+            assert np.array_equal(W[0], r["W"][i]), (name, p, i)
+            assert np.array_equal(X[0], r["X"][i]), (name, p, i, np.abs(X[0] - r["X"][i]).max())
+            mean, m2, cnt = sc.mcstats(i, p)
+            assert cnt == iters and np.array_equal(mean, r["mean"][i]) and np.array_equal(m2, r["m2"][i])
+        assert np.array_equal(ll[:, p], r["ll"])
+
+
 @pytest.mark.parametrize("kind", ["lorenz", "linpro2", "ou1"])
 def test_time_blocked_paths_equal_plain_paths(ctx, kind, monkeypatch):
     """d <= 3 without pooled statistics keeps the segments' paths time-blocked in parity halves (accept = parity flip, mcnext!
