@@ -279,6 +279,35 @@ def test_joint_mh_over_partial_bridge_segments(ctx, name):
         assert np.array_equal(ll[:, p], r["ll"])
 
 
+@pytest.mark.parametrize("defer", [None, "3 1", "7 3"])
+def test_deferred_statistics_over_many_iterations(ctx, defer, monkeypatch):
+    """600 iterations in calls of irregular length: the ring of path buffers is walked hundreds of times in every pattern of accepts
+    and rejects; chains, statistics and acceptance counts equal the oracle's."""
+    segs, refs, mu, chol, d = build_segments(ctx, "lorenz", m=2, M=20)
+    n, iters = 200, 600
+    rng = np.random.default_rng(77)
+    rho_ = np.exp(-0.5 * rng.exponential(size=iters))
+    w_new, w_old = np.sqrt(rho_), np.sqrt(1 - rho_)
+    if defer:
+        monkeypatch.setenv("BHIP_SEG_DEFER", defer)
+    sc = bh.SegChains(segs, mu, chol, n, seed=5, path0=0, mcnext=True)
+    if defer:
+        monkeypatch.delenv("BHIP_SEG_DEFER")
+    a = 0
+    while a < iters:
+        b = min(iters, a + int(rng.integers(1, 40)))
+        sc.step(w_old[a:b], w_new[a:b])
+        a = b
+    ll, acc, y0 = sc.state()
+    for p in (0, 101, n - 1):
+        r = o.smooth_mcmc(refs, mu, chol, w_old, w_new, 5, p, stats=True)
+        assert acc[p] == r["acc"] and 0 < r["acc"] < iters
+        for i in range(2):
+            assert np.array_equal(sc.paths(i, p, 1)[0][0], r["X"][i])
+            mean, m2, cnt = sc.mcstats(i, p)
+            assert cnt == iters and np.array_equal(mean, r["mean"][i]) and np.array_equal(m2, r["m2"][i])
+
+
 @pytest.mark.parametrize("kind", ["lorenz", "linpro2", "ou1"])
 def test_time_blocked_paths_equal_plain_paths(ctx, kind, monkeypatch):
     """d <= 3 without pooled statistics keeps the segments' paths time-blocked in parity halves (accept = parity flip, mcnext!
