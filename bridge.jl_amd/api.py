@@ -944,13 +944,13 @@ class SegChains:
     a pCN move of the starting point and (optionally) mcnext! per iteration -- the loop of
     supplements/smoothing/smoothing.jl:99-213 (bhip_segchains_*).  pos: the m proposals; pi0 = N(mu, C C')."""
 
-    def __init__(self, pos, mu, chol, nchains, seed=0, path0=0, skip=0, mcnext=False, pooled=False, mcnext_mean_only=False):
+    def __init__(self, pos, mu, chol, nchains, seed=0, path0=0, skip=0, mcnext=False, pooled=False, mcnext_mean_only=False, stats_every_iteration=False):
         self.pos, self.ctx = list(pos), pos[0].ctx
         self.m, self.n, self.d, self.mp, self.N = len(self.pos), int(nchains), pos[0].d, pos[0].mp, len(pos[0].tt)
         self.mean_only = bool(mcnext_mean_only) and not mcnext
         hs = (vp * self.m)(*[P.h for P in self.pos])
         h = vp()
-        self.ctx.check(self.ctx.lib.bhip_segchains_create(self.ctx.h, self.m, hs, self.n, path0, seed, (1 if mcnext else 0) | (2 if pooled else 0) | (4 if mcnext_mean_only else 0), C.byref(h)))
+        self.ctx.check(self.ctx.lib.bhip_segchains_create(self.ctx.h, self.m, hs, self.n, path0, seed, (1 if mcnext else 0) | (2 if pooled else 0) | (4 if mcnext_mean_only else 0) | (8 if stats_every_iteration else 0), C.byref(h)))
         self.h = h
         mu = np.ascontiguousarray(np.atleast_1d(mu), dtype=np.float64)
         self.ctx.check(self.ctx.lib.bhip_segchains_init(h, _dptr(mu), _dptr(_cm(np.atleast_2d(chol))), skip))

@@ -354,6 +354,7 @@ int bhip_welford_merge(long entries, int d, double *na, double *mean_a, double *
 typedef struct bhip_segchains bhip_segchains;
 #define BHIP_SEGCHAINS_MCNEXT 1   /* keep the per-chain mcnext! state (mean, m2 per grid point) of every segment on the device */
 #define BHIP_SEGCHAINS_MCNEXT_MEAN 4 /* an economy for ensembles: keep the per-chain MEANS only (what the adaptation reads, smoothing.jl:133); mcnext! itself also keeps the second moments -- 3x the traffic of the commit pass */
+#define BHIP_SEGCHAINS_STATS_EVERY_ITERATION 8 /* with BHIP_SEGCHAINS_MCNEXT[_MEAN] at d <= 3: one statistics pass per iteration and two path buffers per segment (the least memory) instead of one pass per four iterations on a ring of eight (bhip_segchains_statistics_info); same results */
 #define BHIP_SEGCHAINS_POOLED 2   /* keep ONE state per segment pooled over chains x iterations (one extra read of the current paths per iteration) */
 int bhip_segchains_create(bhip_ctx *ctx, int m, const bhip_proposal *const *pos, long nchains, uint32_t path0, uint64_t seed,
                           int flags, bhip_segchains **out);

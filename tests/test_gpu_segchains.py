@@ -293,6 +293,12 @@ def test_deferred_statistics_over_many_iterations(ctx, defer, monkeypatch):
     sc = bh.SegChains(segs, mu, chol, n, seed=5, path0=0, mcnext=True)
     if defer:
         monkeypatch.delenv("BHIP_SEG_DEFER")
+        assert sc.statistics_info() == (int(defer.split()[0]), sum(int(x) for x in defer.split()))
+    else:
+        assert sc.statistics_info() == (4, 8)
+        every = bh.SegChains(segs, mu, chol, n, seed=5, path0=0, mcnext=True, stats_every_iteration=True)   # BHIP_SEGCHAINS_STATS_EVERY_ITERATION
+        assert every.statistics_info() == (1, 2)
+        every.step(w_old[:50], w_new[:50])
     a = 0
     while a < iters:
         b = min(iters, a + int(rng.integers(1, 40)))
@@ -306,6 +312,12 @@ def test_deferred_statistics_over_many_iterations(ctx, defer, monkeypatch):
             assert np.array_equal(sc.paths(i, p, 1)[0][0], r["X"][i])
             mean, m2, cnt = sc.mcstats(i, p)
             assert cnt == iters and np.array_equal(mean, r["mean"][i]) and np.array_equal(m2, r["m2"][i])
+    if not defer:
+        r50 = o.smooth_mcmc(refs, mu, chol, w_old[:50], w_new[:50], 5, 101, stats=True)
+        for i in range(2):
+            assert np.array_equal(every.paths(i, 101, 1)[0][0], r50["X"][i])
+            for u, v in zip(every.mcstats(i, 101)[:2], (r50["mean"][i], r50["m2"][i])):
+                assert np.array_equal(u, v)
 
 
 @pytest.mark.parametrize("kind", ["lorenz", "linpro2", "ou1"])
