@@ -1,4 +1,7 @@
-mkdir -p gpurun_out/r4ae
-BENCH_SAME_DEVICE=1 python bench.py --gpus 8 --steps 10 --warmup 3 > gpurun_out/r4ae/bench8.json 2> gpurun_out/r4ae/bench8.err
-BENCH_SAME_DEVICE=1 python bench.py --gpus 2 --steps 10 --warmup 3 > gpurun_out/r4ae/bench2.json 2> gpurun_out/r4ae/bench2.err
-gcc -O2 -o /tmp/fhn_multi examples/fhn_chains_multi.c -Iinclude -Lbridge.jl_amd -lbridgehip -lm -Wl,-rpath,$PWD/bridge.jl_amd && /tmp/fhn_multi > gpurun_out/r4ae/c_example.txt 2>&1
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r4ah; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_BUSY_CYCLES -d $OUT/lds -o t -- python $R/bench.py --mode c2 --steps 8 --warmup 2 --no-cpu-baseline --no-other-modes > $OUT/lds.log 2>&1
+f=$(ls $OUT/lds/*.db 2>/dev/null | head -1); [ -n "$f" ] && python $R/scripts/rocpd_summary.py $f > $R/gpurun_out/r4ah/c2_lds.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_BUSY_CYCLES -d $OUT/lds2 -o t -- python $R/bench.py --mode proposals --steps 8 --warmup 2 --no-cpu-baseline --no-other-modes > $OUT/lds2.log 2>&1
+f=$(ls $OUT/lds2/*.db 2>/dev/null | head -1); [ -n "$f" ] && python $R/scripts/rocpd_summary.py $f > $R/gpurun_out/r4ah/proposals_lds.txt 2>&1
+rm -rf $OUT/lds $OUT/lds2
