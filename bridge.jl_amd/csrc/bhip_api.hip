@@ -1741,7 +1741,7 @@ int bhip_chains_placement_info(const bhip_chains *ch, int *tries, float *ms_firs
 // ONE pCN proposal of every chain of a segment with the decision deferred (multi-segment ensembles): Wo = w_old*W + w_new*W2,
 // starts from x0_dev, proposal paths to Xo, llo to llo_dev; cur / llcur / acc are left alone (bhip_segchains_step decides)
 // launches on per-chain coefficient rows (device-built guides): the monolithic kernels, PerPathRow instantiations
-static int launch_ppr(bhip_chains *ch, int noise, KArgs &a)
+static int launch_ppr(bhip_chains *ch, int noise, KArgs &a, hipStream_t st = nullptr, bool on_st = false)   // on_st: launch on `st` instead of the context's stream
 {
     bhip_ctx *ctx = ch->ctx;
     const bhip_proposal *po = ch->po;
@@ -1752,7 +1752,7 @@ static int launch_ppr(bhip_chains *ch, int noise, KArgs &a)
     if (a.Xtb && !(noise == NOISE_PCN_LINES && a.rdtp)) return fail(ctx, BHIP_ESTATE, "time-blocked paths need the line layout");
     launch_fn f = find_launch_ppr(po->mh, noise, fl | ((noise == NOISE_PCN_LINES && !((ctx->wave_specialised || a.noise_spec == 2 || a.Xtb) && a.rdtp)) ? 2 : 0));
     if (!f) return fail(ctx, BHIP_EUNSUPPORTED, "no per-chain-guide kernel for this model");
-    HIPCHK(ctx, f(a, ctx->stream));
+    HIPCHK(ctx, f(a, on_st ? st : ctx->stream));
     return BHIP_OK;
 }
 
@@ -1777,13 +1777,13 @@ static int chains_propose_deferred(bhip_chains *ch, double w_old, double w_new, 
 }
 
 // llikelihood(LeftRule(), X, Po) of every chain's path under the chain's OWN guide
-static int chains_llikelihood_ppr(bhip_chains *ch, const double *X_dev, long ldX, double *ll_dev, int skip)
+static int chains_llikelihood_ppr(bhip_chains *ch, const double *X_dev, long ldX, double *ll_dev, int skip, hipStream_t st = nullptr, bool on_st = false)
 {
     KArgs a;
     int rc = fill_common(ch->po, a, ch->x0.data(), nullptr, ch->n, skip);
     if (rc) return rc;
     a.Win = X_dev; a.ldWin = ldX; a.ll = ll_dev;
-    return launch_ppr(ch, NOISE_LLONLY, a);
+    return launch_ppr(ch, NOISE_LLONLY, a, st, on_st);
 }
 
 // argument checks of bhip_chains_step / bhip_chains_step_group for one ensemble; resolves BHIP_SKIP_OF_INIT
