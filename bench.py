@@ -452,6 +452,10 @@ def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
     ms_mo = t_iters(sm, 2 * reps)
     del sm
     torch.cuda.empty_cache()
+    se = bh.SegChains(segs, v, bh.cholupper_t(H), n, seed=1, mcnext=True, stats_every_iteration=True)   # a statistics pass per iteration, two path buffers
+    ms_se = t_iters(se, 2 * reps)
+    del se
+    torch.cuda.empty_cache()
     # ALGORITHMIC bytes per path-step = what the reference's loop must move (smoothing.jl:160-213 swaps references on accept, it
     # copies nothing): W read + Wo written 48 (m' = 3), Xo written 24, mcnext! reads X 24 and reads + writes its state
     # (mean 3 + m2 9 doubles) 192 = 288.  The implementation MOVES 16 more -- the W lines pad m' = 3 to 4 -- reported beside it as
@@ -472,6 +476,9 @@ def smoothing_record(ctx, m=4, M=250, n=32768, reps=10):
                                         "note": f"mcnext! applied every {K} iterations to the {K} current paths kept in a ring of {nbuf} path buffers per segment (same bits as a pass per iteration, "
                                                 "which this record timed at 2.15-2.28 ms in round 3 and 1.70-1.77 ms with the paths in parity halves); the iteration is now bound by its four "
                                                 "dependent proposal launches (0.68 ms alone at one wave per SIMD), not by HBM"},
+            "iteration_shared_guides_stats_every_iteration": {"ms": ms_se, "path_steps_per_s": ps / ms_se * 1e3, "algorithmic_bytes_per_path_step": b_ref,
+                                                              "moved_bytes_per_path_step": SMOOTH_MOVED_BYTES, "hbm_frac": ps * b_ref / ms_se / 1e6 / HBM_PEAK_GBS,
+                                                              "note": "BHIP_SEGCHAINS_STATS_EVERY_ITERATION: the same loop with mcnext! applied after every iteration (K = 1), the reference's count of bytes"},
             "iteration_shared_guides_means_only": {"ms": ms_mo, "path_steps_per_s": ps / ms_mo * 1e3, "algorithmic_bytes_per_path_step": b_sh - 144 / K,
                                                    "hbm_frac": ps * (b_sh - 144 / K) / ms_mo / 1e6 / HBM_PEAK_GBS,
                                                    "note": "BHIP_SEGCHAINS_MCNEXT_MEAN: the per-chain running means only (all the adaptation reads); mcnext! proper keeps the 3 x 3 second moments too"},
@@ -854,7 +861,8 @@ def main_local(args):
             ro = o["roofline"]
             modes[o["mode"]] = [round(ro["kernel_avg_ms"], 4), round(ro["frac"], 3), ro["bound"]]
         sm = out.get("smoothing") or {}
-        for key, short in (("iteration_shared_guides", "smooth_shared"), ("iteration_shared_guides_means_only", "smooth_means"),
+        for key, short in (("iteration_shared_guides", "smooth_shared"), ("iteration_shared_guides_stats_every_iteration", "smooth_shared_k1"),
+                           ("iteration_shared_guides_means_only", "smooth_means"),
                            ("adapt_device", "smooth_adapt"), ("iteration_per_chain_guides", "smooth_perchain")):
             if key in sm:
                 modes[short] = [round(sm[key]["ms"], 4), round(sm[key]["hbm_frac"], 3), "hbm"]

@@ -1661,6 +1661,25 @@ static int chains_time_iterations(bhip_chains *ch, int skip, float *ms, int reps
 //      turn, six pairs at most --, each timed with the partner of the best pair so far; the fastest pair is kept, the rest is freed.
 //      Each candidate costs one allocation and ~4 launches (a new W also its set-up).
 // Results are those of an ensemble placed anywhere (the state of iteration 0 is set up afresh at the end; tests/test_gpu_pc.py).
+// GB/s of two write streams of `bytes` each into a and b on the context's stream (k_two_write_streams); 0 on any error
+static float two_stream_rate(bhip_ctx *ctx, void *a, void *b, size_t bytes)
+{
+    const size_t m = bytes / 16;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!m || hipEventCreate(&e0) != hipSuccess) return 0.f;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return 0.f; }
+    float ms = 0.f;
+    hipLaunchKernelGGL(k_two_write_streams, dim3(4096), dim3(256), 0, ctx->stream, (d2v *)a, (d2v *)b, m);   // untimed
+    hipError_t e = hipEventRecord(e0, ctx->stream);
+    for (int r = 0; r < 2; r++) hipLaunchKernelGGL(k_two_write_streams, dim3(4096), dim3(256), 0, ctx->stream, (d2v *)a, (d2v *)b, m);
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (e != hipSuccess || !(ms > 0.f)) { (void)hipGetLastError(); return 0.f; }
+    return (float)(2.0 * 2.0 * (double)bytes / (ms * 1e6));
+}
+
 static int chains_place(bhip_chains *ch, const double *x0, int skip)
 {
     bhip_ctx *ctx = ch->ctx;
@@ -1696,6 +1715,39 @@ static int chains_place(bhip_chains *ch, const double *x0, int skip)
     const int max_tries = 6;
     auto slowest = [&]() { float s = t_ref; for (const Cand &c : cands) s = std::max(s, c.ms); return s; };
     auto best = [&]() { size_t ib = 0; for (size_t k = 1; k < cands.size(); k++) if (cands[k].ms < cands[ib].ms) ib = k; return ib; };
+    // 2b. the pair the ensemble was created with shares a piece: look for an Xo elsewhere with PLAIN STREAMS first -- two write streams
+    // into W and into a candidate tell in half a millisecond whether the candidate lies in W's piece (4.3-5.1 TB/s) or not (5.9-6.7);
+    // consecutive allocations of a process change pieces every 4 to 8 blocks of this size at the latest (scripts/alloc_sequence_probe.hip:
+    // of 27 blocks held together, 10 to 17 lay in another piece than the first, never more than 8 in a row in the same), so up to 16
+    // candidates are held at once, the scan stops at the first one 30 % above the same-piece rate (W's own two halves), and the best
+    // one is timed with the ensemble's kernel below.  (Six kernel-timed pairs alone missed in about one fresh process out of ten.)
+    if (!(cands[0].ms < 0.93f * slowest()) && ch->wbytes >= ((size_t)64 << 20)) {
+        const size_t sb = std::min<size_t>({ch->wbytes / 2, ch->xbytes, (size_t)1 << 30}) / 4096 * 4096;
+        const float r_same = two_stream_rate(ctx, cur.w, (char *)cur.w + ch->wbytes / 2, sb);
+        void *pick = nullptr;
+        float r_pick = 0.f;
+        for (int k = 0; k < 16 && r_same > 0.f; k++) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * ch->xbytes) break;
+            void *q = nullptr;
+            if (alloc_run(&q, ch->xbytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            held.push_back(q);
+            const float r = two_stream_rate(ctx, cur.w, q, sb);
+            if (r > r_pick) { r_pick = r; pick = q; }
+            if (r >= 1.30f * r_same) break;
+        }
+        if (pick && r_pick >= 1.12f * r_same) {
+            Cand c = cur;
+            c.xo = pick;
+            ch->Wc = (double *)c.w; ch->Xo = (double *)c.xo;
+            int rct = chains_init_impl(ch, x0, nullptr, 0, skip, 0u);   // (the streams wrote over W)
+            if (!rct) rct = chains_time_iterations(ch, skip, &c.ms);
+            if (!rct) cands.push_back(c);
+        } else {
+            ch->Wc = (double *)cur.w; ch->Xo = (double *)cur.xo;
+            (void)chains_init_impl(ch, x0, nullptr, 0, skip, 0u);
+        }
+    }
     while ((int)cands.size() < max_tries && !(cands[best()].ms < 0.93f * slowest())) {
         const bool roll_w = cands.size() >= 3 && cands.size() % 2 == 1;   // tries 1, 2: Xo; then W, Xo, W
         const size_t bytes = roll_w ? ch->wbytes : ch->xbytes;

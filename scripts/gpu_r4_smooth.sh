@@ -1,5 +1,3 @@
-mkdir -p gpurun_out/r4ai
-python -m pytest tests/test_gpu_adapt_device.py tests/test_gpu_segchains.py tests/test_c_example.py tests/test_linearappr.py -x -q -m gpu 2>&1 | tail -12 > gpurun_out/r4ai/tests.txt
-python scripts/gpu_smooth_ab.py one "ring" 2>&1 | grep -v amdgpu.ids > gpurun_out/r4ai/ab.txt
-BHIP_SEG_ONE_STREAM=1 python scripts/gpu_smooth_ab.py one "ring one stream" 2>&1 | grep -v amdgpu.ids >> gpurun_out/r4ai/ab.txt
-python scripts/gpu_smooth_ab.py one "ring" 2>&1 | grep -v amdgpu.ids >> gpurun_out/r4ai/ab.txt
+mkdir -p gpurun_out/r4al
+for i in 1 2 3 4 5 6; do python bench.py --no-other-modes --no-cpu-baseline --no-live-traffic > gpurun_out/r4al/b$i.json 2> gpurun_out/r4al/b$i.err; done
+python -m pytest tests/test_gpu_pc.py tests/test_gpu_segchains.py tests/test_gpu_group.py -x -q -m gpu 2>&1 | tail -12 > gpurun_out/r4al/tests.txt
