@@ -531,6 +531,7 @@ def timed_region(w, steps, world, ctx, stats, comm=None):
     """the contract's timed region (one process per GPU, launched by torch.distributed.run): K steps bracketed by barrier +
     synchronize on both sides, MAX over ranks; ends with the device-side statistics reduction and the ONE all-gather of the
     statistics block"""
+    prewarm([w])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -558,6 +559,31 @@ def timed_region(w, steps, world, ctx, stats, comm=None):
     return elapsed, [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)], gathered
 
 
+PREWARM_S = 0.5   # see prewarm()
+
+
+def prewarm(ws, seconds=PREWARM_S):
+    """Untimed, after the W warm-up steps and every other set-up, immediately before the synchronisation that opens the timed region:
+    `seconds` worth of the workload's own step QUEUED on the devices, so that the timed steps start on devices that have been busy up
+    to that synchronisation.  The first process on an idle box otherwise measures the clocks' way up -- 1.55-1.57 ms per step of the
+    headline where every later process of the same box reads 1.505-1.515 (thirty fresh processes on five boxes; it is the idle gap
+    before the timed region that counts: a second of such steps FOLLOWED by the set-up of the collective left the first process at
+    1.56-1.57, 400 queued warm-up steps that were still running when the set-up ended put it at 1.511).  Not part of W, not part of the
+    timed region; the record says so (config.prewarm_s)."""
+    for x in ws:
+        torch.cuda.synchronize(x.ctx.device)
+    t0 = time.perf_counter()
+    for _ in range(8):
+        for x in ws:
+            x.step()
+    for x in ws:
+        torch.cuda.synchronize(x.ctx.device)
+    per = max((time.perf_counter() - t0) / 8, 1e-5)
+    for _ in range(min(4000, int(seconds / per) + 1)):
+        for x in ws:
+            x.step()
+
+
 def timed_region_local(ws, steps, stats, group):
     """the same region with ONE process driving len(ws) devices (no launcher): synchronize every device, issue the K steps
     round-robin (launches are asynchronous: one host thread keeps all devices busy), the per-device statistics reductions and
@@ -573,6 +599,7 @@ def timed_region_local(ws, steps, stats, group):
     # statistics (bhip_chains_stats_group); host_issue = host time inside those step calls, per iteration
     grp = bdist.ChainsGroup([w.chains for w in ws]) if all(w.chains is not None for w in ws) else None
     host_issue = 0.0
+    prewarm(ws)
     for d in devs:
         torch.cuda.synchronize(d)
     t0 = time.perf_counter()
@@ -638,6 +665,7 @@ def base_record(args, world, w, elapsed, kern_ms, launch):
         "config": {"workload": w.workload, "mode": args.mode, "paths_per_gpu": w.P, "grid_points": N_GRID,
                    "path_steps_per_step": w.P * steps_per_unit * world,
                    "noise_spec": NOISE_SPEC,
+                   "prewarm_s": PREWARM_S,   # untimed, before the W warm-up steps: the devices kept busy with the same step (clocks of an idle box)
                    "parallelism": f"chains sharded over {world} GPU(s) by contiguous global id, no data-path collective, one RCCL all-gather "
                                   "of the 64-byte statistics block inside libbridgehip.so",
                    "launch": launch},
