@@ -559,27 +559,20 @@ def timed_region(w, steps, world, ctx, stats, comm=None):
     return elapsed, [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)], gathered
 
 
-PREWARM_S = 0.5   # see prewarm()
+PREWARM_S = 0.5   # see prewarm(): what the step counts below amount to at the bench sizes
+PREWARM_STEPS = {"linpro32": 40, "linpro32_mcmc": 32}   # every other mode: 300
 
 
-def prewarm(ws, seconds=PREWARM_S):
+def prewarm(ws):
     """Untimed, after the W warm-up steps and every other set-up, immediately before the synchronisation that opens the timed region:
-    `seconds` worth of the workload's own step QUEUED on the devices, so that the timed steps start on devices that have been busy up
-    to that synchronisation.  The first process on an idle box otherwise measures the clocks' way up -- 1.55-1.57 ms per step of the
-    headline where every later process of the same box reads 1.505-1.515 (thirty fresh processes on five boxes; it is the idle gap
-    before the timed region that counts: a second of such steps FOLLOWED by the set-up of the collective left the first process at
-    1.56-1.57, 400 queued warm-up steps that were still running when the set-up ended put it at 1.511).  Not part of W, not part of the
-    timed region; the record says so (config.prewarm_s)."""
-    for x in ws:
-        torch.cuda.synchronize(x.ctx.device)
-    t0 = time.perf_counter()
-    for _ in range(8):
-        for x in ws:
-            x.step()
-    for x in ws:
-        torch.cuda.synchronize(x.ctx.device)
-    per = max((time.perf_counter() - t0) / 8, 1e-5)
-    for _ in range(min(4000, int(seconds / per) + 1)):
+    about half a second of the workload's own step QUEUED on the devices -- a fixed number of steps per mode, so that the chains' state
+    at the start of the timed region does not depend on the machine or on how the chains are sharded -- so that the timed steps start
+    on devices that have been busy up to that synchronisation.  The first process on an idle box otherwise measures the clocks' way up
+    -- 1.55-1.57 ms per step of the headline where every later process of the same box reads 1.505-1.515 (thirty fresh processes on five
+    boxes; it is the idle gap before the timed region that counts: a second of such steps FOLLOWED by the set-up of the collective left
+    the first process at 1.56-1.57, 400 queued warm-up steps that were still running when the set-up ended put it at 1.511).  Not part
+    of W, not part of the timed region; the record says so (config.prewarm_steps)."""
+    for _ in range(PREWARM_STEPS.get(ws[0].mode, 300)):
         for x in ws:
             x.step()
 
@@ -665,7 +658,7 @@ def base_record(args, world, w, elapsed, kern_ms, launch):
         "config": {"workload": w.workload, "mode": args.mode, "paths_per_gpu": w.P, "grid_points": N_GRID,
                    "path_steps_per_step": w.P * steps_per_unit * world,
                    "noise_spec": NOISE_SPEC,
-                   "prewarm_s": PREWARM_S,   # untimed, before the W warm-up steps: the devices kept busy with the same step (clocks of an idle box)
+                   "prewarm_steps": PREWARM_STEPS.get(args.mode, 300),   # untimed, queued right before the timed region opens: the same step (clocks of an idle box)
                    "parallelism": f"chains sharded over {world} GPU(s) by contiguous global id, no data-path collective, one RCCL all-gather "
                                   "of the 64-byte statistics block inside libbridgehip.so",
                    "launch": launch},
