@@ -122,8 +122,8 @@ def cpu_baseline(seconds_budget=20.0):
                       "Bridge.jl's four-pass loop, not Bridge.jl (no Julia here)"}
 
 
-NOISE_SPEC = ("bhip-philox-v3: Philox4x32-10, four normals per call = two Box-Muller pairs of 40 bits of radius + 24 bits of angle "
-              "(|z| <= 7.45; DESIGN 4); the reference's randn is a 52-bit ziggurat")
+NOISE_SPEC = ("bhip-philox-v4: Philox4x32-10, four normals per call = one per 32-bit word through a piecewise polynomial inverse distribution "
+              "function (256 segments of degree 4, within 3.7e-9 of the quantile, |z| <= 6.34; DESIGN 4); the reference's randn is a 52-bit ziggurat")
 PROFILE_TAG = "r4"   # profiles/<PROFILE_TAG>_<mode>_{trace,fetch,write}.txt, written by scripts/gpu_profile_all.sh this round
 
 
@@ -248,26 +248,27 @@ def _nclar(ctx):
     return bh.PartialBridge(tau_grid(0.5, N_GRID), P, Pt, [[1.0, 0, 0]], [5 / 128], [[1e-10]], ctx=ctx)
 
 
-def pc_pairs(P):
-    """workgroup shape the wave-specialised kernel is launched with (bhip_pc_kernel.h launch_pc)"""
+def pc_shape(P):
+    """workgroup shape the wave-specialised kernel is launched with under the default noise specification (bhip_pc_kernel.h launch_pc):
+    template arguments `NPAIR, PPR, RLDS` -- 2 / 4 pairs with the coefficient rows through LDS for small ensembles, four pairs sharing
+    one table of the generator without them beyond 65 536 chains"""
     g = (P + 63) // 64
-    return 2 if g <= 512 else 4 if g <= 1024 else 1
+    return "2, false, true" if g <= 512 else "4, false, true" if g <= 1024 else "4, false, false"
 
 
 def fresh_small(margs, P):
-    """fresh proposals of a small ensemble: the wave-specialised kernel with 2 / 4 / 1 producer-consumer pairs per workgroup"""
-    g = (P + 63) // 64
-    return f"k_pc<{margs}, 6, 1, {2 if g <= 512 else 4 if g <= 1024 else 1}, false>"
+    """fresh proposals of a small ensemble: the wave-specialised kernel"""
+    return f"k_pc<{margs}, 6, 1, {pc_shape(P)}>"
 
 
 # mode -> (proposal builder, d, m', x0, default paths, chains?, rho, workload text, kernel-name builder)
 MODES = {
     "mcmc": (build_proposal, 2, 1, X0, 262144, True, RHO,
              FHN_WORKLOAD + "pCN-MCMC rho=0.9: one step = one MH iteration of every chain",
-             lambda P: f"k_pc<bhip::MFHN, 2, 1, 7, 1, {pc_pairs(P)}, false>"),
+             lambda P: f"k_pc<bhip::MFHN, 2, 1, 7, 1, {pc_shape(P)}>"),
     "c4shard": (build_proposal, 2, 1, X0, 32768, True, RHO,
                 FHN_WORKLOAD + "pCN-MCMC rho=0.9, SURVEY-C4 shard size (32 768 chains per GPU)",
-                lambda P: f"k_pc<bhip::MFHN, 2, 1, 7, 1, {pc_pairs(P)}, false>"),
+                lambda P: f"k_pc<bhip::MFHN, 2, 1, 7, 1, {pc_shape(P)}>"),
     "proposals": (build_proposal, 2, 1, X0, 262144, False, None,
                   FHN_WORKLOAD + "independent fused proposals (sample!+solve!+llikelihood)",
                   lambda P: (fresh_small("bhip::MFHN, 2, 1", P) if P <= 98304 else "k_paths<bhip::MFHN, 2, 1, 1, 1, false>")),
@@ -280,7 +281,7 @@ MODES = {
               lambda P: (fresh_small("bhip::MNCLAR, 2, 1", P) if P <= 98304 else "k_paths<bhip::MNCLAR, 2, 1, 1, 1, false>")),
     "nclar_mcmc": (_nclar, 3, 1, (0.0, 0.0, 0.0), 262144, True, 0.95,
                    "NCLAR 3-d PartialBridge (scalar noise, L=[1 0 0], v=5/128), 1001-point tau-grid T=0.5, pCN-MCMC rho=0.95",
-                   lambda P: f"k_pc<bhip::MNCLAR, 2, 1, 7, 1, {pc_pairs(P)}, false>"),
+                   lambda P: f"k_pc<bhip::MNCLAR, 2, 1, 7, 1, {pc_shape(P)}>"),
     "linpro4": (lambda ctx: _linpro(ctx, 4), 4, 4, tuple([0.0] * 4), 262144, False, None,
                 "LinPro d=4 GuidedBridge (dense sigma, pre-inverted Hdiamond), 1001-point grid T=1, independent fused proposals: one path per lane "
                 "(dimensions 4..8 stay off the matrix cores)",
@@ -305,19 +306,24 @@ class Workload:
             mode = mode[:-len("_fused")]
             ctx = bh.Context(ctx.device.index)
             ctx.set_option(bh.OPT_FUSED_ARITHMETIC, 1)
-        self.v2noise = mode.endswith("_v2noise")
-        if self.v2noise:   # the same workload under the full-resolution noise specification bhip-philox-v2 (BHIP_OPT_NOISE_SPEC = 2)
-            mode = mode[:-len("_v2noise")]
-            ctx = bh.Context(ctx.device.index)
-            ctx.set_option(bh.OPT_NOISE_SPEC, 2)
+        self.v2noise = 0
+        for spec in (2, 3):   # the same workload under an earlier noise specification, bhip-philox-v2 / -v3 (BHIP_OPT_NOISE_SPEC = 2 / 3)
+            if mode.endswith(f"_v{spec}noise"):
+                self.v2noise = spec
+                mode = mode[:-len("_v2noise")]
+                ctx = bh.Context(ctx.device.index)
+                ctx.set_option(bh.OPT_NOISE_SPEC, spec)
         build, d, mp, x0, default_P, is_chains, rho, text, kname = MODES[mode]
         self.mode, self.ctx = mode, ctx
         self.P = chains if chains else default_P
         self.path0 = rank * self.P                   # contiguous shard of the global ids; the RNG is keyed by the global id
         self.Po = build(ctx)
         self.workload = text + (" [BHIP_OPT_FUSED_ARITHMETIC: tolerance parity 1e-9 / 1e-8]" if self.fused else "") + \
-            (" [BHIP_OPT_NOISE_SPEC = 2: bhip-philox-v2, one Box-Muller pair of 53 + 53 bits per Philox call]" if self.v2noise else "")
+            (" [BHIP_OPT_NOISE_SPEC = 2: bhip-philox-v2, one Box-Muller pair of 53 + 53 bits per Philox call]" if self.v2noise == 2 else
+             " [BHIP_OPT_NOISE_SPEC = 3: bhip-philox-v3, two Box-Muller pairs of 40 + 24 bits per Philox call]" if self.v2noise == 3 else "")
         self.kernel = kname(self.P).replace("bhip::", "bhip_fused::") if self.fused else kname(self.P)
+        if self.v2noise:   # large ensembles under v3 / v2: one pair per workgroup (bhip_pc_kernel.h launch_pc)
+            self.kernel = self.kernel.replace("4, false, false>", "1, false, false>")
         self.flops_per_pathstep = 5 * 2 * d * d if d > 8 else None   # d = 32: five d x d mat-vecs per path-step on the matrix cores
         self.chains = None
         if is_chains:
@@ -832,7 +838,7 @@ def main_local(args):
         del w, ws
         torch.cuda.empty_cache()
         for mode in ("c4shard", "c2", "proposals", "nclar", "nclar_mcmc", "linpro4", "linpro32", "linpro32_mcmc", "c2_fused", "proposals_fused", "nclar_fused",
-                     "mcmc_v2noise", "proposals_v2noise", "c2_v2noise"):
+                     "mcmc_v3noise", "proposals_v3noise", "c2_v3noise", "mcmc_v2noise", "proposals_v2noise", "c2_v2noise"):
             wo = Workload(mode, ctx, 0, 0)
             ms = kernel_times(wo, args.steps, args.warmup, min_ms=100.0)
             others.append({"mode": mode, "workload": wo.workload, "paths": wo.P,
@@ -920,7 +926,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chains", type=int, default=0, help="chains (paths) per GPU; 0 = the mode's named size")
-    ap.add_argument("--mode", choices=sorted(MODES) + sorted(m + "_fused" for m in MODES if MODES[m][1] <= 3) + sorted(m + "_v2noise" for m in MODES),
+    ap.add_argument("--mode", choices=sorted(MODES) + sorted(m + "_fused" for m in MODES if MODES[m][1] <= 3) + sorted(m + "_v2noise" for m in MODES) + sorted(m + "_v3noise" for m in MODES),
                     default="mcmc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true")

@@ -42,7 +42,7 @@ OPT_WAVE_SPECIALISED = 1   # BHIP_OPT_WAVE_SPECIALISED
 OPT_TUNE_PLACEMENT = 2     # BHIP_OPT_TUNE_PLACEMENT
 OPT_MID_VALU = 3           # BHIP_OPT_MID_VALU
 OPT_FUSED_ARITHMETIC = 4   # BHIP_OPT_FUSED_ARITHMETIC
-OPT_NOISE_SPEC = 5         # BHIP_OPT_NOISE_SPEC: 3 (bhip-philox-v3, default) | 2 (bhip-philox-v2, full resolution)
+OPT_NOISE_SPEC = 5         # BHIP_OPT_NOISE_SPEC: 4 (bhip-philox-v4, default) | 3 (bhip-philox-v3) | 2 (bhip-philox-v2, full resolution)
 AUX_LINEARAPPR = 4         # BHIP_AUX_LINEARAPPR
 
 

@@ -142,7 +142,7 @@ struct bhip_ctx {
     int mid_max = BHIP_MID_MAX_DEFAULT;   // BHIP_OPT_MID_VALU: LinPro targets / component-wise drifts of dimension 4..mid_max one path per lane (0: all of them on the MFMA tile kernel)
     bool fused = false;             // BHIP_OPT_FUSED_ARITHMETIC: the d <= 3 kernels built with a*b + c contracted (tolerance parity)
     bool tune_placement = true;     // BHIP_OPT_TUNE_PLACEMENT: large chain ensembles try a few allocations and keep the fastest (bhip_chains_init)
-    int noise_spec = 3;             // BHIP_OPT_NOISE_SPEC: 3 = bhip-philox-v3 (default), 2 = bhip-philox-v2, the full-resolution stream (bhip_rng.h)
+    int noise_spec = 4;             // BHIP_OPT_NOISE_SPEC: 4 = bhip-philox-v4 (default), 3 = bhip-philox-v3, 2 = bhip-philox-v2 (bhip_rng.h)
     // lifetime: every proposal / chain ensemble / communicator holds a reference.  bhip_ctx_destroy with live children only
     // closes the context (garbage collectors -- Python at interpreter exit, Julia finalizers -- destroy handles in any order);
     // the last child releases it.  A closed context's stream is no longer synchronised (it was borrowed and may be gone).
@@ -226,7 +226,7 @@ struct bhip_chains {
     const double *prows = nullptr, *vend_pc = nullptr;
     const unsigned char *uv_pc = nullptr;
     int lna = 0;                  // the per-chain rows carry LinearNoiseAppr slopes instead of linearisation points
-    int noise_spec = 3;           // the noise specification the ensemble was created under (the context's BHIP_OPT_NOISE_SPEC then); fixed for its life
+    int noise_spec = 4;           // the noise specification the ensemble was created under (the context's BHIP_OPT_NOISE_SPEC then); fixed for its life
 };
 
 static int fail(bhip_ctx *ctx, int code, const std::string &msg)
@@ -388,7 +388,8 @@ int bhip_ctx_set_option(bhip_ctx *ctx, int option, int value)
     }
     if (option == BHIP_OPT_FUSED_ARITHMETIC) { ctx->fused = value != 0; return BHIP_OK; }
     if (option == BHIP_OPT_NOISE_SPEC) {
-        if (value != 2 && value != 3) return fail(ctx, BHIP_EINVAL, "BHIP_OPT_NOISE_SPEC: 3 (bhip-philox-v3, the default) or 2 (bhip-philox-v2, full resolution)");
+        if (value != 2 && value != 3 && value != 4)
+            return fail(ctx, BHIP_EINVAL, "BHIP_OPT_NOISE_SPEC: 4 (bhip-philox-v4, the default), 3 (bhip-philox-v3) or 2 (bhip-philox-v2, full resolution)");
         ctx->noise_spec = value;
         return BHIP_OK;
     }
@@ -1171,9 +1172,9 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
     // the pCN step on the 16-byte slots is refused (chains at d > 3 were created on the tile kernel under this specification,
     // bhip_chains_create; at d <= 3 the slots only serve grids too long for the line layout), the one-lane line kernel gives way to
     // the wave-specialised one
-    const bool v2 = a.noise_spec == 2;
+    const bool v2 = a.noise_spec == 2 || a.noise_spec == 3;   // (a non-default specification)
     if (v2 && noise == NOISE_PCN)
-        return fail(ctx, BHIP_EUNSUPPORTED, "BHIP_OPT_NOISE_SPEC = 2: the pCN step on the 16-byte slots draws the default noise stream only");
+        return fail(ctx, BHIP_EUNSUPPORTED, "BHIP_OPT_NOISE_SPEC = 2 / 3: the pCN step on the 16-byte slots draws the default noise stream only");
     const bool wave_spec = ctx->wave_specialised || v2 || a.Xtb;   // (time-blocked path stores exist in the wave-specialised kernel only)
     if (a.Xtb && !(noise == NOISE_PCN_LINES && a.rdtp && po->mh.mp <= 3 && a.wstride == 1 && !po->mid)) return fail(ctx, BHIP_ESTATE, "time-blocked paths need the line layout");
     if (po->mid) {   // LinPro, d = 4..12: rows in the (nu, H) form, one kernel family
@@ -1237,7 +1238,11 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         if (wave_spec && a.rdtp && po->mh.mp <= 3 && a.wstride == 1) {
             if (noise == NOISE_FRESH && a.P <= pc_fresh_max_paths()) knoise = NOISE_FRESH_PC;
             else if (noise == NOISE_PCN_LINES) knoise = NOISE_PCN_LINES_PC;
-            if (knoise != noise) npair = groups <= PC_MAX_GROUPS_2PAIR ? 2 : groups <= PC_MAX_GROUPS_4PAIR ? 4 : 1;
+            if (knoise != noise) {   // the workgroup shape launch_pc would choose
+                bool rlds = true;
+                npair = pc_choose_npair_rt(a, groups, po->mh.d, a.rs, po->mh.mp, &rlds);
+                if (!rlds && npair > 1) npair = -npair;
+            }
         }
         hipFunction_t fn = nullptr;
         {
@@ -1254,11 +1259,10 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         }
         KArgs args = a;
         void *params[] = {&args};
-        if (npair > 0) {
-            const int spc = LINE_DOUBLES / line_mpp(po->mh.mp);
-            const unsigned lds = (npair == 1 ? (unsigned)PC_LDS : (unsigned)(sizeof(double) * (RNG_TAB_DOUBLES + npair * (2 * PC_TILE + 2 * spc * a.rs)))) +
-                                 (a.Xtb ? (unsigned)pc_xs_bytes(po->mh.d, npair) : 0u);
-            HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)((groups + npair - 1) / npair), 1, 1, 128 * npair, 1, 1, lds, ctx->stream, params, nullptr));
+        if (npair != 0) {
+            const int spc = LINE_DOUBLES / line_mpp(po->mh.mp), np = npair < 0 ? -npair : npair;
+            const unsigned lds = (unsigned)(pc_lds_bytes(a.noise_spec, np, npair > 1 ? spc * a.rs : 0) + (a.Xtb ? pc_xs_bytes(po->mh.d, np) : 0));
+            HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)((groups + np - 1) / np), 1, 1, 128 * np, 1, 1, lds, ctx->stream, params, nullptr));
             return BHIP_OK;
         }
         const long grid = (a.P + 255) / 256;
@@ -1537,7 +1541,7 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     const size_t N = po->tt.size();
     // d > 3: one path per lane (slots) up to the chains' cut -- lower than the proposals' (the slots' traffic and registers: 8.5 vs 5.6 ms at
     // d = 9) --, and never under the full-resolution noise specification (the slot kernel draws the default stream only)
-    ch->tile = po->mh.d > 3 && !(po->mid && po->mh.d <= std::min(ctx->mid_max, (int)BHIP_MID_MAX_CHAINS) && ctx->noise_spec != 2);
+    ch->tile = po->mh.d > 3 && !(po->mid && po->mh.d <= std::min(ctx->mid_max, (int)BHIP_MID_MAX_CHAINS) && ctx->noise_spec == 4);
     ch->lines = po->mh.d <= 3 && po->mh.mp <= 3;
     const size_t spc = LINE_DOUBLES / (ch->lines ? line_mpp(po->mh.mp) : 1);   // grid points per line (m' = 3: padded to 4 components)
     ch->nch = (int)((N + spc - 1) / spc);
@@ -1800,9 +1804,9 @@ static int launch_ppr(bhip_chains *ch, int noise, KArgs &a, hipStream_t st = nul
     a.prows = ch->prows; a.ldr = ch->ld; a.vend_pc = ch->vend_pc; a.uv_pc = ch->uv_pc; a.lna = ch->lna;
     const int fl = (noise == NOISE_PCN || noise == NOISE_PCN_LINES) ? (a.Xo ? 1 : 0) : 0;
     // (bit 1 of the selector: the monolithic line kernel instead of the wave-specialised one)
-    if (a.noise_spec == 2 && noise == NOISE_PCN) return fail(ctx, BHIP_EUNSUPPORTED, "BHIP_OPT_NOISE_SPEC = 2: the pCN step on the 16-byte slots draws the default noise stream only");
+    if (a.noise_spec != 4 && noise == NOISE_PCN) return fail(ctx, BHIP_EUNSUPPORTED, "BHIP_OPT_NOISE_SPEC = 2 / 3: the pCN step on the 16-byte slots draws the default noise stream only");
     if (a.Xtb && !(noise == NOISE_PCN_LINES && a.rdtp)) return fail(ctx, BHIP_ESTATE, "time-blocked paths need the line layout");
-    launch_fn f = find_launch_ppr(po->mh, noise, fl | ((noise == NOISE_PCN_LINES && !((ctx->wave_specialised || a.noise_spec == 2 || a.Xtb) && a.rdtp)) ? 2 : 0));
+    launch_fn f = find_launch_ppr(po->mh, noise, fl | ((noise == NOISE_PCN_LINES && !((ctx->wave_specialised || a.noise_spec != 4 || a.Xtb) && a.rdtp)) ? 2 : 0));
     if (!f) return fail(ctx, BHIP_EUNSUPPORTED, "no per-chain-guide kernel for this model");
     HIPCHK(ctx, f(a, on_st ? st : ctx->stream));
     return BHIP_OK;
@@ -2331,19 +2335,14 @@ void bhip_normals_host_spec(int spec, uint64_t seed, uint32_t path, uint32_t ite
     double z0 = 0, z1 = 0; long have = -1;
     for (int j = 0; j < n; j++) {
         const int idx = n0 + j;
-        if ((idx >> 1) != have) { normal_pair_spec(spec, TabConst(), (uint32_t)seed, (uint32_t)(seed >> 32), path, iter, (uint32_t)(idx >> 1), z0, z1); have = idx >> 1; }
+        if ((idx >> 1) != have) { normal_pair_spec(spec, (uint32_t)seed, (uint32_t)(seed >> 32), path, iter, (uint32_t)(idx >> 1), z0, z1); have = idx >> 1; }
         z[j] = (idx & 1) ? z1 : z0;
     }
 }
 
 void bhip_normals_host(uint64_t seed, uint32_t path, uint32_t iter, int n0, int n, double *z)
 {
-    double z0 = 0, z1 = 0; long have = -1;
-    for (int j = 0; j < n; j++) {
-        const int idx = n0 + j;
-        if ((idx >> 1) != have) { normal_pair((uint32_t)seed, (uint32_t)(seed >> 32), path, iter, (uint32_t)(idx >> 1), z0, z1); have = idx >> 1; }
-        z[j] = (idx & 1) ? z1 : z0;
-    }
+    bhip_normals_host_spec(4, seed, path, iter, n0, n, z);   // the default specification
 }
 
 }  // extern "C"

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, BHIP_LINES_STAGE ? 2 : 4) void k_chain_lines(c
             __builtin_amdgcn_wave_barrier();   // the tile is overwritten by the next chunk only after these reads
         }
     };
-    run_chunks(TabConst());   // (the default stream only: under BHIP_OPT_NOISE_SPEC = 2 the host launches the wave-specialised kernel, do_launch)
+    run_chunks(IcdfConst());   // (the default stream only: under BHIP_OPT_NOISE_SPEC = 2 / 3 the host launches the wave-specialised kernel, do_launch)
 
     if constexpr (PPR) {
         if (a.uv_pc[p]) {

@@ -82,7 +82,7 @@ struct KArgs {
     uint32_t k0, k1, iter, path0;
     uint32_t blk0;        // offset of the Philox block index (multi-segment chains: segment << 24; 0 otherwise)
     int defer_accept;     // pCN modes: do not decide -- only report llo in `ll` (joint accept over segments, bhip_segchains_*)
-    int noise_spec;       // 2: the full-resolution stream bhip-philox-v2 (BHIP_OPT_NOISE_SPEC); anything else: bhip-philox-v3 (bhip_rng.h)
+    int noise_spec;       // BHIP_OPT_NOISE_SPEC: 4 (and anything else) the default stream bhip-philox-v4, 3: bhip-philox-v3, 2: bhip-philox-v2 (bhip_rng.h)
     double x0[BHIP_MAXD_LANE];       // d <= 3 for every process; LinPro targets of dimension 4..12 run one path per lane too
     double vend[BHIP_MAXD_LANE];
     double mu_aux[BHIP_MAXD_LANE];
@@ -320,7 +320,8 @@ template <class ST> BHIP_DEV void pc_mark(ST &st, int k)
 //   FL    : bit0 store X, bit1 store W, bit2 PartialBridge!-style log-likelihood (two dots)
 //   RowPtr: where the step's coefficient row is read from -- cptr_t (constant address space: scalar loads into SGPRs)
 //           or an LDS pointer (the consumer waves of bhip_pc_kernel.h at small ensembles: broadcast ds_reads)
-//   Tab   : where the generator's tables are read from (TabConst, or TabLDS when the kernel keeps a copy in LDS)
+//   Tab   : where the generator's table is read from and -- its TYPE -- under which noise specification (bhip_rng.h: IcdfLDS / IcdfConst
+//           the default v4, TabLDS / TabConst v3, FullRes<..> v2); the modes that draw nothing never touch it
 template <class M, int GK, int MO, int NOISE, int FL, class RowPtr = cptr_t, class Tab = TabConst>
 BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int nll, uint32_t path, const double *win_k,
                         double *wout, long ldwo, double *xout, long ldx, LaneState<M::D, M::MP> &st, const Tab &tab = Tab(),
@@ -519,15 +520,18 @@ __global__ __launch_bounds__(256, (PPR || M::D > 4 || (M::D > 3 && NOISE == NOIS
 {
     constexpr int D = M::D, MP = M::MP;
     using RL = RowLayout<GK, D, MO, is_constdiff<M>::value>;
-    // the instantiations that draw normals keep the generator's tables in LDS (2.5 KB per block)
+    // the instantiations that draw normals keep the generator's table in LDS (10 KB per block under the default specification v4;
+    // fresh proposals can also draw v3 / v2 and load that table, 2.5 KB, instead)
     constexpr bool DRAWS = NOISE == NOISE_FRESH || NOISE == NOISE_PCN;
-    __shared__ __attribute__((aligned(16))) double rng_tab[DRAWS ? RNG_TAB_DOUBLES : 2];
+    constexpr bool TWO_COPIES = DRAWS && NOISE == NOISE_FRESH;   // (three since round 5: one time loop per specification)
+    __shared__ __attribute__((aligned(16))) double rng_tab[DRAWS ? (TWO_COPIES ? RNG_LDS_DOUBLES : ICDF_TAB_DOUBLES) : 2];
     if constexpr (DRAWS) {
-        TabLDS::load(rng_tab, threadIdx.x, blockDim.x);
+        if (TWO_COPIES && (a.noise_spec == 2 || a.noise_spec == 3)) TabLDS::load(rng_tab, threadIdx.x, blockDim.x);
+        else IcdfLDS::load(rng_tab, threadIdx.x, blockDim.x);
         __syncthreads();
     }
-    using TabT = typename bhip_cond<DRAWS, TabLDS, TabConst>::type;
-    const TabT tab = [&]() { if constexpr (DRAWS) return TabLDS(rng_tab); else return TabConst(); }();
+    using TabT = typename bhip_cond<DRAWS, IcdfLDS, TabConst>::type;
+    const TabT tab = [&]() { if constexpr (DRAWS) return IcdfLDS(rng_tab); else return TabConst(); }();
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.P) return;
     // the model functor: built once from the kernel arguments, or (STREAMED) re-opened from the device copy at every step
@@ -693,13 +697,13 @@ __global__ __launch_bounds__(256, (PPR || M::D > 4 || (M::D > 3 && NOISE == NOIS
             rr[0] = rr[1];
         }
     };
-    // Fresh proposals hold the loop twice (every copy one basic block per step: the scheduler interleaves the generator with the
-    // recurrence; a branch at the draw instead cost the 4..8-dimensional kernels 40 %).  The pCN step on the slots has no registers
-    // for two copies (they spilled) and stays on the default stream: under BHIP_OPT_NOISE_SPEC = 2 the host sends chains to the
-    // wave-specialised kernel (d <= 3) or the tile kernel (d > 3) and refuses what only this kernel could run (do_launch).
-    constexpr bool TWO_COPIES = DRAWS && NOISE == NOISE_FRESH;
+    // Fresh proposals hold the loop once per specification (every copy one basic block per step: the scheduler interleaves the
+    // generator with the recurrence; a branch at the draw instead cost the 4..8-dimensional kernels 40 %).  The pCN step on the slots
+    // has no registers for several copies (they spilled) and stays on the default stream: under BHIP_OPT_NOISE_SPEC = 2 / 3 the host sends
+    // chains to the wave-specialised kernel (d <= 3) or the tile kernel (d > 3) and refuses what only this kernel could run (do_launch).
     if constexpr (TWO_COPIES) {
-        if (a.noise_spec == 2) time_loop(FullRes<TabT>(tab));
+        if (a.noise_spec == 2) time_loop(FullRes<TabLDS>(TabLDS(rng_tab)));
+        else if (a.noise_spec == 3) time_loop(TabLDS(rng_tab));
         else time_loop(tab);
     } else time_loop(tab);
 
@@ -728,7 +732,7 @@ __global__ __launch_bounds__(256, (PPR || M::D > 4 || (M::D > 3 && NOISE == NOIS
         if (!a.defer_accept) {
             const double u = accept_uniform(a.k0, a.k1, path, a.iter);
             const double llc = a.llcur[p];
-            if (det_log(u, tab) <= st.ll - llc) {
+            if (det_log(u) <= st.ll - llc) {
                 a.cur[p] = (unsigned char)(c ^ 1);
                 a.llcur[p] = st.ll;
                 a.acc[p] += 1u;

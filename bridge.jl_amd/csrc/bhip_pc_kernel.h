@@ -11,7 +11,7 @@
 //           the pCN mix Wo = rho*W + sqrt(1-rho^2)*W2 (partialbridge_fitzhugh.jl:147) and the whole chain-state traffic
 //           (the 128-byte lines of bhip_chain_kernel.h, read, mixed in an LDS tile, written to the other parity half).
 //           Eight independent Philox blocks per 16-value chunk: instruction-level parallelism instead of a dependent chain.
-//           The generator's tables live in LDS (TabLDS).
+//           The generator's table lives in LDS (IcdfLDS under the default noise specification v4, TabLDS under v3 / v2).
 //   wave 1, the CONSUMER: solve!(Euler(), Xo, x0, Wo, Po) + llikelihood (src/euler.jl:247-268, src/partialbridge.jl:67-77
 //           ...) exactly as path_step<.., NOISE_EXT, ..> does them, with the driving Wiener values read from the
 //           producer's LDS tile instead of HBM; stores Xo; Metropolis-Hastings accept at the end.
@@ -53,7 +53,14 @@ enum { NOISE_FRESH_PC = 6, NOISE_PCN_LINES_PC = 7 };
 #define PC_CONS_UNROLL (RLDS ? PC_CONS_UNROLL_SMALL : 2)
 #endif
 constexpr int PC_TILE = 64 * LINE_ROW;                          // doubles per hand-over tile
-constexpr size_t PC_LDS = sizeof(double) * (RNG_TAB_DOUBLES + 2 * PC_TILE);   // 19 984 bytes: 8 workgroups per CU
+// LDS of a workgroup: the generator's table of the launch's noise specification (v4: 10 240 bytes, v3 / v2: 2 576), then per pair the two
+// hand-over tiles (17 408 bytes) and, with RLDS, two chunks of coefficient rows.  Large ensembles want 8 pairs per CU: one pair per
+// workgroup under v3 / v2 (19 984 bytes), FOUR pairs sharing one table under v4 (79 872 bytes, two workgroups per CU).
+constexpr int pc_tab_doubles(int noise_spec) { return noise_spec == 2 || noise_spec == 3 ? RNG_TAB_DOUBLES : ICDF_TAB_DOUBLES; }
+constexpr size_t pc_lds_bytes(int noise_spec, int npair, int crow /* doubles of coefficient rows per chunk, 0 without RLDS */)
+{
+    return sizeof(double) * (pc_tab_doubles(noise_spec) + npair * (2 * PC_TILE + 2 * crow));
+}
 // time-blocked path stores (KArgs::Xtb): a consumer lane collects sixteen grid points of its chain in LDS -- [k][16] + 1 double of padding
 // per lane: conflict-free 8-byte accesses -- and the wave writes them out as whole 128-byte lines, eight lanes per line
 constexpr int pc_xs_row(int d) { return 16 * d + 1; }
@@ -95,8 +102,9 @@ struct PcStamp {
 // the Wiener increment INTO grid point j, so that a chunk reads 16/m' consecutive, aligned values and grid point 0
 // (W[0] = 0 + 0*z = 0) needs no special case.
 
-template <class M, int GK, int MO, int MODE, int FL, int NPAIR, bool PPR = false /* per-chain guide rows (bhip_guide_kernel.h) */>
-__global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void k_pc(const KArgs a)
+template <class M, int GK, int MO, int MODE, int FL, int NPAIR, bool PPR = false /* per-chain guide rows (bhip_guide_kernel.h) */,
+          bool RLDS = (NPAIR > 1) /* coefficient rows through LDS (small ensembles); false at NPAIR = 4: the large-ensemble workgroup of v4 */>
+__global__ __launch_bounds__(128 * NPAIR, (RLDS || PPR) ? 2 : PC_WPE) void k_pc(const KArgs a)
 {
     constexpr int D = M::D, MP = M::MP;
     static_assert(MP >= 1 && MP <= 3, "a chunk holds 16/m' grid points (m' = 3: lines padded to 4 components)");
@@ -112,16 +120,18 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
     // of a 4-pair workgroup put one producer and one consumer on every SIMD, whereas the waves of independent 128-thread
     // workgroups may share a SIMD while another one idles (measured at 32 768 chains: producer-only 0.21 ms,
     // consumer-only 0.21 ms, both 0.31 ms in 128-thread workgroups, 0.25 ms in 256-thread ones).
-    constexpr bool RLDS = NPAIR > 1;
+    static_assert(RLDS ? NPAIR > 1 : true, "RLDS workgroups hold 2 or 4 pairs");
     extern __shared__ __attribute__((aligned(16))) double pc_lds_all[];
-    double *tab = pc_lds_all;                                           // [RNG_TAB_DOUBLES], shared by the pairs
+    double *tab = pc_lds_all;                                           // [pc_tab_doubles(noise_spec)], shared by the pairs
+    const int tabd = pc_tab_doubles(a.noise_spec);
     constexpr int CROW = SPC * RL::RS;                                  // doubles of coefficient rows per chunk
     const int wave = threadIdx.x >> 6, pair = wave % NPAIR, role = wave / NPAIR;   // waves 0..NPAIR-1 produce, the others consume
-    double *pc_lds = pc_lds_all + RNG_TAB_DOUBLES + pair * (2 * PC_TILE + (RLDS ? 2 * CROW : 0));   // [2][PC_TILE] then (RLDS) [2][CROW]
+    double *pc_lds = pc_lds_all + tabd + pair * (2 * PC_TILE + (RLDS ? 2 * CROW : 0));   // [2][PC_TILE] then (RLDS) [2][CROW]
     double *crow = pc_lds + 2 * PC_TILE;
     // (time-blocked path stores: the consumers' staging rows lie behind the pairs' tiles -- allocated by the launch only when a.Xtb is set)
-    double *xs_all = pc_lds_all + RNG_TAB_DOUBLES + NPAIR * (2 * PC_TILE + (RLDS ? 2 * CROW : 0));
-    TabLDS::load(tab, threadIdx.x, 128 * NPAIR);
+    double *xs_all = pc_lds_all + tabd + NPAIR * (2 * PC_TILE + (RLDS ? 2 * CROW : 0));
+    if (a.noise_spec == 2 || a.noise_spec == 3) TabLDS::load(tab, threadIdx.x, 128 * NPAIR);
+    else IcdfLDS::load(tab, threadIdx.x, 128 * NPAIR);
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -278,7 +288,8 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
                     }
                 };
                 if (a.noise_spec == 2) draws(FullRes<TabLDS>(rtab));
-                else draws(rtab);
+                else if (a.noise_spec == 3) draws(rtab);
+                else draws(IcdfLDS(tab));
                 if constexpr (PCN) {
                     __builtin_amdgcn_wave_barrier();
                     double *kb = chunk_base(k);
@@ -481,7 +492,7 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
         if (live) {
             if (!a.defer_accept) {
                 const double u = accept_uniform(a.k0, a.k1, path, a.iter);
-                if (det_log(u, TabLDS(tab)) <= st.ll - a.llcur[p]) {
+                if (det_log(u) <= st.ll - a.llcur[p]) {   // (the log's table from constant memory: once per chain and launch)
                     a.cur[p] = (unsigned char)(a.cur[p] ^ 1);
                     a.llcur[p] = st.ll;
                     a.acc[p] += 1u;
@@ -498,31 +509,63 @@ __global__ __launch_bounds__(128 * NPAIR, (NPAIR > 1 || PPR) ? 2 : PC_WPE) void 
 
 // Small ensembles: up to 512 groups of 64 chains (32 768 chains) as 2-pair workgroups -- one wave per SIMD on up to 256
 // CUs --, up to 1024 groups (65 536) as 4-pair workgroups -- one producer and one consumer per SIMD; both RLDS (LDS and
-// 256 registers per lane are free at two waves per SIMD).  Larger ensembles: one pair per 128-thread workgroup, 8 per CU.
+// 256 registers per lane are free at two waves per SIMD).  Larger ensembles: 8 pairs per CU at the 128-register cap -- under the noise
+// specification v4 as two 4-pair workgroups (the 10-KB table shared by four pairs; one pair per workgroup would fit five per CU), under
+// v3 / v2 as eight 128-thread workgroups.
 #ifndef PC_MAX_GROUPS_2PAIR
 #define PC_MAX_GROUPS_2PAIR 512
 #endif
 #ifndef PC_MAX_GROUPS_4PAIR
 #define PC_MAX_GROUPS_4PAIR 1024
 #endif
-template <class M, int GK, int MO, int MODE, int FL, int NPAIR, bool PPR = false>
-void launch_pc_n(const KArgs &a, hipStream_t st, long groups)
+// pairs per workgroup of the LARGE ensembles under v4 (measurement hook: BHIP_PC_LARGE_NPAIR = 1 | 4 in the environment, read once)
+inline int pc_large_npair()
+{
+    static const int v = []() { const char *e = getenv("BHIP_PC_LARGE_NPAIR"); return e && e[0] == '1' ? 1 : 4; }();
+    return v;
+}
+// the LDS a time-blocked launch (a.Xtb) needs on top must still fit: 160 KB per workgroup
+constexpr size_t PC_LDS_MAX = 160 * 1024;
+template <class M, int GK, int MO, int MODE, int FL, int NPAIR, bool PPR = false, bool RLDS = (NPAIR > 1)>
+hipError_t launch_pc_n(const KArgs &a, hipStream_t st, long groups)
 {
     using RL = RowLayout<GK, M::D, MO, is_constdiff<M>::value>;
-    const size_t lds = (NPAIR == 1 ? PC_LDS : sizeof(double) * (RNG_TAB_DOUBLES + NPAIR * (2 * PC_TILE + 2 * (LINE_DOUBLES / line_mpp(M::MP)) * RL::RS))) +
-                       (a.Xtb ? pc_xs_bytes(M::D, NPAIR) : 0);
+    const size_t lds = pc_lds_bytes(a.noise_spec, NPAIR, RLDS ? (LINE_DOUBLES / line_mpp(M::MP)) * RL::RS : 0) + (a.Xtb ? pc_xs_bytes(M::D, NPAIR) : 0);
+    if (lds > PC_LDS_MAX) return hipErrorInvalidValue;
     // more than the default 64 KB of dynamic LDS: opt in -- per device and cheap, so on every launch (a process may drive several devices)
-    if (lds > 65536) (void)hipFuncSetAttribute((const void *)k_pc<M, GK, MO, MODE, FL, NPAIR, PPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_pc<M, GK, MO, MODE, FL, NPAIR, PPR>), dim3((unsigned)((groups + NPAIR - 1) / NPAIR)), dim3(128 * NPAIR), lds, st, a);
+    if (lds > 65536) {
+        const hipError_t e = hipFuncSetAttribute((const void *)k_pc<M, GK, MO, MODE, FL, NPAIR, PPR, RLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_pc<M, GK, MO, MODE, FL, NPAIR, PPR, RLDS>), dim3((unsigned)((groups + NPAIR - 1) / NPAIR)), dim3(128 * NPAIR), lds, st, a);
+    return hipGetLastError();
+}
+// pairs per workgroup of a launch (also what the hipRTC route of do_launch follows): 2 / 4 (RLDS) for small ensembles -- fewer when
+// the time-blocked staging rows of a d = 3 guide would not fit next to four pairs' tiles --, then 1 or 4 without RLDS
+inline int pc_choose_npair_rt(const KArgs &a, long groups, int d, int rs, int mp, bool *rlds)
+{
+    const int crow = (LINE_DOUBLES / line_mpp(mp)) * rs;
+    auto fits = [&](int np, bool rl) { return pc_lds_bytes(a.noise_spec, np, rl ? crow : 0) + (a.Xtb ? pc_xs_bytes(d, np) : 0) <= PC_LDS_MAX; };
+    *rlds = true;
+    if (groups <= PC_MAX_GROUPS_2PAIR && fits(2, true)) return 2;
+    if (groups <= PC_MAX_GROUPS_4PAIR && fits(4, true)) return 4;
+    if (groups <= PC_MAX_GROUPS_4PAIR && fits(2, true)) return 2;
+    *rlds = false;
+    const bool v4 = !(a.noise_spec == 2 || a.noise_spec == 3);
+    if (v4 && pc_large_npair() == 4 && fits(4, false)) return 4;
+    return 1;
 }
 template <class M, int GK, int MO, int MODE, int FL, bool PPR>
 hipError_t launch_pc(const KArgs &a, hipStream_t st)
 {
+    using RL = RowLayout<GK, M::D, MO, is_constdiff<M>::value>;
     const long groups = (a.P + 63) / 64;
-    if (groups <= PC_MAX_GROUPS_2PAIR) launch_pc_n<M, GK, MO, MODE, FL, 2, PPR>(a, st, groups);
-    else if (groups <= PC_MAX_GROUPS_4PAIR) launch_pc_n<M, GK, MO, MODE, FL, 4, PPR>(a, st, groups);
-    else launch_pc_n<M, GK, MO, MODE, FL, 1, PPR>(a, st, groups);
-    return hipGetLastError();
+    bool rlds;
+    const int np = pc_choose_npair_rt(a, groups, M::D, RL::RS, M::MP, &rlds);
+    if (np == 2) return launch_pc_n<M, GK, MO, MODE, FL, 2, PPR>(a, st, groups);
+    if (np == 4 && rlds) return launch_pc_n<M, GK, MO, MODE, FL, 4, PPR>(a, st, groups);
+    if (np == 4) return launch_pc_n<M, GK, MO, MODE, FL, 4, PPR, false>(a, st, groups);
+    return launch_pc_n<M, GK, MO, MODE, FL, 1, PPR>(a, st, groups);
 }
 
 }  // namespace bhip

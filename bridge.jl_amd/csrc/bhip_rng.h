@@ -1,4 +1,5 @@
-// bhip_rng.h -- RNG specifications "bhip-philox-v3" (the default) and "bhip-philox-v2" (full resolution, selectable), host + device.
+// bhip_rng.h -- RNG specifications "bhip-philox-v4" (the default: inverse distribution function, one normal per 32-bit word),
+//               "bhip-philox-v3" (Box-Muller, 40 + 24 bits per pair) and "bhip-philox-v2" (Box-Muller, 53 + 53 bits), host + device.
 //
 // Replaces the reference's global randn() (src/wiener.jl:31,44,55), which is not reproducible
 // outside Julia, with a counter-based generator whose output depends only on
@@ -19,6 +20,17 @@
 // tables (bhip_rng_tables.h, generated correctly rounded by scripts/gen_rng_tables.py), so that every host and
 // device evaluates bit-identical normals (no libm / ocml dependence).
 //
+// v4 (round 5, the default): the same generator, counters and call layout -- call q of stream 0 still gives the normals 4q .. 4q+3,
+// pair h = half h & 1 of call h >> 1 -- but word r[j] of the call IS normal 4q + j, through a piecewise polynomial inverse of the
+// normal distribution function (icdf_normal below, table bhip_icdf_table.h from scripts/gen_icdf_table.py):
+//     v = 2*(w mod 2^31) + 1 (odd),  upper-tail probability p = v*2^-33,  d = (double)v,  row R = (highword(d) >> 17) & 255
+//     (octave of p and its eighth),  |z| = c0 + d*(c1 + d*(c2 + d*(c3 + d*c4))) in four fma,  sign = bit 31 of w.
+// 32 bits per normal (v3: 40 + 24 per pair), |z| <= 6.34 (mass beyond: 2.3e-10), 2^32 equiprobable values; the polynomial is within
+// 3.7e-9 of -Phi^-1(p) (Kolmogorov distance of the marginal to N(0,1) <= 1.3e-9 + 2^-33).  ~9 VALU + two LDS reads per normal on top
+// of the Philox share instead of ~33: the reference's randn is a ziggurat (a handful of instructions); Box-Muller's log / sqrt /
+// sincos were the first limiter of every kernel but the memory-bound headline.  Exact integer -> double conversion
+// and fma only: host and device agree bit for bit as before.
+//
 // v1 -> v2 (round 2): table-driven argument reduction for the log and the rotation instead of a division + 11-term series
 // and 7 + 8 Taylor terms: ~147 -> ~119 VALU instructions per Philox call (then: two normals).
 // v2 -> v3 (round 3): v2 spent all 128 bits of a Philox call on ONE Box-Muller pair (53 + 53 bits); the ten Philox rounds
@@ -30,6 +42,7 @@
 #pragma once
 #include <stdint.h>
 #include "bhip_rng_tables.h"
+#include "bhip_icdf_table.h"
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define BHIP_HD __host__ __device__ __forceinline__
@@ -168,6 +181,72 @@ struct TabLDS {
 };
 #endif
 
+// ---- specification v4: the table of the piecewise inverse distribution function, BHIP_ICDF_ROWS rows {c0 .. c4}.
+// IcdfConst reads it from constant memory (per-lane loads) / the host array; IcdfLDS from a copy in LDS laid out in three planes --
+// {c0, c1}[R], {c2, c3}[R], c4[R] -- so that the 16-byte reads of neighbouring rows fall into different banks (the sixteen most
+// probable rows, octaves p >= 1/8, hit sixteen different bank groups).  The TYPE of the accessor carries the specification.
+alignas(16) static const double icdf_host[5 * BHIP_ICDF_ROWS] = BHIP_ICDF_INIT;
+#if defined(__HIPCC__)
+alignas(16) static __device__ const double icdf_dev[5 * BHIP_ICDF_ROWS] = BHIP_ICDF_INIT;
+#endif
+struct IcdfConst {
+    static constexpr int NOISE_SPEC = 4;
+    BHIP_HD void row(uint32_t R, double &c0, double &c1, double &c2, double &c3, double &c4) const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double *c = icdf_dev + 5 * R;
+#else
+        const double *c = icdf_host + 5 * R;
+#endif
+        c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4];
+    }
+};
+#if defined(__HIPCC__)
+constexpr int ICDF_TAB_DOUBLES = 5 * BHIP_ICDF_ROWS;   // 1280 doubles = 10 240 bytes of LDS
+struct IcdfLDS {
+    static constexpr int NOISE_SPEC = 4;
+    typedef const __attribute__((address_space(3))) rng_d2v *lds2_t;
+    typedef const __attribute__((address_space(3))) double *lds1_t;
+    lds2_t pa;   // {c0, c1}[R]; {c2, c3}[R] follows at + BHIP_ICDF_ROWS, c4[R] at + 2*BHIP_ICDF_ROWS (as doubles: + 4*BHIP_ICDF_ROWS)
+    // `base` points to ICDF_TAB_DOUBLES doubles of LDS (16-byte aligned), filled by load() + a barrier
+    __device__ __forceinline__ explicit IcdfLDS(double *base) : pa((lds2_t)(__attribute__((address_space(3))) double *)base) {}
+    static __device__ __forceinline__ void load(double *base, int tid, int nthreads)
+    {
+        for (int q = tid; q < 5 * BHIP_ICDF_ROWS; q += nthreads) {
+            const int R = q / 5, k = q - 5 * R;
+            base[k < 4 ? (k >> 1) * (2 * BHIP_ICDF_ROWS) + 2 * R + (k & 1) : 4 * BHIP_ICDF_ROWS + R] = icdf_dev[q];
+        }
+    }
+    __device__ __forceinline__ void row(uint32_t R, double &c0, double &c1, double &c2, double &c3, double &c4) const
+    {
+        const rng_d2v a = pa[R], b = pa[BHIP_ICDF_ROWS + R];
+        c4 = ((lds1_t)pa)[4 * BHIP_ICDF_ROWS + R];
+        c0 = a.x; c1 = a.y; c2 = b.x; c3 = b.y;
+    }
+};
+// the larger of the two LDS tables: what a kernel that can draw under every specification reserves
+constexpr int RNG_LDS_DOUBLES = ICDF_TAB_DOUBLES > RNG_TAB_DOUBLES ? ICDF_TAB_DOUBLES : RNG_TAB_DOUBLES;
+#endif
+
+// one standard normal from one 32-bit word (specification v4, see the head of this file)
+template <class Tab>
+BHIP_HD double icdf_normal(const Tab &tab, uint32_t w)
+{
+    union { double d; uint64_t u; } b;
+    b.d = (double)((w << 1) | 1u);                 // exact: an odd integer below 2^32
+    const double d = b.d;
+    const uint32_t R = ((uint32_t)(b.u >> 32) >> 17) & 255u;
+    double c0, c1, c2, c3, c4;
+    tab.row(R, c0, c1, c2, c3, c4);
+    double q = fma_(c4, d, c3);
+    q = fma_(q, d, c2);
+    q = fma_(q, d, c1);
+    q = fma_(q, d, c0);
+    b.d = q;
+    b.u = (b.u & 0x7fffffffffffffffULL) | ((uint64_t)(w & 0x80000000u) << 32);
+    return b.d;
+}
+
 // L = -2*ln(x) for x in (0,1], normal doubles.  x = 2^e * m0, m0 in [1,2);  k = round(128*m0) - 128 selects the
 // table row {A, B}: s = fma(m0, A, 2) = -2*(m/c - 1) with |s| <= 2^-7, and
 //     L = e'*(-2 ln2) + B + (s + s^2/4 + s^3/12 + s^4/32 + s^5/80 + s^6/192 + s^7/448)      (= -2*log1p(-s/2))
@@ -278,12 +357,16 @@ template <class...> using rng_void_t = void;
 template <class Tab, class = void> struct noise_spec_of { static constexpr int value = 3; };
 template <class Tab> struct noise_spec_of<Tab, rng_void_t<decltype(Tab::NOISE_SPEC)>> { static constexpr int value = Tab::NOISE_SPEC; };
 
-// normals 4q .. 4q+3 of stream 0: v3 -- Philox call q, two 40 + 24-bit pairs;  v2 -- calls 2q and 2q+1, one 53 + 53-bit pair each
+// normals 4q .. 4q+3 of stream 0: v4 -- Philox call q, one normal per word;  v3 -- call q, two 40 + 24-bit pairs;
+// v2 -- calls 2q and 2q+1, one 53 + 53-bit pair each
 template <class Tab>
 BHIP_HD void normal_quad(const Tab &tab, uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t q, double &z0, double &z1, double &z2,
                          double &z3, uint32_t stream = 0u)
 {
-    if constexpr (noise_spec_of<Tab>::value == 2) {
+    if constexpr (noise_spec_of<Tab>::value == 4) {
+        const u32x4 r = philox4x32_10(path, stream, iter, q, k0, k1);
+        z0 = icdf_normal(tab, r.x); z1 = icdf_normal(tab, r.y); z2 = icdf_normal(tab, r.z); z3 = icdf_normal(tab, r.w);
+    } else if constexpr (noise_spec_of<Tab>::value == 2) {
         const u32x4 ra = philox4x32_10(path, stream, iter, 2u * q, k0, k1);
         const u32x4 rb = philox4x32_10(path, stream, iter, 2u * q + 1u, k0, k1);
         box_muller_53_53(tab, ra, z0, z1);
@@ -301,7 +384,12 @@ template <class Tab>
 BHIP_HD void normal_pair(const Tab &tab, uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t h, double &z0, double &z1,
                          uint32_t stream = 0u)
 {
-    if constexpr (noise_spec_of<Tab>::value == 2) {
+    if constexpr (noise_spec_of<Tab>::value == 4) {
+        const u32x4 r = philox4x32_10(path, stream, iter, h >> 1, k0, k1);
+        const bool second = (h & 1u) != 0u;
+        z0 = icdf_normal(tab, second ? r.z : r.x);
+        z1 = icdf_normal(tab, second ? r.w : r.y);
+    } else if constexpr (noise_spec_of<Tab>::value == 2) {
         box_muller_53_53(tab, philox4x32_10(path, stream, iter, h, k0, k1), z0, z1);
     } else {
         const u32x4 r = philox4x32_10(path, stream, iter, h >> 1, k0, k1);
@@ -309,18 +397,14 @@ BHIP_HD void normal_pair(const Tab &tab, uint32_t k0, uint32_t k1, uint32_t path
         box_muller_40_24(tab, second ? r.z : r.x, second ? r.w : r.y, z0, z1);
     }
 }
-// the same with the specification chosen at run time (2: full resolution; anything else: v3) -- host code and the kernels that
-// draw a handful of normals per launch
-template <class Tab>
-BHIP_HD void normal_pair_spec(int spec, const Tab &tab, uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t h, double &z0, double &z1,
+// the same with the specification chosen at run time (2: full resolution; 3: v3; anything else: v4, the default) -- host code and
+// the kernels that draw a handful of normals per launch; the tables from constant memory / the host arrays
+BHIP_HD void normal_pair_spec(int spec, uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t h, double &z0, double &z1,
                               uint32_t stream = 0u)
 {
-    if (spec == 2) normal_pair(FullRes<Tab>(tab), k0, k1, path, iter, h, z0, z1, stream);
-    else normal_pair(tab, k0, k1, path, iter, h, z0, z1, stream);
-}
-BHIP_HD void normal_pair(uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter, uint32_t blk, double &z0, double &z1)
-{
-    normal_pair(TabConst(), k0, k1, path, iter, blk, z0, z1);
+    if (spec == 2) normal_pair(FullRes<TabConst>(TabConst()), k0, k1, path, iter, h, z0, z1, stream);
+    else if (spec == 3) normal_pair(TabConst(), k0, k1, path, iter, h, z0, z1, stream);
+    else normal_pair(IcdfConst(), k0, k1, path, iter, h, z0, z1, stream);
 }
 
 BHIP_HD double accept_uniform(uint32_t k0, uint32_t k1, uint32_t path, uint32_t iter)

@@ -59,12 +59,14 @@ inline UserModel *find_user_model(int id)
 }
 
 // the instantiation behind (noise, npair): npair > 0 selects the wave-specialised kernel k_pc (noise 6 / 7 = NOISE_FRESH_PC /
-// NOISE_PCN_LINES_PC of bhip_pc_kernel.h) with that many producer/consumer pairs per workgroup
+// NOISE_PCN_LINES_PC of bhip_pc_kernel.h) with that many producer/consumer pairs per workgroup (npair < 0: see below)
 inline std::string rtc_kernel_name(int gk, int mo, int noise, int fl, int npair, bool qualified)
 {
     const std::string ns = qualified ? "bhip::" : "";
     const std::string args = std::to_string(gk) + ", " + std::to_string(mo) + ", ";
     if (npair > 0) return ns + "k_pc<" + ns + "MUser, " + args + std::to_string(noise) + ", " + std::to_string(fl) + ", " + std::to_string(npair) + ">";
+    if (npair < 0)   // -n: n pairs WITHOUT the coefficient rows in LDS (the large-ensemble workgroup of the noise specification v4)
+        return ns + "k_pc<" + ns + "MUser, " + args + std::to_string(noise) + ", " + std::to_string(fl) + ", " + std::to_string(-npair) + ", false, false>";
     if (noise == NOISE_PCN_LINES) return ns + "k_chain_lines<" + ns + "MUser, " + args + std::to_string(fl) + ">";
     return ns + "k_paths<" + ns + "MUser, " + args + std::to_string(noise) + ", " + std::to_string(fl) + ">";
 }

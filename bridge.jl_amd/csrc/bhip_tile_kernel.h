@@ -69,7 +69,7 @@ struct TArgs {
     long ldx0;
     uint32_t blk0;          // offset of the noise stream in pairs (multi-segment chains: segment << 24), as KArgs::blk0
     int defer_accept;       // pCN: do not decide -- only report llo in `ll` (joint accept over segments, bhip_segchains_*)
-    int noise_spec;         // 2: the full-resolution stream bhip-philox-v2; anything else: bhip-philox-v3 (bhip_rng.h), as KArgs::noise_spec
+    int noise_spec;         // 4 (default) / 3 / 2: the noise specification (bhip_rng.h), as KArgs::noise_spec
 };
 // The target drift of the built-in instantiations is LinPro's B(x - mu), one of the five MFMA products.  A hipRTC user process
 // supplies its drift COMPONENT-WISE instead: UD::bk(k, t, x, par) = b_k(t, x, P), where x points to the path's whole state
@@ -413,8 +413,11 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                     __builtin_amdgcn_wave_barrier();   // ... and the reads precede the next pass's writes
                 }
             };
+            // (the default specification v4 reads its table from constant memory: the 10 KB do not fit next to the fragment matrices at
+            // two workgroups per CU; 2.6 KB of v3 / v2 tables do)
             if (a.noise_spec == 2) draw_rows(FullRes<TabLDS>(rtab));
-            else draw_rows(rtab);
+            else if (a.noise_spec == 3) draw_rows(rtab);
+            else draw_rows(IcdfConst());
             if constexpr (BHIP_TILE_DMA_LATE) issue_dmas();   // the reads of wb are long done; the DMAs still have the products' time
             land_stage();
             double *qo = wop;

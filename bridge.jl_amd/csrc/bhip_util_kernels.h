@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void k_wiener(const double *__restrict__ rootd
         }
     };
     if (noise_spec == 2) run(FullRes<TabConst>(TabConst()));
-    else run(TabConst());
+    else if (noise_spec == 3) run(TabConst());
+    else run(IcdfConst());
 }
 // mp > 4 (large-d Wiener): state kept in memory instead of registers
 __global__ __launch_bounds__(256) void k_wiener_big(const double *__restrict__ rootdt, int N, int mp, double *__restrict__ W, long ld, long P,
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void k_wiener_big(const double *__restrict__ r
         for (int k = 0; k < mp; k++) {
             const int n = i * mp + k;
             double z;
-            if ((n & 1) == 0) normal_pair_spec(noise_spec, TabConst(), k0, k1, path, iter, (uint32_t)(n >> 1), z, zc);
+            if ((n & 1) == 0) normal_pair_spec(noise_spec, k0, k1, path, iter, (uint32_t)(n >> 1), z, zc);
             else z = zc;
             W[((size_t)(i + 1) * mp + k) * ld + p] = W[((size_t)i * mp + k) * ld + p] + rdt * z;
         }
@@ -276,7 +277,7 @@ __global__ void k_seg_y0(long n, long ld, double w_old, double w_new, const doub
 #pragma unroll
     for (int k = 0; k < D * D; k++) ch[k] = chol_pc ? chol_pc[(size_t)k * ld + p] : geo.mpar[k];
 #pragma unroll
-    for (int k = 0; k < D; k += 2) normal_pair_spec(geo.noise_spec, TabConst(), k0, k1, path0 + (uint32_t)p, iter, (uint32_t)(k >> 1), xi[k], xi[k + 1], 2u);
+    for (int k = 0; k < D; k += 2) normal_pair_spec(geo.noise_spec, k0, k1, path0 + (uint32_t)p, iter, (uint32_t)(k >> 1), xi[k], xi[k + 1], 2u);
 #pragma unroll
     for (int r = 0; r < D; r++) {
         double cz = ch[r] * xi[0];
@@ -299,7 +300,7 @@ static __global__ void k_seg_y0_big(long n, long ld, int d, double w_old, double
         return;
     }
     double xi[34];   // d <= 32
-    for (int k = 0; k < d; k += 2) normal_pair_spec(noise_spec, TabConst(), k0, k1, path0 + (uint32_t)p, iter, (uint32_t)(k >> 1), xi[k], xi[k + 1], 2u);
+    for (int k = 0; k < d; k += 2) normal_pair_spec(noise_spec, k0, k1, path0 + (uint32_t)p, iter, (uint32_t)(k >> 1), xi[k], xi[k + 1], 2u);
     for (int r = 0; r < d; r++) {
         double cz = chol[r] * xi[0];
         for (int c = 1; c < d; c++) cz += chol[r + d * c] * xi[c];

@@ -116,7 +116,7 @@ int bhip_ctx_sync(bhip_ctx *ctx);
  *   4 .. 12  one path per lane up to that dimension (chains: up to min(that, 8));
  *   0        off: every d > 3 on the tile kernel.
  * Same results to the tile kernel's tolerance (the guide solve is a product with the pre-inverted matrix in both), identical accept
- * decisions and Wiener states.  Under BHIP_OPT_NOISE_SPEC = 2 chains at d > 3 always run on the tile kernel. */
+ * decisions and Wiener states.  Under BHIP_OPT_NOISE_SPEC = 2 / 3 chains at d > 3 always run on the tile kernel. */
 #define BHIP_OPT_MID_VALU 3
 /* BHIP_OPT_FUSED_ARITHMETIC (default 0): 1 runs the d <= 3 path kernels (built-in processes; ensembles and chains with a guide
  * shared by the ensemble) from a second build of the same source in which the compiler may contract a*b + c into one fused
@@ -125,15 +125,22 @@ int bhip_ctx_sync(bhip_ctx *ctx);
  * fp64 tolerance -- and issues ~15 % fewer vector instructions in the instruction-bound modes.  Noise is unaffected up to the
  * last bit of the Wiener cumulation W[i] + sqrt(dt)*xi.  Per-chain device-built guides and hipRTC user processes ignore it. */
 #define BHIP_OPT_FUSED_ARITHMETIC 4
-/* BHIP_OPT_NOISE_SPEC (default 3): which stream of standard normals replaces the reference's randn (src/wiener.jl:31,44,55).
- *   3  bhip-philox-v3: one Philox4x32-10 call gives FOUR normals (two Box-Muller pairs, 40 bits of radius + 24 bits of angle each:
- *      |z| <= 7.45, the angle on a 2^24 grid) -- the faster generator, the one every figure in BENCH / profiles is quoted on;
+/* BHIP_OPT_NOISE_SPEC (default 4): which stream of standard normals replaces the reference's randn (src/wiener.jl:31,44,55 -- a
+ * ziggurat on Julia's global generator, not reproducible outside Julia).  Philox4x32-10, counter = (global path id, stream, iteration,
+ * call), in all three:
+ *   4  bhip-philox-v4: one call gives FOUR normals, one per 32-bit word, through a piecewise polynomial inverse of the normal
+ *      distribution function (256 segments of degree 4: within 3.7e-9 of the exact quantile, Kolmogorov distance of the marginal
+ *      <= 1.3e-9; |z| <= 6.34, 2^32 equiprobable values) -- the cheap normal (the reference's own randn costs a handful of
+ *      instructions), the one every figure in BENCH / profiles is quoted on since round 5;
+ *   3  bhip-philox-v3: one call gives FOUR normals as two Box-Muller pairs (40 bits of radius + 24 bits of angle each: |z| <= 7.45,
+ *      the angle on a 2^24 grid) -- the default of rounds 3 and 4;
  *   2  bhip-philox-v2: one call gives TWO normals (one pair, 53 + 53 bits: |z| <= 8.57) -- the full-resolution stream, for callers
  *      who want nothing between them and the reference's 52-bit ziggurat but the Box-Muller map; twice the Philox calls.
- * Both are bit-identical on host and device and keyed by (seed, global path id, iteration, normal index).  Takes effect for
+ * All are bit-identical on host and device and keyed by (seed, global path id, iteration, normal index).  Takes effect for
  * everything drawn afterwards on the context (bhip_wiener_sample, bhip_sample_solve, chain and multi-segment ensembles); an
  * ensemble keeps the specification it was created under (its saved state carries it) and refuses to run under another
- * (BHIP_ESTATE). */
+ * (BHIP_ESTATE).  Under 3 and 2 chains at d > 3 always run on the tile kernel and the pCN step on the 16-byte slots is refused
+ * (BHIP_EUNSUPPORTED): the register-tight kernels hold the default stream only. */
 #define BHIP_OPT_NOISE_SPEC 5
 int bhip_ctx_set_option(bhip_ctx *ctx, int option, int value);
 const char *bhip_last_error(const bhip_ctx *ctx);
@@ -455,8 +462,9 @@ void bhip_comm_destroy(bhip_comm *comm);
 
 /* ------------------------------------------------------------------ RNG specification helpers (host)
  * Philox4x32-10, key = (seed lo, hi), counter = (path, stream, iter, call).  bhip_normals_host: normals n0 .. n0+n-1 of stream 0
- * under the default specification bhip-philox-v3 (call q -> normals 4q .. 4q+3); bhip_normals_host_spec: under `spec` = 3 or 2
- * (bhip-philox-v2: call h -> normals 2h, 2h+1; BHIP_OPT_NOISE_SPEC) -- the very values the kernels draw, bit for bit. */
+ * under the default specification bhip-philox-v4 (call q -> normals 4q .. 4q+3, word j of the call -> normal 4q + j);
+ * bhip_normals_host_spec: under `spec` = 4, 3 (call q -> two Box-Muller pairs) or 2 (bhip-philox-v2: call h -> normals 2h, 2h+1;
+ * BHIP_OPT_NOISE_SPEC) -- the very values the kernels draw, bit for bit. */
 void bhip_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void bhip_normals_host(uint64_t seed, uint32_t path, uint32_t iter, int n0, int n, double *z);
 void bhip_normals_host_spec(int spec, uint64_t seed, uint32_t path, uint32_t iter, int n0, int n, double *z);

@@ -223,7 +223,7 @@ double bo_logpdfnormal(int d, const double *x, const double *Sigma)
 }
 
 /* ------------------------------------------------------------------------------------------
- * RNG, specification "bhip-philox-v3" (DESIGN.md).  The reference draws from Julia's global
+ * RNG, specifications "bhip-philox-v4" (default), "-v3" and "-v2" (DESIGN.md section 4).  The reference draws from Julia's global
  * randn (src/wiener.jl:31,44,55) which cannot be reproduced outside Julia; this is
  * the counter-based replacement shared, by specification, with the HIP kernels.
  * ------------------------------------------------------------------------------------------ */
@@ -332,8 +332,35 @@ BO_CLONES void bo_sincos2pi_k24(uint32_t k24, double *sn, double *cs)
 /* Specification v2 (selectable in the product: BHIP_OPT_NOISE_SPEC = 2; here: bo_set_noise_spec(2)) -- the full-resolution stream the
  * round-2 library drew and tests/golden/guided_paths_v2 / _v3.npz hold: Philox call h -> pair h (normals 2h, 2h+1) with all 128 bits,
  *   u1 = (bits53(r0, r1) + 1) 2^-53 in (0,1],   u2 = bits53(r2, r3) 2^-53 in [0,1)   (bits53(lo, hi) = ((hi << 32 | lo) >> 11)). */
-static int bo_noise_spec = 3;
-void bo_set_noise_spec(int spec) { bo_noise_spec = spec == 2 ? 2 : 3; }
+/* Specification v4 (round 5; the product's default): the same calls and pairs as v3 -- pair h = half h & 1 of call h >> 1, words
+ * a = r[2s], b = r[2s+1] -- but each 32-bit word is ONE normal through a piecewise polynomial inverse of the normal distribution
+ * function: v = 2 (w mod 2^31) + 1 (odd; upper-tail probability p = v 2^-33), d = (double) v, row R = bits 17..24 of the high word
+ * of d (five exponent bits, three mantissa bits: the octave of p and its eighth) of the table BO_ICDF (data; generated by
+ * scripts/gen_icdf_table.py: degree-4 minimax polynomials of d -> -Phi^-1(d 2^-33)), |z| by Horner in four fma, sign = bit 31 of w. */
+#include "bo_icdf_table.h"
+static const double BO_ICDF[5 * BO_ICDF_ROWS] = BO_ICDF_INIT;
+BO_CLONES double bo_icdf_normal(uint32_t w)
+{
+    union { double d; uint64_t u; } b;
+    uint32_t v = (w << 1) | 1u;
+    b.d = (double)v;
+    double d = b.d;
+    uint32_t R = ((uint32_t)(b.u >> 32) >> 17) & 255u;
+    const double *c = BO_ICDF + 5 * R;
+    double q = fma(c[4], d, c[3]);
+    q = fma(q, d, c[2]);
+    q = fma(q, d, c[1]);
+    q = fma(q, d, c[0]);
+    b.d = q;
+    b.u = (b.u & 0x7fffffffffffffffULL) | ((uint64_t)(w & 0x80000000u) << 32);
+    return b.d;
+}
+void bo_icdf_normals(const uint32_t *w, long n, double *z)
+{
+    for (long i = 0; i < n; i++) z[i] = bo_icdf_normal(w[i]);
+}
+static int bo_noise_spec = 4;
+void bo_set_noise_spec(int spec) { bo_noise_spec = (spec == 2 || spec == 3) ? spec : 4; }
 int bo_get_noise_spec(void) { return bo_noise_spec; }
 static void bo_normal_pair_v2(uint64_t seed, uint32_t path, uint32_t stream, uint32_t iter, uint32_t h, double z[2])
 {
@@ -354,6 +381,7 @@ BO_CLONES void bo_normal_pair_stream(uint64_t seed, uint32_t path, uint32_t stre
     uint32_t ctr[4] = {path, stream, iter, h >> 1}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, r[4];
     bo_philox4x32_10(ctr, key, r);
     uint32_t a = r[2 * (h & 1u)], b = r[2 * (h & 1u) + 1];
+    if (bo_noise_spec != 3) { z[0] = bo_icdf_normal(a); z[1] = bo_icdf_normal(b); return; }
     uint64_t k40 = ((uint64_t)(b >> 24) << 32) | a;
     double u1 = (double)(k40 + 1) * 0x1.0p-40;          /* (0,1] */
     double rad = sqrt(bo_m2log(u1));

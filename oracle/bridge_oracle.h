@@ -77,11 +77,13 @@ enum {
     BO_GUIDE_NUH_INPLACE = 4  /* PartialBridge!    src/partialbridgen!.jl:32-97 (nu, H; ll as two dots) */
 };
 
-/* ---- RNG (specification "bhip-philox-v1"; not part of the reference) ---- */
+/* ---- RNG (specifications "bhip-philox-v4" (default) / -v3 / -v2; not part of the reference) ---- */
 void bo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double bo_log(double x);                                  /* deterministic log, x in (0,1]        */
 double bo_m2log(double x);                                /* deterministic -2 ln x, x in (0,1]     */
 void bo_sincos2pi(double u, uint32_t w, double *s, double *c); /* deterministic sin/cos(2*pi*u), u = K 2^-53 in [0,1), w = K >> 21 */
+double bo_icdf_normal(uint32_t w);                        /* specification v4: one standard normal from one 32-bit word */
+void bo_icdf_normals(const uint32_t *w, long n, double *z);
 void bo_normal_pair(uint64_t seed, uint32_t path, uint32_t iter, uint32_t block, double z[2]);
 double bo_uniform_accept(uint64_t seed, uint32_t path, uint32_t iter);
 /* fill z[0..n) with the normals n0..n0+n-1 of stream (seed,path,iter) */

@@ -1,7 +1,11 @@
 #!/usr/bin/env python
-"""Writes tests/golden/guided_paths_v4.npz: for every problem of tests/problems.py (N = 101) the Wiener paths of the noise
-specification bhip-philox-v3 (four normals per Philox call, round 3), the guided paths, the log-likelihoods and a short
-pCN chain, as computed by the CPU oracle (oracle/bridge_oracle.c) AFTER it passed its pins (tests/test_oracle.py, K1..K14).
+"""Writes tests/golden/guided_paths_v5.npz: for every problem of tests/problems.py (N = 101) the Wiener paths of the noise
+specification bhip-philox-v4 (one normal per 32-bit Philox word through the piecewise inverse distribution function, round 5),
+the guided paths, the log-likelihoods and a short pCN chain, as computed by the CPU oracle (oracle/bridge_oracle.c) AFTER it
+passed its pins (tests/test_oracle.py, K1..K14).
+
+guided_paths_v4.npz (round 3) holds the same under the noise specification bhip-philox-v3: the oracle still reproduces it FROM
+ITS SEEDS with that specification selected (bo_set_noise_spec(3); tests/test_oracle.py), as it does _v3.npz under specification v2.
 
 guided_paths_v2.npz / _v3.npz (noise specification v2; v3 = v2 + the shared fdlibm-form sin / cos of the drift functions)
 stay committed for what v1 is kept for: the paths and log-likelihoods GIVEN their stored Wiener paths.
@@ -10,7 +14,7 @@ guided_paths_v1.npz (round 1, noise specification v1) stays committed: its Wiene
 generator draws, but the guided paths and log-likelihoods GIVEN those stored Wiener paths do not involve the
 generator, and both the oracle and the kernels must still reproduce them bit for bit (the tests do that), so the
 frozen round-1 arithmetic keeps guarding the solver across the change of the noise specification.  This script
-refuses to write v2 unless that holds.
+refuses to write a new file unless that holds.
 
 The reference (Julia) stores no guided paths or llikelihood values and cannot run here, so these
 vectors do not come from Bridge.jl: they freeze the oracle + noise specification, so that a later
@@ -67,9 +71,10 @@ def check_given_W(version):
 
 
 if __name__ == "__main__":
-    for v in ("v1", "v2", "v3"):
+    for v in ("v1", "v2", "v3", "v4"):
         check_given_W(v)
+    assert o.lib().bo_get_noise_spec() == 4
     data = build()
-    fn = os.path.join(HERE, "guided_paths_v4.npz")
+    fn = os.path.join(HERE, "guided_paths_v5.npz")
     np.savez_compressed(fn, **data)
     print(fn, os.path.getsize(fn), "bytes,", len(data), "arrays")

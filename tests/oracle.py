@@ -32,6 +32,7 @@ def load():
     _build()
     lib = C.CDLL(_SO)
     lib.bo_log.restype = C.c_double
+    lib.bo_icdf_normal.restype = C.c_double
     lib.bo_log.argtypes = [C.c_double]
     lib.bo_uniform_accept.restype = C.c_double
     lib.bo_uniform_accept.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
@@ -104,8 +105,8 @@ def sincos2pi(u):
 
 
 class noise_spec:
-    """`with o.noise_spec(2): ...` -- the oracle draws the full-resolution stream bhip-philox-v2 (bo_set_noise_spec) inside the block,
-    the default bhip-philox-v3 outside.  The twin of the product's BHIP_OPT_NOISE_SPEC."""
+    """`with o.noise_spec(2): ...` -- the oracle draws the full-resolution stream bhip-philox-v2 (3: bhip-philox-v3) inside the block
+    (bo_set_noise_spec), the default bhip-philox-v4 outside.  The twin of the product's BHIP_OPT_NOISE_SPEC."""
 
     def __init__(self, spec):
         self.spec = spec
@@ -118,6 +119,16 @@ class noise_spec:
     def __exit__(self, *exc):
         lib().bo_set_noise_spec(C.c_int(self.old))
         return False
+
+
+def icdf_normal(w):
+    """specification v4: the standard normal of one 32-bit word (scalar), or of an array of words"""
+    if np.ndim(w) == 0:
+        return lib().bo_icdf_normal(C.c_uint32(int(w)))
+    w = np.ascontiguousarray(w, dtype=np.uint32)
+    z = np.empty(w.shape)
+    lib().bo_icdf_normals(w.ctypes.data_as(C.c_void_p), C.c_long(w.size), z.ctypes.data_as(dp))
+    return z
 
 
 def normals(seed, path, it, n0, n):

@@ -305,10 +305,10 @@ def test_device_forms_of_the_generator_are_bit_identical(tmp_path):
 
 @pytest.mark.parametrize("case", problems.cases(101) + problems.forward_cases(101), ids=lambda c: c.name)
 def test_committed_golden_vectors_on_device(ctx, case):
-    """the frozen vectors (tests/golden/guided_paths_v4.npz, noise specification v3) through the C ABI: in-kernel noise, guided
+    """the frozen vectors (tests/golden/guided_paths_v5.npz, noise specification v4) through the C ABI: in-kernel noise, guided
     solve, fused log-likelihood and a pCN chain reproduce them bit for bit without the oracle being involved"""
     import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "guided_paths_v4.npz"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "guided_paths_v5.npz"))
     N, npaths, seed, iters = (int(v) for v in g["meta"])
     rho = float(g["rho"])
     Po = case.bh_proposal(bh, ctx)
@@ -326,10 +326,10 @@ def test_committed_golden_vectors_on_device(ctx, case):
         assert ch.ll()[1] == g[case.name + "/chain_ll_acc"][0] and ch.acc()[1] == g[case.name + "/chain_ll_acc"][1]
 
 
-@pytest.mark.parametrize("version", ["v1", "v2", "v3"])
+@pytest.mark.parametrize("version", ["v1", "v2", "v3", "v4"])
 @pytest.mark.parametrize("case", problems.cases(101) + problems.forward_cases(101), ids=lambda c: c.name)
 def test_earlier_golden_paths_given_their_wiener_paths_on_device(ctx, case, version):
-    """guided_paths_v1.npz (noise specification v1), _v2.npz, _v3.npz (specification v2): the guided paths and
+    """guided_paths_v1.npz (noise specification v1), _v2.npz, _v3.npz (specification v2), _v4.npz (specification v3): the guided paths and
     log-likelihoods GIVEN their stored Wiener paths do not involve the generator; the external-W solve must still reproduce
     them (the frozen arithmetic of rounds 1 and 2 guards the solver across the changes of the noise specification)"""
     import os
@@ -410,7 +410,7 @@ def test_chain_checkpoint_and_resume(ctx, name):
     old[60:64] = 0                                           # ChainStateHeader.rng_spec
     with pytest.raises(bh.BridgeError, match="noise specification"):
         b.load(old)
-    assert int(np.frombuffer(state[60:64].tobytes(), dtype=np.int32)[0]) == 3   # bhip-philox-v3
+    assert int(np.frombuffer(state[60:64].tobytes(), dtype=np.int32)[0]) == 4   # bhip-philox-v4
     old[60:64] = np.frombuffer(np.int32(2).tobytes(), dtype=np.uint8)           # a round-2 (v2) state
     with pytest.raises(bh.BridgeError, match="bhip-philox-v2"):
         b.load(old)

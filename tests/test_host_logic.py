@@ -67,12 +67,12 @@ def test_rng_spec_matches_oracle_bitwise():
         z = np.empty(n)
         lib.bhip_normals_host(seed, path, it, n0, n, bh.api._dptr(z))
         assert np.array_equal(z, o.normals(seed, path, it, n0, n))
-        for spec in (3, 2):       # BHIP_OPT_NOISE_SPEC: the product's host form of both streams against the oracle's
+        for spec in (4, 3, 2):    # BHIP_OPT_NOISE_SPEC: the product's host form of every stream against the oracle's
             zs = np.empty(n)
             lib.bhip_normals_host_spec(spec, seed, path, it, n0, n, bh.api._dptr(zs))
             with o.noise_spec(spec):
                 assert np.array_equal(zs, o.normals(seed, path, it, n0, n)), spec
-            assert np.array_equal(zs, z) == (spec == 3)
+            assert np.array_equal(zs, z) == (spec == 4)
 
 
 @pytest.mark.parametrize("case", problems.cases(101), ids=lambda c: c.name)
@@ -263,13 +263,13 @@ def test_bench_without_launcher_refuses_more_gpus_than_visible():
 
 
 def test_context_options_are_validated():
-    """bhip_ctx_set_option on a host-only context: the value ranges of the round-4 options (BHIP_OPT_NOISE_SPEC: 3 | 2;
+    """bhip_ctx_set_option on a host-only context: the value ranges of the round-4 options (BHIP_OPT_NOISE_SPEC: 4 | 3 | 2;
     BHIP_OPT_MID_VALU: 0, 1 or the largest dimension 4..12 that runs one path per lane), unknown options refused with a message"""
     c = bh.Context(-1)
     lib = c.lib
-    for v in (3, 2, 3):
+    for v in (3, 2, 4):
         assert lib.bhip_ctx_set_option(c.h, bh.OPT_NOISE_SPEC, v) == 0
-    for v in (0, 1, 4, -2):
+    for v in (0, 1, 5, -2):
         assert lib.bhip_ctx_set_option(c.h, bh.OPT_NOISE_SPEC, v) == -1
         assert b"NOISE_SPEC" in lib.bhip_last_error(c.h)
     for v in (0, 1, 4, 8, 10, 12, 1):

@@ -53,6 +53,78 @@ def test_normal_moments_and_uniform_range():
     assert np.array_equal(a[13:33], b)
 
 
+def _icdf_table():
+    """the specification's table as DATA, parsed from the oracle's header: rows {c0 .. c4} of exact doubles"""
+    import re
+    txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "bo_icdf_table.h")).read()
+    body = txt[txt.index("BO_ICDF_INIT {") + len("BO_ICDF_INIT {"):]
+    vals = [float.fromhex(t) for t in re.findall(r"-?0x[0-9a-f.]+p[+-]?\d+", body)]
+    assert len(vals) == 5 * 256
+    return np.array(vals).reshape(256, 5)
+
+
+def test_v4_inverse_distribution_function_restated_exactly():
+    """bhip-philox-v4 maps one 32-bit word to one normal: v = 2 (w mod 2^31) + 1, d = (double) v, row R = bits 17..24 of d's high
+    word, |z| = Horner in four fused multiply-adds, sign = bit 31.  Restated here with exact rational arithmetic (every fma = ONE
+    rounding of the exact a*b + c) from the table as data: the C function must agree bit for bit."""
+    from fractions import Fraction
+    tab = _icdf_table()
+    rng = np.random.default_rng(4)
+    words = [0, 1, 2, 3, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF, 0x3FFFFFFF, 0x40000000, 0x0FFFFFFF, 0x10000000] + [int(x) for x in rng.integers(0, 2 ** 32, 300)]
+    words += [int(x) >> int(k) for x, k in zip(rng.integers(0, 2 ** 31, 120), rng.integers(0, 31, 120))]      # the far octaves too
+    for w in words:
+        v = ((w & 0x7FFFFFFF) << 1) | 1
+        e = 31 - (v.bit_length() - 1)                      # octave: 2^(31-e) <= v < 2^(32-e)
+        s = ((v << e) >> 28) & 7                           # its eighth
+        R = ((((1023 + 31 - e) & 31) << 3) | s) & 255      # = (highword((double) v) >> 17) & 255
+        hi = np.array([float(v)]).view(np.uint64)[0] >> np.uint64(32)
+        assert R == (int(hi) >> 17) & 255
+        c = [Fraction(float(x)) for x in tab[R]]
+        q = c[4]
+        for k in (3, 2, 1, 0):
+            q = Fraction(float(q * v + c[k]))              # float(Fraction) rounds to nearest even: one fma
+        z = float(q)
+        z = -abs(z) if w >> 31 else abs(z)
+        assert z == o.icdf_normal(w), hex(w)
+
+
+def test_v4_kolmogorov_distance_read_off_the_table():
+    """The marginal of bhip-philox-v4 is the law of z(w), w uniform on 2^32 words: 2^31 magnitudes |z|(v) at the upper-tail
+    probabilities p = v 2^-33 (v odd), each with both signs.  Its distribution function differs from Phi by at most
+        max_v |Q(|z|(v)) - p(v)| + 2^-33          (Q = 1 - Phi; the second term is half a step of the 2^-32-spaced grid of p)
+    -- evaluated here, not asserted: on 2^22 evenly spaced magnitudes, on all 2 x 255 neighbours of the row boundaries, and on every
+    word of the 14 farthest octaves.  Bound required by the round-4 review: 2^-24; found: ~1.3e-9.  Also: the absolute error of the
+    quantile itself (3.7e-9), monotonicity inside every row, symmetry, range, and the first moments of the discrete law."""
+    from scipy.special import ndtr, ndtri
+    v = np.unique(np.concatenate([
+        (np.arange(1 << 22, dtype=np.uint64) << np.uint64(10)) | np.uint64(1),
+        np.arange(1, 1 << 18, 2, dtype=np.uint64),                               # octaves 31 .. 14 in full
+        np.concatenate([[(((8 + s) << (28 - e)) - 1) | 1, ((8 + s) << (28 - e)) | 1] for e in range(28) for s in range(8)]).astype(np.uint64),
+    ]))
+    v = v[(v >= 1) & (v < (1 << 32))]
+    w = (v >> np.uint64(1)).astype(np.uint32)
+    z = o.icdf_normal(w)
+    p = v.astype(np.float64) * 2.0 ** -33
+    assert z.min() > 0 and z.max() < 6.3380 and z.max() == o.icdf_normal(0)
+    assert np.array_equal(o.icdf_normal(w | np.uint32(0x80000000)), -z)
+    err_z = np.abs(z + ndtri(p)).max()
+    err_F = np.abs(ndtr(-z) - p).max()
+    assert err_z < 3.8e-9, err_z
+    kolmogorov = err_F + 2.0 ** -33
+    assert kolmogorov < 1.5e-9 < 2.0 ** -24, kolmogorov
+    # the header states what the generator script measured
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "bo_icdf_table.h")).read()
+    assert "#define BO_ICDF_MAXERR 3.690e-09" in hdr
+    # |z| falls as p grows, inside rows strictly and across a row change up to twice the fit error
+    order = np.argsort(v)
+    dz = np.diff(z[order])
+    assert dz.max() < 8e-9
+    # moments of the discrete law by the midpoint rule on the evenly spaced part (2^22 points of 2^31): E z^2 = 1, E z^4 = 3
+    ev = (np.arange(1 << 22, dtype=np.uint64) << np.uint64(10)) | np.uint64(513)
+    ze = o.icdf_normal((ev >> np.uint64(1)).astype(np.uint32))
+    assert abs((ze ** 2).mean() - 1.0) < 2e-5 and abs((ze ** 4).mean() - 3.0) < 2e-3
+
+
 def test_wiener_draw_order_time_major_component_minor():
     # K3 test/with_srand.jl:1-11 -- vector Wiener consumes normals time-major, component-minor
     tt = np.linspace(0.0, 1.0, 50)
@@ -443,11 +515,27 @@ def _check_given_W(g, with_noise, libm_trig=False):
 
 
 def test_oracle_reproduces_committed_golden_vectors():
-    """tests/golden/guided_paths_v4.npz (written by tests/golden/make_golden.py) freezes the oracle and the noise
-    specification bhip-philox-v3: Wiener paths, guided paths, log-likelihoods and a short pCN chain for every test problem,
+    """tests/golden/guided_paths_v5.npz (written by tests/golden/make_golden.py) freezes the oracle and the noise
+    specification bhip-philox-v4: Wiener paths, guided paths, log-likelihoods and a short pCN chain for every test problem,
     all bit for bit."""
     assert os.path.exists(os.path.join(GOLD, "make_golden.py"))
-    _check_given_W(np.load(os.path.join(GOLD, "guided_paths_v4.npz")), True)
+    _check_given_W(np.load(os.path.join(GOLD, "guided_paths_v5.npz")), True)
+
+
+def test_noise_spec_v3_reproduces_golden_v4_from_its_seeds():
+    """bhip-philox-v3 (two Box-Muller pairs of 40 + 24 bits per Philox call; the default of rounds 3 and 4) stays selectable
+    (product: BHIP_OPT_NOISE_SPEC = 3; oracle: bo_set_noise_spec(3)): tests/golden/guided_paths_v4.npz was written under it, so
+    with it selected the oracle must reproduce the file FROM ITS SEEDS -- Wiener paths, guided paths, log-likelihoods and the
+    pCN chains, decisions included -- bit for bit; and the default specification must not (the streams differ)."""
+    g = np.load(os.path.join(GOLD, "guided_paths_v4.npz"))
+    with o.noise_spec(3):
+        _check_given_W(g, True)
+        z3 = o.normals(7, 3, 1, 0, 64)
+    z4 = o.normals(7, 3, 1, 0, 64)
+    assert not np.array_equal(z3, z4)
+    import problems
+    c = problems.cases(int(g["meta"][0]))[0]
+    assert not np.array_equal(o.wiener_sample(c.tt, c.mp, int(g["meta"][2]), 0, 0), g[c.name + "/W"][0])
 
 
 def test_full_resolution_noise_spec_reproduces_golden_v3_from_its_seeds():
@@ -460,7 +548,8 @@ def test_full_resolution_noise_spec_reproduces_golden_v3_from_its_seeds():
     with o.noise_spec(2):
         _check_given_W(g, True)
         z2 = o.normals(7, 3, 1, 0, 64)
-    z3 = o.normals(7, 3, 1, 0, 64)
+    with o.noise_spec(3):
+        z3 = o.normals(7, 3, 1, 0, 64)
     assert not np.array_equal(z2, z3)
     import problems
     c = problems.cases(int(g["meta"][0]))[0]
@@ -471,11 +560,13 @@ def test_full_resolution_noise_spec_reproduces_golden_v3_from_its_seeds():
 
 
 def test_oracle_reproduces_earlier_golden_vectors_given_their_wiener_paths():
-    """guided_paths_v2.npz / _v3.npz were written under the noise specification v2 (round 2): their Wiener paths are no longer
-    what the generator draws, but the guided paths and log-likelihoods GIVEN those stored paths do not involve it and must
-    still come out bit for bit (v2 predates the shared sin / cos restatement: its sin-drift problems compare to 1e-12)."""
+    """guided_paths_v2.npz / _v3.npz were written under the noise specification v2 (round 2), _v4.npz under v3: their Wiener
+    paths are not what the default generator draws, but the guided paths and log-likelihoods GIVEN those stored paths do not
+    involve it and must still come out bit for bit (v2 predates the shared sin / cos restatement: its sin-drift problems compare
+    to 1e-12)."""
     _check_given_W(np.load(os.path.join(GOLD, "guided_paths_v2.npz")), False, libm_trig=True)
     _check_given_W(np.load(os.path.join(GOLD, "guided_paths_v3.npz")), False)
+    _check_given_W(np.load(os.path.join(GOLD, "guided_paths_v4.npz")), False)
 
 
 def test_drift_sin_cos_restatement_is_accurate():
