@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def kernels(obj):
     with tempfile.TemporaryDirectory() as td:
         fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "k.co")
-        subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj], check=True, stderr=subprocess.DEVNULL)
+        # (with an explicit output file: llvm-objcopy otherwise rewrites `obj` IN PLACE -- a fresh mtime on a stale object makes `make` skip it)
+        subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj, os.path.join(td, "copy.o")], check=True, stderr=subprocess.DEVNULL)
         subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
                         "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True, stderr=subprocess.DEVNULL)
         notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
