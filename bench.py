@@ -672,6 +672,28 @@ def base_record(args, world, w, elapsed, kern_ms, launch):
     }
 
 
+def rccl_version_string(v):
+    """ncclGetVersion's integer (major*10000 + minor*100 + patch since 2.9; major*1000 + minor*100 + patch before)"""
+    v = int(v)
+    return f"{v // 10000}.{v // 100 % 100}.{v % 100}" if v >= 10000 else f"{v // 1000}.{v // 100 % 10}.{v % 100}"
+
+
+def comm_record(infos, gathered, backend="rccl", note=None):
+    """The communicator in the record: what the library and RCCL ITSELF (ncclCommCount / ncclCommUserRank / ncclGetVersion through
+    bhip_comm_query) report, rank by rank, and how many statistics blocks the gather delivered -- a SCALE line answers "did RCCL see N
+    ranks" by itself.  infos: one dict per rank this process knows about (all of them in the one-process form; in the per-rank form the
+    ranks' own reports, gathered)."""
+    rec = {"backend": backend, "gathered_blocks": int(gathered.shape[0]) if gathered is not None else None}
+    if infos:
+        rec.update({"nranks": infos[0]["nranks"], "rccl_nranks": infos[0]["rccl_nranks"],
+                    "ranks_seen": sorted(i["rccl_rank"] for i in infos), "rccl_version": rccl_version_string(infos[0]["rccl_version"]),
+                    "consistent": all(i["nranks"] == i["rccl_nranks"] == len(infos) and i["rank"] == i["rccl_rank"] for i in infos)
+                                  and sorted(i["rccl_rank"] for i in infos) == list(range(len(infos)))})
+    if note:
+        rec["note"] = note
+    return rec
+
+
 def add_chain_summary(out, gathered, w=None):
     if w is not None and w.chains is not None:
         # BHIP_OPT_TUNE_PLACEMENT (setup, before any timing): Xo allocations timed, ms per iteration of the same-piece reference and of the kept pair
@@ -748,12 +770,23 @@ def main_per_rank(args, world):
         allms.copy_(mine)
     per_gpu_ms = [float(x) for x in allms.cpu()]
 
+    # the communicator's own report, from every rank (gathered as python objects: outside every timed region)
+    my_info = comm.info() if comm is not None else None
+    infos = [None] * world
+    if world > 1:
+        dist.all_gather_object(infos, my_info)
+    else:
+        infos = [my_info]
     out = None
     if rank == 0:
         how = ("bhip_comm_init_rank + bhip_comm_allgather_stats" if comm is not None else
                "statistics all-gather by torch.distributed" + (f" (product communicator: {comm_note})" if comm_note else " (gloo test double)"))
         out = base_record(args, world, w, elapsed, kern_ms, "one process per GPU (torch.distributed.run); " + how)
         out["per_gpu_ms_per_step"] = [t / args.steps for t in per_gpu_ms]
+        if comm is not None and all(i is not None for i in infos):
+            out["comm"] = comm_record(infos, gathered, "rccl", "bhip_comm_init_rank, one process per GPU")
+        else:
+            out["comm"] = comm_record(None, gathered, "gloo (test double)" if single else "torch.distributed nccl (fall-back)", comm_note)
         if w.chains is not None:
             add_chain_summary(out, gathered, w)
     if args.mode == "mcmc" and args.chains == 0:
@@ -815,6 +848,10 @@ def main_local(args):
                       "one process, one context per device; bhip_comm_init_all + bhip_comm_allgather_group" + (f" [{comm_note}]" if comm_note else ""))
     out["per_gpu_ms_per_step"] = [t / args.steps for t in per_gpu_ms]
     out["allgather_ms"] = gather_ms
+    if isinstance(group, bdist.CommGroup):
+        out["comm"] = comm_record(group.info(), gathered, "rccl", "bhip_comm_init_all, one process")
+    else:
+        out["comm"] = comm_record(None, gathered, "host emulation (BENCH_SAME_DEVICE test double)" if group is not None else "none", comm_note)
     if issue_us is not None:   # host time inside bhip_chains_step_group per iteration (all n devices' launches: one FFI crossing)
         out["host_issue_us_per_step"] = issue_us
     if w.chains is not None:

@@ -61,6 +61,7 @@ SIGNATURES = {
     "bhip_chains_step": (C.c_int, [vp, C.c_double, C.c_int, C.c_int]),
     "bhip_chains_step_group": (C.c_int, [C.c_int, C.POINTER(vp), C.c_double, C.c_int, C.c_int]),
     "bhip_chains_stats_group": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(vp)]),
+    "bhip_chains_iterations": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
     "bhip_chains_placement_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "bhip_chains_stats": (C.c_int, [vp, vp]),
     "bhip_chains_get": (C.c_int, [vp, dp, C.POINTER(C.c_int64)]),
@@ -91,6 +92,7 @@ SIGNATURES = {
     "bhip_comm_init_rank": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
     "bhip_comm_init_all": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(vp)]),
     "bhip_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bhip_comm_query": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bhip_comm_allgather": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "bhip_comm_allgather_stats": (C.c_int, [vp, vp, vp]),
     "bhip_comm_init": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(vp)]),

@@ -1862,9 +1862,12 @@ static int chains_step_check(bhip_chains *ch, double rho, int iters, int &skip)
 static int chains_step_once(bhip_chains *ch, double rho, int skip, bool store_x)
 {
     const bhip_proposal *po = ch->po;
+    // (ch->iter counts COMPLETED iterations -- bhip_chains_iterations --: an iteration whose launch failed is not counted)
     if (ch->tile) {
         ++ch->iter;
-        return launch_tile_path(po, ch->x0.data(), nullptr, 0, nullptr, 0, store_x ? ch->Xo : nullptr, ch->ld, nullptr, skip, ch->n, 2, ch->seed, ch->iter, ch->path0, 1, ch, rho);
+        const int rct = launch_tile_path(po, ch->x0.data(), nullptr, 0, nullptr, 0, store_x ? ch->Xo : nullptr, ch->ld, nullptr, skip, ch->n, 2, ch->seed, ch->iter, ch->path0, 1, ch, rho);
+        if (rct) --ch->iter;
+        return rct;
     }
     KArgs a;
     int rc = fill_common(po, a, ch->x0.data(), nullptr, ch->n, skip);   // (makes the context's device current)
@@ -1875,7 +1878,9 @@ static int chains_step_once(bhip_chains *ch, double rho, int skip, bool store_x)
     a.rho = rho; a.srho = std::sqrt(1 - rho * rho);
     a.k0 = (uint32_t)ch->seed; a.k1 = (uint32_t)(ch->seed >> 32); a.path0 = ch->path0;
     a.iter = ch->iter;
-    return do_launch(po, ch->lines ? NOISE_PCN_LINES : NOISE_PCN, a);
+    rc = do_launch(po, ch->lines ? NOISE_PCN_LINES : NOISE_PCN, a);
+    if (rc) --ch->iter;
+    return rc;
 }
 
 int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip)
@@ -1908,6 +1913,13 @@ int bhip_chains_step_group(int n, bhip_chains *const *chs, double rho, int iters
             const int rc = chains_step_once(chs[k], rho, skips[k], it == iters - 1);
             if (rc) return rc;
         }
+    return BHIP_OK;
+}
+
+int bhip_chains_iterations(const bhip_chains *ch, uint32_t *iterations)
+{
+    if (!ch || !iterations) return BHIP_EINVAL;
+    *iterations = ch->iter;
     return BHIP_OK;
 }
 
@@ -2264,6 +2276,23 @@ int bhip_comm_info(const bhip_comm *comm, int *nranks, int *rank)
     if (!comm) return BHIP_EINVAL;
     if (nranks) *nranks = comm->nranks;
     if (rank) *rank = comm->rank;
+    return BHIP_OK;
+}
+
+int bhip_comm_query(const bhip_comm *comm, int *rccl_version, int *rccl_nranks, int *rccl_rank)
+{
+    if (!comm) return BHIP_EINVAL;
+    bhip_ctx *ctx = comm->ctx;
+    RCCL_READY(ctx);
+    if (!api.GetVersion || !api.CommCount || !api.CommUserRank) return fail(ctx, BHIP_EHIP, "RCCL without ncclGetVersion / ncclCommCount / ncclCommUserRank");
+    int v = 0, n = 0, r = 0;
+    ncclResult_t e = api.GetVersion(&v);
+    if (e == ncclSuccess) e = api.CommCount(comm->comm, &n);
+    if (e == ncclSuccess) e = api.CommUserRank(comm->comm, &r);
+    if (e != ncclSuccess) return rccl_fail(ctx, "ncclGetVersion / ncclCommCount / ncclCommUserRank", e);
+    if (rccl_version) *rccl_version = v;
+    if (rccl_nranks) *rccl_nranks = n;
+    if (rccl_rank) *rccl_rank = r;
     return BHIP_OK;
 }
 

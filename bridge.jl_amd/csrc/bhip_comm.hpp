@@ -27,6 +27,9 @@ struct RcclApi {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;              // what bhip_comm_query reports: RCCL's own view of the communicator
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     std::string err;
 };
 
@@ -54,6 +57,9 @@ inline RcclApi &rccl()
         api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
         api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        api.GetVersion = (decltype(api.GetVersion))sym("ncclGetVersion");
+        api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
+        api.CommUserRank = (decltype(api.CommUserRank))sym("ncclCommUserRank");
     });
     return api;
 }

@@ -224,6 +224,38 @@ struct IcdfLDS {
         c0 = a.x; c1 = a.y; c2 = b.x; c3 = b.y;
     }
 };
+// IcdfLDSHot: only the 128 rows of the octaves p >= 2^-17 in LDS (5 KB, the same three planes) -- for the kernels whose LDS has no room
+// for the whole table (the d = 16 / 32 tile kernel: fragment matrices + step buffers fill all but 2.7 KB of half a CU).  A word from a
+// farther octave comes up once in 2^16 draws: row() then reads a valid but WRONG row and reports the lane `cold`; normal_quad redraws the
+// call's four normals from the constant-memory table (IcdfConst) for the whole wave behind ONE wave-uniform branch per call (taken by
+// 0.4 % of the calls; every lane gets the value the full table gives, whichever way it went).
+constexpr int ICDF_HOT_ROWS = 128, ICDF_HOT_FIRST = 120;   // rows 120 .. 247 = octaves e = 15 .. 0 (row R holds octave (30 - (R >> 3)) mod 32)
+constexpr int ICDF_HOT_DOUBLES = 5 * ICDF_HOT_ROWS;       // 640 doubles = 5 120 bytes of LDS
+struct IcdfLDSHot {
+    static constexpr int NOISE_SPEC = 4;
+    static constexpr bool HOT_ONLY = true;
+    typedef const __attribute__((address_space(3))) rng_d2v *lds2_t;
+    typedef const __attribute__((address_space(3))) double *lds1_t;
+    lds2_t pa;
+    bool *cold;   // (a register of the caller: set when a lane's word fell outside the rows held here)
+    __device__ __forceinline__ IcdfLDSHot(double *base, bool *cold_) : pa((lds2_t)(__attribute__((address_space(3))) double *)base), cold(cold_) {}
+    static __device__ __forceinline__ void load(double *base, int tid, int nthreads)
+    {
+        for (int q = tid; q < 5 * ICDF_HOT_ROWS; q += nthreads) {
+            const int R = q / 5, k = q - 5 * R;
+            base[k < 4 ? (k >> 1) * (2 * ICDF_HOT_ROWS) + 2 * R + (k & 1) : 4 * ICDF_HOT_ROWS + R] = icdf_dev[5 * ICDF_HOT_FIRST + q];
+        }
+    }
+    __device__ __forceinline__ void row(uint32_t R, double &c0, double &c1, double &c2, double &c3, double &c4) const
+    {
+        const uint32_t h = R - (uint32_t)ICDF_HOT_FIRST;
+        *cold = *cold || h >= (uint32_t)ICDF_HOT_ROWS;
+        const uint32_t hc = h & (uint32_t)(ICDF_HOT_ROWS - 1);
+        const rng_d2v a = pa[hc], b = pa[ICDF_HOT_ROWS + hc];
+        c4 = ((lds1_t)pa)[4 * ICDF_HOT_ROWS + hc];
+        c0 = a.x; c1 = a.y; c2 = b.x; c3 = b.y;
+    }
+};
 // the larger of the two LDS tables: what a kernel that can draw under every specification reserves
 constexpr int RNG_LDS_DOUBLES = ICDF_TAB_DOUBLES > RNG_TAB_DOUBLES ? ICDF_TAB_DOUBLES : RNG_TAB_DOUBLES;
 #endif
@@ -357,6 +389,9 @@ template <class...> using rng_void_t = void;
 template <class Tab, class = void> struct noise_spec_of { static constexpr int value = 3; };
 template <class Tab> struct noise_spec_of<Tab, rng_void_t<decltype(Tab::NOISE_SPEC)>> { static constexpr int value = Tab::NOISE_SPEC; };
 
+template <class Tab, class = void> struct is_hot_only { static constexpr bool value = false; };
+template <class Tab> struct is_hot_only<Tab, rng_void_t<decltype(Tab::HOT_ONLY)>> { static constexpr bool value = Tab::HOT_ONLY; };
+
 // normals 4q .. 4q+3 of stream 0: v4 -- Philox call q, one normal per word;  v3 -- call q, two 40 + 24-bit pairs;
 // v2 -- calls 2q and 2q+1, one 53 + 53-bit pair each
 template <class Tab>
@@ -366,6 +401,14 @@ BHIP_HD void normal_quad(const Tab &tab, uint32_t k0, uint32_t k1, uint32_t path
     if constexpr (noise_spec_of<Tab>::value == 4) {
         const u32x4 r = philox4x32_10(path, stream, iter, q, k0, k1);
         z0 = icdf_normal(tab, r.x); z1 = icdf_normal(tab, r.y); z2 = icdf_normal(tab, r.z); z3 = icdf_normal(tab, r.w);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (is_hot_only<Tab>::value) {   // a table that holds the near octaves only (IcdfLDSHot): the rare far word redraws the call
+            if (__builtin_amdgcn_ballot_w64(*tab.cold) != 0ull) {
+                z0 = icdf_normal(IcdfConst(), r.x); z1 = icdf_normal(IcdfConst(), r.y); z2 = icdf_normal(IcdfConst(), r.z); z3 = icdf_normal(IcdfConst(), r.w);
+                *tab.cold = false;
+            }
+        }
+#endif
     } else if constexpr (noise_spec_of<Tab>::value == 2) {
         const u32x4 ra = philox4x32_10(path, stream, iter, 2u * q, k0, k1);
         const u32x4 rb = philox4x32_10(path, stream, iter, 2u * q + 1u, k0, k1);

@@ -33,6 +33,7 @@
 namespace bhip {
 
 typedef double double4v __attribute__((ext_vector_type(4)));
+constexpr int TILE_RNG_DOUBLES = ICDF_HOT_DOUBLES > RNG_TAB_DOUBLES ? ICDF_HOT_DOUBLES : RNG_TAB_DOUBLES;   // 640
 constexpr int TILE_ZB = 16 * 18;   // doubles of noise-exchange buffer per wave (k_tile): 16 columns x 16 normals, row stride 18
 
 // Timing experiments only (results become WRONG): bit0 no per-step barrier / matrix staging, bit1 no normal
@@ -149,8 +150,8 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *cm = lds;                  // 4*DD fragment matrices + 5*D vectors
     double *hb = lds + 4 * DD + 5 * D; // 2 * STEP
-    double *rtab_lds = hb + 2 * STEP;  // the generator's tables (RNG_TAB_DOUBLES), for the noise-drawing instantiations
-    double *xs_lds = rtab_lds + RNG_TAB_DOUBLES;   // UD::ON: the state vectors of the block's 64 paths, [4 waves][16 paths][D]
+    double *rtab_lds = hb + 2 * STEP;  // the generator's table (TILE_RNG_DOUBLES), for the noise-drawing instantiations
+    double *xs_lds = rtab_lds + TILE_RNG_DOUBLES;   // UD::ON: the state vectors of the block's 64 paths, [4 waves][16 paths][D]
     double *zb_lds = xs_lds + (UD::ON ? 64 * D : 0);   // noise exchange: per wave 16 paths x 16 normals (row stride 18: conflict-free)
     double *wb_lds = zb_lds + 4 * TILE_ZB;             // NOISE == 2: per wave 2T x 64 16-byte pieces of the chain's current W (LDS-DMA target)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -167,9 +168,16 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 
     for (int c = tid; c < 4 * DD + 5 * D; c += 256) cm[c] = a.cst[c];
     for (int c = tid; c < STEP; c += 256) hb[c] = a.steps[c];
-    if constexpr (NOISE == 1 || NOISE == 2) TabLDS::load(rtab_lds, tid, 256);
+    // the generator's table of the launch's noise specification: v4 (the default) the 128 rows of the near octaves (IcdfLDSHot), v3 / v2 the
+    // log + sincos tables
+    const bool icdf = !(a.noise_spec == 2 || a.noise_spec == 3);
+    if constexpr (NOISE == 1 || NOISE == 2) {
+        if (icdf) IcdfLDSHot::load(rtab_lds, tid, 256);
+        else TabLDS::load(rtab_lds, tid, 256);
+    }
     __syncthreads();
     const TabLDS rtab(rtab_lds);
+    bool cold = false;
     const double *Bf = cm, *Btf = cm + DD, *Af = cm + 2 * DD, *Sf = cm + 3 * DD;
     const double *mu = cm + 4 * DD, *mua = mu + D, *beta = mu + 2 * D, *vend = mu + 3 * D;
 
@@ -413,11 +421,9 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                     __builtin_amdgcn_wave_barrier();   // ... and the reads precede the next pass's writes
                 }
             };
-            // (the default specification v4 reads its table from constant memory: the 10 KB do not fit next to the fragment matrices at
-            // two workgroups per CU; 2.6 KB of v3 / v2 tables do)
             if (a.noise_spec == 2) draw_rows(FullRes<TabLDS>(rtab));
             else if (a.noise_spec == 3) draw_rows(rtab);
-            else draw_rows(IcdfConst());
+            else draw_rows(IcdfLDSHot(rtab_lds, &cold));
             if constexpr (BHIP_TILE_DMA_LATE) issue_dmas();   // the reads of wb are long done; the DMAs still have the products' time
             land_stage();
             double *qo = wop;
@@ -606,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
         // if log(rand()) <= llo - ll: W <- Wo (parity flip), ll <- llo, acc += 1     partialbridge_fitzhugh.jl:160-167
         if (live && kq == 0 && !a.defer_accept) {
             const double u = accept_uniform(a.k0, a.k1, path, a.iter);
-            if (det_log(u, rtab) <= ll - a.llcur[p]) {
+            if (det_log(u) <= ll - a.llcur[p]) {   // (the log's table from constant memory: once per chain and launch)
                 a.cur[p] = (unsigned char)(cpar ^ 1);
                 a.llcur[p] = ll;
                 a.acc[p] += 1u;
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 // dynamic LDS of k_tile<D, ., ., UD>: constants, two step buffers, generator tables (+ the gathered states for a user drift)
 constexpr size_t tile_lds_bytes(int D, bool user, bool chains = true)
 {
-    return sizeof(double) * (4 * D * D + 5 * D + 2 * (D * D + D + 2) + RNG_TAB_DOUBLES + (user ? 64 * D : 0) + 4 * TILE_ZB + (chains ? 4 * 2 * (D / 16) * 128 : 0));
+    return sizeof(double) * (4 * D * D + 5 * D + 2 * (D * D + D + 2) + TILE_RNG_DOUBLES + (user ? 64 * D : 0) + 4 * TILE_ZB + (chains ? 4 * 2 * (D / 16) * 128 : 0));
 }
 
 template <int D, int NOISE, bool PAD = false>

@@ -45,6 +45,14 @@ def shard(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def comm_info(ctx, h):
+    import ctypes as C
+    n, r, v, rn, rr = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    ctx.check(ctx.lib.bhip_comm_info(h, C.byref(n), C.byref(r)))
+    ctx.check(ctx.lib.bhip_comm_query(h, C.byref(v), C.byref(rn), C.byref(rr)))
+    return {"nranks": n.value, "rank": r.value, "rccl_version": v.value, "rccl_nranks": rn.value, "rccl_rank": rr.value}
+
+
 class Comm:
     """The product's own communicator (bhip_comm, RCCL over xGMI, include/bridgehip.h): the all-gather of the statistics
     block runs inside libbridgehip.so on the context's stream.  One process per GPU: rank 0 draws the RCCL unique id and
@@ -86,6 +94,10 @@ class Comm:
         self.ctx.check(self.ctx.lib.bhip_comm_allgather(self.h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), send.numel()))
         return recv.reshape(self.nranks, -1)
 
+    def info(self):
+        """what the library (bhip_comm_info) and RCCL itself (bhip_comm_query: ncclGetVersion, ncclCommCount, ncclCommUserRank) say"""
+        return comm_info(self.ctx, self.h)
+
     def destroy(self):
         if getattr(self, "h", None):
             self.ctx.lib.bhip_comm_destroy(self.h)
@@ -123,6 +135,10 @@ class CommGroup:
         self.ctxs[0].check(self.ctxs[0].lib.bhip_comm_allgather_group(n, self._comms, sp, rp, count))
         return [r.reshape(n, -1) for r in recvs]
 
+    def info(self):
+        """one bhip_comm_info / bhip_comm_query record per rank of the group"""
+        return [comm_info(self.ctxs[k], self._comms[k]) for k in range(self.nranks)]
+
     def destroy(self):
         if getattr(self, "_comms", None) is not None:
             for k in range(self.nranks):
@@ -150,15 +166,19 @@ class ChainsGroup:
         self.lib = self.chains[0].ctx.lib
 
     def step(self, rho, iters=1, skip=-1):
+        import ctypes as C
         rc = self.lib.bhip_chains_step_group(self.n, self._hs, float(rho), int(iters), int(skip))
+        # the library is the authority on how far every ensemble got: after a failing launch they stand at different counts
+        for k, c in enumerate(self.chains):
+            it = C.c_uint32()
+            if self.lib.bhip_chains_iterations(self._hs[k], C.byref(it)) == 0:
+                c.iterations = int(it.value)
         if rc:
             for c in self.chains:   # the failing ensemble's context holds the message
                 msg = c.ctx.lib.bhip_last_error(c.ctx.h)
                 if msg:
                     raise RuntimeError(f"bhip_chains_step_group: rc {rc}: {msg.decode()}")
             raise RuntimeError(f"bhip_chains_step_group: rc {rc}")
-        for c in self.chains:
-            c.iterations += iters
 
     def stats(self, outs):
         """outs[k]: float64 tensor [STATS_LEN] on the device of chains[k]"""

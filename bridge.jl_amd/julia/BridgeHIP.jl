@@ -335,6 +335,17 @@ function step_group!(chs::Vector{Chains}, ρ, iterations; skip = -1)
     check(chs[1].ctx, ccall((:bhip_chains_step_group, lib), Cint, (Cint, Ptr{Ptr{Cvoid}}, Cdouble, Cint, Cint), length(hs), hs, ρ, iterations, skip))
     chs
 end
+"""
+    iterations(ch::Chains) -> Int
+
+pCN iterations the ensemble has completed (`bhip_chains_iterations`; the library keeps the count -- after a `step_group!` that threw,
+the ensembles of the group stand at different counts).
+"""
+function iterations(ch::Chains)
+    r = Ref{UInt32}(0)
+    check(ch.ctx, ccall((:bhip_chains_iterations, lib), Cint, (Ptr{Cvoid}, Ref{UInt32}), ch.h, r))
+    Int(r[])
+end
 function stats_group!(chs::Vector{Chains}, stats_dev::Vector{Ptr{Cvoid}})
     hs = Ptr{Cvoid}[ch.h for ch in chs]
     check(chs[1].ctx, ccall((:bhip_chains_stats_group, lib), Cint, (Cint, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}), length(hs), hs, stats_dev))

@@ -3,7 +3,16 @@
 # tests/golden/, so that the CPU oracle (and through it the HIP kernels) can be compared with the reference bit for bit.
 #
 # NEVER EXECUTED BY THE BUILD: there is no `julia` in the build image or on the GPU box.  Anyone with Julia >= 1.5 and
-# Bridge v0.11.7:
+# Bridge v0.11.7 -- but mind the VERSION (written to <outdir>/VERSION.txt, read by the test):
+#
+#   The bit-for-bit comparison is DEFINED ON JULIA <= 1.6 (Bridge.jl's CI pins 1.5).  src/partialbridge.jl:54,57 write the guided
+#   drift as `a*L'*M*q` and `L'*M*q`.  Up to Julia 1.6 `*` with several arguments is the generic left fold, ((a*L')*M)*q and (L'*M)*q:
+#   what the oracle (oracle/bridge_oracle.c bo_guided_drift) and the kernels (bhip_path_kernel.h guide_terms, LMMU branch) evaluate.
+#   From Julia 1.7 on LinearAlgebra defines 3- and 4-argument `*` for AbstractMatrix ... AbstractVector chains and associates
+#   them from the RIGHT (A*(B*x), A*B*(C*x)); SMatrix / SVector are AbstractMatrix / AbstractVector, so THE SAME SOURCE LINE rounds
+#   differently: 1-ulp differences per step, amplified by the stiff guide near the end point.  On Julia >= 1.7 the test therefore
+#   compares at the stated fp64 tolerance (1e-9 on paths, 1e-8 on log-likelihoods) and says why; a mismatch there under `==`
+#   would not be a parity failure.  (GuidedBridge, src/guip.jl:192-193, has no such chain: H \ (V - x) and a*r.)
 #
 #     python tests/golden/export_for_julia.py            # writes tests/golden/julia_in/<case>_{tt,W}.csv
 #     julia --project=/path/to/Bridge.jl bridge.jl_amd/julia/bridgejl_fixtures.jl tests/golden/julia_in tests/golden/julia_out
@@ -58,6 +67,9 @@ end
 
 function main(indir, outdir)
     mkpath(outdir)
+    open(joinpath(outdir, "VERSION.txt"), "w") do f
+        println(f, string(VERSION))      # the test picks == (Julia <= 1.6) or the stated tolerance (>= 1.7) from this
+    end
     fhn(v) = tt -> begin
         P = FHN(0.1, 0.0, 1.5, 0.8, 0.3)
         Pt = FHNAuxEnd(0.1, 0.0, 1.5, 0.8, 0.3, v)

@@ -314,8 +314,14 @@ int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip);
 /* The loop of partialbridge_fitzhugh.jl:143-176 for n ensembles -- one per device of a node, each created on its own context --
  * in ONE call: iteration by iteration the n launches go out round-robin, each on its context's stream (asynchronous), so a
  * single host thread (a Julia `ccall` host) keeps every device busy with one FFI crossing per call instead of one per device
- * and iteration.  Same results as bhip_chains_step on every ensemble by itself.  n <= 64, no ensemble twice. */
+ * and iteration.  Same results as bhip_chains_step on every ensemble by itself.  n <= 64, no ensemble twice.
+ * Arguments, state and the context's noise specification are checked for ALL ensembles before the first launch; should a launch
+ * itself fail after that (no kernel for the combination, a device error), the call returns at once and the ensembles are left at
+ * DIFFERENT iteration counts -- bhip_chains_iterations says where each one stands (only completed iterations are counted; a caller
+ * keeping its own counter re-reads it after an error). */
 int bhip_chains_step_group(int n, bhip_chains *const *chs, double rho, int iters, int skip);
+/* pCN iterations the ensemble has completed since bhip_chains_init (the `iter` word of its noise counter; what a saved state resumes from) */
+int bhip_chains_iterations(const bhip_chains *ch, uint32_t *iterations);
 /* device-side reduction of the ensemble statistics into stats_dev[8] =
  *   {nchains, iterations done, sum acc, sum ll, sum ll^2, min ll, max ll, sum acc^2}
  * (the block that is all-gathered over RCCL in the multi-GPU run) */
@@ -444,6 +450,10 @@ int bhip_comm_unique_id(void *id, size_t bytes);
 int bhip_comm_init_rank(bhip_ctx *ctx, int nranks, int rank, const void *id, bhip_comm **out);
 int bhip_comm_init_all(int ndev, bhip_ctx *const *ctxs, bhip_comm **comms_out);
 int bhip_comm_info(const bhip_comm *comm, int *nranks, int *rank);
+/* what RCCL ITSELF reports for the communicator -- ncclGetVersion (e.g. 22606), ncclCommCount, ncclCommUserRank -- so that a record
+ * of a multi-GPU run can answer "did RCCL see N ranks" by itself (bench.py's "comm" object).  The reference has no counterpart
+ * (single-threaded Julia; the unit being sharded is project_partialbridge/partialbridge_fitzhugh.jl:143-176). */
+int bhip_comm_query(const bhip_comm *comm, int *rccl_version, int *rccl_nranks, int *rccl_rank);
 int bhip_comm_allgather(bhip_comm *comm, const double *send_dev, double *recv_dev, size_t count);
 /* = bhip_comm_allgather(comm, stats_dev, all_dev, BHIP_STATS_LEN): all_dev [nranks][BHIP_STATS_LEN] */
 int bhip_comm_allgather_stats(bhip_comm *comm, const double *stats_dev, double *all_dev);

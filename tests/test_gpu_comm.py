@@ -39,6 +39,9 @@ def test_rccl_allgather_of_the_statistics_block_world_of_one(ctx):
     n, r = C.c_int(-1), C.c_int(-1)
     ctx.check(ctx.lib.bhip_comm_info(comm.h, C.byref(n), C.byref(r)))
     assert (n.value, r.value) == (1, 0)
+    # ... and what RCCL itself says about the communicator (bhip_comm_query: ncclGetVersion / ncclCommCount / ncclCommUserRank)
+    info = comm.info()
+    assert info["nranks"] == info["rccl_nranks"] == 1 and info["rank"] == info["rccl_rank"] == 0 and info["rccl_version"] >= 2000
     g = bdist.allgather_stats(stats, 1, comm)       # bhip_comm_allgather -> ncclAllGather on the context's stream
     torch.cuda.synchronize()
     assert g.shape == (1, bh.STATS_LEN) and torch.equal(g[0], stats)
@@ -106,6 +109,10 @@ def test_bench_single_process_path_runs_the_collective_at_one_gpu():
     assert j["n_gpus"] == 1 and "bhip_comm_init_all" in j["config"]["launch"] and "unavailable" not in j["config"]["launch"]
     assert j["allgather_ms"] >= 0.0 and len(j["per_gpu_ms_per_step"]) == 1 and j["config"]["chains_total"] == 4096
     assert j["per_gpu_ms_per_step"][0] <= j["ms_per_step"] * 1.0001
+    # the communicator in the record: RCCL's own count and rank, its version, the number of gathered blocks
+    cm = j["comm"]
+    assert cm["backend"] == "rccl" and cm["nranks"] == cm["rccl_nranks"] == 1 and cm["ranks_seen"] == [0] and cm["gathered_blocks"] == 1
+    assert cm["consistent"] is True and cm["rccl_version"].count(".") == 2 and int(cm["rccl_version"].split(".")[0]) >= 2
 
 
 def test_bench_under_the_launcher_at_one_rank_and_its_fallback():
@@ -123,6 +130,8 @@ def test_bench_under_the_launcher_at_one_rank_and_its_fallback():
         assert len(lines) == 1
         out.append(json.loads(lines[0]))
     assert "bhip_comm_init_rank" in out[0]["config"]["launch"]
+    assert out[0]["comm"]["backend"] == "rccl" and out[0]["comm"]["rccl_nranks"] == 1 and out[0]["comm"]["ranks_seen"] == [0] and out[0]["comm"]["consistent"]
+    assert "fall-back" in out[1]["comm"]["backend"] and "rccl_nranks" not in out[1]["comm"] and out[1]["comm"]["gathered_blocks"] == 1
     assert "torch.distributed" in out[1]["config"]["launch"] and "forced by BENCH_FORCE_COMM_FAILURE" in out[1]["config"]["launch"]
     assert out[0]["config"]["acceptance_rate"] == out[1]["config"]["acceptance_rate"] and out[0]["config"]["chains_total"] == 4096
     assert len(out[0]["per_gpu_ms_per_step"]) == 1 and 0 < out[0]["per_gpu_ms_per_step"][0] <= out[0]["ms_per_step"] * 1.0001

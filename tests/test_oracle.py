@@ -599,6 +599,34 @@ def test_round1_golden_paths_given_their_wiener_paths():
     _check_given_W(np.load(os.path.join(GOLD, "guided_paths_v1.npz")), False, libm_trig=True)
 
 
+def _bridgejl_comparison(outdir):
+    """(exact, why): the fixture script writes Julia's VERSION.  src/partialbridge.jl:54,57 spell the guided drift `a*L'*M*q` / `L'*M*q`;
+    up to Julia 1.6 that is the left fold ((a*L')*M)*q the oracle and the kernels evaluate, from 1.7 on LinearAlgebra's 3- / 4-argument
+    `*` associates matrix ... vector chains from the right: the same source line, other roundings.  Bit for bit is defined on <= 1.6;
+    from 1.7 on (or with no version recorded) PartialBridge cases compare at the stated fp64 tolerance."""
+    fn = os.path.join(outdir, "VERSION.txt")
+    if not os.path.exists(fn):
+        return False, "tests/golden/julia_out/VERSION.txt missing: Julia version unknown, PartialBridge compared at 1e-9 / 1e-8"
+    ver = open(fn).read().strip()
+    try:
+        major, minor = (int(x) for x in ver.split(".")[:2])
+    except ValueError:
+        return False, f"unparsable Julia version '{ver}': PartialBridge compared at 1e-9 / 1e-8"
+    if (major, minor) <= (1, 6):
+        return True, f"Julia {ver}: `a*L'*M*q` is the left fold, == applies"
+    return False, (f"Julia {ver} >= 1.7 associates `a*L'*M*q` (src/partialbridge.jl:54) from the right: not the reference CI's arithmetic "
+                   "(Julia 1.5); PartialBridge compared at the stated tolerance 1e-9 / 1e-8, not ==")
+
+
+def test_bridgejl_comparison_rule_follows_the_julia_version(tmp_path):
+    for ver, exact in (("1.5.4", True), ("1.6.7", True), ("1.7.0", False), ("1.10.4", False), ("2.0.0", False)):
+        (tmp_path / "VERSION.txt").write_text(ver + "\n")
+        e, why = _bridgejl_comparison(str(tmp_path))
+        assert e == exact and ver in why
+    (tmp_path / "VERSION.txt").unlink()
+    assert _bridgejl_comparison(str(tmp_path))[0] is False
+
+
 def test_bridgejl_fixtures_if_present():
     """Outputs of Bridge.jl ITSELF (bridge.jl_amd/julia/bridgejl_fixtures.jl, run by someone who has Julia) on the Wiener
     paths of the golden file: when tests/golden/julia_out/ exists the oracle must reproduce Bridge.jl's paths and
@@ -607,6 +635,7 @@ def test_bridgejl_fixtures_if_present():
     out = os.path.join(GOLD, "julia_out")
     if not os.path.isdir(out):
         pytest.skip("no Bridge.jl fixture present (tests/golden/julia_out): parity with Bridge.jl itself stays unpinned")
+    exact, why = _bridgejl_comparison(out)
     g = np.load(os.path.join(GOLD, "guided_paths_v2.npz"))
     N, npaths = int(g["meta"][0]), int(g["meta"][1])
     for c in problems.cases(N):
@@ -618,8 +647,13 @@ def test_bridgejl_fixtures_if_present():
         ref = c.oracle_proposal()
         for p in range(npaths):
             Xo = o.solve_guided(ref, c.x0, g[c.name + "/W"][p])
-            assert np.array_equal(Xo, X[p]), c.name
-            assert o.llikelihood(ref, Xo) == ll[p], c.name
+            llo = o.llikelihood(ref, Xo)
+            if exact or c.kind != o.GUIDE_LMMU:      # (only the (L, M, mu) drift holds a multi-argument matrix product)
+                assert np.array_equal(Xo, X[p]), c.name
+                assert llo == ll[p], c.name
+            else:
+                assert np.abs(Xo - X[p]).max() <= 1e-9 * (1 + np.abs(X[p]).max()), (c.name, why)
+                assert abs(llo - ll[p]) <= 1e-8 * (1 + abs(ll[p])), (c.name, why)
 
 
 def test_adaptive_smoother_without_adaptation_equals_the_plain_smoother_and_chol():
