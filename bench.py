@@ -124,7 +124,7 @@ def cpu_baseline(seconds_budget=20.0):
 
 NOISE_SPEC = ("bhip-philox-v4: Philox4x32-10, four normals per call = one per 32-bit word through a piecewise polynomial inverse distribution "
               "function (256 segments of degree 4, within 3.7e-9 of the quantile, |z| <= 6.34; DESIGN 4); the reference's randn is a 52-bit ziggurat")
-PROFILE_TAG = "r4"   # profiles/<PROFILE_TAG>_<mode>_{trace,fetch,write}.txt, written by scripts/gpu_profile_all.sh this round
+PROFILE_TAG = "r5"   # profiles/<PROFILE_TAG>_<mode>_{trace,fetch,write}.txt, written by scripts/gpu_profile_all.sh this round
 
 
 def profiled_traffic(mode, kernel_name):
@@ -152,6 +152,22 @@ def profiled_traffic(mode, kernel_name):
                                                            f"profiles/{PROFILE_TAG}_{mode}_write.txt")
 
 
+CALIB_BYTES = 1 << 30
+
+
+def calib_copy():
+    """BENCH_CALIB_COPY=1 (set by live_traffic for its rocprofv3 child runs): three launches of a plain streaming kernel that reads exactly
+    CALIB_BYTES and writes exactly CALIB_BYTES (torch's elementwise add of a 1-GiB tensor into another) -- the yardstick the FETCH_SIZE /
+    WRITE_SIZE counters of the same pass are checked against."""
+    x = torch.zeros(CALIB_BYTES // 8, dtype=torch.float64, device="cuda")
+    y = torch.empty_like(x)
+    for _ in range(3):
+        torch.add(x, 1.0, out=y)
+    torch.cuda.synchronize()
+    del x, y
+    torch.cuda.empty_cache()
+
+
 def live_traffic(mode, kernel_name, steps=6):
     """HBM bytes per launch of the dominant kernel measured ON THIS BOX, now: two rocprofv3 runs of `bench.py --mode <mode>` (one
     --pmc pass each: FETCH_SIZE and WRITE_SIZE cannot share a pass, MI355X_MICROARCH.md PMC slots; never combined with other trace
@@ -170,7 +186,7 @@ def live_traffic(mode, kernel_name, steps=6):
         try:
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "t", "--", sys.executable, os.path.abspath(__file__), "--mode", mode,
                    "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-other-modes", "--no-live-traffic"]
-            env = dict(os.environ, TMPDIR="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp", BENCH_CALIB_COPY="1")   # the child also runs a streaming kernel of KNOWN size (calib_copy)
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
             dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp) for f in fs if f.endswith(".db")]
             if not dbs:
@@ -190,12 +206,29 @@ def live_traffic(mode, kernel_name, steps=6):
                 vals[counter] = float(np.mean(list(per.values())))
             else:
                 vals[counter] = float(np.mean([v for _, v in rows]))
+            # the unit of the counter, validated IN THIS RUN (advisor r4): the child's calibration kernel reads and writes exactly
+            # CALIB_BYTES; KiB reported for it -> the factor that turns this counter into bytes on this box (FETCH_SIZE: ~2 on gfx950 for
+            # a wide coalesced read stream, the guide's correction; WRITE_SIZE: ~1)
+            crow = list(cur.execute(f"select {idcol or namecol}, value from counters_collection where {namecol} like ? and counter_name = ?",
+                                    ("%elementwise%", counter)))
+            if crow:
+                per = {}
+                for did, v in crow:
+                    per[did] = per.get(did, 0.0) + v
+                big = [v for v in per.values() if v > 0.25 * CALIB_BYTES / 1024.0]   # the 1-GiB launches, not torch's small fills
+                if big:
+                    vals[counter + "_factor"] = CALIB_BYTES / 1024.0 / float(np.mean(big))
         except Exception as e:   # noqa: BLE001 -- the record is context, never a reason to fail the bench
             return None, f"rocprofv3 --pmc {counter}: {type(e).__name__}: {e}"
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
+    ff, wf = vals.get("FETCH_SIZE_factor"), vals.get("WRITE_SIZE_factor")
+    note = (f"; factors validated in the same passes on a {CALIB_BYTES >> 20}-MiB streaming kernel of known size: FETCH_SIZE x {ff:.3f}, WRITE_SIZE x {wf:.3f} "
+            "(applied: 2 and 1)" if ff and wf else "; calibration kernel not found in the passes (factors 2 and 1 as the guide prescribes)")
+    if ff and wf and not (1.9 <= ff <= 2.1 and 0.95 <= wf <= 1.05):
+        return None, f"counter units off on this box: FETCH_SIZE x {ff:.3f}, WRITE_SIZE x {wf:.3f} against the known-size kernel -- no traffic figure"
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, ("measured on this box in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE (x2, gfx950 "
-                                                                       "correction) and --pmc WRITE_SIZE, separate passes of `bench.py --mode " + mode + "`")
+                                                                       "correction) and --pmc WRITE_SIZE, separate passes of `bench.py --mode " + mode + "`" + note)
 
 
 def profiled_valu(mode, kernel_name, paths):
@@ -758,6 +791,13 @@ def main_per_rank(args, world):
 
     for _ in range(args.warmup):
         w.step()
+    # the protocol of rounds 1-3 beside the headline (same steps in both launch forms: two ranks == one rank with twice the chains)
+    torch.cuda.synchronize()
+    t_np = time.perf_counter()
+    for _ in range(args.steps):
+        w.step()
+    torch.cuda.synchronize()
+    no_prewarm_ms = (time.perf_counter() - t_np) / args.steps * 1e3
     stats.zero_()
     bdist.allgather_stats(stats, world, comm)
     elapsed, kern_ms, gathered = timed_region(w, args.steps, world, ctx, stats, comm)
@@ -783,6 +823,7 @@ def main_per_rank(args, world):
                "statistics all-gather by torch.distributed" + (f" (product communicator: {comm_note})" if comm_note else " (gloo test double)"))
         out = base_record(args, world, w, elapsed, kern_ms, "one process per GPU (torch.distributed.run); " + how)
         out["per_gpu_ms_per_step"] = [t / args.steps for t in per_gpu_ms]
+        out["no_prewarm"] = {"ms_per_step": no_prewarm_ms, "note": f"rank 0's own clock over the same {args.steps} steps right after the warm-up steps, before the pre-warm; not the headline"}
         if comm is not None and all(i is not None for i in infos):
             out["comm"] = comm_record(infos, gathered, "rccl", "bhip_comm_init_rank, one process per GPU")
         else:
@@ -821,6 +862,8 @@ def main_local(args):
         print(f"bench.py: --gpus {n} but only {ndev} device(s) visible to this process", file=sys.stderr)
         sys.exit(2)
     ctxs = [bh.Context(0 if same else k) for k in range(n)]
+    if os.environ.get("BENCH_CALIB_COPY") == "1":
+        calib_copy()
     comm_note = None
     try:
         group = _HostGather(n) if same and n > 1 else bdist.CommGroup(ctxs)
@@ -837,6 +880,17 @@ def main_local(args):
     for _ in range(args.warmup):
         for x in ws:
             x.step()
+    # the protocol of rounds 1-3 beside the headline (advisor r4: round-to-round comparability): K steps right after the W warm-up
+    # steps, NO pre-warm -- on an idle box this reads the clocks' way up.  Wall clock around synchronised devices, like the timed region.
+    for c in ctxs:
+        torch.cuda.synchronize(c.device)
+    t_np = time.perf_counter()
+    for _ in range(args.steps):
+        for x in ws:
+            x.step()
+    for c in ctxs:
+        torch.cuda.synchronize(c.device)
+    no_prewarm_ms = (time.perf_counter() - t_np) / args.steps * 1e3
     if group is not None:   # untimed: the first collective sets up RCCL's channels
         for k, c in enumerate(ctxs):
             with torch.cuda.device(c.device):
@@ -847,6 +901,9 @@ def main_local(args):
     out = base_record(args, n, w, elapsed, kern_ms,
                       "one process, one context per device; bhip_comm_init_all + bhip_comm_allgather_group" + (f" [{comm_note}]" if comm_note else ""))
     out["per_gpu_ms_per_step"] = [t / args.steps for t in per_gpu_ms]
+    out["no_prewarm"] = {"ms_per_step": no_prewarm_ms, "value": float(n) * P * steps_per_unit / (no_prewarm_ms * 1e-3),
+                         "note": f"the same {args.steps} steps right after the {args.warmup} warm-up steps, before the pre-warm (the protocol of rounds 1-3): "
+                                 "first process on an idle box = clocks on their way up; not the headline"}
     out["allgather_ms"] = gather_ms
     if isinstance(group, bdist.CommGroup):
         out["comm"] = comm_record(group.info(), gathered, "rccl", "bhip_comm_init_all, one process")
@@ -882,6 +939,16 @@ def main_local(args):
                            "path_steps_per_s": wo.P * steps_per_unit / (float(np.mean(ms)) * 1e-3), "roofline": wo.roofline(ms)})
             del wo
             torch.cuda.empty_cache()
+            if mode in ("c4shard", "c2", "proposals") and not args.no_live_traffic:
+                # the named small configurations' HBM bytes from THIS box's counters as well (two rocprofv3 child runs each, outside
+                # every timed region), like the headline's below; the committed look-up stays as the fall-back
+                ro = others[-1]["roofline"]
+                tr, src = live_traffic(mode, ro["kernel"])
+                if tr is not None:
+                    ro.update({"traffic": tr, "traffic_source": src, "traffic_box": "this box, this run",
+                               "traffic_over_algorithmic": tr / (ro["algorithmic_bytes_per_path_step"] * ro["path_steps_per_launch"])})
+                else:
+                    ro["traffic_live_failed"] = src
         out["other_modes"] = others
         out["smoothing"] = smoothing_record(ctx)
         out["box"] = box_calibration(ctx.device)

@@ -55,6 +55,21 @@ namespace bhip {
 
 struct u32x4 { uint32_t x, y, z, w; };
 
+// a ^ b ^ c: ONE instruction on gfx950 (v_bitop3_b32, truth table 0x96) -- the compiler pairs the xors of a Philox round into two
+// v_xor_b32 each otherwise (35 instead of 20 per call)
+BHIP_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__has_builtin) && !defined(BHIP_NO_BITOP3)   /* (BHIP_NO_BITOP3: A/B builds, scripts/noise_rate_probe.hip) */
+#if __has_builtin(__builtin_amdgcn_bitop3_b32)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+#else
+    return a ^ b ^ c;
+#endif
+}
+
 BHIP_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
@@ -63,7 +78,7 @@ BHIP_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, 
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        const uint32_t n0 = xor3(hi1, c1, k0), n2 = xor3(hi0, c3, k1);
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
@@ -183,8 +198,9 @@ struct TabLDS {
 
 // ---- specification v4: the table of the piecewise inverse distribution function, BHIP_ICDF_ROWS rows {c0 .. c4}.
 // IcdfConst reads it from constant memory (per-lane loads) / the host array; IcdfLDS from a copy in LDS laid out in three planes --
-// {c0, c1}[R], {c2, c3}[R], c4[R] -- so that the 16-byte reads of neighbouring rows fall into different banks (the sixteen most
-// probable rows, octaves p >= 1/8, hit sixteen different bank groups).  The TYPE of the accessor carries the specification.
+// {c0, c1}[R], {c2, c3}[R], {c4, -}[R], all with a 16-byte stride: ONE address register (row * 16) serves the three reads, and the
+// 16-byte reads of neighbouring rows fall into different banks (the sixteen most probable rows, octaves p >= 1/8, hit sixteen
+// different bank groups).  The TYPE of the accessor carries the specification.
 alignas(16) static const double icdf_host[5 * BHIP_ICDF_ROWS] = BHIP_ICDF_INIT;
 #if defined(__HIPCC__)
 alignas(16) static __device__ const double icdf_dev[5 * BHIP_ICDF_ROWS] = BHIP_ICDF_INIT;
@@ -202,25 +218,25 @@ struct IcdfConst {
     }
 };
 #if defined(__HIPCC__)
-constexpr int ICDF_TAB_DOUBLES = 5 * BHIP_ICDF_ROWS;   // 1280 doubles = 10 240 bytes of LDS
+constexpr int ICDF_TAB_DOUBLES = 6 * BHIP_ICDF_ROWS;   // 1536 doubles = 12 288 bytes of LDS (the third plane half empty)
 struct IcdfLDS {
     static constexpr int NOISE_SPEC = 4;
     typedef const __attribute__((address_space(3))) rng_d2v *lds2_t;
     typedef const __attribute__((address_space(3))) double *lds1_t;
-    lds2_t pa;   // {c0, c1}[R]; {c2, c3}[R] follows at + BHIP_ICDF_ROWS, c4[R] at + 2*BHIP_ICDF_ROWS (as doubles: + 4*BHIP_ICDF_ROWS)
+    lds2_t pa;   // {c0, c1}[R]; {c2, c3}[R] follows at + BHIP_ICDF_ROWS, {c4, unused}[R] at + 2*BHIP_ICDF_ROWS
     // `base` points to ICDF_TAB_DOUBLES doubles of LDS (16-byte aligned), filled by load() + a barrier
     __device__ __forceinline__ explicit IcdfLDS(double *base) : pa((lds2_t)(__attribute__((address_space(3))) double *)base) {}
     static __device__ __forceinline__ void load(double *base, int tid, int nthreads)
     {
         for (int q = tid; q < 5 * BHIP_ICDF_ROWS; q += nthreads) {
             const int R = q / 5, k = q - 5 * R;
-            base[k < 4 ? (k >> 1) * (2 * BHIP_ICDF_ROWS) + 2 * R + (k & 1) : 4 * BHIP_ICDF_ROWS + R] = icdf_dev[q];
+            base[(k >> 1) * (2 * BHIP_ICDF_ROWS) + 2 * R + (k & 1)] = icdf_dev[q];
         }
     }
     __device__ __forceinline__ void row(uint32_t R, double &c0, double &c1, double &c2, double &c3, double &c4) const
     {
         const rng_d2v a = pa[R], b = pa[BHIP_ICDF_ROWS + R];
-        c4 = ((lds1_t)pa)[4 * BHIP_ICDF_ROWS + R];
+        c4 = ((lds1_t)pa)[2 * (2 * BHIP_ICDF_ROWS + R)];   // an 8-byte read at the same row * 16
         c0 = a.x; c1 = a.y; c2 = b.x; c3 = b.y;
     }
 };
@@ -274,9 +290,9 @@ BHIP_HD double icdf_normal(const Tab &tab, uint32_t w)
     q = fma_(q, d, c2);
     q = fma_(q, d, c1);
     q = fma_(q, d, c0);
-    b.d = q;
-    b.u = (b.u & 0x7fffffffffffffffULL) | ((uint64_t)(w & 0x80000000u) << 32);
-    return b.d;
+    // |q| with the sign bit of w: copysign from a double whose high word is w (one v_bfi_b32 on the device)
+    b.u = (uint64_t)w << 32;
+    return __builtin_copysign(q, b.d);
 }
 
 // L = -2*ln(x) for x in (0,1], normal doubles.  x = 2^e * m0, m0 in [1,2);  k = round(128*m0) - 128 selects the
