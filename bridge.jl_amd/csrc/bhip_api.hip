@@ -799,10 +799,22 @@ static int build_tile_data(bhip_proposal *po)
     if (!plain && (!po->has_aux || (po->aux.kind != BHIP_AUX_AFFINE && po->aux.kind != BHIP_AUX_LINPRO)))
         return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: time-constant auxiliary process");
     const int Dp = tile_dim(d);
-    const size_t DD = (size_t)Dp * Dp, STEP = DD + Dp + 2, dd = (size_t)d * d;   // Hm_i fragments, nu_i, then (dt_i, sqrt(dt_i))
+    // The step regrouped into four products with path-independent accumulator starts (bhip_tile_kernel.h, head of the file):
+    //   per step   -Hm_i, P_i = I + dt_i (B - a Hm_i)  (fragment order),  hnu_i = Hm_i nu_i,  q_i = dt_i (a Hm_i nu_i - B mu),  dt_i, sqrt(dt_i)
+    //   constant   B - B~, sigma  (fragment order),  c = B~ mu~ - B mu - beta~,  vend
+    // (a component-wise user drift takes the place of B (x - mu) as a vector term in the kernel: B = 0, mu = 0 here)
+    const size_t DD = (size_t)Dp * Dp, STEP = 2 * DD + 2 * Dp + 2, dd = (size_t)d * d;
+    const double *par = po->mh.par.data();
+    const double *sig = user ? par + (po->mh.par.size() - (size_t)dd) : par + dd + d;   // user: [drift parameters, sigma]; LinPro: [B, mu, sigma]
+    const Mat Bm = user ? Mat(d, d) : Mat(d, d, par);
+    Mat mu(d, 1);
+    if (!user) std::memcpy(mu.a.data(), par + dd, sizeof(double) * d);
+    const Mat Bmu = Bm * mu;
+    Mat Id(d, d);
+    for (int k = 0; k < d; k++) Id(k, k) = 1.0;
     std::vector<double> steps((size_t)(N - 1) * STEP, 0.0), hdr((size_t)(N - 1) * 2);
     for (int i = 0; i < N - 1; i++) {
-        // Every guide is brought to the form r = Hm_i (nu_i - x) the tile kernel evaluates:
+        // Every guide is brought to the form r = Hm_i (nu_i - x):
         //   GuidedBridge : Hdiamond_i \ (V_i - x)  ->  Hm = inv(Hdiamond_i) (LU, path-independent), nu = V_i
         //   (nu,H)       : H_i (nu_i - x) as in the reference (PartialBridge! likewise)
         //   PartialBridge: L'M(v - mu - Lx) = (L'ML)(nu - x) with any nu solving L nu = v - mu: nu = L'(LL')^-1 (v - mu)
@@ -814,26 +826,33 @@ static int build_tile_data(bhip_proposal *po)
             Hm = (tr(L) * po->g.M[i]) * L;
             nu = tr(L) * solve(L * tr(L), po->g.v - po->g.mu[i]);
         } else { Hm = po->g.H[i]; nu = po->g.nu[i]; }
-        to_fragments(pad_mat(Hm, Dp), &steps[(size_t)i * STEP]);
-        std::memcpy(&steps[(size_t)i * STEP + DD], nu.a.data(), sizeof(double) * d);
-        hdr[2 * i] = po->tt[i + 1] - po->tt[i];
-        hdr[2 * i + 1] = std::sqrt(po->tt[i + 1] - po->tt[i]);
-        steps[(size_t)i * STEP + DD + Dp] = hdr[2 * i];           // travel to LDS with the step's matrix (no separate load in the time loop)
-        steps[(size_t)i * STEP + DD + Dp + 1] = hdr[2 * i + 1];
+        const double dt = po->tt[i + 1] - po->tt[i];
+        const Mat aHm = po->mh.a * Hm, hnu = Hm * nu;
+        const Mat P = Id + dt * (Bm - aHm), q = dt * (po->mh.a * hnu - Bmu);
+        double *st = &steps[(size_t)i * STEP];
+        to_fragments(pad_mat(-Hm, Dp), st);
+        to_fragments(pad_mat(P, Dp), st + DD);
+        std::memcpy(st + 2 * DD, hnu.a.data(), sizeof(double) * d);
+        std::memcpy(st + 2 * DD + Dp, q.a.data(), sizeof(double) * d);
+        hdr[2 * i] = dt;
+        hdr[2 * i + 1] = std::sqrt(dt);
+        st[2 * DD + 2 * Dp] = hdr[2 * i];           // travel to LDS with the step's matrices (no separate load in the time loop)
+        st[2 * DD + 2 * Dp + 1] = hdr[2 * i + 1];
     }
-    std::vector<double> cst(4 * DD + 5 * Dp, 0.0);
-    const double *par = po->mh.par.data();
-    const double *sig = user ? par + (po->mh.par.size() - (size_t)dd) : par + dd + d;   // user: [drift parameters, sigma]; LinPro: [B, mu, sigma]
-    if (!user) to_fragments(pad_mat(Mat(d, d, par), Dp), &cst[0]);               // B (user drift: evaluated component-wise, no matrix)
-    if (!plain) to_fragments(pad_mat(po->aux.B(po->tt[0]), Dp), &cst[DD]);       // B~
-    to_fragments(pad_mat(po->mh.a, Dp), &cst[2 * DD]);                           // a = sigma*sigma'
-    to_fragments(pad_mat(Mat(d, d, sig), Dp), &cst[3 * DD]);                     // sigma
-    if (!user) std::memcpy(&cst[4 * DD], par + dd, sizeof(double) * d);          // mu
-    if (!plain) {
-        if (po->aux.linpro_form()) std::memcpy(&cst[4 * DD + Dp], po->aux.mu(), sizeof(double) * d);                        // mu~ (else 0)
-        else { const Mat be = po->aux.beta(po->tt[0]); std::memcpy(&cst[4 * DD + 2 * Dp], be.a.data(), sizeof(double) * d); }   // beta~ (else 0)
+    std::vector<double> cst(2 * DD + 2 * Dp, 0.0);
+    {
+        Mat Bt(d, d), mua(d, 1), beta(d, 1);
+        if (!plain) {
+            Bt = po->aux.B(po->tt[0]);
+            if (po->aux.linpro_form()) std::memcpy(mua.a.data(), po->aux.mu(), sizeof(double) * d);   // B~ (x - mu~)
+            else beta = po->aux.beta(po->tt[0]);                                                        // B~ x + beta~
+        }
+        to_fragments(pad_mat(Bm - Bt, Dp), &cst[0]);
+        to_fragments(pad_mat(Mat(d, d, sig), Dp), &cst[DD]);
+        const Mat c = Bt * mua - Bmu - beta;
+        std::memcpy(&cst[2 * DD], c.a.data(), sizeof(double) * d);
     }
-    if (po->g.kind == BHIP_GUIDE_HV) std::memcpy(&cst[4 * DD + 3 * Dp], po->g.V[N - 1].a.data(), sizeof(double) * d);       // vend
+    if (po->g.kind == BHIP_GUIDE_HV) std::memcpy(&cst[2 * DD + Dp], po->g.V[N - 1].a.data(), sizeof(double) * d);       // vend
     for (double **q : {&po->d_steps, &po->d_hdr, &po->d_cst, &po->d_tt})
         if (*q) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(*q)); *q = nullptr; }
     if (user) {   // b_k(t, x, P) may depend on t

@@ -2,7 +2,7 @@
 // (config C5: LinPro d = 32, SVector{32}; SURVEY 8(a) rows a4/a5/a7/a8 at d > 3).
 //
 // For d <= 3 a lane owns a path (bhip_path_kernel.h).  At d = 32 the state no longer fits a lane and
-// the work per step is five dense d x d mat-vecs
+// the reference's work per step is five dense d x d mat-vecs
 //     r  = Hm_i (nu_i - x)      guide: Hm = inv(Hdiamond_i) (GuidedBridge, src/guip.jl:192-193) or H_i (nuH)
 //     bT = B (x - mu)           target LinPro drift            src/linpro.jl:80
 //     bA = B~ (x - mu~) + beta~ auxiliary drift                src/guip.jl:434
@@ -10,6 +10,18 @@
 //     s  = sigma dW             _scale(dW, sigma)              src/euler.jl:264
 // batched over paths they are a dense contraction, so a WAVE owns a 16-path tile and runs them on the
 // fp64 matrix cores:  Y(d x 16) = M(d x d) X(d x 16) as v_mfma_f64_16x16x4_f64 chains.
+//
+// Round 5: on gfx950 fp64 MFMA and fp64 VALU work of a SIMD do not overlap (profiles/r1_mfma_valu_overlap.txt), so every vector
+// instruction of the step costs MFMA time.  Both the target and the auxiliary are affine and everything but x and dW is
+// path-independent, so the step is regrouped ON THE HOST (build_tile_data) into FOUR products whose accumulators start from
+// path-independent vectors -- no vector arithmetic is left but the Wiener increment and the dot product of the log-likelihood:
+//     r       = hnu_i + (-Hm_i) x                          hnu_i = Hm_i nu_i
+//     bT - bA = c + (B - B~) x                             c = B~ mu~ - B mu - beta~                      (only this difference enters ll)
+//     x_{i+1} = q_i + P_i x + sigma dW                     P_i = I + dt_i (B - a Hm_i),  q_i = dt_i (a Hm_i nu_i - B mu)
+// 64 instead of 80 MFMAs and ~45 instead of ~165 vector instructions per wave and step besides the noise; two per-step matrices
+// (-Hm_i, P_i) travel to LDS instead of one.  Same algebra, another association: parity with the oracle stays tolerance-based here.
+// A component-wise user drift b(t, x) takes the place of B (x - mu) as a vector term: B = 0 in the formulas, + b in the difference and
+// + dt b in the update.
 //
 // Tile layout of every d x 16 operand (T = d/16 row tiles): lane (kq = lane>>4, j = lane&15) holds
 // v[t][r] = element (row 16t + 4r + kq, path j).  This is at once the MFMA C/D layout of a result and
@@ -43,9 +55,9 @@ constexpr int TILE_ZB = 16 * 18;   // doubles of noise-exchange buffer per wave 
 #endif
 
 struct TArgs {
-    const double *steps;   // [N-1][D*D + D + 2]: Hm_i in fragment order, nu_i (natural order), dt_i, sqrt(dt_i)
+    const double *steps;   // [N-1][2*D*D + 2*D + 2]: -Hm_i, P_i in fragment order, hnu_i, q_i (natural order), dt_i, sqrt(dt_i) -- see the head of the file
     const double *hdr;     // [N-1][2]: dt_i, sqrt(dt_i) (the same values, for the instantiations that load them directly)
-    const double *cst;     // 4 fragment matrices (B, B~, a, sigma), then mu, mu~, beta~, vend (D each; a fifth D-slot is unused)
+    const double *cst;     // 2 fragment matrices (B - B~, sigma), then c = B~ mu~ - B mu - beta~ and vend (D each)
     double x0[32];         // shared starting point (zero padded), passed by value: launches on one proposal do not interfere
     int dtrue;             // state dimension of the process (<= the kernel's D; the rest is zero padding, template PAD)
     int N, skip, use_vend, noise;   // noise: 0 = external W, 1 = fresh Philox, 2 = pCN chain step, 3 = llikelihood of a stored X (Win = X)
@@ -113,19 +125,17 @@ struct TileNoHook { __device__ __forceinline__ void operator()(int) const {} };
 // PADK (zero-padded processes, template PAD of k_tile): K-slices nks .. 4T-1 hold nothing but the zero padding of the operand and of the
 // matrix's columns -- their products add +0.0 and are skipped behind a wave-uniform branch (d = 9..12 on the 16-row tile: three k-steps
 // instead of four)
+// acc += M v (acc in the MFMA C/D layout of the head of the file; the caller initialises it -- zero, or a path-independent vector)
 template <int T, class HOOK = TileNoHook, bool PADK = false>
-__device__ __forceinline__ void tile_mv(const double *__restrict__ Mf, const double (&v)[T][4], double (&out)[T][4], int lane, HOOK hook = HOOK(), int nks = 4 * T)
+__device__ __forceinline__ void tile_mv_acc(const double *__restrict__ Mf, const double (&v)[T][4], double4v (&acc)[T], int lane, HOOK hook = HOOK(), int nks = 4 * T)
 {
     if constexpr ((BHIP_TILE_EXP & 4) != 0) {
 #pragma unroll
         for (int tp = 0; tp < T; tp++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) out[tp][r] = v[tp][r] * Mf[lane];
+            for (int r = 0; r < 4; r++) acc[tp][r] += v[tp][r] * Mf[lane];
         return;
     }
-    double4v acc[T];
-#pragma unroll
-    for (int tp = 0; tp < T; tp++) acc[tp] = double4v{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int ks = 0; ks < 4 * T; ks++) {
         if (!PADK || ks < nks) {
@@ -135,10 +145,6 @@ __device__ __forceinline__ void tile_mv(const double *__restrict__ Mf, const dou
         }
         hook(ks);   // (statically unrolled: ks is a constant in the hook)
     }
-#pragma unroll
-    for (int tp = 0; tp < T; tp++) {
-        out[tp][0] = acc[tp][0]; out[tp][1] = acc[tp][1]; out[tp][2] = acc[tp][2]; out[tp][3] = acc[tp][3];
-    }
 }
 
 template <int D, int NOISE, bool PAD = false, class UD = NoUserDrift>
@@ -146,10 +152,10 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 {
     constexpr int T = D / 16;
     constexpr int DD = D * D;
-    constexpr int STEP = DD + D + 2;   // Hm_i (fragment order), nu_i, dt_i, sqrt(dt_i)
+    constexpr int STEP = 2 * DD + 2 * D + 2;   // -Hm_i, P_i (fragment order), hnu_i, q_i, dt_i, sqrt(dt_i)
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *cm = lds;                  // 4*DD fragment matrices + 5*D vectors
-    double *hb = lds + 4 * DD + 5 * D; // 2 * STEP
+    double *cm = lds;                  // 2*DD fragment matrices + 2*D vectors
+    double *hb = lds + 2 * DD + 2 * D; // 2 * STEP
     double *rtab_lds = hb + 2 * STEP;  // the generator's table (TILE_RNG_DOUBLES), for the noise-drawing instantiations
     double *xs_lds = rtab_lds + TILE_RNG_DOUBLES;   // UD::ON: the state vectors of the block's 64 paths, [4 waves][16 paths][D]
     double *zb_lds = xs_lds + (UD::ON ? 64 * D : 0);   // noise exchange: per wave 16 paths x 16 normals (row stride 18: conflict-free)
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     auto ok = [&](int t, int r) { return !PAD || 16 * t + 4 * r + kq < dtr; };
     const int nks = PAD ? (dtr + 3) >> 2 : 4 * T;   // live K-slices of the matrix products (tile_mv)
 
-    for (int c = tid; c < 4 * DD + 5 * D; c += 256) cm[c] = a.cst[c];
+    for (int c = tid; c < 2 * DD + 2 * D; c += 256) cm[c] = a.cst[c];
     for (int c = tid; c < STEP; c += 256) hb[c] = a.steps[c];
     // the generator's table of the launch's noise specification: v4 (the default) the 128 rows of the near octaves (IcdfLDSHot), v3 / v2 the
     // log + sincos tables
@@ -178,8 +184,8 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     __syncthreads();
     const TabLDS rtab(rtab_lds);
     bool cold = false;
-    const double *Bf = cm, *Btf = cm + DD, *Af = cm + 2 * DD, *Sf = cm + 3 * DD;
-    const double *mu = cm + 4 * DD, *mua = mu + D, *beta = mu + 2 * D, *vend = mu + 3 * D;
+    const double *Dmf = cm, *Sf = cm + DD;                       // B - B~, sigma
+    const double *cvec = cm + 2 * DD, *vend = cvec + D;          // B~ mu~ - B mu - beta~;  V[N-1]
 
     // Addressing: the lane's element (t, r) of grid row i lives at  base + i*D*ld + (4t + r)*(4*ld), base = array +
     // kq*ld + p.  One running pointer per array is advanced once per step and the 4T elements are reached by a
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     constexpr bool HASX = decltype(hasx_tag)::value, HASW = decltype(hasw_tag)::value;
     for (int i = 0; i < nsteps; i++) {
         const int cur = (BHIP_TILE_EXP & 1) ? 0 : i & 1;
-        const double *hm = hb + cur * STEP, *nu = hm + DD;
+        const double *hm = hb + cur * STEP, *pm = hm + DD, *hnu = hm + 2 * DD, *qv = hnu + D;   // -Hm_i, P_i, Hm_i nu_i, q_i
         // stage step i+1's matrix: global -> registers now, registers -> LDS after the compute
         // (unconditional loads from clamped indices: a conditional `idx < STEP ? load : 0.0` made the compiler clear the staging
         // registers at the top of the step, and a register that a load of the previous step may still be writing cannot be cleared
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
         // compiler's rule while an LDS-DMA is in flight -- i.e. for the chain-state DMA issued just above, a full memory
         // latency per step; a scalar load would turn every lgkmcnt(N) of the LDS -> MFMA pipeline into lgkmcnt(0)
         // (the instantiations without a DMA keep the plain load: measured 2 % faster there than the LDS read)
-        const double dt = (NOISE == 2 && BHIP_TILE_LDSDMA) ? hm[DD + D] : a.hdr[2 * i], rdt = (NOISE == 2 && BHIP_TILE_LDSDMA) ? hm[DD + D + 1] : a.hdr[2 * i + 1];
+        const double dt = (NOISE == 2 && BHIP_TILE_LDSDMA) ? hm[2 * DD + 2 * D] : a.hdr[2 * i], rdt = (NOISE == 2 && BHIP_TILE_LDSDMA) ? hm[2 * DD + 2 * D + 1] : a.hdr[2 * i + 1];
 
         auto issue_dmas = [&]() {
             if constexpr (NOISE == 2 && BHIP_TILE_LDSDMA) {
@@ -522,20 +528,22 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
             xp += (size_t)dtr * a.ldX;
         }
 
-        double w[T][4], xm[T][4], xa[T][4];
+        // the four products (head of the file); mv = 0 .. 3 numbers them for the store slots
+        auto init = [&](double4v (&acc)[T], const double *vec) {
 #pragma unroll
-        for (int t = 0; t < T; t++)
+            for (int t = 0; t < T; t++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = 16 * t + 4 * r + kq;
-                w[t][r] = nu[row] - x[t][r];
-                xm[t][r] = x[t][r] - mu[row];
-                xa[t][r] = x[t][r] - mua[row];
-            }
-        double rr[T][4], bT[T][4], bA[T][4], g[T][4], s[T][4];
+                for (int r = 0; r < 4; r++) acc[t][r] = vec[16 * t + 4 * r + kq];
+        };
+        double4v rr[T], db[T], xn[T];
+        init(rr, hnu);
         spread(0);
-        tile_mv<T, decltype(hook_at(0)), PAD>(hm, w, rr, lane, hook_at(0), nks);
+        tile_mv_acc<T, decltype(hook_at(0)), PAD>(hm, x, rr, lane, hook_at(0), nks);        // r = hnu_i - Hm_i x
         spread(1);
+        init(db, cvec);
+        tile_mv_acc<T, decltype(hook_at(0)), PAD>(Dmf, x, db, lane, hook_at(1), nks);       // bT - bA = c + (B - B~) x
+        spread(2);
+        double bu[UD::ON ? T : 1][4];
         if constexpr (UD::ON) {
             // gather the path's state (its components sit in 4 lanes x 8 registers) and evaluate b_k for this lane's rows
             double *xv = xs_lds + (size_t)(wave * 16 + j) * D;
@@ -551,15 +559,15 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int row = 16 * t + 4 * r + kq;
-                    bT[t][r] = (!PAD || row < dtr) ? UD::bk(row, ti, xv, a.upar) : 0.0;
+                    bu[t][r] = (!PAD || row < dtr) ? UD::bk(row, ti, xv, a.upar) : 0.0;
+                    db[t][r] += bu[t][r];
                 }
-        } else tile_mv<T, decltype(hook_at(1)), PAD>(Bf, xm, bT, lane, hook_at(1), nks);
-        spread(2);
-        tile_mv<T, decltype(hook_at(0)), PAD>(Btf, xa, bA, lane, hook_at(UD::ON ? 1 : 2), nks);
-        spread(3);
+        }
         if constexpr (NOISE != 3) {
-            tile_mv<T, decltype(hook_at(0)), PAD>(Af, rr, g, lane, hook_at(UD::ON ? 2 : 3), nks);
-            tile_mv<T, decltype(hook_at(0)), PAD>(Sf, dw, s, lane, hook_at(UD::ON ? 3 : 4), nks);
+            init(xn, qv);
+            tile_mv_acc<T, decltype(hook_at(0)), PAD>(pm, x, xn, lane, hook_at(2), nks);    // q_i + P_i x
+            spread(3);
+            tile_mv_acc<T, decltype(hook_at(0)), PAD>(Sf, dw, xn, lane, hook_at(3), nks);   //   + sigma dW
         }
 
         // ---- llikelihood: som += dot(b - b~, r)*dt, reduced over the path's 4 row groups
@@ -567,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 #pragma unroll
         for (int t = 0; t < T; t++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) part += (bT[t][r] - (bA[t][r] + beta[16 * t + 4 * r + kq])) * rr[t][r];
+            for (int r = 0; r < 4; r++) part += db[t][r] * rr[t][r];
         part += __shfl_xor(part, 16, 64);
         part += __shfl_xor(part, 32, 64);
         if (i < nll) ll += part * dt;
@@ -576,7 +584,10 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 #pragma unroll
             for (int t = 0; t < T; t++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) x[t][r] = x[t][r] + (bT[t][r] + g[t][r]) * dt + s[t][r];
+                for (int r = 0; r < 4; r++) {
+                    if constexpr (UD::ON) x[t][r] = xn[t][r] + bu[t][r] * dt;
+                    else x[t][r] = xn[t][r];
+                }
         }
 
         // LDS-only barrier: this wave's reads of hb[cur] and its writes of hb[cur ^ 1] are done (lgkmcnt), the block meets; no
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 // dynamic LDS of k_tile<D, ., ., UD>: constants, two step buffers, generator tables (+ the gathered states for a user drift)
 constexpr size_t tile_lds_bytes(int D, bool user, bool chains = true)
 {
-    return sizeof(double) * (4 * D * D + 5 * D + 2 * (D * D + D + 2) + TILE_RNG_DOUBLES + (user ? 64 * D : 0) + 4 * TILE_ZB + (chains ? 4 * 2 * (D / 16) * 128 : 0));
+    return sizeof(double) * (2 * D * D + 2 * D + 2 * (2 * D * D + 2 * D + 2) + TILE_RNG_DOUBLES + (user ? 64 * D : 0) + 4 * TILE_ZB + (chains ? 4 * 2 * (D / 16) * 128 : 0));
 }
 
 template <int D, int NOISE, bool PAD = false>
