@@ -393,12 +393,13 @@ class Workload:
         if self.flops_per_pathstep:   # compute-bound kernel: report against the fp64 matrix-core peak
             tf = per_launch * self.flops_per_pathstep / avg_s / 1e12
             # achieved / frac: the ALGORITHMIC flops (the reference's five d x d mat-vecs per path-step, SURVEY 8(d): 10 240 at d = 32).  Since
-            # round 5 the kernel regroups the affine step into FOUR products (bhip_tile_kernel.h): executed flops and the share of the
-            # matrix pipe they occupy are stated beside it -- the work left out is work not done, not work done faster
-            ex = self.flops_per_pathstep * 4 // 5
+            # round 5 the kernel regroups the affine step into THREE products (bhip_tile_kernel.h: the log-likelihood's dot product as one
+            # quadratic form, the update as one accumulation): executed flops and the share of the matrix pipe they occupy are stated
+            # beside it -- the work left out is work not done, not work done faster
+            ex = self.flops_per_pathstep * 3 // 5
             r.update({"bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TF,
                       "algorithmic_flops_per_path_step": self.flops_per_pathstep, "executed_flops_per_path_step": ex,
-                      "mfma_pipe_frac": tf * 0.8 / MFMA_F64_PEAK_TF, "hbm_algorithmic_GBs": gbs})
+                      "mfma_pipe_frac": tf * 0.6 / MFMA_F64_PEAK_TF, "hbm_algorithmic_GBs": gbs})
         tr, src = (None, "not profiled (fused build / v2 noise)") if (self.fused or self.v2noise) else profiled_traffic(self.mode, self.kernel)
         if tr is not None and self.P != MODES[self.mode][4]:
             tr, src = None, "profiled at the mode's default size only"

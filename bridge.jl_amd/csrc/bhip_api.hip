@@ -799,17 +799,28 @@ static int build_tile_data(bhip_proposal *po)
     if (!plain && (!po->has_aux || (po->aux.kind != BHIP_AUX_AFFINE && po->aux.kind != BHIP_AUX_LINPRO)))
         return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: time-constant auxiliary process");
     const int Dp = tile_dim(d);
-    // The step regrouped into four products with path-independent accumulator starts (bhip_tile_kernel.h, head of the file):
-    //   per step   -Hm_i, P_i = I + dt_i (B - a Hm_i)  (fragment order),  hnu_i = Hm_i nu_i,  q_i = dt_i (a Hm_i nu_i - B mu),  dt_i, sqrt(dt_i)
-    //   constant   B - B~, sigma  (fragment order),  c = B~ mu~ - B mu - beta~,  vend
-    // (a component-wise user drift takes the place of B (x - mu) as a vector term in the kernel: B = 0, mu = 0 here)
-    const size_t DD = (size_t)Dp * Dp, STEP = 2 * DD + 2 * Dp + 2, dd = (size_t)d * d;
+    // The step regrouped into products with path-independent accumulator starts (bhip_tile_kernel.h, head of the file):
+    //   built-in (LinPro) target, three products:
+    //     per step   A_i = -(B - B~)' Hm_i, P_i = I + dt_i (B - a Hm_i)  (fragment order),  b_i = (B - B~)' hnu_i - Hm_i' c,
+    //                q_i = dt_i (a hnu_i - B mu),  dt_i, sqrt(dt_i), c0_i = c . hnu_i          (hnu_i = Hm_i nu_i, c = B~ mu~ - B mu - beta~)
+    //     constant   sigma (fragment order), vend
+    //   component-wise user drift (it takes the place of B (x - mu) as a vector term in the kernel: B = 0, mu = 0 here), four products:
+    //     per step   -Hm_i, P_i (fragment order), hnu_i, q_i, dt_i, sqrt(dt_i)
+    //     constant   sigma, B - B~ = -B~ (fragment order), vend, c
+    const size_t DD = (size_t)Dp * Dp, STEP = 2 * DD + 2 * Dp + 4, dd = (size_t)d * d;
     const double *par = po->mh.par.data();
     const double *sig = user ? par + (po->mh.par.size() - (size_t)dd) : par + dd + d;   // user: [drift parameters, sigma]; LinPro: [B, mu, sigma]
     const Mat Bm = user ? Mat(d, d) : Mat(d, d, par);
     Mat mu(d, 1);
     if (!user) std::memcpy(mu.a.data(), par + dd, sizeof(double) * d);
     const Mat Bmu = Bm * mu;
+    Mat Bt(d, d), mua(d, 1), beta(d, 1);
+    if (!plain) {
+        Bt = po->aux.B(po->tt[0]);
+        if (po->aux.linpro_form()) std::memcpy(mua.a.data(), po->aux.mu(), sizeof(double) * d);   // B~ (x - mu~)
+        else beta = po->aux.beta(po->tt[0]);                                                        // B~ x + beta~
+    }
+    const Mat Dm = Bm - Bt, DmT = tr(Dm), c = Bt * mua - Bmu - beta;
     Mat Id(d, d);
     for (int k = 0; k < d; k++) Id(k, k) = 1.0;
     std::vector<double> steps((size_t)(N - 1) * STEP, 0.0), hdr((size_t)(N - 1) * 2);
@@ -830,9 +841,16 @@ static int build_tile_data(bhip_proposal *po)
         const Mat aHm = po->mh.a * Hm, hnu = Hm * nu;
         const Mat P = Id + dt * (Bm - aHm), q = dt * (po->mh.a * hnu - Bmu);
         double *st = &steps[(size_t)i * STEP];
-        to_fragments(pad_mat(-Hm, Dp), st);
+        if (user) {
+            to_fragments(pad_mat(-Hm, Dp), st);
+            std::memcpy(st + 2 * DD, hnu.a.data(), sizeof(double) * d);
+        } else {
+            const Mat A = -(DmT * Hm), b = DmT * hnu - tr(Hm) * c;
+            to_fragments(pad_mat(A, Dp), st);
+            std::memcpy(st + 2 * DD, b.a.data(), sizeof(double) * d);
+            st[2 * DD + 2 * Dp + 2] = dot(c, hnu);
+        }
         to_fragments(pad_mat(P, Dp), st + DD);
-        std::memcpy(st + 2 * DD, hnu.a.data(), sizeof(double) * d);
         std::memcpy(st + 2 * DD + Dp, q.a.data(), sizeof(double) * d);
         hdr[2 * i] = dt;
         hdr[2 * i + 1] = std::sqrt(dt);
@@ -840,19 +858,12 @@ static int build_tile_data(bhip_proposal *po)
         st[2 * DD + 2 * Dp + 1] = hdr[2 * i + 1];
     }
     std::vector<double> cst(2 * DD + 2 * Dp, 0.0);
-    {
-        Mat Bt(d, d), mua(d, 1), beta(d, 1);
-        if (!plain) {
-            Bt = po->aux.B(po->tt[0]);
-            if (po->aux.linpro_form()) std::memcpy(mua.a.data(), po->aux.mu(), sizeof(double) * d);   // B~ (x - mu~)
-            else beta = po->aux.beta(po->tt[0]);                                                        // B~ x + beta~
-        }
-        to_fragments(pad_mat(Bm - Bt, Dp), &cst[0]);
-        to_fragments(pad_mat(Mat(d, d, sig), Dp), &cst[DD]);
-        const Mat c = Bt * mua - Bmu - beta;
-        std::memcpy(&cst[2 * DD], c.a.data(), sizeof(double) * d);
+    to_fragments(pad_mat(Mat(d, d, sig), Dp), &cst[0]);
+    if (user) {
+        to_fragments(pad_mat(Dm, Dp), &cst[DD]);
+        std::memcpy(&cst[2 * DD + Dp], c.a.data(), sizeof(double) * d);
     }
-    if (po->g.kind == BHIP_GUIDE_HV) std::memcpy(&cst[2 * DD + Dp], po->g.V[N - 1].a.data(), sizeof(double) * d);       // vend
+    if (po->g.kind == BHIP_GUIDE_HV) std::memcpy(&cst[2 * DD], po->g.V[N - 1].a.data(), sizeof(double) * d);       // vend
     for (double **q : {&po->d_steps, &po->d_hdr, &po->d_cst, &po->d_tt})
         if (*q) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(*q)); *q = nullptr; }
     if (user) {   // b_k(t, x, P) may depend on t

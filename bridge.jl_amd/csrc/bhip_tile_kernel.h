@@ -18,10 +18,14 @@
 //     r       = hnu_i + (-Hm_i) x                          hnu_i = Hm_i nu_i
 //     bT - bA = c + (B - B~) x                             c = B~ mu~ - B mu - beta~                      (only this difference enters ll)
 //     x_{i+1} = q_i + P_i x + sigma dW                     P_i = I + dt_i (B - a Hm_i),  q_i = dt_i (a Hm_i nu_i - B mu)
-// 64 instead of 80 MFMAs and ~45 instead of ~165 vector instructions per wave and step besides the noise; two per-step matrices
-// (-Hm_i, P_i) travel to LDS instead of one.  Same algebra, another association: parity with the oracle stays tolerance-based here.
-// A component-wise user drift b(t, x) takes the place of B (x - mu) as a vector term: B = 0 in the formulas, + b in the difference and
-// + dt b in the update.
+// and, r and bT - bA entering nothing but their dot product, that dot product as ONE quadratic form:
+//     dot(bT - bA, r) = c0_i + x . (b_i + A_i x)           A_i = -(B - B~)' Hm_i,  b_i = (B - B~)' hnu_i - Hm_i' c,  c0_i = c . hnu_i
+// THREE products -- A_i x, P_i x, sigma dW: 48 instead of 80 MFMAs -- and ~45 instead of ~165 vector instructions per wave and step
+// besides the noise; two per-step matrices (A_i, P_i) travel to LDS instead of one.  Same algebra, another association: parity with the
+// oracle stays tolerance-based here (the cancellation inside the quadratic form costs three digits at the stiff end of a GuidedBridge:
+// 1e-13 relative, against the stated 1e-8 on ll).
+// A component-wise user drift b(t, x) (hipRTC, UD::ON) takes the place of B (x - mu) as a vector term -- B = 0 in the formulas, + b in the
+// difference, + dt b in the update -- and needs r itself for b . r: that instantiation keeps the two products r and bT - bA (four in all).
 //
 // Tile layout of every d x 16 operand (T = d/16 row tiles): lane (kq = lane>>4, j = lane&15) holds
 // v[t][r] = element (row 16t + 4r + kq, path j).  This is at once the MFMA C/D layout of a result and
@@ -55,9 +59,9 @@ constexpr int TILE_ZB = 16 * 18;   // doubles of noise-exchange buffer per wave 
 #endif
 
 struct TArgs {
-    const double *steps;   // [N-1][2*D*D + 2*D + 2]: -Hm_i, P_i in fragment order, hnu_i, q_i (natural order), dt_i, sqrt(dt_i) -- see the head of the file
+    const double *steps;   // [N-1][2*D*D + 2*D + 4]: A_i (user drift: -Hm_i), P_i in fragment order, b_i (hnu_i), q_i (natural order), dt_i, sqrt(dt_i), c0_i, 0
     const double *hdr;     // [N-1][2]: dt_i, sqrt(dt_i) (the same values, for the instantiations that load them directly)
-    const double *cst;     // 2 fragment matrices (B - B~, sigma), then c = B~ mu~ - B mu - beta~ and vend (D each)
+    const double *cst;     // 2 fragment matrices (sigma, B - B~ [user drift only]), then vend and c = B~ mu~ - B mu - beta~ [user drift only] (D each)
     double x0[32];         // shared starting point (zero padded), passed by value: launches on one proposal do not interfere
     int dtrue;             // state dimension of the process (<= the kernel's D; the rest is zero padding, template PAD)
     int N, skip, use_vend, noise;   // noise: 0 = external W, 1 = fresh Philox, 2 = pCN chain step, 3 = llikelihood of a stored X (Win = X)
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 {
     constexpr int T = D / 16;
     constexpr int DD = D * D;
-    constexpr int STEP = 2 * DD + 2 * D + 2;   // -Hm_i, P_i (fragment order), hnu_i, q_i, dt_i, sqrt(dt_i)
+    constexpr int STEP = 2 * DD + 2 * D + 4;   // A_i | -Hm_i, P_i (fragment order), b_i | hnu_i, q_i, dt_i, sqrt(dt_i), c0_i, 0
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *cm = lds;                  // 2*DD fragment matrices + 2*D vectors
     double *hb = lds + 2 * DD + 2 * D; // 2 * STEP
@@ -184,8 +188,8 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     __syncthreads();
     const TabLDS rtab(rtab_lds);
     bool cold = false;
-    const double *Dmf = cm, *Sf = cm + DD;                       // B - B~, sigma
-    const double *cvec = cm + 2 * DD, *vend = cvec + D;          // B~ mu~ - B mu - beta~;  V[N-1]
+    const double *Sf = cm, *Dmf = cm + DD;                       // sigma; B - B~ (user drift only)
+    const double *vend = cm + 2 * DD, *cvec = vend + D;          // V[N-1]; B~ mu~ - B mu - beta~ (user drift only)
 
     // Addressing: the lane's element (t, r) of grid row i lives at  base + i*D*ld + (4t + r)*(4*ld), base = array +
     // kq*ld + p.  One running pointer per array is advanced once per step and the 4T elements are reached by a
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     constexpr bool HASX = decltype(hasx_tag)::value, HASW = decltype(hasw_tag)::value;
     for (int i = 0; i < nsteps; i++) {
         const int cur = (BHIP_TILE_EXP & 1) ? 0 : i & 1;
-        const double *hm = hb + cur * STEP, *pm = hm + DD, *hnu = hm + 2 * DD, *qv = hnu + D;   // -Hm_i, P_i, Hm_i nu_i, q_i
+        const double *hm = hb + cur * STEP, *pm = hm + DD, *hnu = hm + 2 * DD, *qv = hnu + D;   // A_i | -Hm_i, P_i, b_i | Hm_i nu_i, q_i
         // stage step i+1's matrix: global -> registers now, registers -> LDS after the compute
         // (unconditional loads from clamped indices: a conditional `idx < STEP ? load : 0.0` made the compiler clear the staging
         // registers at the top of the step, and a register that a load of the previous step may still be writing cannot be cleared
@@ -311,6 +315,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
         // latency per step; a scalar load would turn every lgkmcnt(N) of the LDS -> MFMA pipeline into lgkmcnt(0)
         // (the instantiations without a DMA keep the plain load: measured 2 % faster there than the LDS read)
         const double dt = (NOISE == 2 && BHIP_TILE_LDSDMA) ? hm[2 * DD + 2 * D] : a.hdr[2 * i], rdt = (NOISE == 2 && BHIP_TILE_LDSDMA) ? hm[2 * DD + 2 * D + 1] : a.hdr[2 * i + 1];
+        // (c0_i is read from the step's LDS row in every instantiation: it is needed after the products, when the row has long landed)
 
         auto issue_dmas = [&]() {
             if constexpr (NOISE == 2 && BHIP_TILE_LDSDMA) {
@@ -504,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
                 }
             }
         };
-        static_assert(BHIP_TILE_SPREAD != 2 || 6 * T * BHIP_TILE_SPREAD_EVERY <= 4 * 4 * T, "every store of the step needs its slot among the products that always run");
+        static_assert(BHIP_TILE_SPREAD != 2 || 6 * T * BHIP_TILE_SPREAD_EVERY <= 3 * 4 * T, "every store of the step needs its slot among the three products that always run");
         auto hook_at = [&](int mv) {
             return [&, mv](int ks) {
                 if constexpr (BHIP_TILE_SPREAD == 2) {
@@ -535,16 +540,21 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 #pragma unroll
                 for (int r = 0; r < 4; r++) acc[t][r] = vec[16 * t + 4 * r + kq];
         };
-        double4v rr[T], db[T], xn[T];
-        init(rr, hnu);
-        spread(0);
-        tile_mv_acc<T, decltype(hook_at(0)), PAD>(hm, x, rr, lane, hook_at(0), nks);        // r = hnu_i - Hm_i x
-        spread(1);
-        init(db, cvec);
-        tile_mv_acc<T, decltype(hook_at(0)), PAD>(Dmf, x, db, lane, hook_at(1), nks);       // bT - bA = c + (B - B~) x
-        spread(2);
+        double4v rr[T], db[UD::ON ? T : 1], xn[T];
         double bu[UD::ON ? T : 1][4];
-        if constexpr (UD::ON) {
+        double part = 0.0;
+        if constexpr (!UD::ON) {
+            init(rr, hnu);
+            spread(0);
+            tile_mv_acc<T, decltype(hook_at(0)), PAD>(hm, x, rr, lane, hook_at(0), nks);        // y = b_i + A_i x
+            spread(1);
+        } else {
+            init(rr, hnu);
+            spread(0);
+            tile_mv_acc<T, decltype(hook_at(0)), PAD>(hm, x, rr, lane, hook_at(0), nks);        // r = hnu_i - Hm_i x
+            spread(1);
+            init(db, cvec);
+            tile_mv_acc<T, TileNoHook, PAD>(Dmf, x, db, lane, TileNoHook(), nks);                 // bT - bA = c + (0 - B~) x  (+ b below)
             // gather the path's state (its components sit in 4 lanes x 8 registers) and evaluate b_k for this lane's rows
             double *xv = xs_lds + (size_t)(wave * 16 + j) * D;
             __builtin_amdgcn_wave_barrier();   // the previous step's reads of xv are done
@@ -565,19 +575,23 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
         }
         if constexpr (NOISE != 3) {
             init(xn, qv);
-            tile_mv_acc<T, decltype(hook_at(0)), PAD>(pm, x, xn, lane, hook_at(2), nks);    // q_i + P_i x
+            spread(2);
+            tile_mv_acc<T, decltype(hook_at(0)), PAD>(pm, x, xn, lane, hook_at(1), nks);    // q_i + P_i x
             spread(3);
-            tile_mv_acc<T, decltype(hook_at(0)), PAD>(Sf, dw, xn, lane, hook_at(3), nks);   //   + sigma dW
+            tile_mv_acc<T, decltype(hook_at(0)), PAD>(Sf, dw, xn, lane, hook_at(2), nks);   //   + sigma dW
         }
 
         // ---- llikelihood: som += dot(b - b~, r)*dt, reduced over the path's 4 row groups
-        double part = 0.0;
 #pragma unroll
         for (int t = 0; t < T; t++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) part += db[t][r] * rr[t][r];
+            for (int r = 0; r < 4; r++) {
+                if constexpr (UD::ON) part += db[t][r] * rr[t][r];
+                else part += x[t][r] * rr[t][r];                       // x . (b_i + A_i x)
+            }
         part += __shfl_xor(part, 16, 64);
         part += __shfl_xor(part, 32, 64);
+        if constexpr (!UD::ON) part += hm[2 * DD + 2 * D + 2];        // + c0_i
         if (i < nll) ll += part * dt;
 
         if constexpr (NOISE != 3) {
@@ -638,7 +652,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 // dynamic LDS of k_tile<D, ., ., UD>: constants, two step buffers, generator tables (+ the gathered states for a user drift)
 constexpr size_t tile_lds_bytes(int D, bool user, bool chains = true)
 {
-    return sizeof(double) * (2 * D * D + 2 * D + 2 * (2 * D * D + 2 * D + 2) + TILE_RNG_DOUBLES + (user ? 64 * D : 0) + 4 * TILE_ZB + (chains ? 4 * 2 * (D / 16) * 128 : 0));
+    return sizeof(double) * (2 * D * D + 2 * D + 2 * (2 * D * D + 2 * D + 4) + TILE_RNG_DOUBLES + (user ? 64 * D : 0) + 4 * TILE_ZB + (chains ? 4 * 2 * (D / 16) * 128 : 0));
 }
 
 template <int D, int NOISE, bool PAD = false>
