@@ -210,7 +210,7 @@ def live_traffic(mode, kernel_name, steps=6):
             # CALIB_BYTES; KiB reported for it -> the factor that turns this counter into bytes on this box (FETCH_SIZE: ~2 on gfx950 for
             # a wide coalesced read stream, the guide's correction; WRITE_SIZE: ~1)
             crow = list(cur.execute(f"select {idcol or namecol}, value from counters_collection where {namecol} like ? and counter_name = ?",
-                                    ("%elementwise%", counter)))
+                                    ("%elementwise%add%", counter)))   # torch.add(x, 1.0, out=y): ...elementwise_kernel<.., CUDAFunctorOnSelf_add<double>, ..> -- not the fills
             if crow:
                 per = {}
                 for did, v in crow:
