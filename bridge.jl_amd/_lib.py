@@ -63,6 +63,8 @@ SIGNATURES = {
     "bhip_chains_stats_group": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(vp)]),
     "bhip_chains_iterations": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
     "bhip_chains_placement_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "bhip_chains_placement_pieces": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bhip_ctx_piece_of": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_int)]),
     "bhip_chains_stats": (C.c_int, [vp, vp]),
     "bhip_chains_get": (C.c_int, [vp, dp, C.POINTER(C.c_int64)]),
     "bhip_chains_get_paths": (C.c_int, [vp, C.c_long, C.c_long, dp, dp]),

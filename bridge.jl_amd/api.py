@@ -848,11 +848,13 @@ class Chains:
         self.iterations += iters
 
     def placement(self):
-        """what the placement did (bhip_chains_placement_info): allocations of Xo that were timed (0 = not placed), ms per iteration
-        with W and Xo in ONE contiguous block (the same-piece reference), ms per iteration on the pair that was kept"""
-        n, a, b = C.c_int(), C.c_float(), C.c_float()
+        """what the placement did (bhip_chains_placement_info / _pieces): allocations of Xo tested against W (0 = not placed, 1 = the
+        first pair already lay in different pieces), GB/s of two write streams into one piece (the context's reference) and into the
+        kept (W, Xo) pair, the pieces of the context's map W and Xo lie in"""
+        n, a, b, pw, px = C.c_int(), C.c_float(), C.c_float(), C.c_int(), C.c_int()
         self.ctx.check(self.ctx.lib.bhip_chains_placement_info(self.h, C.byref(n), C.byref(a), C.byref(b)))
-        return {"tries": n.value, "ms_first": a.value, "ms_best": b.value, "ms_same_piece_reference": a.value, "ms_kept": b.value}
+        self.ctx.check(self.ctx.lib.bhip_chains_placement_pieces(self.h, C.byref(pw), C.byref(px)))
+        return {"tries": n.value, "gbs_same_piece": a.value, "gbs_kept": b.value, "piece_w": pw.value, "piece_xo": px.value}
 
     def stats(self, out=None):
         """device tensor [8]: {nchains, iterations, sum acc, sum ll, sum ll^2, min ll, max ll, sum acc^2}"""

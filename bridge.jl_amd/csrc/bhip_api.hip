@@ -141,7 +141,12 @@ struct bhip_ctx {
     bool wave_specialised = true;   // BHIP_OPT_WAVE_SPECIALISED: producer/consumer kernels (bhip_pc_kernel.h) where they exist
     int mid_max = BHIP_MID_MAX_DEFAULT;   // BHIP_OPT_MID_VALU: LinPro targets / component-wise drifts of dimension 4..mid_max one path per lane (0: all of them on the MFMA tile kernel)
     bool fused = false;             // BHIP_OPT_FUSED_ARITHMETIC: the d <= 3 kernels built with a*b + c contracted (tolerance parity)
-    bool tune_placement = true;     // BHIP_OPT_TUNE_PLACEMENT: large chain ensembles try a few allocations and keep the fastest (bhip_chains_init)
+    bool tune_placement = true;     // BHIP_OPT_TUNE_PLACEMENT: large chain ensembles place W and Xo in different pieces of the device memory (bhip_chains_init)
+    // the piece map (chains_place below): which 96-GiB piece of the device memory the large buffers of the context's live ensembles lie in --
+    // the reference points a new buffer is classified against; r_same = GB/s of two write streams into ONE piece, measured once
+    struct PieceEnt { void *p; size_t bytes; int piece; };
+    std::vector<PieceEnt> pieces;
+    float r_same = 0.f;
     int noise_spec = 4;             // BHIP_OPT_NOISE_SPEC: 4 = bhip-philox-v4 (default), 3 = bhip-philox-v3, 2 = bhip-philox-v2 (bhip_rng.h)
     // lifetime: every proposal / chain ensemble / communicator holds a reference.  bhip_ctx_destroy with live children only
     // closes the context (garbage collectors -- Python at interpreter exit, Julia finalizers -- destroy handles in any order);
@@ -213,9 +218,11 @@ struct bhip_chains {
     long xtb_half = 0;
     const unsigned char *xsel = nullptr;   // the buffer of the ring that receives each chain's proposal (null: the half that is not cur[p])
     size_t wbytes = 0, xbytes = 0;
-    // placement tuning (bhip_chains_init): allocations tried, ms per pCN iteration of the first and of the chosen one
+    // placement (bhip_chains_init): Xo allocations classified, GB/s of two write streams into one piece and into the kept (W, Xo) pair,
+    // the pieces W and Xo were found in (-1: astride a cut / not placed)
     int place_tries = 0;
     float place_ms_first = 0.f, place_ms_best = 0.f;
+    int piece_w = -1, piece_xo = -1;
     int skip0 = 0;
     unsigned char *cur = nullptr;
     double *llcur = nullptr;
@@ -1503,7 +1510,7 @@ static hipError_t alloc_run(void **q, size_t bytes)
     return e;
 }
 #ifdef BHIP_PLACE_EXPERIMENTS
-#include "bhip_place_experiments.inc"   /* the BHIP_PLACE measurement hooks behind profiles/r4_placement_*.txt */
+#include "../../scripts/bhip_place_experiments.inc"   /* measurement builds only (EXTRA=-DBHIP_PLACE_EXPERIMENTS): the BHIP_PLACE hooks behind profiles/r4_placement_*.txt */
 #endif
 static void arena_free(Arena &ar)
 {
@@ -1599,6 +1606,8 @@ void bhip_chains_destroy(bhip_chains *ch)
     if (!ch) return;
     bhip_ctx *ctx = ch->ctx;
     ctx_quiesce(ctx);
+    for (size_t k = ctx->pieces.size(); k-- > 0;)   // the piece map forgets the buffers that go away
+        if (ctx->pieces[k].p == ch->arena.base || ctx->pieces[k].p == ch->arena.base2) ctx->pieces.erase(ctx->pieces.begin() + (long)k);
     arena_free(ch->arena);
     if (ch->cur && !ch->shares_state) (void)hipFree(ch->cur);
     if (ch->llcur && !ch->shares_state) (void)hipFree(ch->llcur);
@@ -1666,35 +1675,31 @@ static int chains_init_impl(bhip_chains *ch, const double *x0, const double *x0_
 
 extern "C" int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip);
 // ms per pCN iteration on the ensemble's present allocations (one untimed iteration, then `reps`)
-static int chains_time_iterations(bhip_chains *ch, int skip, float *ms, int reps = 3)
-{
-    bhip_ctx *ctx = ch->ctx;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIPCHK(ctx, hipEventCreate(&e0));
-    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(ctx, BHIP_EHIP, "hipEventCreate failed"); }
-    int rc = bhip_chains_step(ch, 0.9, 1, skip);   // untimed: instruction cache, page tables
-    hipError_t e = hipSuccess;
-    if (!rc) e = hipEventRecord(e0, ctx->stream);
-    for (int k = 0; k < reps && !rc; k++) rc = bhip_chains_step(ch, 0.9, 1, skip);
-    if (!rc && e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
-    if (!rc && e == hipSuccess) e = hipEventSynchronize(e1);
-    if (!rc && e == hipSuccess) { e = hipEventElapsedTime(ms, e0, e1); *ms /= reps; }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (rc) return rc;
-    if (e != hipSuccess) return fail(ctx, BHIP_EHIP, std::string("placement: ") + hipGetErrorString(e));
-    return BHIP_OK;
-}
-
 // Placement of a large ensemble (BHIP_OPT_TUNE_PLACEMENT, default on): W and Xo -- two physically contiguous allocations,
-// chains_alloc_state -- have to lie in DIFFERENT 96-GiB pieces of the device memory (see above; profiles/r4_placement_regions.txt),
-// and since nothing reports where an allocation lies, that is measured with the ensemble's own kernel:
-//   1. the reference: ONE contiguous block holding W and Xo together -- one piece by construction (unless it straddles a cut) -- timed
-//      for a few iterations and freed: what this kernel takes when the streams share a piece;
-//   2. the ensemble's own W and Xo: timed; 7 % under the reference (the two cases lie 14-16 % apart) means different pieces: done;
-//   3. otherwise further allocations are made while the earlier ones stay held (so that they land elsewhere) -- Xo, Xo, then W and Xo in
-//      turn, six pairs at most --, each timed with the partner of the best pair so far; the fastest pair is kept, the rest is freed.
-//      Each candidate costs one allocation and ~4 launches (a new W also its set-up).
+// chains_alloc_state -- have to lie in DIFFERENT 96-GiB pieces of the device memory (see above; profiles/r4_placement_regions.txt).
+// Nothing reports where an allocation lies, but piece membership is a property of a BUFFER that two plain write streams tell in
+// half a millisecond: into two buffers of one piece they run at ~4.7 TB/s, into buffers of different pieces at ~6.1.  Round 4 searched
+// per ensemble with the ensemble's own kernel (a same-piece reference block of |W| + |Xo|, kernel-timed pairs, up to 16 candidates
+// held: 23-60 ms and up to 67 GiB of transient memory per ensemble).  Since round 5 the CONTEXT keeps a piece map -- the large buffers
+// of its live ensembles with the piece each was found in -- and a new buffer is classified against one representative per piece:
+//   1. r_same, the two-stream rate inside one piece, is measured once per context (W's own two halves and Xo's, the smaller);
+//   2. W is classified against the map (no test for the first ensemble: piece 0);
+//   3. the pair (W, Xo) is tested with ONE two-stream run: different pieces -> done (tries = 1).  Otherwise further Xo candidates are
+//      allocated while the earlier ones stay held (the allocator changes pieces every 4 to 8 blocks of this size at the latest:
+//      profiles/r4_alloc_sequence_raw.txt), each tested against W, until one lies elsewhere; the rest is freed at once;
+//   4. Xo is classified against the map and both buffers are entered.  No kernel-timed run, no reference block.
 // Results are those of an ensemble placed anywhere (the state of iteration 0 is set up afresh at the end; tests/test_gpu_pc.py).
+// Every threshold of the procedure:
+struct PlaceParams {
+    size_t stream_bytes = (size_t)512 << 20;   // bytes per write stream of a test: beyond the 256-MB Infinity Cache
+    float same_max = 1.10f;     // rate <= same_max * r_same: the two buffers share a piece          (measured: 4.3-5.1 TB/s in one piece,
+    float diff_min = 1.20f;     // rate >= diff_min * r_same: they lie in different pieces            5.9-6.7 across; between: astride a cut)
+    int max_candidates = 8;     // Xo candidates held at once at most (never more than 8 consecutive 4-GiB blocks of one piece were seen) ...
+    size_t held_bytes = (size_t)24 << 30;   // ... or, for smaller buffers (the allocator's runs inside one piece are longer in blocks), as many as fit here, 24 at most
+    size_t min_bytes = (size_t)64 << 20;   // buffers below this are not classified (a test needs streams of some length)
+};
+static const PlaceParams PLACE;
+
 // GB/s of two write streams of `bytes` each into a and b on the context's stream (k_two_write_streams); 0 on any error
 static float two_stream_rate(bhip_ctx *ctx, void *a, void *b, size_t bytes)
 {
@@ -1713,98 +1718,84 @@ static float two_stream_rate(bhip_ctx *ctx, void *a, void *b, size_t bytes)
     if (e != hipSuccess || !(ms > 0.f)) { (void)hipGetLastError(); return 0.f; }
     return (float)(2.0 * 2.0 * (double)bytes / (ms * 1e6));
 }
+static size_t place_stream_bytes(size_t a_bytes, size_t b_bytes)
+{
+    return std::min<size_t>({a_bytes, b_bytes, PLACE.stream_bytes}) / 4096 * 4096;
+}
+// the piece of [ptr, ptr + bytes) by the context's map: the id of the representative it shares a piece with; a NEW id (the smallest
+// unused one, *is_new set) when it lies apart from every piece the map knows; -1 when the tests are inconclusive (a buffer astride
+// a cut, a plain allocation mixed from several pieces) or the map is empty.  The contents of the tested ranges are overwritten.
+static int place_classify(bhip_ctx *ctx, void *ptr, size_t bytes, bool *is_new)
+{
+    if (is_new) *is_new = false;
+    if (!(ctx->r_same > 0.f) || bytes < PLACE.min_bytes) return -1;
+    bool seen[3] = {false, false, false}, all_apart = true;
+    int known = 0;
+    for (const bhip_ctx::PieceEnt &e : ctx->pieces) {
+        if (e.piece < 0 || e.piece > 2 || seen[e.piece] || e.p == ptr || e.bytes < PLACE.min_bytes) continue;
+        seen[e.piece] = true; known++;
+        const float r = two_stream_rate(ctx, e.p, ptr, place_stream_bytes(e.bytes, bytes));
+        if (!(r > 0.f)) return -1;
+        if (r <= PLACE.same_max * ctx->r_same) return e.piece;
+        if (r < PLACE.diff_min * ctx->r_same) all_apart = false;
+    }
+    if (!known || !all_apart || known >= 3) return -1;
+    for (int k = 0; k < 3; k++)
+        if (!seen[k]) { if (is_new) *is_new = true; return k; }
+    return -1;
+}
 
 static int chains_place(bhip_chains *ch, const double *x0, int skip)
 {
     bhip_ctx *ctx = ch->ctx;
-    const size_t MB2 = (size_t)2 << 20, wspan = (ch->wbytes + MB2 - 1) / MB2 * MB2;
-    float t_ref = 0.f;
-    {   // 1. the same-piece reference
-        void *ref = nullptr;
-        if (hipExtMallocWithFlags(&ref, wspan + ch->xbytes, hipDeviceMallocContiguous) == hipSuccess) {
-            double *w0 = ch->Wc, *x0o = ch->Xo;
-            ch->Wc = (double *)ref; ch->Xo = (double *)((char *)ref + wspan);
-            int rc = chains_init_impl(ch, x0, nullptr, 0, skip, 0u);
-            if (!rc) rc = chains_time_iterations(ch, skip, &t_ref, 2);
-            (void)hipStreamSynchronize(ctx->stream);
-            ch->Wc = w0; ch->Xo = x0o;
-            (void)hipFree(ref);
-            if (rc) t_ref = 0.f;   // no reference: the candidates are compared with each other
-        } else (void)hipGetLastError();
+    void *w = ch->arena.base, *xo = ch->arena.base2;
+    const size_t sb = place_stream_bytes(ch->wbytes / 2, ch->xbytes / 2);
+    if (sb < PLACE.min_bytes / 2) return BHIP_OK;
+    // 1. the rate inside one piece, once per context: a contiguous run lies in one piece unless it straddles a cut -- the smaller of two runs
+    if (!(ctx->r_same > 0.f)) {
+        const float ra = two_stream_rate(ctx, w, (char *)w + ch->wbytes / 2, sb), rb = two_stream_rate(ctx, xo, (char *)xo + ch->xbytes / 2, sb);
+        ctx->r_same = ra > 0.f && rb > 0.f ? std::min(ra, rb) : std::max(ra, rb);
+        if (!(ctx->r_same > 0.f)) return chains_init_impl(ch, x0, nullptr, 0, skip, 0u);   // no measurement: the pair stays as it is
     }
-    // the pairs tried: every new allocation -- Xo, Xo, then W and Xo in turn -- is timed with the partner of the best pair so far.  All the
-    // buffers that came out "same piece" lie in ONE piece, so a buffer from another piece is fast with any of them; re-rolling W as well
-    // matters when the allocator keeps handing out runs of W's piece while the earlier candidates are held (two of six ensembles of
-    // one process found no second piece with Xo alone).
-    struct Cand { void *w, *xo; float ms; };
+    // 2. W against the map
+    bool fresh = false;
+    int pw = ctx->pieces.empty() ? 0 : place_classify(ctx, w, ch->wbytes, &fresh);
+    // 3. the pair, then further candidates for Xo
+    struct Cand { void *p; float r; };
     std::vector<Cand> cands;
-    std::vector<void *> held;   // every allocation made here or at create time, freed below unless kept
-    int rc = chains_init_impl(ch, x0, nullptr, 0, skip, 0u);   // (the reference run used other memory)
-    if (rc) return rc;
-    Cand cur{ch->arena.base, ch->arena.base2, 0.f};
-    rc = chains_time_iterations(ch, skip, &cur.ms);
-    if (rc) return rc;
-    cands.push_back(cur);
-    held.push_back(cur.w); held.push_back(cur.xo);
-    const int max_tries = 6;
-    auto slowest = [&]() { float s = t_ref; for (const Cand &c : cands) s = std::max(s, c.ms); return s; };
-    auto best = [&]() { size_t ib = 0; for (size_t k = 1; k < cands.size(); k++) if (cands[k].ms < cands[ib].ms) ib = k; return ib; };
-    // 2b. the pair the ensemble was created with shares a piece: look for an Xo elsewhere with PLAIN STREAMS first -- two write streams
-    // into W and into a candidate tell in half a millisecond whether the candidate lies in W's piece (4.3-5.1 TB/s) or not (5.9-6.7);
-    // consecutive allocations of a process change pieces every 4 to 8 blocks of this size at the latest (scripts/alloc_sequence_probe.hip:
-    // of 27 blocks held together, 10 to 17 lay in another piece than the first, never more than 8 in a row in the same), so up to 16
-    // candidates are held at once, the scan stops at the first one 30 % above the same-piece rate (W's own two halves), and the best
-    // one is timed with the ensemble's kernel below.  (Six kernel-timed pairs alone missed in about one fresh process out of ten.)
-    if (!(cands[0].ms < 0.93f * slowest()) && ch->wbytes >= ((size_t)64 << 20)) {
-        const size_t sb = std::min<size_t>({ch->wbytes / 2, ch->xbytes, (size_t)1 << 30}) / 4096 * 4096;
-        const float r_same = two_stream_rate(ctx, cur.w, (char *)cur.w + ch->wbytes / 2, sb);
-        void *pick = nullptr;
-        float r_pick = 0.f;
-        for (int k = 0; k < 16 && r_same > 0.f; k++) {
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * ch->xbytes) break;
-            void *q = nullptr;
-            if (alloc_run(&q, ch->xbytes) != hipSuccess) { (void)hipGetLastError(); break; }
-            held.push_back(q);
-            const float r = two_stream_rate(ctx, cur.w, q, sb);
-            if (r > r_pick) { r_pick = r; pick = q; }
-            if (r >= 1.30f * r_same) break;
-        }
-        if (pick && r_pick >= 1.12f * r_same) {
-            Cand c = cur;
-            c.xo = pick;
-            ch->Wc = (double *)c.w; ch->Xo = (double *)c.xo;
-            int rct = chains_init_impl(ch, x0, nullptr, 0, skip, 0u);   // (the streams wrote over W)
-            if (!rct) rct = chains_time_iterations(ch, skip, &c.ms);
-            if (!rct) cands.push_back(c);
-        } else {
-            ch->Wc = (double *)cur.w; ch->Xo = (double *)cur.xo;
-            (void)chains_init_impl(ch, x0, nullptr, 0, skip, 0u);
-        }
-    }
-    while ((int)cands.size() < max_tries && !(cands[best()].ms < 0.93f * slowest())) {
-        const bool roll_w = cands.size() >= 3 && cands.size() % 2 == 1;   // tries 1, 2: Xo; then W, Xo, W
-        const size_t bytes = roll_w ? ch->wbytes : ch->xbytes;
+    const size_t sp = place_stream_bytes(ch->wbytes, ch->xbytes);
+    cands.push_back(Cand{xo, two_stream_rate(ctx, w, xo, sp)});
+    auto apart = [&](float r) { return r >= PLACE.diff_min * ctx->r_same; };
+    const int max_cands = (int)std::min<size_t>(24, std::max<size_t>((size_t)PLACE.max_candidates, PLACE.held_bytes / std::max<size_t>(ch->xbytes, 1)));
+    while (!apart(cands.back().r) && (int)cands.size() < max_cands) {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bytes) break;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * ch->xbytes) break;
         void *q = nullptr;
-        if (alloc_run(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-        held.push_back(q);
-        Cand c = cands[best()];
-        if (roll_w) c.w = q; else c.xo = q;
-        ch->Wc = (double *)c.w; ch->Xo = (double *)c.xo;
-        int rct = roll_w ? chains_init_impl(ch, x0, nullptr, 0, skip, 0u) : BHIP_OK;   // a new W needs its state
-        if (!rct) rct = chains_time_iterations(ch, skip, &c.ms);
-        if (rct) break;   // a candidate that cannot be set up or timed is dropped, not reported (freed below)
-        cands.push_back(c);
+        if (alloc_run(&q, ch->xbytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        cands.push_back(Cand{q, two_stream_rate(ctx, w, q, sp)});
     }
-    const Cand keep = cands[best()];
+    size_t ib = 0;
+    for (size_t k = 1; k < cands.size(); k++) if (cands[k].r > cands[ib].r) ib = k;
     (void)hipStreamSynchronize(ctx->stream);
-    for (void *q : held) if (q != keep.w && q != keep.xo) (void)hipFree(q);
-    ch->arena.base = keep.w; ch->arena.base2 = keep.xo;
-    ch->Wc = (double *)keep.w; ch->Xo = (double *)keep.xo;
-    ch->place_tries = (int)cands.size(); ch->place_ms_first = t_ref > 0.f ? t_ref : cands[0].ms; ch->place_ms_best = keep.ms;
-    return chains_init_impl(ch, x0, nullptr, 0, skip, 0u);   // the state of iteration 0, whatever the timing runs did to it
+    for (size_t k = 0; k < cands.size(); k++) if (k != ib) (void)hipFree(cands[k].p);
+    xo = cands[ib].p;
+    ch->arena.base2 = xo; ch->Xo = (double *)xo;
+    // 4. the map learns both buffers
+    int px = -1;
+    if (cands[ib].r <= PLACE.same_max * ctx->r_same) px = pw;
+    else if (apart(cands[ib].r)) {
+        if (pw < 0) px = -1;
+        else {
+            ctx->pieces.push_back(bhip_ctx::PieceEnt{w, ch->wbytes, pw});   // (so that Xo is not given W's id as a new one)
+            px = place_classify(ctx, xo, ch->xbytes, &fresh);
+            ctx->pieces.pop_back();
+        }
+    }
+    if (pw >= 0) ctx->pieces.push_back(bhip_ctx::PieceEnt{w, ch->wbytes, pw});
+    if (px >= 0) ctx->pieces.push_back(bhip_ctx::PieceEnt{xo, ch->xbytes, px});
+    ch->place_tries = (int)cands.size(); ch->place_ms_first = ctx->r_same; ch->place_ms_best = cands[ib].r;
+    ch->piece_w = pw; ch->piece_xo = px;
+    return chains_init_impl(ch, x0, nullptr, 0, skip, 0u);   // the state of iteration 0: the write streams went over W and Xo
 }
 
 int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
@@ -1815,12 +1806,35 @@ int bhip_chains_init(bhip_chains *ch, const double *x0, int skip)
     return chains_place(ch, x0, skip);
 }
 
-int bhip_chains_placement_info(const bhip_chains *ch, int *tries, float *ms_first, float *ms_best)
+int bhip_chains_placement_info(const bhip_chains *ch, int *tries, float *gbs_same_piece, float *gbs_kept)
 {
     if (!ch) return BHIP_EINVAL;
     if (tries) *tries = ch->place_tries;
-    if (ms_first) *ms_first = ch->place_ms_first;
-    if (ms_best) *ms_best = ch->place_ms_best;
+    if (gbs_same_piece) *gbs_same_piece = ch->place_ms_first;
+    if (gbs_kept) *gbs_kept = ch->place_ms_best;
+    return BHIP_OK;
+}
+
+int bhip_chains_placement_pieces(const bhip_chains *ch, int *piece_w, int *piece_xo)
+{
+    if (!ch) return BHIP_EINVAL;
+    if (piece_w) *piece_w = ch->piece_w;
+    if (piece_xo) *piece_xo = ch->piece_xo;
+    return BHIP_OK;
+}
+
+int bhip_ctx_piece_of(bhip_ctx *ctx, void *dev_ptr, size_t bytes, int *piece)
+{
+    if (!ctx || !dev_ptr || !piece) return BHIP_EINVAL;
+    NEED_DEVICE(ctx);
+    *piece = -1;
+    if (ctx->pieces.empty() || !(ctx->r_same > 0.f)) return fail(ctx, BHIP_ESTATE, "bhip_ctx_piece_of: the context's piece map is empty (it is built by the first placed chain ensemble and lives with the ensembles)");
+    if (bytes < PLACE.min_bytes) return fail(ctx, BHIP_EINVAL, "bhip_ctx_piece_of: the buffer is too small to be classified (64 MiB at least)");
+    for (const bhip_ctx::PieceEnt &e : ctx->pieces)
+        if (e.p == dev_ptr) { *piece = e.piece; return BHIP_OK; }   // a buffer the map holds: no test, nothing overwritten
+    bool fresh = false;
+    *piece = place_classify(ctx, dev_ptr, bytes, &fresh);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return BHIP_OK;
 }
 

@@ -100,11 +100,13 @@ int bhip_ctx_sync(bhip_ctx *ctx);
 /* BHIP_OPT_TUNE_PLACEMENT (default 1): placement of large chain ensembles.  On MI355X the pCN iteration (three streams: read W,
  * write Wo, write Xo) runs 14-16 % faster when the chain state W and the proposal paths Xo lie in DIFFERENT 96-GiB pieces of the
  * device's physical memory (each piece has its own DRAM banks; three streams inside one piece close each other's rows:
- * profiles/r4_placement_regions.txt).  HIP neither reports nor accepts physical addresses, so ensembles of 1 GiB or more keep W and
- * Xo in two physically contiguous allocations and bhip_chains_init MEASURES whether they share a piece: a few iterations on one
- * contiguous block holding both (the same-piece reference, freed again), a few on the ensemble's own pair, and -- only if that is
- * not 7 % faster -- on further allocations (Xo, Xo, then W and Xo in turn: six pairs at most), of which the fastest pair is kept
- * (bhip_chains_placement_info; ~10 ms per step, once per ensemble).  0 keeps the first pair.  Results do not depend on it. */
+ * profiles/r4_placement_regions.txt).  HIP neither reports nor accepts physical addresses, but two plain write streams tell in half
+ * a millisecond whether two buffers share a piece (~4.7 TB/s) or not (~6.1).  Ensembles of 1 GiB or more keep W and Xo in two
+ * physically contiguous allocations; bhip_chains_init tests the pair with such streams and, only if it shares a piece, allocates
+ * further candidates for Xo (8 to 24 by size, freed at once) until one lies elsewhere.  The CONTEXT keeps a piece map -- the large
+ * buffers of its live ensembles with the piece each was found in -- against which new buffers are classified
+ * (bhip_chains_placement_info / _pieces, bhip_ctx_piece_of).  No kernel-timed runs, no reference block: a few milliseconds per
+ * ensemble.  0 keeps the pair the ensemble was created with.  Results do not depend on it. */
 #define BHIP_OPT_TUNE_PLACEMENT 2
 /* BHIP_OPT_MID_VALU (default 1): LinPro targets and component-wise user drifts of "middle" dimension run one path per lane like the
  * d <= 3 processes (the d x d products as scalar FMAs, coefficients through the scalar unit) in bhip_sample_solve, bhip_solve,
@@ -302,9 +304,16 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
 void bhip_chains_destroy(bhip_chains *ch);
 /* iteration 0: W = sample(tt, Wiener()); solve!(X, x0, W, Po); ll = llikelihood(X, Po; skip) */
 int bhip_chains_init(bhip_chains *ch, const double *x0, int skip);
-/* what BHIP_OPT_TUNE_PLACEMENT did for this ensemble: (W, Xo) pairs that were timed (0: not placed), ms per pCN iteration with W
- * and Xo in ONE contiguous block (the same-piece reference; without one: on the first pair), and on the pair that was kept */
-int bhip_chains_placement_info(const bhip_chains *ch, int *tries, float *ms_first, float *ms_best);
+/* what BHIP_OPT_TUNE_PLACEMENT did for this ensemble: allocations of Xo that were tested against W (0: not placed; 1: the pair the
+ * ensemble was created with already lay in different pieces), GB/s of two write streams into ONE piece (the context's reference,
+ * measured once) and into the (W, Xo) pair that was kept; and the pieces (ids 0..2 of the context's map, -1: astride a cut or not
+ * placed) W and Xo were found in.  The reference has no counterpart (memory placement is not its concern). */
+int bhip_chains_placement_info(const bhip_chains *ch, int *tries, float *gbs_same_piece, float *gbs_kept);
+int bhip_chains_placement_pieces(const bhip_chains *ch, int *piece_w, int *piece_xo);
+/* the piece of the device memory a buffer of >= 64 MiB lies in, by the context's map (built by the first placed ensemble, alive with
+ * the ensembles): a buffer the map holds is looked up; any other is classified with write streams -- ITS CONTENTS ARE OVERWRITTEN --
+ * against one representative per known piece: that piece's id, a new id when it lies apart from all of them, -1 when inconclusive */
+int bhip_ctx_piece_of(bhip_ctx *ctx, void *dev_ptr, size_t bytes, int *piece);
 /* `iters` pCN iterations: sample!(W2); Wo = rho*W + sqrt(1-rho^2)*W2; solve!; llo; accept iff
  * log(U) <= llo - ll.  skip applies to llo like partialbridge_nclar.jl:121; pass BHIP_SKIP_OF_INIT to use the skip the
  * ensemble was initialised with, so that llo and ll sum the same terms (partialbridge_fitzhugh.jl:131,155 passes its

@@ -493,6 +493,6 @@ def test_large_segments_are_placed_and_results_do_not_depend_on_it(ctx):
     (lla, acca, y0a, Xa, ia), (llb, accb, y0b, Xb, ib) = outs
     assert np.array_equal(lla, llb) and np.array_equal(acca, accb) and np.array_equal(y0a, y0b) and np.array_equal(Xa, Xb)
     assert acca.sum() > 0
-    assert all(1 <= t <= 6 for t in ia) and all(t == 0 for t in ib)
+    assert all(1 <= t <= 24 for t in ia) and all(t == 0 for t in ib)
     r = o.smooth_mcmc(refs, mu, chol, w_old, w_new, 3, n - 1)
     assert acca[n - 1] == r["acc"] and np.array_equal(Xa[1], r["X"][1])
