@@ -652,7 +652,9 @@ int bhip_proposal_set_aux_linearappr(bhip_proposal *po, const double *xx, const 
     if (!xx || !B || !b || !Sigma) return fail(ctx, BHIP_EINVAL, "bhip_proposal_set_aux_linearappr: null array");
     const int d = po->mh.d, mp = po->mh.mp;
     const size_t N = po->tt.size();
-    if (d > 3) return fail(ctx, BHIP_EUNSUPPORTED, "LinearAppr auxiliary: d <= 3");
+    // (d > 3 since round 5: LinPro targets -- one path per lane or the tile kernel, whose per-step coefficients take B~_i, beta~_i by
+    // grid index like every time-dependent auxiliary; the per-chain device-built guides of bhip_segchains_adapt_device stay at d <= 3)
+    if (d > 3 && po->mh.id != BHIP_MODEL_LINPRO) return fail(ctx, BHIP_EUNSUPPORTED, "LinearAppr auxiliary at d > 3: LinPro targets");
     if (!po->mh.constdiff) return fail(ctx, BHIP_EUNSUPPORTED, "LinearAppr auxiliary: the target must have a constant sigma");
     // constant-diffusivity log-likelihood: the linearisation's Sigma_i must be the target's sigma (a~ = a)
     const double *sg = po->mh.id == BHIP_MODEL_LINPRO ? po->mh.par.data() + d * d + d : nullptr;
@@ -742,7 +744,7 @@ int bhip_proposal_set_aux_linearnoiseappr(bhip_proposal *po, const double *Y)
     if (!po || !Y) return BHIP_EINVAL;
     bhip_ctx *ctx = po->ctx;
     const int d = po->mh.d, mp = po->mh.mp, N = (int)po->tt.size();
-    if (d > 3) return fail(ctx, BHIP_EUNSUPPORTED, "LinearNoiseAppr auxiliary: d <= 3");
+    if (d > 3 && po->mh.id != BHIP_MODEL_LINPRO) return fail(ctx, BHIP_EUNSUPPORTED, "LinearNoiseAppr auxiliary at d > 3: LinPro targets");
     if (!po->mh.constdiff) return fail(ctx, BHIP_EUNSUPPORTED, "LinearNoiseAppr auxiliary: the target must have a constant sigma");
     if (po->mh.id >= USER_MODEL_BASE || (po->mh.id != BHIP_MODEL_LORENZ && po->mh.id != BHIP_MODEL_PENDULUM && po->mh.id != BHIP_MODEL_LINPRO && po->mh.id != BHIP_MODEL_WIENER))
         return fail(ctx, BHIP_EUNSUPPORTED, "LinearNoiseAppr auxiliary: targets Lorenz, Pendulum, LinPro, Wiener");
@@ -803,8 +805,12 @@ static int build_tile_data(bhip_proposal *po)
     const bool user = po->mh.id >= USER_MODEL_BASE;   // component-wise hipRTC drift (bhip_model_define_components): no B, mu
     if ((po->mh.id != BHIP_MODEL_LINPRO && !user) || d > 32)
         return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: LinPro target or a component-wise user drift, dimension 4 <= d <= 32");
-    if (!plain && (!po->has_aux || (po->aux.kind != BHIP_AUX_AFFINE && po->aux.kind != BHIP_AUX_LINPRO)))
-        return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: time-constant auxiliary process");
+    // the auxiliary's B~(t), beta~(t) are taken per grid point (src/partialbridge.jl:13-15: functions of t throughout the reference): constant
+    // LinPro / affine forms, a caller's callback, LinearAppr / LinearNoiseAppr coefficients by grid index.  A component-wise user drift
+    // keeps -B~ as a CONSTANT matrix in the kernel (bhip_tile_kernel.h, UD::ON): time-constant auxiliaries only.
+    const bool aux_const = po->has_aux && (po->aux.kind == BHIP_AUX_AFFINE || po->aux.kind == BHIP_AUX_LINPRO);
+    if (!plain && (!po->has_aux || (user && !aux_const) || po->aux.kind == BHIP_AUX_FHN_STARTEND))
+        return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: no auxiliary process, or a time-dependent one with a component-wise user drift");
     const int Dp = tile_dim(d);
     // The step regrouped into products with path-independent accumulator starts (bhip_tile_kernel.h, head of the file):
     //   built-in (LinPro) target, three products:
@@ -821,13 +827,17 @@ static int build_tile_data(bhip_proposal *po)
     Mat mu(d, 1);
     if (!user) std::memcpy(mu.a.data(), par + dd, sizeof(double) * d);
     const Mat Bmu = Bm * mu;
-    Mat Bt(d, d), mua(d, 1), beta(d, 1);
-    if (!plain) {
-        Bt = po->aux.B(po->tt[0]);
+    // (the auxiliary at grid point i; for the constant forms the same matrices every time)
+    auto aux_at = [&](int i, Mat &Bt, Mat &mua, Mat &beta) {
+        Bt = Mat(d, d); mua = Mat(d, 1); beta = Mat(d, 1);
+        if (plain) return;
+        Bt = po->aux.B(po->tt[i]);
         if (po->aux.linpro_form()) std::memcpy(mua.a.data(), po->aux.mu(), sizeof(double) * d);   // B~ (x - mu~)
-        else beta = po->aux.beta(po->tt[0]);                                                        // B~ x + beta~
-    }
-    const Mat Dm = Bm - Bt, DmT = tr(Dm), c = Bt * mua - Bmu - beta;
+        else beta = po->aux.beta(po->tt[i]);                                                        // B~ x + beta~
+    };
+    Mat Bt, mua, beta;
+    aux_at(0, Bt, mua, beta);
+    Mat Dm = Bm - Bt, DmT = tr(Dm), c = Bt * mua - Bmu - beta;
     Mat Id(d, d);
     for (int k = 0; k < d; k++) Id(k, k) = 1.0;
     std::vector<double> steps((size_t)(N - 1) * STEP, 0.0), hdr((size_t)(N - 1) * 2);
@@ -845,6 +855,10 @@ static int build_tile_data(bhip_proposal *po)
             nu = tr(L) * solve(L * tr(L), po->g.v - po->g.mu[i]);
         } else { Hm = po->g.H[i]; nu = po->g.nu[i]; }
         const double dt = po->tt[i + 1] - po->tt[i];
+        if (!aux_const && !plain) {   // b~(t_i, .) of the log-likelihood's left rule (src/guip.jl:434): the coefficients of grid point i
+            aux_at(i, Bt, mua, beta);
+            Dm = Bm - Bt; DmT = tr(Dm); c = Bt * mua - Bmu - beta;
+        }
         const Mat aHm = po->mh.a * Hm, hnu = Hm * nu;
         const Mat P = Id + dt * (Bm - aHm), q = dt * (po->mh.a * hnu - Bmu);
         double *st = &steps[(size_t)i * STEP];

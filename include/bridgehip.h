@@ -181,8 +181,9 @@ int bhip_model_define_sigma(bhip_ctx *ctx, int d, int mp, int npar, const char *
  *     inputs  int k (component, 0-based), int d, double t, const double* x (d), const double* par (npar <= 16);  output double o, e.g.
  *     Lorenz-96:  "o = (x[(k+1)%d] - x[(k+d-2)%d])*x[(k+d-1)%d] - x[k] + par[0];"
  * Proposals on the returned model id take par = [npar drift parameters, sigma (d x d, column-major)].  Runs everything the
- * built-in LinPro target runs at large d: plain Euler-Maruyama, GuidedBridge / (nu,H) / PartialBridge guides with a
- * time-constant auxiliary, fused and stand-alone llikelihood, pCN chains (and innovations! at d <= 12). */
+ * built-in LinPro target runs at large d: plain Euler-Maruyama, GuidedBridge / (nu,H) / PartialBridge guides, fused and
+ * stand-alone llikelihood, pCN chains (and innovations! at d <= 12) -- with a time-constant auxiliary (a LinPro target also takes
+ * B~(t), beta~(t) per grid point: a callback or LinearAppr coefficients). */
 int bhip_model_define_components(bhip_ctx *ctx, int d, int npar, const char *component_src, int *model_id);
 
 /* ------------------------------------------------------------------ proposal  ("Po")
@@ -201,7 +202,8 @@ int bhip_proposal_set_aux_callback(bhip_proposal *po, bhip_aux_fn fn, void *user
  * bhip_proposal_guide_hv then integrates (Hdiamond, V) with the index-based Heun scheme of src/guip.jl:181-189 /
  * src/ode.jl:98-113 (restated with the loop index it evidently means, see DESIGN.md: the reference constructor reads an
  * undefined variable).  The log-likelihood uses the constant-diffusivity form, i.e. Sigma_i must equal the target's sigma
- * (checked): the reference's own !constdiff branch for GuidedBridge is not defined. */
+ * (checked): the reference's own !constdiff branch for GuidedBridge is not defined.  d <= 3: every target; 4 <= d <= 32:
+ * LinPro targets (the coefficients of grid index i enter step i's coefficient row / the tile kernel's per-step matrices). */
 int bhip_proposal_set_aux_linearappr(bhip_proposal *po, const double *xx, const double *B, const double *b, const double *Sigma);
 /* linearappr(Y, P) / linearappr!(Pt, Y, P)  src/linpro.jl:196-204 (host): fills B, b, Sigma (layouts as above) for the
  * target of `po` along Y [N][d]; for the processes the reference defines bderiv for: Lorenz, Pendulum, LinPro, Wiener. */

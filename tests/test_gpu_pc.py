@@ -131,7 +131,7 @@ def test_placement_tuning_changes_nothing_but_the_allocation(ctx):
     n = 36000                                            # x 32 KB of state per chain > 1 GiB
     a = bh.Chains(Po, case.x0, n, seed=9)
     info = a.placement()
-    assert 1 <= info["tries"] <= 8 and info["gbs_same_piece"] > 1000 and info["gbs_kept"] > 0
+    assert 1 <= info["tries"] <= 24 and info["gbs_same_piece"] > 1000 and info["gbs_kept"] > 0
     assert info["gbs_kept"] >= 0.95 * info["gbs_same_piece"]      # the pair that was kept is never slower than two streams in one piece
     a.step(0.9, 3)
     ctx.set_option(bh.OPT_TUNE_PLACEMENT, 0)
@@ -199,3 +199,4 @@ def test_piece_map_of_the_context_places_six_ensembles_alive_at_once():
     assert max(setup_ms[1:]) < 150.0, (setup_ms, infos)
     del ens, ref
     torch.cuda.empty_cache()
+

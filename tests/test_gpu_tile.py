@@ -7,6 +7,8 @@ pre-inverted matrix and accumulates on the matrix cores with fused multiply-adds
 |X - X_oracle| <= 1e-9 * (1 + max|X|), |ll - ll_oracle| <= 1e-8 * (1 + |ll|) (SURVEY 7 "hard parts").
 The Wiener paths themselves are bit-exact (same generator, same operation order).
 """
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -382,3 +384,53 @@ def test_mid_dimension_guidedbridge_with_diagonal_hdiamond(ctx, d):
                          o.GUIDE_HV, d, d, v=0.5 * np.ones(d), exact=False)
     with pytest.raises(Exception, match="singular"):
         sing.bh_proposal(bh, ctx)
+
+
+@pytest.mark.parametrize("d", [5, 16])
+def test_time_dependent_auxiliary_above_three_dimensions(ctx, d):
+    """B~(t), beta~(t) are functions of t throughout the reference (src/partialbridge.jl:13-15, src/linpro.jl:188-189).  Round 5 lifts the
+    "time-constant auxiliary" restriction of the large-d paths for LinPro targets: a LinearAppr auxiliary whose coefficients differ at every
+    grid index (B_i, xx_i, b_i: NOT the linearisation of the target -- a genuinely different affine drift per step), GuidedBridge by the
+    index-based Heun guide (src/guip.jl:181-189), at d = 5 (one path per lane: per-step B~_i, beta~_i in the coefficient rows) and d = 16
+    (the tile kernel: they enter its per-step matrices A_i, b_i, c0_i).  Fresh proposals with the fused log-likelihood, the stand-alone
+    llikelihood and pCN chains against the oracle at the large-d tolerance."""
+    N = 81
+    rng = np.random.default_rng(11)
+    tt = np.linspace(0.0, 0.8, N)
+    G = rng.standard_normal((d, d)) / math.sqrt(d)
+    B = -np.eye(d) + 0.2 * G
+    sig = 0.6 * np.eye(d) + 0.05 * rng.standard_normal((d, d)) / math.sqrt(d)
+    mu = 0.1 * rng.standard_normal(d)
+    x0, v = 0.2 * rng.standard_normal(d), 0.3 * np.ones(d)
+    # the auxiliary by grid index
+    xx = 0.3 * np.sin(np.outer(1.0 + tt, np.arange(1, d + 1)))
+    Bi = np.stack([-(1.0 + 0.7 * t) * np.eye(d) + 0.1 * math.cos(3 * t) * G.T for t in tt])
+    bi = np.stack([0.2 * np.cos((2.0 + k) * tt) for k in range(d)], axis=1)
+    Si = np.broadcast_to(sig, (N, d, d)).copy()
+    P = bh.LinPro(B, mu, sig)
+    Po = bh.GuidedBridge(tt, P, bh.LinearAppr(xx, Bi, bi, Si), v, ctx=ctx)
+    par = o.linpro_par(B, mu, sig)
+    ref = o.proposal_hv(tt, d, d, o.MODEL_LINPRO, par, o.AUX_LINEARAPPR, o.linearappr_par(tt, xx, Bi, bi, Si), Po.Hd, Po.V)
+    Hd, V = o.gp_hv_heuni(tt, d, d, xx, Bi, bi, Si, v)
+    assert np.abs(Po.Hd - Hd).max() <= 1e-12 * (1 + np.abs(Hd).max()) and np.abs(Po.V - V).max() <= 1e-12 * (1 + np.abs(V).max())
+    X, W, ll = bh.sample_solve(x0, Po, 70, seed=13, iter=1, path0=4, store_W=True)
+    Xh, Wh, llh = X.paths(), W.paths(), ll.cpu().numpy()
+    ll2 = bh.llikelihood(bh.LeftRule(), X, Po).cpu().numpy()
+    for p in (0, 33, 69):
+        Wr = o.wiener_sample(tt, d, 13, 4 + p, 1)
+        assert np.array_equal(Wh[p], Wr)
+        Xr = o.solve_guided(ref, x0, Wr)
+        llr = o.llikelihood(ref, Xr)
+        assert np.abs(Xh[p] - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max()), (d, p)
+        assert abs(llh[p] - llr) <= 1e-8 * (1 + abs(llr)) and abs(ll2[p] - llr) <= 1e-8 * (1 + abs(llr)), (d, p, llh[p], ll2[p], llr)
+    assert abs(llr) > 1e-3                                   # (the auxiliary does differ from the target: the weights are not trivial)
+    ch = bh.Chains(Po, x0, 40, seed=8)
+    ch.step(0.9, 5)
+    acc, llc = ch.acc(), ch.ll()
+    same = 0
+    for p in (0, 13, 39):
+        r = o.mcmc(ref, x0, 0.9, 5, 8, p)
+        if acc[p] == r["acc"]:
+            same += 1
+            assert abs(llc[p] - r["ll"]) <= 1e-8 * (1 + abs(r["ll"]))
+    assert same >= 2
