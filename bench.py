@@ -318,7 +318,7 @@ MODES = {
     "linpro4": (lambda ctx: _linpro(ctx, 4), 4, 4, tuple([0.0] * 4), 262144, False, None,
                 "LinPro d=4 GuidedBridge (dense sigma, pre-inverted Hdiamond), 1001-point grid T=1, independent fused proposals: one path per lane "
                 "(dimensions 4..8 stay off the matrix cores)",
-                lambda P: "k_paths<bhip::MLinPro<4, double const AS4*>, 3, 1, 1, 1, false>"),
+                lambda P: "k_paths<bhip::MLinPro<4, double const AS4*>, 5, 1, 1, 1, false>"),
     "linpro32": (_linpro32, 32, 32, tuple([0.0] * 32), 65536, False, None,
                  "LinPro d=32 GuidedBridge (dense sigma, pre-inverted Hdiamond), 1001-point grid T=1, independent fused proposals",
                  lambda P: "k_tile<32, 1, false, bhip::NoUserDrift>"),

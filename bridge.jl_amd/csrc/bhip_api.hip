@@ -185,6 +185,8 @@ struct bhip_proposal {
     bool has_aux = false;
     Guide g;
     double *d_rows = nullptr;
+    double *d_rows_innov = nullptr;   // LinPro target at 4 <= d <= 12: the (nu, H) rows innovations! reads (d_rows holds the regrouped ones)
+    int rs_innov = 0;
     int rs = 0;
     double *d_rdtp = nullptr;   // rdtp[j] = sqrt(tt[j] - tt[j-1]), rdtp[0] = 0, zero padded to a multiple of 16 (bhip_pc_kernel.h)
     bool use_vend = false;
@@ -617,6 +619,7 @@ void bhip_proposal_destroy(bhip_proposal *po)
     if (!ctx->host_only) {
         ctx_quiesce(ctx);
         if (po->d_rows) (void)hipFree(po->d_rows);
+        if (po->d_rows_innov) (void)hipFree(po->d_rows_innov);
         if (po->d_tt) (void)hipFree(po->d_tt);
         if (po->d_rdtp) (void)hipFree(po->d_rdtp);
         if (po->d_steps) (void)hipFree(po->d_steps);
@@ -1006,6 +1009,41 @@ static int finish_guide(bhip_proposal *po)
             }
         }
         pack_rows(po->tt, po->mh, po->has_aux ? &po->aux : nullptr, g2, rows, rs);
+        if (po->d_rows_innov) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(po->d_rows_innov)); po->d_rows_innov = nullptr; }
+        if (po->mh.id == BHIP_MODEL_LINPRO && g2.kind != BHIP_GUIDE_NONE) {
+            // LinPro target: the REGROUPED step (bhip_path_kernel.h GUIDE_QF; the algebra of build_tile_data): per step A_i, bv_i, P_i, q_i,
+            // c0_i in place of B~_i, beta~_i, H_i, nu_i.  innovations! keeps the (nu, H) rows packed above (a second, small array).
+            HIPCHK(ctx, hipMalloc((void **)&po->d_rows_innov, sizeof(double) * rows.size()));
+            HIPCHK(ctx, hipMemcpy(po->d_rows_innov, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice));
+            po->rs_innov = rs;
+            const int rq = row_stride(BHIP_GUIDE_QF, d, 1, true);
+            std::vector<double> rowsq((size_t)(N - 1) * rq, 0.0);
+            const double *par = po->mh.par.data();
+            const Mat Bm(d, d, par), mu(d, 1, par + (size_t)d * d);
+            const Mat Bmu = Bm * mu;
+            Mat Id(d, d);
+            for (int k = 0; k < d; k++) Id(k, k) = 1.0;
+            for (int i = 0; i < N - 1; i++) {
+                Mat Bt = po->aux.B(po->tt[i]), mua(d, 1), beta(d, 1);
+                if (po->aux.linpro_form()) std::memcpy(mua.a.data(), po->aux.mu(), sizeof(double) * d);
+                else beta = po->aux.beta(po->tt[i]);
+                const Mat Dm = Bm - Bt, DmT = tr(Dm), c = Bt * mua - Bmu - beta;
+                const Mat &Hm = g2.H[i], &nu = g2.nu[i];
+                const double dt = po->tt[i + 1] - po->tt[i];
+                const Mat hnu = Hm * nu;
+                const Mat A = -(DmT * Hm), bv = DmT * hnu - tr(Hm) * c;
+                const Mat P = Id + dt * (Bm - po->mh.a * Hm), q = dt * (po->mh.a * hnu - Bmu);
+                double *r = &rowsq[(size_t)i * rq];
+                std::memcpy(r, &rows[(size_t)i * rs], 3 * sizeof(double));                       // t, dt, sqrt(dt)
+                std::memcpy(r + 3, A.a.data(), sizeof(double) * d * d);
+                std::memcpy(r + 3 + d * d, bv.a.data(), sizeof(double) * d);
+                std::memcpy(r + 3 + d * d + d, P.a.data(), sizeof(double) * d * d);
+                std::memcpy(r + 3 + 2 * d * d + d, q.a.data(), sizeof(double) * d);
+                r[3 + 2 * d * d + 2 * d] = dot(c, hnu);
+            }
+            rows.swap(rowsq);
+            rs = rq;
+        }
         if (!po->d_mpar) HIPCHK(ctx, hipMalloc((void **)&po->d_mpar, sizeof(double) * po->mh.dpar.size()));
         HIPCHK(ctx, hipMemcpy(po->d_mpar, po->mh.dpar.data(), sizeof(double) * po->mh.dpar.size(), hipMemcpyHostToDevice));
     } else
@@ -1229,8 +1267,16 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
     const bool wave_spec = ctx->wave_specialised || v2 || a.Xtb;   // (time-blocked path stores exist in the wave-specialised kernel only)
     if (a.Xtb && !(noise == NOISE_PCN_LINES && a.rdtp && po->mh.mp <= 3 && a.wstride == 1 && !po->mid)) return fail(ctx, BHIP_ESTATE, "time-blocked paths need the line layout");
     if (po->mid) {   // LinPro, d = 4..12: rows in the (nu, H) form, one kernel family
-        const int gkm = po->g.kind == BHIP_GUIDE_NONE ? BHIP_GUIDE_NONE : BHIP_GUIDE_NUH;
-        if (a.rs != row_stride(gkm, po->mh.d, 1, true)) return fail(ctx, BHIP_ESTATE, "row stride mismatch");
+        // LinPro targets: the regrouped rows (GUIDE_QF), except for innovations!, which reads the (nu, H) rows kept beside them; component-wise
+        // user drifts: the (nu, H) rows
+        const bool user_mid = po->mh.id >= USER_MODEL_BASE;
+        const int gkm = po->g.kind == BHIP_GUIDE_NONE ? BHIP_GUIDE_NONE : (user_mid || noise == NOISE_INNOV) ? BHIP_GUIDE_NUH : BHIP_GUIDE_QF;
+        KArgs am = a;
+        if (!user_mid && gkm == BHIP_GUIDE_NUH) {
+            if (!po->d_rows_innov) return fail(ctx, BHIP_ESTATE, "proposal has no (nu, H) coefficient rows");
+            am.rows = po->d_rows_innov; am.rs = po->rs_innov;
+        }
+        if (am.rs != row_stride(gkm, po->mh.d, 1, true)) return fail(ctx, BHIP_ESTATE, "row stride mismatch");
         if (po->mh.id >= USER_MODEL_BASE) {   // component-wise user drift: k_paths<MUser (streamed), gk, 1, noise, fl> through hipRTC
             if (!(noise == NOISE_EXT || noise == NOISE_FRESH || noise == NOISE_PCN || noise == NOISE_LLONLY || noise == NOISE_INNOV) ||
                 (gkm == BHIP_GUIDE_NONE && (noise == NOISE_PCN || noise == NOISE_LLONLY)))
@@ -1267,7 +1313,7 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         case 12: fm = get_launch_mid12(gkm, noise, fl); break;
         }
         if (!fm) return fail(ctx, BHIP_EUNSUPPORTED, "no path-per-lane kernel for this mode at 4 <= d <= 12");
-        HIPCHK(ctx, fm(a, ctx->stream));
+        HIPCHK(ctx, fm(am, ctx->stream));
         return BHIP_OK;
     }
     if (a.rs != row_stride(gk, po->mh.d, po->g.m, po->mh.constdiff)) return fail(ctx, BHIP_ESTATE, "row stride mismatch");

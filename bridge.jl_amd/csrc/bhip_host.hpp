@@ -519,6 +519,7 @@ inline int model_setup(int id, int d_hint, const double *par, int npar, ModelHos
 inline int row_stride(int gk, int d, int mo, bool constdiff = true)
 {
     if (gk == BHIP_GUIDE_NONE) return 4;
+    if (gk == 5 /* BHIP_GUIDE_QF, bhip_path_kernel.h: A_i, bv_i, P_i, q_i, c0_i */) return (3 + 2 * d * d + 2 * d + 1 + 1) & ~1;
     int glen = 0;
     if (gk == BHIP_GUIDE_HV) glen = d == 1 ? 3 : d == 2 ? 8 : 14;   // + the reciprocal of the row's divisor (bhip_smallmat.h sm_recip)
     else if (gk == BHIP_GUIDE_LMMU) glen = mo * d + mo + 2 * d * mo + (constdiff ? 0 : 2 * d * d);

@@ -44,6 +44,12 @@ template <class M> struct has_sinv<M, bhip_void_t<decltype(&M::sinv_mul)>> { sta
 template <class M, class = void> struct is_constdiff { static constexpr bool value = true; };
 template <class M> struct is_constdiff<M, bhip_void_t<decltype(M::STATE_SIGMA)>> { static constexpr bool value = !M::STATE_SIGMA; };
 
+// GUIDE_QF (internal, not part of the ABI; round 5): the REGROUPED step of the LinPro family at 4 <= d <= 12.  Target and auxiliary are
+// affine and everything but x and dW is path-independent, so the host (finish_guide, regroup_step) turns the five d x d products of a
+// step into three whose accumulators start from path-independent vectors, exactly as for the tile kernel (bhip_tile_kernel.h):
+//     dot(b - b~, r) = c0_i + x . (bv_i + A_i x)        x_{i+1} = q_i + P_i x + sigma dW
+// row: t, dt, sqrt(dt), A_i (d*d), bv_i (d), P_i (d*d), q_i (d), c0_i.  Tolerance parity, like every path at d > 3.
+#define BHIP_GUIDE_QF 5
 constexpr int BHIP_MAXD_LANE = 12;   // one path per lane up to here (4..8 since round 3, 9..12 since round 4); beyond: the MFMA tile kernel
 
 // processes whose parameter block is re-opened from device memory at every step (MLinPro<4..8, bhip_cptr_t>)
@@ -165,7 +171,7 @@ struct RowLayout {
     static constexpr int G = 3 + D * D + D;  // guide part
     static constexpr int GLEN = GK == BHIP_GUIDE_HV ? (D == 1 ? 3 : D == 2 ? 8 : 14)   // Hd / cofactors, det, V, 1/divisor
                               : GK == BHIP_GUIDE_LMMU ? (MO * D + MO + 2 * D * MO + (CD ? 0 : 2 * D * D))
-                              : GK == BHIP_GUIDE_NUH ? (D * D + D) : 0;
+                              : GK == BHIP_GUIDE_NUH ? (D * D + D) : GK == BHIP_GUIDE_QF ? (D * D + D + 1) : 0;
     static constexpr int LM_H = G + MO * D + MO + 2 * D * MO;   // LMMU, !CD: H (D*D), then a~ (D*D)
     static constexpr int LEN = GK == BHIP_GUIDE_NONE ? 3 : G + GLEN;
     static constexpr int RS = (LEN + 1) & ~1;
@@ -417,6 +423,30 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int n
     }
     PSTAMP(1);   // phase 1: dw + the issue of the X stores (back-pressure shows here)
 
+    if constexpr (GK == BHIP_GUIDE_QF) {
+        // the regrouped step (see BHIP_GUIDE_QF above): three products, accumulators started from the row's vectors
+        static_assert(STR, "the regrouped rows exist for the streamed LinPro family (4 <= d <= 12)");
+        double yv[D], xn[D];
+        RowPtr ra = row;
+        bhip_after(ra, st.y[D - 1]);
+        matvec_streamed_init<D, RowPtr>(ra + RL::B, ra + RL::BETA, st.y, yv);          // bv_i + A_i x
+        double part = st.y[0] * yv[0];
+#pragma unroll
+        for (int k = 1; k < D; k++) part = __builtin_fma(st.y[k], yv[k], part);
+        RowPtr rc = row;
+        bhip_after(rc, part);
+        const double lln = st.ll + (part + rc[RL::G + D * D + D]) * dt;                 // + c0_i
+        st.ll = (i < nll) ? lln : st.ll;
+        if constexpr (NOISE != NOISE_LLONLY) {
+            matvec_streamed_init<D, RowPtr>(rc + RL::G, rc + RL::G + D * D, st.y, xn);   // q_i + P_i x
+            auto S = model.p + D * D + D;                                                // sigma of the LinPro block [B, mu, sigma, a, ...]
+            matvec_streamed_acc<D>(S, dw, xn);                                           //   + sigma dW
+#pragma unroll
+            for (int k = 0; k < D; k++) st.y[k] = xn[k];
+        }
+        PSTAMP(2); PSTAMP(3); PSTAMP(4);
+        return;
+    }
     double bT[D];
     model.b(t, st.y, bT);
     if constexpr (GK != BHIP_GUIDE_NONE) {
@@ -847,18 +877,19 @@ launch_fn get_launch_mid(int gk, int noise, int fl)
         }
         return nullptr;
     }
+    // guided: the regrouped rows (GUIDE_QF) for everything but innovations!, which needs _b = b + a r itself and keeps the (nu, H) rows
+    if (gk == BHIP_GUIDE_NUH) return noise == NOISE_INNOV ? launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_INNOV, 2> : nullptr;   // inv(sigma) by LU on the host, streamed like the other matrices
     switch (noise) {
-    case NOISE_EXT: return (fl & 1) ? launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_EXT, 1> : launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_EXT, 0>;
+    case NOISE_EXT: return (fl & 1) ? launch_paths<M, BHIP_GUIDE_QF, 1, NOISE_EXT, 1> : launch_paths<M, BHIP_GUIDE_QF, 1, NOISE_EXT, 0>;
     case NOISE_FRESH:
         switch (fl & 3) {
-        case 0: return launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_FRESH, 0>;
-        case 1: return launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_FRESH, 1>;
-        case 2: return launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_FRESH, 2>;
-        default: return launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_FRESH, 3>;
+        case 0: return launch_paths<M, BHIP_GUIDE_QF, 1, NOISE_FRESH, 0>;
+        case 1: return launch_paths<M, BHIP_GUIDE_QF, 1, NOISE_FRESH, 1>;
+        case 2: return launch_paths<M, BHIP_GUIDE_QF, 1, NOISE_FRESH, 2>;
+        default: return launch_paths<M, BHIP_GUIDE_QF, 1, NOISE_FRESH, 3>;
         }
-    case NOISE_LLONLY: return launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_LLONLY, 0>;
-    case NOISE_PCN: return (fl & 1) ? launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_PCN, 1> : launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_PCN, 0>;   // pCN chains on the 16-byte slots
-    case NOISE_INNOV: return launch_paths<M, BHIP_GUIDE_NUH, 1, NOISE_INNOV, 2>;   // innovations!: inv(sigma) by LU on the host, streamed like the other matrices
+    case NOISE_LLONLY: return launch_paths<M, BHIP_GUIDE_QF, 1, NOISE_LLONLY, 0>;
+    case NOISE_PCN: return (fl & 1) ? launch_paths<M, BHIP_GUIDE_QF, 1, NOISE_PCN, 1> : launch_paths<M, BHIP_GUIDE_QF, 1, NOISE_PCN, 0>;   // pCN chains on the 16-byte slots
     }
     return nullptr;
 }

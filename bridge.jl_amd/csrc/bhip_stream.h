@@ -37,4 +37,36 @@ BHIP_DEV void matvec_streamed(PTR Mp, const double *v, double *o)
     }
 }
 
+// o = init + M v, the same blocks: the accumulators START from a path-independent vector read through `ip` (the regrouped step of
+// the LinPro family at 4 <= d <= 12, bhip_path_kernel.h GUIDE_QF)
+template <int D, class PTR>
+BHIP_DEV void matvec_streamed_init(PTR Mp, PTR ip, const double *v, double *o)
+{
+    constexpr int CB = 16 / D > 0 ? 16 / D : 1;
+#pragma unroll
+    for (int j0 = 0; j0 < D; j0 += CB) {
+        PTR q = Mp, qi = ip;
+        if (j0 > 0) bhip_after(q, o[D - 1]);
+#pragma unroll
+        for (int j = j0; j < (j0 + CB < D ? j0 + CB : D); j++)
+#pragma unroll
+            for (int i = 0; i < D; i++) o[i] = __builtin_fma(q[i + D * j], v[j], j == 0 ? qi[i] : o[i]);
+    }
+}
+// o += M v
+template <int D, class PTR>
+BHIP_DEV void matvec_streamed_acc(PTR Mp, const double *v, double *o)
+{
+    constexpr int CB = 16 / D > 0 ? 16 / D : 1;
+#pragma unroll
+    for (int j0 = 0; j0 < D; j0 += CB) {
+        PTR q = Mp;
+        bhip_after(q, o[D - 1]);
+#pragma unroll
+        for (int j = j0; j < (j0 + CB < D ? j0 + CB : D); j++)
+#pragma unroll
+            for (int i = 0; i < D; i++) o[i] = __builtin_fma(q[i + D * j], v[j], o[i]);
+    }
+}
+
 }  // namespace bhip
