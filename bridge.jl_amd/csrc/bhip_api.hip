@@ -1753,9 +1753,14 @@ extern "C" int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip
 // Every threshold of the procedure:
 struct PlaceParams {
     size_t stream_bytes = (size_t)512 << 20;   // bytes per write stream of a test: beyond the 256-MB Infinity Cache
-    float same_max = 1.10f;     // rate <= same_max * r_same: the two buffers share a piece          (measured: 4.3-5.1 TB/s in one piece,
-    float diff_min = 1.20f;     // rate >= diff_min * r_same: they lie in different pieces            5.9-6.7 across; between: astride a cut)
+    // Every 512-MiB test region lies in ONE piece (unless it straddles a cut itself), so a single two-stream run is bimodal -- the
+    // one-piece rate or the across-pieces rate -- and a run astride a cut shows as a LOW corner among the four of a pair, not as an
+    // intermediate value.  Measured over the rounds' boxes, relative to the context's own one-piece rate (4.1-4.5 TB/s): one piece
+    // 0.97-1.10, across pieces 1.19-1.55 (5.2-5.4 TB/s on the slow boxes of round 5, 5.9-6.7 on the others).  The cut between:
+    float same_max = 1.07f;     // rate <= same_max * r_same: the two regions share a piece (used for the map's labels only)
+    float diff_min = 1.13f;     // rate >= diff_min * r_same: they lie in different pieces (1.20 rejected good pairs on a box whose across-rate is 1.19)
     int max_candidates = 8;     // Xo candidates held at once at most (never more than 8 consecutive 4-GiB blocks of one piece were seen) ...
+    int more_candidates = 4;    // ... and this many more after each of the two W re-rolls
     size_t held_bytes = (size_t)24 << 30;   // ... or, for smaller buffers (the allocator's runs inside one piece are longer in blocks), as many as fit here, 24 at most
     size_t min_bytes = (size_t)64 << 20;   // buffers below this are not classified (a test needs streams of some length)
 };
@@ -1806,6 +1811,28 @@ static int place_classify(bhip_ctx *ctx, void *ptr, size_t bytes, bool *is_new)
     return -1;
 }
 
+static int chains_step_once(bhip_chains *ch, double rho, int skip, bool store_x);
+// BHIP_PLACE_TRACE only: ms per pCN iteration of the ensemble with W at wq and the proposal paths at q (the ground truth the
+// two-stream readings are compared with in profiles/r5_piece_map.txt); the ensemble's state is set up again afterwards by the caller
+static float place_trace_iteration_ms(bhip_chains *ch, const double *x0, int skip, void *wq, void *q)
+{
+    void *w0 = ch->arena.base, *x0p = ch->arena.base2;
+    ch->arena.base = wq; ch->arena.base2 = q; ch->Wc = (double *)wq; ch->Xo = (double *)q;
+    float ms = 0.f;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && !chains_init_impl(ch, x0, nullptr, 0, skip, 0u)) {
+        for (int it = 0; it < 2; it++) (void)chains_step_once(ch, 0.9, skip, true);
+        (void)hipEventRecord(e0, ch->ctx->stream);
+        for (int it = 0; it < 4; it++) (void)chains_step_once(ch, 0.9, skip, true);
+        (void)hipEventRecord(e1, ch->ctx->stream);
+        if (hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    ch->arena.base = w0; ch->arena.base2 = x0p; ch->Wc = (double *)w0; ch->Xo = (double *)x0p;
+    return ms / 4;
+}
+
 static int chains_place(bhip_chains *ch, const double *x0, int skip)
 {
     bhip_ctx *ctx = ch->ctx;
@@ -1830,21 +1857,27 @@ static int chains_place(bhip_chains *ch, const double *x0, int skip)
     const size_t sp = place_stream_bytes(ch->wbytes, ch->xbytes);
     const float apart = PLACE.diff_min * ctx->r_same;
     int tests = 0;
+    const bool trace = getenv("BHIP_PLACE_TRACE") != nullptr;   // every two-stream run of the procedure to stderr (scripts/gpu_piece_map_probe.py)
+    if (trace) fprintf(stderr, "[bhip place] %ld chains, W %zu MiB, Xo %zu MiB, one-piece rate %.0f GB/s, apart from %.0f\n", ch->n, ch->wbytes >> 20, ch->xbytes >> 20, ctx->r_same, apart);
     auto judge = [&](void *wq, void *q) {
         char *we[2] = {(char *)wq, (char *)wq + (ch->wbytes - sp) / 4096 * 4096}, *qe[2] = {(char *)q, (char *)q + (ch->xbytes - sp) / 4096 * 4096};
         float score = 1e30f;
         for (int k = 0; k < 4; k++) {
             tests++;
-            score = std::min(score, two_stream_rate(ctx, we[k >> 1], qe[k & 1], sp));
-            if (score < apart) return Cand{wq, q, score, false};
+            const float r = two_stream_rate(ctx, we[k >> 1], qe[k & 1], sp);
+            if (trace) fprintf(stderr, "[bhip place]   W %p %s x Xo %p %s: %.0f GB/s (%.3f)\n", wq, k >> 1 ? "tail" : "head", q, k & 1 ? "tail" : "head", r, r / ctx->r_same);
+            score = std::min(score, r);
+            if (score < apart && !trace) return Cand{wq, q, score, false};
         }
-        return Cand{wq, q, score, true};
+        if (trace) fprintf(stderr, "[bhip place]   -> smallest %.3f, %.4f ms per iteration with this pair\n", score / ctx->r_same, place_trace_iteration_ms(ch, x0, skip, wq, q));
+        return Cand{wq, q, score, score >= apart};
     };
-    const int max_cands = (int)std::min<size_t>(24, std::max<size_t>((size_t)PLACE.max_candidates, PLACE.held_bytes / std::max<size_t>(ch->xbytes, 1)));
+    const int cands0 = (int)std::min<size_t>(24, std::max<size_t>((size_t)PLACE.max_candidates, PLACE.held_bytes / std::max<size_t>(ch->xbytes, 1)));
     std::vector<void *> ws{w}, xs{xo};
     Cand best{w, xo, 0.f, false};
     for (int attempt = 0; attempt < 3 && !best.good; attempt++) {
         void *wq = ws.back();
+        const int max_cands = cands0 + attempt * PLACE.more_candidates;   // (a W re-roll walks on: the allocator has not left W's piece yet)
         for (size_t k = 0; k < xs.size() && !best.good; k++) {
             const Cand c = judge(wq, xs[k]);
             if (c.good || c.score > best.score) best = c;

@@ -38,6 +38,17 @@ end
 check(ctx::Context, rc) = rc == 0 ? nothing :
     throw(BHIPError(rc, unsafe_string(ccall((:bhip_last_error, lib), Cstring, (Ptr{Cvoid},), ctx.h))))
 
+# bhip_ctx_set_option: the BHIP_OPT_* ids of include/bridgehip.h
+const OPT_WAVE_SPECIALISED, OPT_TUNE_PLACEMENT, OPT_MID_VALU, OPT_FUSED_ARITHMETIC, OPT_NOISE_SPEC = 1, 2, 3, 4, 5
+"""
+    set_option!(c::Context, option, value)
+
+e.g. `set_option!(c, OPT_NOISE_SPEC, 3)`: everything drawn afterwards on `c` uses the Box-Muller stream bhip-philox-v3 instead of the
+default bhip-philox-v4 (one normal per 32-bit Philox word through the inverse distribution function); 2: bhip-philox-v2.
+"""
+set_option!(c::Context, option::Integer, value::Integer) =
+    check(c, ccall((:bhip_ctx_set_option, lib), Cint, (Ptr{Cvoid}, Cint, Cint), c.h, option, value))
+
 const default_ctx = Ref{Union{Nothing,Context}}(nothing)
 function default_context()          # (not named `ctx`: a keyword default `ctx = ctx()` would refer to the keyword itself)
     default_ctx[] === nothing && (default_ctx[] = Context())
@@ -345,6 +356,18 @@ function iterations(ch::Chains)
     r = Ref{UInt32}(0)
     check(ch.ctx, ccall((:bhip_chains_iterations, lib), Cint, (Ptr{Cvoid}, Ref{UInt32}), ch.h, r))
     Int(r[])
+end
+"""
+    placement(ch::Chains) -> (tries, gbs_same_piece, gbs_kept, piece_w, piece_xo)
+
+What `BHIP_OPT_TUNE_PLACEMENT` did for a large ensemble (`bhip_chains_placement_info`, `bhip_chains_placement_pieces`): candidates tested,
+GB/s of two write streams into one piece of the device memory and into the kept (W, Xo) pair, the pieces of the context's map.
+"""
+function placement(ch::Chains)
+    n = Ref{Cint}(0); a = Ref{Cfloat}(0); b = Ref{Cfloat}(0); pw = Ref{Cint}(-1); px = Ref{Cint}(-1)
+    check(ch.ctx, ccall((:bhip_chains_placement_info, lib), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cfloat}, Ref{Cfloat}), ch.h, n, a, b))
+    check(ch.ctx, ccall((:bhip_chains_placement_pieces, lib), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}), ch.h, pw, px))
+    (tries = Int(n[]), gbs_same_piece = a[], gbs_kept = b[], piece_w = Int(pw[]), piece_xo = Int(px[]))
 end
 function stats_group!(chs::Vector{Chains}, stats_dev::Vector{Ptr{Cvoid}})
     hs = Ptr{Cvoid}[ch.h for ch in chs]
