@@ -1737,30 +1737,36 @@ extern "C" int bhip_chains_step(bhip_chains *ch, double rho, int iters, int skip
 // ms per pCN iteration on the ensemble's present allocations (one untimed iteration, then `reps`)
 // Placement of a large ensemble (BHIP_OPT_TUNE_PLACEMENT, default on): W and Xo -- two physically contiguous allocations,
 // chains_alloc_state -- have to lie in DIFFERENT 96-GiB pieces of the device memory (see above; profiles/r4_placement_regions.txt).
-// Nothing reports where an allocation lies, but piece membership is a property of a BUFFER that two plain write streams tell in
-// half a millisecond: into two buffers of one piece they run at ~4.7 TB/s, into buffers of different pieces at ~6.1.  Round 4 searched
-// per ensemble with the ensemble's own kernel (a same-piece reference block of |W| + |Xo|, kernel-timed pairs, up to 16 candidates
-// held: 23-60 ms and up to 67 GiB of transient memory per ensemble).  Since round 5 the CONTEXT keeps a piece map -- the large buffers
-// of its live ensembles with the piece each was found in -- and a new buffer is classified against one representative per piece:
-//   1. r_same, the two-stream rate inside one piece, is measured once per context (head against tail of W and of Xo, the smaller);
-//   2. the pair: head and tail of W against head and tail of Xo, four two-stream runs -- all "apart": done (tries = 1).  Otherwise
-//      further candidates for Xo are allocated while the earlier ones stay held (the allocator changes pieces every 4 to 8 blocks of
-//      this size at the latest: profiles/r4_alloc_sequence_raw.txt) until one passes;
-//   3. when every candidate fails, W itself may lie astride a cut: another W (twice at most), the held candidates judged again;
-//      everything not kept is freed at once;
+// Nothing reports where an allocation lies, but two plain write streams tell: into two buffers of one piece they run at ~4.4 TB/s,
+// into buffers of different pieces at ~5.3-6.5.  Round 4 searched per ensemble with the ensemble's own kernel (a same-piece reference
+// block of |W| + |Xo|, kernel-timed pairs, up to 16 candidates held: 23-60 ms and up to 67 GiB of transient memory per ensemble).
+// Since round 5 the CONTEXT keeps a piece map -- the large buffers of its live ensembles with the piece each was found in -- and a new
+// buffer is classified against one representative per piece:
+//   1. r_same, the two-stream rate inside one piece, is measured once per context: the MEDIAN of six runs inside W and inside Xo
+//      (head x tail, head x middle, middle x tail of each; runs too short for three regions: the mean of the two head x tail runs);
+//   2. the pair: head and tail of W against head and tail of Xo, four two-stream runs judged TOGETHER (place_apart): done (tries = 1).
+//      Otherwise further candidates for Xo are allocated while the earlier ones stay held (the allocator changes pieces every 4 to 8
+//      blocks of this size at the latest: profiles/r4_alloc_sequence_raw.txt) until one passes;
+//   3. when every candidate fails -- the allocator is still inside W's piece --, a spacer allocation and another W beyond it (twice at
+//      most, four more candidates each time), the held candidates judged again; everything not kept is freed at once;
 //   4. W and Xo of a good pair are classified against the map and entered.  No kernel-timed run, no reference block.
 // Results are those of an ensemble placed anywhere (the state of iteration 0 is set up afresh at the end; tests/test_gpu_pc.py).
 // Every threshold of the procedure:
 struct PlaceParams {
     size_t stream_bytes = (size_t)512 << 20;   // bytes per write stream of a test: beyond the 256-MB Infinity Cache
-    // Every 512-MiB test region lies in ONE piece (unless it straddles a cut itself), so a single two-stream run is bimodal -- the
-    // one-piece rate or the across-pieces rate -- and a run astride a cut shows as a LOW corner among the four of a pair, not as an
-    // intermediate value.  Measured over the rounds' boxes, relative to the context's own one-piece rate (4.1-4.5 TB/s): one piece
-    // 0.97-1.10, across pieces 1.19-1.55 (5.2-5.4 TB/s on the slow boxes of round 5, 5.9-6.7 on the others).  The cut between:
-    float same_max = 1.07f;     // rate <= same_max * r_same: the two regions share a piece (used for the map's labels only)
-    float diff_min = 1.13f;     // rate >= diff_min * r_same: they lie in different pieces (1.20 rejected good pairs on a box whose across-rate is 1.19)
+    // ONE two-stream run does not separate the classes: the rate also depends on where in their runs the two regions lie (0.77-1.27 x
+    // r_same for regions of one piece, 1.07-1.66 across pieces).  The MEAN of the four runs of a pair does.  Ground truth: 81 pairs at the
+    // headline size, five processes, each with its pCN iteration timed as well (BHIP_PLACE_TRACE; profiles/r5_piece_map.txt) -- the 47
+    // slow pairs (1.61-1.68 ms) have mean-of-four 0.92-1.107 x r_same, the 34 fast ones (1.39-1.45 under that short warm-up)
+    // 1.171-1.39.  Against the SMALLER of two head x tail runs as r_same (the round's first version) the classes touched (slow up to
+    // 1.19, fast from 1.18): one low run moved every ratio of the process.  The smallest of the four overlaps (fast pairs from 1.07,
+    // slow ones up to 1.08): it only guards against a run astride a cut (two of its four corners in W's piece: ~1.0).
+    float mean_min = 1.14f;        // mean of the four >= mean_min * r_same ...
+    float smallest_min = 1.03f;    // ... and every one of them >= smallest_min * r_same: the two buffers lie in different pieces
+    float same_mean_max = 1.11f;   // mean of the four <= this x r_same: they share a piece (the map's labels); between: not attributed
     int max_candidates = 8;     // Xo candidates held at once at most (never more than 8 consecutive 4-GiB blocks of one piece were seen) ...
     int more_candidates = 4;    // ... and this many more after each of the two W re-rolls
+    size_t spacer_bytes = (size_t)24 << 30;   // held (unwritten) before each W re-roll when the free memory allows: 8 x 4 + 24 + 4 x 4 + 24 + ... GiB walk past a 96-GiB piece
     size_t held_bytes = (size_t)24 << 30;   // ... or, for smaller buffers (the allocator's runs inside one piece are longer in blocks), as many as fit here, 24 at most
     size_t min_bytes = (size_t)64 << 20;   // buffers below this are not classified (a test needs streams of some length)
 };
@@ -1788,10 +1794,32 @@ static size_t place_stream_bytes(size_t a_bytes, size_t b_bytes)
 {
     return std::min<size_t>({a_bytes, b_bytes, PLACE.stream_bytes}) / 4096 * 4096;
 }
+// The four two-stream runs of a pair of buffers -- head and tail of a against head and tail of b -- : the smallest rate and the mean.
+// With stop_below > 0 the runs end at the first rate below it (the pair has failed by then; *mean is that of the runs made).
+struct PairRates { float smallest, mean; int runs; };
+static PairRates place_pair_rates(bhip_ctx *ctx, void *a, size_t abytes, void *b, size_t bbytes, float stop_below, bool trace)
+{
+    const size_t sp = place_stream_bytes(abytes, bbytes);
+    char *ae[2] = {(char *)a, (char *)a + (abytes - sp) / 4096 * 4096}, *be[2] = {(char *)b, (char *)b + (bbytes - sp) / 4096 * 4096};
+    PairRates pr{1e30f, 0.f, 0};
+    for (int k = 0; k < 4; k++) {
+        const float r = two_stream_rate(ctx, ae[k >> 1], be[k & 1], sp);
+        if (trace) fprintf(stderr, "[bhip place]   %p %s x %p %s: %.0f GB/s (%.3f)\n", a, k >> 1 ? "tail" : "head", b, k & 1 ? "tail" : "head", r, r / ctx->r_same);
+        pr.smallest = std::min(pr.smallest, r); pr.mean += r; pr.runs++;
+        if (pr.smallest < stop_below) break;
+    }
+    pr.mean /= (float)pr.runs;
+    return pr;
+}
+static bool place_apart(const bhip_ctx *ctx, const PairRates &pr)
+{
+    return pr.runs == 4 && pr.smallest >= PLACE.smallest_min * ctx->r_same && pr.mean >= PLACE.mean_min * ctx->r_same;
+}
 // the piece of [ptr, ptr + bytes) by the context's map: the id of the representative it shares a piece with; a NEW id (the smallest
 // unused one, *is_new set) when it lies apart from every piece the map knows; -1 when the tests are inconclusive (a buffer astride
-// a cut, a plain allocation mixed from several pieces) or the map is empty.  The contents of the tested ranges are overwritten.
-static int place_classify(bhip_ctx *ctx, void *ptr, size_t bytes, bool *is_new)
+// a cut, a plain allocation mixed from several pieces) or the map is empty.  apart_piece: a piece the buffer is already known to lie
+// apart from (the W of its own pair), not tested again.  The contents of the tested ranges are overwritten.
+static int place_classify(bhip_ctx *ctx, void *ptr, size_t bytes, bool *is_new, int apart_piece = -1)
 {
     if (is_new) *is_new = false;
     if (!(ctx->r_same > 0.f) || bytes < PLACE.min_bytes) return -1;
@@ -1800,10 +1828,11 @@ static int place_classify(bhip_ctx *ctx, void *ptr, size_t bytes, bool *is_new)
     for (const bhip_ctx::PieceEnt &e : ctx->pieces) {
         if (e.piece < 0 || e.piece > 2 || seen[e.piece] || e.p == ptr || e.bytes < PLACE.min_bytes) continue;
         seen[e.piece] = true; known++;
-        const float r = two_stream_rate(ctx, e.p, ptr, place_stream_bytes(e.bytes, bytes));
-        if (!(r > 0.f)) return -1;
-        if (r <= PLACE.same_max * ctx->r_same) return e.piece;
-        if (r < PLACE.diff_min * ctx->r_same) all_apart = false;
+        if (e.piece == apart_piece) continue;
+        const PairRates pr = place_pair_rates(ctx, e.p, e.bytes, ptr, bytes, 0.f, false);
+        if (!(pr.smallest > 0.f)) return -1;
+        if (pr.mean <= PLACE.same_mean_max * ctx->r_same) return e.piece;
+        if (!place_apart(ctx, pr)) all_apart = false;
     }
     if (!known || !all_apart || known >= 3) return -1;
     for (int k = 0; k < 3; k++)
@@ -1839,41 +1868,39 @@ static int chains_place(bhip_chains *ch, const double *x0, int skip)
     void *w = ch->arena.base, *xo = ch->arena.base2;
     const size_t sb = place_stream_bytes(ch->wbytes / 2, ch->xbytes / 2);
     if (sb < PLACE.min_bytes / 2) return BHIP_OK;
-    // 1. the rate inside one piece, once per context: head against tail of W and of Xo, the smaller (a run astride a cut reads high)
+    // 1. the rate inside one piece, once per context: the median of six runs inside W and inside Xo
+    const bool trace = getenv("BHIP_PLACE_TRACE") != nullptr;   // every two-stream run of the procedure to stderr (scripts/gpu_piece_map_probe.py)
     if (!(ctx->r_same > 0.f)) {
-        const float ra = two_stream_rate(ctx, w, (char *)w + (ch->wbytes - sb) / 4096 * 4096, sb);
-        const float rb = two_stream_rate(ctx, xo, (char *)xo + (ch->xbytes - sb) / 4096 * 4096, sb);
-        ctx->r_same = ra > 0.f && rb > 0.f ? std::min(ra, rb) : std::max(ra, rb);
-        if (!(ctx->r_same > 0.f)) return chains_init_impl(ch, x0, nullptr, 0, skip, 0u);   // no measurement: the pair stays as it is
+        std::vector<float> rr;
+        for (int b = 0; b < 2; b++) {
+            char *p = (char *)(b ? xo : w);
+            const size_t nb = b ? ch->xbytes : ch->wbytes, mid = (nb - sb) / 2 / 4096 * 4096, tail = (nb - sb) / 4096 * 4096;
+            rr.push_back(two_stream_rate(ctx, p, p + tail, sb));
+            if (nb >= 3 * sb) { rr.push_back(two_stream_rate(ctx, p, p + mid, sb)); rr.push_back(two_stream_rate(ctx, p + mid, p + tail, sb)); }
+        }
+        if (trace) { fprintf(stderr, "[bhip place] one-piece runs:"); for (float r : rr) fprintf(stderr, " %.0f", r); fprintf(stderr, " GB/s\n"); }
+        rr.erase(std::remove_if(rr.begin(), rr.end(), [](float r) { return !(r > 0.f); }), rr.end());
+        if (rr.empty()) return chains_init_impl(ch, x0, nullptr, 0, skip, 0u);   // no measurement: the pair stays as it is
+        std::sort(rr.begin(), rr.end());
+        ctx->r_same = 0.5f * (rr[(rr.size() - 1) / 2] + rr[rr.size() / 2]);
     }
     auto can_alloc = [&](size_t bytes) { size_t f = 0, t = 0; return hipMemGetInfo(&f, &t) == hipSuccess && f >= 2 * bytes; };
     // 2./3. candidates for Xo.  A contiguous run straddles at most one cut, so its head and its tail tell where ALL of it lies: a pair is
-    //    good when head and tail of W against head and tail of the candidate -- four two-stream runs, the later ones only if the
-    //    earlier passed -- all read "apart".  (Head against head alone let a run astride a cut through on the round-5 profile box:
-    //    1.25 x the one-piece rate at the heads, 1.65 ms per iteration where 1.39 was due.)  Score = the smallest rate seen.  When every
-    //    candidate fails against this W, W itself may be the run astride a cut: another W is allocated (twice at most) and the
-    //    candidates -- still held -- are judged against it.  Without a good pair the best-scoring one is kept.
+    //    good when the four two-stream runs -- head and tail of W against head and tail of the candidate -- pass place_apart (the runs end
+    //    at the first one at the one-piece rate).  (Head against head alone is no test: pairs of ONE piece read up to 1.27 x the one-piece
+    //    rate there -- 1.65 ms per iteration on the round-5 profile box where 1.39 was due.)  Score = the mean of the four.  When every
+    //    candidate fails against this W another W is allocated (twice at most) and the candidates -- still held -- are judged against
+    //    it.  Without a good pair the best-scoring one is kept.
     struct Cand { void *w, *x; float score; bool good; };
-    const size_t sp = place_stream_bytes(ch->wbytes, ch->xbytes);
-    const float apart = PLACE.diff_min * ctx->r_same;
-    int tests = 0;
-    const bool trace = getenv("BHIP_PLACE_TRACE") != nullptr;   // every two-stream run of the procedure to stderr (scripts/gpu_piece_map_probe.py)
-    if (trace) fprintf(stderr, "[bhip place] %ld chains, W %zu MiB, Xo %zu MiB, one-piece rate %.0f GB/s, apart from %.0f\n", ch->n, ch->wbytes >> 20, ch->xbytes >> 20, ctx->r_same, apart);
+    const float floor_rate = PLACE.smallest_min * ctx->r_same;
+    if (trace) fprintf(stderr, "[bhip place] %ld chains, W %zu MiB, Xo %zu MiB, one-piece rate %.0f GB/s\n", ch->n, ch->wbytes >> 20, ch->xbytes >> 20, ctx->r_same);
     auto judge = [&](void *wq, void *q) {
-        char *we[2] = {(char *)wq, (char *)wq + (ch->wbytes - sp) / 4096 * 4096}, *qe[2] = {(char *)q, (char *)q + (ch->xbytes - sp) / 4096 * 4096};
-        float score = 1e30f;
-        for (int k = 0; k < 4; k++) {
-            tests++;
-            const float r = two_stream_rate(ctx, we[k >> 1], qe[k & 1], sp);
-            if (trace) fprintf(stderr, "[bhip place]   W %p %s x Xo %p %s: %.0f GB/s (%.3f)\n", wq, k >> 1 ? "tail" : "head", q, k & 1 ? "tail" : "head", r, r / ctx->r_same);
-            score = std::min(score, r);
-            if (score < apart && !trace) return Cand{wq, q, score, false};
-        }
-        if (trace) fprintf(stderr, "[bhip place]   -> smallest %.3f, %.4f ms per iteration with this pair\n", score / ctx->r_same, place_trace_iteration_ms(ch, x0, skip, wq, q));
-        return Cand{wq, q, score, score >= apart};
+        const PairRates pr = place_pair_rates(ctx, wq, ch->wbytes, q, ch->xbytes, trace ? 0.f : floor_rate, trace);
+        if (trace) fprintf(stderr, "[bhip place]   -> smallest %.3f, mean %.3f, %.4f ms per iteration with this pair\n", pr.smallest / ctx->r_same, pr.mean / ctx->r_same, place_trace_iteration_ms(ch, x0, skip, wq, q));
+        return Cand{wq, q, pr.runs == 4 ? pr.mean : std::min(pr.mean, pr.smallest), place_apart(ctx, pr)};   // (a pair judged on all four runs outranks one that fell at a corner)
     };
     const int cands0 = (int)std::min<size_t>(24, std::max<size_t>((size_t)PLACE.max_candidates, PLACE.held_bytes / std::max<size_t>(ch->xbytes, 1)));
-    std::vector<void *> ws{w}, xs{xo};
+    std::vector<void *> ws{w}, xs{xo}, spacers;
     Cand best{w, xo, 0.f, false};
     for (int attempt = 0; attempt < 3 && !best.good; attempt++) {
         void *wq = ws.back();
@@ -1890,11 +1917,17 @@ static int chains_place(bhip_chains *ch, const double *x0, int skip)
             if (c.good || c.score > best.score) best = c;
         }
         if (best.good || attempt == 2 || !can_alloc(ch->wbytes)) break;
+        // every candidate so far shares W's piece: the allocator is walking through it (up to 96 GiB).  A spacer -- a plain allocation,
+        // never written, freed below -- takes the next stretch of that walk in one step, so that the next W lies beyond it
         void *q = nullptr;
+        if (can_alloc(PLACE.spacer_bytes + ch->wbytes) && hipMalloc(&q, PLACE.spacer_bytes) == hipSuccess) spacers.push_back(q);
+        else (void)hipGetLastError();
+        q = nullptr;
         if (alloc_run(&q, ch->wbytes) != hipSuccess) { (void)hipGetLastError(); break; }
         ws.push_back(q);
     }
     (void)hipStreamSynchronize(ctx->stream);
+    for (void *q : spacers) (void)hipFree(q);
     for (void *q : xs) if (q != best.x) (void)hipFree(q);
     for (void *q : ws) if (q != best.w) (void)hipFree(q);
     w = best.w; xo = best.x;
@@ -1907,12 +1940,11 @@ static int chains_place(bhip_chains *ch, const double *x0, int skip)
         pw = ctx->pieces.empty() ? 0 : place_classify(ctx, w, ch->wbytes, &fresh);
         if (pw >= 0) {
             ctx->pieces.push_back(bhip_ctx::PieceEnt{w, ch->wbytes, pw});   // (so that Xo is not given W's id as a new one)
-            px = place_classify(ctx, xo, ch->xbytes, &fresh);
+            px = place_classify(ctx, xo, ch->xbytes, &fresh, pw);
             if (px >= 0) ctx->pieces.push_back(bhip_ctx::PieceEnt{xo, ch->xbytes, px});
         }
     }
     ch->place_tries = (int)(xs.size() + ws.size() - 1); ch->place_ms_first = ctx->r_same; ch->place_ms_best = best.score;
-    (void)tests;
     ch->piece_w = pw; ch->piece_xo = px;
     return chains_init_impl(ch, x0, nullptr, 0, skip, 0u);   // the state of iteration 0: the write streams went over W and Xo
 }

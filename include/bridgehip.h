@@ -308,7 +308,8 @@ void bhip_chains_destroy(bhip_chains *ch);
 int bhip_chains_init(bhip_chains *ch, const double *x0, int skip);
 /* what BHIP_OPT_TUNE_PLACEMENT did for this ensemble: allocations of Xo that were tested against W (0: not placed; 1: the pair the
  * ensemble was created with already lay in different pieces), GB/s of two write streams into ONE piece (the context's reference,
- * measured once) and into the (W, Xo) pair that was kept; and the pieces (ids 0..2 of the context's map, -1: astride a cut or not
+ * measured once: a median of six runs) and into the (W, Xo) pair that was kept (the mean of four runs: head and tail of W against
+ * head and tail of Xo; a kept pair counts as apart from 1.14 x the reference); and the pieces (ids 0..2 of the context's map, -1: astride a cut or not
  * placed) W and Xo were found in.  The reference has no counterpart (memory placement is not its concern). */
 int bhip_chains_placement_info(const bhip_chains *ch, int *tries, float *gbs_same_piece, float *gbs_kept);
 int bhip_chains_placement_pieces(const bhip_chains *ch, int *piece_w, int *piece_xo);

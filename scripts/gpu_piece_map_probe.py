@@ -8,7 +8,7 @@ import bridgehip as bh
 import problems
 
 case = [c for c in problems.cases(1001) if c.name == "fhn_partialbridge_extreme"][0]
-for n in (65536, 262144):
+for n in ([int(a) for a in sys.argv[1:]] or [65536, 262144]):
     ctx = bh.Context(0)
     Po = case.bh_proposal(bh, ctx)
     ens = []
