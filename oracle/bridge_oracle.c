@@ -1573,6 +1573,17 @@ void bo_chol_lower(int n, const double *A, double *C)
         C[0] = a; C[1] = b; C[3] = sqrt(A[3] - b * b);
         return;
     }
+    if (n > 3) {
+        /* n > 3 (StaticArrays' unrolled factorisation of the upper triangle, column by column): U[r,c] = (A[r,c] - sum_{i<r} U[i,r] U[i,c]) / U[r,r];
+           C = U' -- compared at the large-d tolerance only (the closed forms below are the bit-exact ones) */
+        for (int c = 0; c < n; c++)
+            for (int r = 0; r <= c; r++) {
+                double e = A[r + n * c];
+                for (int i = 0; i < r; i++) e -= C[r + n * i] * C[c + n * i];   /* U[i,r] = C[r,i] */
+                C[c + n * r] = r == c ? sqrt(e) : e / C[r + n * r];
+            }
+        return;
+    }
     double a11 = sqrt(A[0]), a12 = A[3] / a11, a22 = sqrt(A[4] - a12 * a12);
     double a13 = A[6] / a11, a23 = (A[7] - a12 * a13) / a22, a33 = sqrt(A[8] - a13 * a13 - a23 * a23);
     C[0] = a11; C[1] = a12; C[2] = a13; C[4] = a22; C[5] = a23; C[8] = a33;

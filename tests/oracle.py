@@ -527,7 +527,8 @@ def smooth_mcmc(props, mu, chol, w_old, w_new, seed, path, skip=0, stats=False):
 
 
 def chol_lower(A):
-    """cholupper(Hermitian(A))' -- the lower factor from A's upper triangle (StaticArrays closed forms, n <= 3)"""
+    """cholupper(Hermitian(A))' -- the lower factor from A's upper triangle (StaticArrays closed forms at n <= 3, the column-by-column
+    factorisation above)"""
     A = np.atleast_2d(np.asarray(A, dtype=np.float64))
     n = A.shape[0]
     a = np.ascontiguousarray(cm(A))

@@ -461,6 +461,67 @@ def test_joint_mh_over_segments_at_large_dimension(ctx, d):
         assert np.array_equal(Xa[:, -1, :], Xb[:, 0, :])
 
 
+@pytest.mark.parametrize("d", [5, 16])
+def test_adaptive_loop_with_shared_guides_above_three_dimensions(ctx, d):
+    """The adaptation block of supplements/smoothing/smoothing.jl:130-160 at d > 3 (the shared-guide half): LinearAppr
+    auxiliaries by grid index over a LinPro target (src/linpro.jl:181-204) on the path-per-lane kernels (d = 5) and the tile kernel
+    (d = 16); every `adaptit` iterations the segments are re-linearised around running means (SegChains.adapt: host-built guides handed
+    over with bhip_segchains_set_proposals), pi0 replaced, newblock / doaccept as in the script.  For a linear target the linearisation
+    does not depend on the point, so the ensemble's shared guides are every chain's own and the run is bo_smooth_adaptive's chain by
+    chain: Wiener paths bit for bit, paths 1e-9, starts, running means, counts; the guides the adaptation built == the oracle's.
+    (Per-chain device-built guides stay at d <= 3: bhip_segchains_adapt_device.)"""
+    rng = np.random.default_rng(3)
+    m, M, n = 3, 24, 70
+    G = rng.standard_normal((d, d)) / np.sqrt(d)
+    B, sig, mu_t = -0.8 * np.eye(d) + 0.3 * G, 0.5 * np.eye(d), 0.2 * rng.standard_normal(d)
+    P = bh.LinPro(B, mu_t, sig)
+    par = o.linpro_par(B, mu_t, sig)
+    mo = 2
+    L = np.zeros((mo, d)); L[0, 0] = L[1, 2] = 1.0                     # two components observed
+    Sig = 0.2 * np.eye(mo)
+    tgrid = np.linspace(0.0, 0.15 * m, m * M + 1)
+    obs = 0.5 * rng.standard_normal((m + 1, mo))
+    HT, vT = bh.gpupdate(1e3 * np.eye(d), np.zeros(d), L, Sig, obs[m])
+    tts = np.stack([tgrid[i * M:(i + 1) * M + 1] for i in range(m)])
+    Y0 = 0.3 * np.sin(np.arange(m * (M + 1) * d).reshape(m, M + 1, d) * 0.37)      # any first linearisation paths
+    H, v, segs = HT, vT, [None] * m
+    for i in range(m - 1, -1, -1):
+        segs[i] = bh.GuidedBridge(tts[i].copy(), P, bh.linearappr(Y0[i]), v, H, ctx=ctx)
+        H, v = bh.gpupdate(segs[i], L, Sig, obs[i])
+    chol = o.chol_lower(H)
+    adaptit, iters = 4, 10
+    w_new = np.sqrt(np.full(iters, 0.2)); w_old = np.sqrt(1 - w_new ** 2)
+    sc = bh.SegChains(segs, v, chol, n, seed=31, mcnext_mean_only=True)
+    sc.step(w_old[:adaptit - 1], w_new[:adaptit - 1])
+    means = [sc.mcstats(i, 11)[0] for i in range(m)]                    # (any chain's means: the linearisation of a linear target is the target)
+    mu1, H1 = sc.adapt(P, L, Sig, obs[:m], HT, vT, means=means, newblock=True, doaccept=True)
+    sc.step(w_old[adaptit - 1:2 * adaptit - 1], w_new[adaptit - 1:2 * adaptit - 1])
+    means = [sc.mcstats(i, 11)[0] for i in range(m)]
+    sc.adapt(P, L, Sig, obs[:m], HT, vT, means=means, newblock=True, doaccept=False)
+    sc.step(w_old[2 * adaptit - 1:], w_new[2 * adaptit - 1:])
+    ll, acc, y0 = sc.state()
+    r1 = o.smooth_adaptive(o.MODEL_LINPRO, d, d, par, tts, Y0, L, Sig, obs[:m], HT, vT, w_old[:adaptit], w_new[:adaptit], adaptit, 10 ** 6, 31, 11)
+    assert np.abs(mu1 - r1["mu"]).max() <= 1e-11 * (1 + np.abs(r1["mu"]).max()) and np.abs(H1 - r1["H"]).max() <= 1e-11 * (1 + np.abs(r1["H"]).max())
+    for i in range(m):
+        assert np.abs(sc.pos[i].Hd - r1["Hd"][i]).max() <= 1e-11 * (1 + np.abs(r1["Hd"][i]).max())
+        assert np.abs(sc.pos[i].V - r1["V"][i]).max() <= 1e-11 * (1 + np.abs(r1["V"][i]).max())
+    for p in (0, 11, 63, 64, n - 1):
+        r = o.smooth_adaptive(o.MODEL_LINPRO, d, d, par, tts, Y0, L, Sig, obs[:m], HT, vT, w_old, w_new, adaptit, 10 ** 6, 31, p)
+        assert acc[p] == r["acc"], (p, acc[p], r["acc"])
+        assert np.abs(y0[p] - r["y0"]).max() <= 1e-10 * (1 + np.abs(r["y0"]).max())
+        for i in range(m):
+            X, W = sc.paths(i, p, 1)
+            assert np.array_equal(W[0], r["W"][i]) or np.abs(W[0] - r["W"][i]).max() <= 1e-14 * (1 + np.abs(r["W"][i]).max())
+            assert np.abs(X[0] - r["X"][i]).max() <= 1e-9 * (1 + np.abs(r["X"][i]).max()), (p, i)
+            assert abs(ll[i, p] - r["ll"][i]) <= 1e-8 * (1 + abs(r["ll"][i]))
+            mean, _, cnt = sc.mcstats(i, p)
+            assert cnt == iters and np.abs(mean - r["mean"][i]).max() <= 1e-9 * (1 + np.abs(r["mean"][i]).max())
+    for i in range(m - 1):                                                # continuity at the joints
+        Xa, _ = sc.paths(i, 0, n)
+        Xb, _ = sc.paths(i + 1, 0, n)
+        assert np.array_equal(Xa[:, -1, :], Xb[:, 0, :])
+
+
 def test_large_segments_are_placed_and_results_do_not_depend_on_it(ctx):
     """Segments of 1 GiB or more keep W and Xo in two contiguous allocations (bhip_api.hip chains_alloc_state); bhip_segchains_init
     places every such pair (different 96-GiB pieces of the device memory, measured: chains_place) before the ensemble's state is set

@@ -660,7 +660,7 @@ def test_adaptive_smoother_without_adaptation_equals_the_plain_smoother_and_chol
     """bo_smooth_adaptive (smoothing.jl:75-213) with adaptation switched off must be bo_smooth_mcmc over the proposals it
     builds itself from the first linearisation paths; bo_chol_lower is a Cholesky factor of the Hermitian(upper) matrix."""
     rng = np.random.default_rng(0)
-    for n in (1, 2, 3):
+    for n in (1, 2, 3, 4, 5, 16):                                              # (n > 3: the column-by-column factorisation, round 5)
         A = rng.standard_normal((n, n)); A = A @ A.T + n * np.eye(n)
         Au = np.triu(A) + 0.1 * np.tril(rng.standard_normal((n, n)), -1)       # garbage below the diagonal must be ignored
         C = o.chol_lower(Au)
