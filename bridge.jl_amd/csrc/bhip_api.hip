@@ -223,7 +223,7 @@ struct bhip_chains {
     // placement (bhip_chains_init): Xo allocations classified, GB/s of two write streams into one piece and into the kept (W, Xo) pair,
     // the pieces W and Xo were found in (-1: astride a cut / not placed)
     int place_tries = 0;
-    float place_ms_first = 0.f, place_ms_best = 0.f;
+    float place_gbs_same = 0.f, place_gbs_kept = 0.f;
     int piece_w = -1, piece_xo = -1;
     int skip0 = 0;
     unsigned char *cur = nullptr;
@@ -1944,7 +1944,7 @@ static int chains_place(bhip_chains *ch, const double *x0, int skip)
             if (px >= 0) ctx->pieces.push_back(bhip_ctx::PieceEnt{xo, ch->xbytes, px});
         }
     }
-    ch->place_tries = (int)(xs.size() + ws.size() - 1); ch->place_ms_first = ctx->r_same; ch->place_ms_best = best.score;
+    ch->place_tries = (int)(xs.size() + ws.size() - 1); ch->place_gbs_same = ctx->r_same; ch->place_gbs_kept = best.score;
     ch->piece_w = pw; ch->piece_xo = px;
     return chains_init_impl(ch, x0, nullptr, 0, skip, 0u);   // the state of iteration 0: the write streams went over W and Xo
 }
@@ -1961,8 +1961,8 @@ int bhip_chains_placement_info(const bhip_chains *ch, int *tries, float *gbs_sam
 {
     if (!ch) return BHIP_EINVAL;
     if (tries) *tries = ch->place_tries;
-    if (gbs_same_piece) *gbs_same_piece = ch->place_ms_first;
-    if (gbs_kept) *gbs_kept = ch->place_ms_best;
+    if (gbs_same_piece) *gbs_same_piece = ch->place_gbs_same;
+    if (gbs_kept) *gbs_kept = ch->place_gbs_kept;
     return BHIP_OK;
 }
 

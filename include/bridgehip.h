@@ -395,7 +395,7 @@ int bhip_segchains_step(bhip_segchains *sc, const double *w_old, const double *w
 /* bhip_chains_placement_info of segment `segment` (large segments whose proposals go to plain path buffers -- d > 3 or pooled
  * statistics -- are placed at bhip_segchains_init: BHIP_OPT_TUNE_PLACEMENT; with d <= 3 and no pooled statistics the paths live
  * in a ring of time-blocked buffers and nothing is placed: tries = 0) */
-int bhip_segchains_placement_info(const bhip_segchains *sc, int segment, int *tries, float *ms_first, float *ms_best);
+int bhip_segchains_placement_info(const bhip_segchains *sc, int segment, int *tries, float *gbs_same_piece, float *gbs_kept);
 /* how the ensemble keeps its mcnext! statistics (supplements/smoothing/smoothing.jl:211-213 updates them every iteration): *every = K,
  * the number of iterations one statistics pass covers (1: a pass per iteration) -- with d <= 3 and BHIP_SEGCHAINS_MCNEXT[_MEAN] the
  * segments' paths live in a ring of *buffers = K + L path buffers, the K current paths of a batch stay where they are until ONE pass has
