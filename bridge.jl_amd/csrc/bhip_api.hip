@@ -1799,7 +1799,7 @@ static size_t place_stream_bytes(size_t a_bytes, size_t b_bytes)
 struct PairRates { float smallest, mean; int runs; };
 static PairRates place_pair_rates(bhip_ctx *ctx, void *a, size_t abytes, void *b, size_t bbytes, float stop_below, bool trace)
 {
-    const size_t sp = place_stream_bytes(abytes, bbytes);
+    const size_t sp = place_stream_bytes(abytes / 2, bbytes / 2);   // (the size r_same was measured with: two disjoint regions of one run)
     char *ae[2] = {(char *)a, (char *)a + (abytes - sp) / 4096 * 4096}, *be[2] = {(char *)b, (char *)b + (bbytes - sp) / 4096 * 4096};
     PairRates pr{1e30f, 0.f, 0};
     for (int k = 0; k < 4; k++) {
