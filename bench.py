@@ -339,6 +339,9 @@ class Workload:
             mode = mode[:-len("_fused")]
             ctx = bh.Context(ctx.device.index)
             ctx.set_option(bh.OPT_FUSED_ARITHMETIC, 1)
+        self.parts = 0
+        if mode.endswith("_parts"):   # fresh proposals with X kept in two buffers lying in different pieces of the device memory (bhip_sample_solve_parts)
+            mode, self.parts = mode[:-len("_parts")], 2
         self.v2noise = 0
         for spec in (2, 3):   # the same workload under an earlier noise specification, bhip-philox-v2 / -v3 (BHIP_OPT_NOISE_SPEC = 2 / 3)
             if mode.endswith(f"_v{spec}noise"):
@@ -353,7 +356,9 @@ class Workload:
         self.Po = build(ctx)
         self.workload = text + (" [BHIP_OPT_FUSED_ARITHMETIC: tolerance parity 1e-9 / 1e-8]" if self.fused else "") + \
             (" [BHIP_OPT_NOISE_SPEC = 2: bhip-philox-v2, one Box-Muller pair of 53 + 53 bits per Philox call]" if self.v2noise == 2 else
-             " [BHIP_OPT_NOISE_SPEC = 3: bhip-philox-v3, two Box-Muller pairs of 40 + 24 bits per Philox call]" if self.v2noise == 3 else "")
+             " [BHIP_OPT_NOISE_SPEC = 3: bhip-philox-v3, two Box-Muller pairs of 40 + 24 bits per Philox call]" if self.v2noise == 3 else "") + \
+            (" [X kept in two buffers of half the paths each, in different 96-GiB pieces of the device memory: bhip_alloc_apart + bhip_sample_solve_parts, "
+             "one launch, the same values]" if self.parts else "")
         self.kernel = kname(self.P).replace("bhip::", "bhip_fused::") if self.fused else kname(self.P)
         if self.v2noise:   # large ensembles under v3 / v2: one pair per workgroup (bhip_pc_kernel.h launch_pc)
             self.kernel = self.kernel.replace("4, false, false>", "1, false, false>")
@@ -370,10 +375,20 @@ class Workload:
 
     def _fresh(self, d, x0, seed):
         ctx, P = self.ctx, self.P
-        self.X = bh.EnsemblePath(self.Po.tt, d, P, ctx)
         self.ll = ctx.empty(P)
         self.it = 0
         self.x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        if self.parts:
+            self.X = X = bh.EnsembleParts(self.Po.tt, d, P, self.parts, ctx)
+            self.parts_apart = X.apart
+
+            def step_parts():
+                self.it += 1
+                ctx.check(ctx.lib.bhip_sample_solve_parts(ctx.h, self.Po.h, bh.api._dptr(self.x0), X.nparts, X._ptrs, X.part_paths, X.part_paths,
+                                                          bh.api.vp(self.ll.data_ptr()), 0, P, seed, self.it, self.path0))
+            self.step = step_parts
+            return
+        self.X = bh.EnsemblePath(self.Po.tt, d, P, ctx)
 
         def step():
             self.it += 1
@@ -937,12 +952,15 @@ def main_local(args):
         others = []
         del w, ws
         torch.cuda.empty_cache()
-        for mode in ("c4shard", "c2", "proposals", "nclar", "nclar_mcmc", "linpro4", "linpro32", "linpro32_mcmc", "c2_fused", "proposals_fused", "nclar_fused",
+        for mode in ("c4shard", "c2", "proposals", "nclar", "nclar_mcmc", "linpro4", "linpro32", "linpro32_mcmc", "c2_fused", "proposals_fused", "nclar_fused", "proposals_parts",
                      "mcmc_v3noise", "proposals_v3noise", "c2_v3noise", "mcmc_v2noise", "proposals_v2noise", "c2_v2noise"):
             wo = Workload(mode, ctx, 0, 0)
             ms = kernel_times(wo, args.steps, args.warmup, min_ms=100.0)
             others.append({"mode": mode, "workload": wo.workload, "paths": wo.P,
                            "path_steps_per_s": wo.P * steps_per_unit / (float(np.mean(ms)) * 1e-3), "roofline": wo.roofline(ms)})
+            if wo.parts:
+                others[-1]["parts"] = {"n": wo.parts, "pairwise_apart": wo.parts_apart}
+                wo.X.free()
             del wo
             torch.cuda.empty_cache()
             if mode in ("c4shard", "c2", "proposals") and not args.no_live_traffic:
@@ -1036,7 +1054,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chains", type=int, default=0, help="chains (paths) per GPU; 0 = the mode's named size")
-    ap.add_argument("--mode", choices=sorted(MODES) + sorted(m + "_fused" for m in MODES if MODES[m][1] <= 3) + sorted(m + "_v2noise" for m in MODES) + sorted(m + "_v3noise" for m in MODES),
+    ap.add_argument("--mode", choices=sorted(MODES) + sorted(m + "_fused" for m in MODES if MODES[m][1] <= 3) + sorted(m + "_v2noise" for m in MODES) + sorted(m + "_v3noise" for m in MODES) + sorted(m + "_parts" for m in MODES if not MODES[m][5] and MODES[m][1] <= 12),
                     default="mcmc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true")

@@ -826,6 +826,77 @@ def sample_solve(u, Po, npaths, seed=0, iter=0, path0=0, store_W=False, store_X=
     return X, W, ll
 
 
+class _PartPath(EnsemblePath):
+    """one part of an EnsembleParts: an ensemble [N, dim, ld] in a library allocation (no tensor behind it)"""
+
+    def __init__(self, tt, dim, npaths, ld, ptr, ctx):
+        self.ctx, self.tt, self.dim, self.npaths = ctx, tt, int(dim), int(npaths)
+        self._ld, self._ptr, self.data = int(ld), ptr, None
+
+    @property
+    def ld(self):
+        return self._ld
+
+    def ptr(self):
+        return vp(self._ptr)
+
+    def copy(self):
+        raise BridgeError("a part of an EnsembleParts is a view of the library's allocation")
+
+
+class EnsembleParts:
+    """An ensemble kept in nparts (1..3) buffers that lie in DIFFERENT pieces of the device memory (bhip_alloc_apart): paths
+    [j*part_paths, (j+1)*part_paths) are part j, an EnsemblePath [N, dim, part_paths] like any other.  Written by sample_solve_parts in one
+    launch -- three write streams in three pieces move 6.8-6.9 TB/s where the one stream of a single buffer moves 4.3-4.4
+    (profiles/r5_three_pieces.txt)."""
+
+    def __init__(self, tt, dim, npaths, nparts=3, ctx=None):
+        self.ctx = ctx or default_context()
+        self.tt = np.array(tt, dtype=np.float64)
+        self.dim, self.npaths, self.nparts = int(dim), int(npaths), int(nparts)
+        self.part_paths = ((self.npaths + self.nparts - 1) // self.nparts + 63) // 64 * 64
+        self._ptrs = (vp * self.nparts)()
+        apart = C.c_int()
+        self.ctx.check(self.ctx.lib.bhip_alloc_apart(self.ctx.h, self.nparts, len(self.tt) * self.dim * self.part_paths * 8, self._ptrs, C.byref(apart)))
+        self.apart = apart.value
+        self.parts = [_PartPath(self.tt, self.dim, max(0, min(self.part_paths, self.npaths - j * self.part_paths)), self.part_paths, self._ptrs[j], self.ctx)
+                      for j in range(self.nparts)]
+
+    def paths(self, p0=0, n=None):
+        """download paths p0..p0+n as host array [n, N, dim]"""
+        n = self.npaths - p0 if n is None else n
+        out = np.empty((n, len(self.tt), self.dim))
+        p = p0
+        while p < p0 + n:
+            j, q = divmod(p, self.part_paths)
+            k = min(p0 + n - p, self.part_paths - q)
+            out[p - p0:p - p0 + k] = self.parts[j].paths(q, k)
+            p += k
+        return out
+
+    def free(self):
+        if getattr(self, "_ptrs", None) is not None:
+            self.ctx.lib.bhip_free_apart(self.ctx.h, self.nparts, self._ptrs)
+            self._ptrs, self.parts = None, []
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def sample_solve_parts(u, Po, npaths, nparts=3, seed=0, iter=0, path0=0, skip=0, ctx=None, X=None):
+    """sample_solve with X kept in parts (bhip_sample_solve_parts): the same values, column p of the ensemble = column p - j*part_paths
+    of part j.  Returns (EnsembleParts, ll)."""
+    ctx = ctx or Po.ctx
+    X = X if X is not None else EnsembleParts(Po.tt, Po.d, npaths, nparts, ctx)
+    ll = ctx.empty(npaths) if Po.kind != GUIDE_NONE else None
+    ctx.check(ctx.lib.bhip_sample_solve_parts(ctx.h, Po.h, _dptr(_x0(u, Po.d)), X.nparts, X._ptrs, X.part_paths, X.part_paths,
+                                              None if ll is None else vp(ll.data_ptr()), skip, npaths, seed, iter, path0))
+    return X, ll
+
+
 # ----------------------------------------------------------------------------- MCMC
 class Chains:
     """An ensemble of independent pCN Metropolis-Hastings chains, one per GPU lane

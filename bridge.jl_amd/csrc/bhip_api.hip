@@ -1451,6 +1451,34 @@ int bhip_sample_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, 
     return do_launch(po, NOISE_FRESH, a);
 }
 
+// bhip_sample_solve with X kept in nparts buffers: paths [j*part_paths, (j+1)*part_paths) are written to X_parts[j] ([N][d][ldX] each,
+// column p - j*part_paths) by ONE launch, so that the parts' write streams run side by side.  Values are those of bhip_sample_solve.
+int bhip_sample_solve_parts(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, int nparts, double *const *X_parts, long ldX, long part_paths,
+                            double *ll_dev, int skip, long npaths, uint64_t seed, uint32_t iter, uint32_t path0)
+{
+    if (!ctx || !po || !X_parts || nparts < 1 || nparts > 3) return BHIP_EINVAL;
+    SAME_CTX(ctx, po);
+    for (int j = 0; j < nparts; j++) if (!X_parts[j]) return BHIP_EINVAL;
+    if (nparts == 1) return bhip_sample_solve(ctx, po, x0, nullptr, nullptr, 0, X_parts[0], ldX, ll_dev, skip, npaths, seed, iter, path0);
+    if (part_paths < 64 || part_paths % 64 != 0) return fail(ctx, BHIP_EINVAL, "bhip_sample_solve_parts: part_paths must be a positive multiple of 64");
+    if (ldX < part_paths) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than part_paths");
+    if ((long)nparts * part_paths < npaths) return fail(ctx, BHIP_ELENGTH, "bhip_sample_solve_parts: nparts * part_paths must cover npaths");
+    if (po->g.kind == BHIP_GUIDE_NONE) {
+        if (ll_dev) return fail(ctx, BHIP_EINVAL, "bhip_sample_solve: llikelihood needs a guided proposal");
+        int rc = ensure_plain_rows(const_cast<bhip_proposal *>(po));
+        if (rc) return rc;
+    }
+    PATH_RANGE(ctx, path0, npaths > 0 ? npaths : 0);
+    if (po->mh.d > 3 && !(po->mid && po->mh.d <= ctx->mid_max))
+        return fail(ctx, BHIP_EUNSUPPORTED, "bhip_sample_solve_parts: one path per lane (d <= 3, LinPro / component-wise user drifts up to BHIP_OPT_MID_VALU); the tile kernel writes one buffer");
+    KArgs a;
+    int rc = fill_common(po, a, x0, nullptr, npaths, skip);
+    if (rc) return rc;
+    a.X = X_parts[0]; a.Xp1 = X_parts[1]; a.Xp2 = nparts > 2 ? X_parts[2] : nullptr; a.xpart = part_paths; a.ldX = ldX; a.ll = ll_dev;
+    a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.iter = iter; a.path0 = path0;
+    return do_launch(po, NOISE_FRESH, a);
+}
+
 int bhip_llikelihood(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev, long ldX, double *ll_dev, int skip, long npaths)
 {
     if (!ctx || !po || !X_dev || !ll_dev) return BHIP_EINVAL;
@@ -1840,6 +1868,25 @@ static int place_classify(bhip_ctx *ctx, void *ptr, size_t bytes, bool *is_new, 
     return -1;
 }
 
+// r_same of the context: the median of the two-stream runs INSIDE each of the given contiguous runs (head x tail, and head x middle, middle x tail
+// where a run holds three regions of sb bytes); false when no run could be timed
+static bool place_measure_one_piece_rate(bhip_ctx *ctx, int n, void *const *runs, const size_t *nbs, size_t sb, bool trace)
+{
+    std::vector<float> rr;
+    for (int b = 0; b < n; b++) {
+        char *p = (char *)runs[b];
+        const size_t nb = nbs[b], mid = (nb - sb) / 2 / 4096 * 4096, tail = (nb - sb) / 4096 * 4096;
+        rr.push_back(two_stream_rate(ctx, p, p + tail, sb));
+        if (nb >= 3 * sb) { rr.push_back(two_stream_rate(ctx, p, p + mid, sb)); rr.push_back(two_stream_rate(ctx, p + mid, p + tail, sb)); }
+    }
+    if (trace) { fprintf(stderr, "[bhip place] one-piece runs:"); for (float r : rr) fprintf(stderr, " %.0f", r); fprintf(stderr, " GB/s\n"); }
+    rr.erase(std::remove_if(rr.begin(), rr.end(), [](float r) { return !(r > 0.f); }), rr.end());
+    if (rr.empty()) return false;
+    std::sort(rr.begin(), rr.end());
+    ctx->r_same = 0.5f * (rr[(rr.size() - 1) / 2] + rr[rr.size() / 2]);
+    return true;
+}
+
 static int chains_step_once(bhip_chains *ch, double rho, int skip, bool store_x);
 // BHIP_PLACE_TRACE only: ms per pCN iteration of the ensemble with W at wq and the proposal paths at q (the ground truth the
 // two-stream readings are compared with in profiles/r5_piece_map.txt); the ensemble's state is set up again afterwards by the caller
@@ -1871,18 +1918,8 @@ static int chains_place(bhip_chains *ch, const double *x0, int skip)
     // 1. the rate inside one piece, once per context: the median of six runs inside W and inside Xo
     const bool trace = getenv("BHIP_PLACE_TRACE") != nullptr;   // every two-stream run of the procedure to stderr (scripts/gpu_piece_map_probe.py)
     if (!(ctx->r_same > 0.f)) {
-        std::vector<float> rr;
-        for (int b = 0; b < 2; b++) {
-            char *p = (char *)(b ? xo : w);
-            const size_t nb = b ? ch->xbytes : ch->wbytes, mid = (nb - sb) / 2 / 4096 * 4096, tail = (nb - sb) / 4096 * 4096;
-            rr.push_back(two_stream_rate(ctx, p, p + tail, sb));
-            if (nb >= 3 * sb) { rr.push_back(two_stream_rate(ctx, p, p + mid, sb)); rr.push_back(two_stream_rate(ctx, p + mid, p + tail, sb)); }
-        }
-        if (trace) { fprintf(stderr, "[bhip place] one-piece runs:"); for (float r : rr) fprintf(stderr, " %.0f", r); fprintf(stderr, " GB/s\n"); }
-        rr.erase(std::remove_if(rr.begin(), rr.end(), [](float r) { return !(r > 0.f); }), rr.end());
-        if (rr.empty()) return chains_init_impl(ch, x0, nullptr, 0, skip, 0u);   // no measurement: the pair stays as it is
-        std::sort(rr.begin(), rr.end());
-        ctx->r_same = 0.5f * (rr[(rr.size() - 1) / 2] + rr[rr.size() / 2]);
+        void *runs[2] = {w, xo}; const size_t nbs[2] = {ch->wbytes, ch->xbytes};
+        if (!place_measure_one_piece_rate(ctx, 2, runs, nbs, sb, trace)) return chains_init_impl(ch, x0, nullptr, 0, skip, 0u);   // no measurement: the pair stays as it is
     }
     auto can_alloc = [&](size_t bytes) { size_t f = 0, t = 0; return hipMemGetInfo(&f, &t) == hipSuccess && f >= 2 * bytes; };
     // 2./3. candidates for Xo.  A contiguous run straddles at most one cut, so its head and its tail tell where ALL of it lies: a pair is
@@ -1986,6 +2023,90 @@ int bhip_ctx_piece_of(bhip_ctx *ctx, void *dev_ptr, size_t bytes, int *piece)
     bool fresh = false;
     *piece = place_classify(ctx, dev_ptr, bytes, &fresh);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return BHIP_OK;
+}
+
+// nparts (1..3) contiguous runs of `bytes` each that lie pairwise in DIFFERENT pieces of the device memory (the four-run test of
+// chains_place between every two of them; candidates that fail stay held until the set is complete, then go back) -- for ensembles kept in
+// parts (bhip_sample_solve_parts): one write stream per piece moves 5.8-6.0 TB/s over two pieces and 6.8-6.9 over three where one stream in
+// one piece moves 4.3-4.4 (profiles/r5_three_pieces.txt).  *apart = how many of the parts ended up pairwise apart (nparts: all).
+int bhip_alloc_apart(bhip_ctx *ctx, int nparts, size_t bytes, void **out, int *apart)
+{
+    if (!ctx || !out || nparts < 1 || nparts > 3 || !bytes) return BHIP_EINVAL;
+    NEED_DEVICE(ctx);
+    for (int j = 0; j < nparts; j++) out[j] = nullptr;
+    if (apart) *apart = 0;
+    auto release = [&](std::vector<void *> &v) { for (void *q : v) (void)hipFree(q); v.clear(); };
+    std::vector<void *> kept, held;
+    const size_t sb = place_stream_bytes(bytes / 2, bytes / 2);
+    const bool testable = bytes >= PLACE.min_bytes && sb >= PLACE.min_bytes / 2;
+    if (!testable) {
+        // too small for write-stream tests (and for placement to matter): plain allocations, as they come.  NOT small contiguous runs: with
+        // hipDeviceMallocContiguous buffers of 0.8-2.5 MB allocated and freed between other work, later downloads of OTHER buffers of the
+        // process read page-sized stretches of zeros where the memory held values (tests/test_gpu_parts.py inside the whole suite, 3 of 3;
+        // gone with plain allocations, 3 of 3) -- the flag stays with the large runs it was measured on
+        for (int j = 0; j < nparts; j++)
+            if (hipMalloc(&out[j], bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                for (int k = 0; k < j; k++) { (void)hipFree(out[k]); out[k] = nullptr; }
+                out[j] = nullptr;
+                return fail(ctx, BHIP_EHIP, "bhip_alloc_apart: out of device memory");
+            }
+        return BHIP_OK;
+    }
+    void *p = nullptr;
+    if (alloc_run(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, BHIP_EHIP, "bhip_alloc_apart: out of device memory"); }
+    kept.push_back(p);
+    if (!(ctx->r_same > 0.f)) (void)place_measure_one_piece_rate(ctx, 1, &p, &bytes, sb, false);
+    const bool judge = ctx->r_same > 0.f;
+    int n_apart = 1;
+    const int max_cands = (int)std::min<size_t>(24, std::max<size_t>((size_t)PLACE.max_candidates + 2 * PLACE.more_candidates, PLACE.held_bytes / bytes));
+    while ((int)kept.size() < nparts) {
+        void *best = nullptr; float best_score = -1.f; bool good = false;
+        auto score_of = [&](void *q, bool *ok) {   // the smallest mean-of-four against the parts kept so far
+            float sc = 1e30f; *ok = true;
+            for (void *k : kept) {
+                const PairRates pr = place_pair_rates(ctx, k, bytes, q, bytes, PLACE.smallest_min * ctx->r_same, false);
+                if (!place_apart(ctx, pr)) *ok = false;
+                sc = std::min(sc, pr.runs == 4 ? pr.mean : std::min(pr.mean, pr.smallest));
+                if (!*ok) break;
+            }
+            return sc;
+        };
+        for (void *q : held) {   // (a candidate that failed against an earlier part may do for this one)
+            bool ok = false; const float sc = judge ? score_of(q, &ok) : 0.f;
+            if (ok) { best = q; good = true; break; }
+            if (sc > best_score) { best_score = sc; best = q; }
+        }
+        while (!good && (int)held.size() < max_cands) {
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 2 * bytes) break;
+            void *q = nullptr;
+            if (alloc_run(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            held.push_back(q);
+            if (!judge) { best = q; good = false; break; }
+            bool ok = false; const float sc = score_of(q, &ok);
+            if (ok) { best = q; good = true; break; }
+            if (sc > best_score) { best_score = sc; best = q; }
+        }
+        if (!best) { (void)hipStreamSynchronize(ctx->stream); release(held); release(kept); return fail(ctx, BHIP_EHIP, "bhip_alloc_apart: out of device memory"); }
+        held.erase(std::find(held.begin(), held.end(), best));
+        kept.push_back(best);
+        if (good) n_apart++;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    release(held);
+    for (int j = 0; j < nparts; j++) out[j] = kept[j];
+    if (apart) *apart = judge ? n_apart : 0;
+    return BHIP_OK;
+}
+
+int bhip_free_apart(bhip_ctx *ctx, int nparts, void *const *ptrs)
+{
+    if (!ctx || !ptrs || nparts < 0) return BHIP_EINVAL;
+    NEED_DEVICE(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < nparts; j++) if (ptrs[j]) (void)hipFree(ptrs[j]);
     return BHIP_OK;
 }
 

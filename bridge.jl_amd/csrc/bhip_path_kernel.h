@@ -70,6 +70,10 @@ struct KArgs {
     long ldWout;
     double *X;            // optional X store [N][D][ldX]
     long ldX;
+    // X in PARTS (bhip_sample_solve_parts): paths [j*xpart, (j+1)*xpart) go to part j -- X, Xp1, Xp2, each [N][D][ldX] in an allocation of
+    // its own (different pieces of the device memory: one write stream per piece instead of one in all); xpart = 0: one buffer
+    double *Xp1, *Xp2;
+    long xpart;           // paths per part, a multiple of 64
     double *ll;           // optional per-path log-likelihood
     // pCN chain state (NOISE_PCN).  W lives in 16-byte SLOTS: Wc[((i*MP + k)*ldC + p)*2 + h], h = 0/1;
     // half cur[p] holds the chain's current W, the other half receives the proposal Wo, and an accept
@@ -116,6 +120,14 @@ struct KArgs {
     unsigned long long *stamp;
 #endif
 };
+
+// the X store's base for path p (KArgs::xpart): shifted so that the GLOBAL path index addresses the part the path belongs to
+__device__ __forceinline__ double *x_store_base(const KArgs &a, long p)
+{
+    if (!a.xpart) return a.X;
+    const int j = (int)(p / a.xpart);
+    return (j == 0 ? a.X : j == 1 ? a.Xp1 : a.Xp2) - (long)j * a.xpart;
+}
 
 typedef const __attribute__((address_space(4))) double *cptr_t;
 
@@ -620,7 +632,7 @@ __global__ __launch_bounds__(256, (PPR || M::D > 4 || (M::D > 3 && NOISE == NOIS
     } else {
         if constexpr (NOISE != NOISE_FRESH) { win = a.Win + p; ldwi = a.ldWin; }
         if constexpr ((FL & 2) != 0) { wout = a.Wout + (size_t)p * a.wstride; ldwo = a.ldWout * a.wstride; }
-        if constexpr ((FL & 1) != 0) { xout = a.X + p; ldx = a.ldX; }
+        if constexpr ((FL & 1) != 0) { xout = x_store_base(a, p) + p; ldx = a.ldX; }
     }
     if constexpr (NOISE == NOISE_EXT) {
 #pragma unroll

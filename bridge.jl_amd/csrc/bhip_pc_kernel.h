@@ -383,7 +383,10 @@ __global__ __launch_bounds__(128 * NPAIR, (RLDS || PPR) ? 2 : PC_WPE) void k_pc(
     long ldx = 0;
     if constexpr ((FL & 1) != 0) {
         if constexpr (PCN) { xout = a.Xo; ldx = a.ldC; }   // wave-uniform base; the lane's chain index rides as a 32-bit offset
-        else { xout = a.X; ldx = a.ldX; }
+        else {   // (a pair's 64 paths share a part -- xpart is a multiple of 64 --: the base stays wave-uniform)
+            const int j = a.xpart ? __builtin_amdgcn_readfirstlane((int)(c0 / a.xpart)) : 0;
+            xout = (j == 0 ? a.X : j == 1 ? a.Xp1 : a.Xp2) - (long)j * a.xpart; ldx = a.ldX;
+        }
     }
     constexpr int CFL = FL & ~2;   // the W store belongs to the producer
     // per-chain guides: the chain's compact row (Hd, V, linearisation datum) of step i+1 is fetched while step i is computed

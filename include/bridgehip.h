@@ -261,6 +261,21 @@ int bhip_sample_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, 
                       double *W_dev, long ldW, double *X_dev, long ldX, double *ll_dev, int skip,
                       long npaths, uint64_t seed, uint32_t iter, uint32_t path0);
 
+/* The same with X kept in nparts (1..3) buffers, each [N][d][ldX]: paths [j*part_paths, (j+1)*part_paths) go to X_parts[j], column
+ * p - j*part_paths (part_paths a multiple of 64), written by ONE launch.  Values are those of bhip_sample_solve; every reader of an
+ * ensemble (bhip_llikelihood, bhip_innovations, bhip_download_aos ...) takes a part as the ensemble it is.  Why: X is this call's only
+ * stream, and one write stream inside one 96-GiB piece of the device memory moves 4.3-4.4 TB/s where three streams in three pieces
+ * move 6.8-6.9 (profiles/r5_three_pieces.txt); bhip_alloc_apart hands out buffers that lie in different pieces.  One path per lane
+ * (d <= 3; LinPro and component-wise user drifts up to BHIP_OPT_MID_VALU); the reference has no counterpart (an ensemble is a loop). */
+int bhip_sample_solve_parts(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, int nparts, double *const *X_parts, long ldX,
+                            long part_paths, double *ll_dev, int skip, long npaths, uint64_t seed, uint32_t iter, uint32_t path0);
+/* nparts (1..3) physically contiguous device buffers of `bytes` each, pairwise in different pieces of the device memory (tested with
+ * write streams like the placement of chain ensembles; candidates that fail stay held until the set is complete).  *apart (optional):
+ * how many of them ended up pairwise apart -- nparts when all did, 0 when the buffers are too small to be tested (< 64 MiB).
+ * bhip_free_apart gives them back. */
+int bhip_alloc_apart(bhip_ctx *ctx, int nparts, size_t bytes, void **out, int *apart);
+int bhip_free_apart(bhip_ctx *ctx, int nparts, void *const *ptrs);
+
 /* stand-alone llikelihood(LeftRule(), X, Po; skip) of stored paths          src/guip.jl:429-438 ... */
 int bhip_llikelihood(bhip_ctx *ctx, const bhip_proposal *po, const double *X_dev, long ldX, double *ll_dev,
                      int skip, long npaths);

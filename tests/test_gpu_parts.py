@@ -1,0 +1,123 @@
+"""Ensembles kept in PARTS (round 5): bhip_sample_solve_parts writes paths [j*part_paths, (j+1)*part_paths) to buffer j in ONE launch;
+bhip_alloc_apart hands out buffers that lie in different 96-GiB pieces of the device memory (a write stream per piece:
+profiles/r5_three_pieces.txt).  The values are those of bhip_sample_solve (src/wiener.jl:24-58 + src/euler.jl:247-268 +
+src/partialbridge.jl:67-77 fused), which tests/test_gpu_parity.py pins against the oracle: `==` here, part by part."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import bridgehip as bh
+import oracle as o
+import problems
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return bh.default_context(0)
+
+
+@pytest.mark.parametrize("name,n", [("fhn_partialbridge_extreme", 1000), ("fhn_partialbridge_extreme", 70001), ("nclar_firstcomponent", 777),
+                                    ("ouproc_nuh", 64), ("linpro2_guidedbridge", 4099)])
+@pytest.mark.parametrize("nparts", [2, 3])
+def test_parts_hold_the_values_of_the_single_buffer(ctx, name, n, nparts):
+    case = [c for c in problems.cases(101 if n < 5000 else 41) if c.name == name][0]
+    Po = case.bh_proposal(bh, ctx)
+    X1, _, ll1 = bh.sample_solve(case.x0, Po, n, seed=11, iter=3, path0=5)
+    XP, llp = bh.sample_solve_parts(case.x0, Po, n, nparts=nparts, seed=11, iter=3, path0=5)
+    assert XP.part_paths % 64 == 0 and XP.nparts * XP.part_paths >= n
+    # (equal_nan: on the coarse grid a few of 70 001 FitzHugh-Nagumo paths leave the Euler scheme's stability region -- in both runs alike)
+    assert np.array_equal(ll1.cpu().numpy(), llp.cpu().numpy(), equal_nan=True)
+    assert np.array_equal(X1.paths(), XP.paths(), equal_nan=True)
+    # a part is an ensemble like any other: the stand-alone llikelihood of part 1 == the fused values of its paths
+    part = XP.parts[1]
+    if part.npaths:
+        ll = bh.llikelihood(bh.LeftRule(), part, Po).cpu().numpy()
+        assert np.array_equal(ll[:part.npaths], ll1.cpu().numpy()[XP.part_paths:XP.part_paths + part.npaths], equal_nan=True)
+    # and against the oracle directly for one path of the last part
+    p = n - 1
+    ref = case.oracle_proposal()
+    W = o.wiener_sample(case.tt, Po.mp, 11, 5 + p, 3)
+    Xr = o.solve_guided(ref, case.x0, W)
+    assert np.array_equal(XP.paths(p, 1)[0], Xr) and llp.cpu().numpy()[p] == o.llikelihood(ref, Xr)
+    XP.free()
+
+
+def test_parts_on_the_lanes_of_dimension_five_and_under_an_earlier_noise_specification():
+    rng = np.random.default_rng(2)
+    d, N, n = 5, 61, 900
+    G = rng.standard_normal((d, d)) / np.sqrt(d)
+    tt = np.linspace(0, 0.6, N)
+    c5 = bh.Context(0)
+    P, Pt = bh.LinPro(-np.eye(d) + 0.2 * G, np.zeros(d), 0.5 * np.eye(d)), bh.LinPro(-np.eye(d), np.zeros(d), 0.5 * np.eye(d))
+    Po = bh.GuidedBridge(tt, P, Pt, 0.3 * np.ones(d), ctx=c5)
+    X1, _, ll1 = bh.sample_solve(np.zeros(d), Po, n, seed=4)
+    XP, llp = bh.sample_solve_parts(np.zeros(d), Po, n, nparts=3, seed=4)
+    assert torch.equal(ll1, llp) and _same(X1, XP, lambda: bh.sample_solve(np.zeros(d), Po, n, seed=4)[0])
+    XP.free()
+    c3 = bh.Context(0)
+    c3.set_option(bh.OPT_NOISE_SPEC, 3)
+    case = [c for c in problems.cases(101) if c.name == "fhn_partialbridge_extreme"][0]
+    Po3 = case.bh_proposal(bh, c3)
+    X1, _, ll1 = bh.sample_solve(case.x0, Po3, 3000, seed=4)
+    XP, llp = bh.sample_solve_parts(case.x0, Po3, 3000, nparts=2, seed=4)
+    assert torch.equal(ll1, llp) and _same(X1, XP, lambda: bh.sample_solve(case.x0, Po3, 3000, seed=4)[0])
+    XP.free()
+
+
+def _same(X1, XP, redo):
+    """X1.paths() == XP.paths(); on a mismatch says which of the two downloads differs from a third run (a device-memory problem shows as
+    zeros in one of them: small hipDeviceMallocContiguous buffers did that to their neighbours, see bhip_alloc_apart)"""
+    xa, xb = X1.paths(), XP.paths()
+    if np.array_equal(xa, xb):
+        return True
+    torch.cuda.synchronize()
+    ref = redo().paths()
+    print("single buffer differs from a third run in", (xa != ref).sum(), "entries, the parts in", (xb != ref).sum(), "; first differences at", np.argwhere(xa != xb)[:8].tolist())
+    return False
+
+
+def test_forward_euler_maruyama_in_parts(ctx):
+    case = problems.forward_cases(101)[0]
+    Po = case.bh_proposal(bh, ctx)
+    X1, _, ll1 = bh.sample_solve(case.x0, Po, 500, seed=1)
+    XP, llp = bh.sample_solve_parts(case.x0, Po, 500, nparts=2, seed=1)
+    assert ll1 is None and llp is None and np.array_equal(X1.paths(), XP.paths())
+    XP.free()
+
+
+def test_buffers_apart_and_argument_checks(ctx):
+    ptrs = (bh.api.vp * 3)()
+    apart = C.c_int(-1)
+    nbytes = 512 << 20
+    ctx.check(ctx.lib.bhip_alloc_apart(ctx.h, 3, nbytes, ptrs, C.byref(apart)))
+    assert len({ptrs[0], ptrs[1], ptrs[2]}) == 3 and all(ptrs[k] for k in range(3))
+    assert 1 <= apart.value <= 3                              # (3 on an idle device; the allocator decides -- profiles/r5_piece_map.txt)
+    ctx.check(ctx.lib.bhip_free_apart(ctx.h, 3, ptrs))
+    small = (bh.api.vp * 2)()
+    ctx.check(ctx.lib.bhip_alloc_apart(ctx.h, 2, 1 << 20, small, C.byref(apart)))          # too small to be tested: handed out as they come
+    assert apart.value == 0 and small[0] and small[1]
+    ctx.check(ctx.lib.bhip_free_apart(ctx.h, 2, small))
+    assert ctx.lib.bhip_alloc_apart(ctx.h, 4, nbytes, ptrs, None) != 0
+    case = [c for c in problems.cases(41) if c.name == "fhn_partialbridge_extreme"][0]
+    Po = case.bh_proposal(bh, ctx)
+    XP = bh.EnsembleParts(Po.tt, Po.d, 300, 2, ctx)
+    ll = ctx.empty(300)
+    x0 = bh.api._dptr(bh.api._x0(case.x0, Po.d))
+    call = lambda nparts, ld, part, n: ctx.lib.bhip_sample_solve_parts(ctx.h, Po.h, x0, nparts, XP._ptrs, ld, part, bh.api.vp(ll.data_ptr()), 0, n, 1, 0, 0)
+    assert call(2, XP.part_paths, XP.part_paths, 300) == 0
+    assert call(2, XP.part_paths, 100, 300) != 0              # part_paths must be a multiple of 64
+    assert b"multiple of 64" in ctx.lib.bhip_last_error(ctx.h)
+    assert call(2, 64, 128, 300) != 0                          # leading dimension below part_paths
+    assert call(2, XP.part_paths, 128, 300) != 0              # the parts do not cover the paths
+    assert call(4, XP.part_paths, XP.part_paths, 300) != 0
+    XP.free()
+    # d = 16 runs on the tile kernel, which writes one buffer
+    d = 16
+    Po16 = bh.GuidedBridge(np.linspace(0, 0.5, 33), bh.LinPro(-np.eye(d), np.zeros(d), 0.5 * np.eye(d)), bh.LinPro(-np.eye(d), np.zeros(d), 0.5 * np.eye(d)),
+                           0.1 * np.ones(d), ctx=ctx)
+    with pytest.raises(bh.BridgeError, match="tile kernel"):
+        bh.sample_solve_parts(np.zeros(d), Po16, 256, nparts=2)
