@@ -244,6 +244,40 @@ solve(m::HIPEuler, u, W::EnsemblePath, Po::HIPProposal{T}; kw...) where {T} =
 "deprecated alias  src/deprecated.jl:16-17"
 bridge!(Y::EnsemblePath, u, W::EnsemblePath, Po::HIPProposal) = solve!(HIPEuler(), Y, u, W, Po)
 
+"""
+An ensemble kept in `nparts` (1..3) buffers that lie in different 96-GiB pieces of the device memory (`bhip_alloc_apart`): paths
+`(j-1)*part_paths+1 : j*part_paths` are `parts[j]`, an `EnsemblePath` like any other (leading dimension `part_paths`).  Written by
+`sample_solve_parts!` in one launch: a write stream per piece moves 5.8-6.9 TB/s where the one stream of a single buffer moves 4.3-4.4.
+"""
+mutable struct EnsembleParts{T}
+    parts::Vector{EnsemblePath{T}}
+    ptrs::Vector{Ptr{Cvoid}}
+    part_paths::Int
+    npaths::Int
+    apart::Int
+    ctx::Context
+end
+function EnsembleParts{T}(tt, dim, npaths, nparts = 2, c::Context = default_context()) where {T}
+    part = cld(cld(npaths, nparts), 64) * 64
+    ptrs = fill(Ptr{Cvoid}(C_NULL), nparts)
+    apart = Ref{Cint}(0)
+    check(c, ccall((:bhip_alloc_apart, lib), Cint, (Ptr{Cvoid}, Cint, Csize_t, Ptr{Ptr{Cvoid}}, Ref{Cint}),
+        c.h, nparts, 8 * length(tt) * dim * part, ptrs, apart))
+    parts = [EnsemblePath{T}(collect(Float64, tt), Ptr{Cdouble}(ptrs[j]), dim, part, c) for j in 1:nparts]   # (inner constructor: no finalizer of their own)
+    E = EnsembleParts{T}(parts, ptrs, part, npaths, Int(apart[]), c)
+    finalizer(e -> ccall((:bhip_free_apart, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}), e.ctx.h, length(e.ptrs), e.ptrs), E)
+end
+"path p (1-based) of the whole ensemble"
+Bridge.SamplePath(E::EnsembleParts, p::Integer) = Bridge.SamplePath(E.parts[cld(p, E.part_paths)], (p - 1) % E.part_paths + 1)
+
+"fused sample! + solve! + llikelihood into an ensemble kept in parts (`bhip_sample_solve_parts`); `ll`: device pointer to npaths values or C_NULL"
+function sample_solve_parts!(E::EnsembleParts, u, Po::HIPProposal; ll::Ptr{Cdouble} = Ptr{Cdouble}(C_NULL), skip = 0, seed = 0, iter = 0, path0 = 0)
+    check(E.ctx, ccall((:bhip_sample_solve_parts, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Ptr{Cvoid}}, Clong, Clong, Ptr{Cdouble}, Cint, Clong, UInt64, UInt32, UInt32),
+        E.ctx.h, Po.h, collect(Float64, u), length(E.ptrs), E.ptrs, E.part_paths, E.part_paths, ll, skip, E.npaths, seed, iter, path0))
+    E
+end
+
 "llikelihood(LeftRule(), X, Po; skip): one value per path  src/partialbridge.jl:67-77 etc."
 function llikelihood(::LeftRule, X::EnsemblePath, Po::HIPProposal; skip = 0)
     out = Vector{Float64}(undef, X.npaths)
