@@ -10,7 +10,7 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 typedef double d2v __attribute__((ext_vector_type(2)));
 struct Trip { const d2v *r; d2v *w1, *w2; };   // r: read (may be null), w1: written (null: none), w2: written (null: none)
-struct Trips { Trip t[3]; int n; };
+struct Trips { Trip t[3]; int n; int wide; };   // wide: w2 takes 32 bytes per element (read 16, write 16, write 32 = the FHN chain step's 8 : 8 : 16)
 constexpr int GRID = 4104;   // divisible by 1, 2, 3
 
 // block j works on triple j % n: reads r[i], writes w1[i] (= r when the update is in place) and w2[i]
@@ -23,7 +23,10 @@ __global__ __launch_bounds__(256) void k_mix(Trips T, size_t m)
         d2v v = {(double)i, 1.0};
         if (t.r) { const d2v u = __builtin_nontemporal_load(t.r + i); v.x += 0.9 * u.x; v.y += 0.9 * u.y; }
         if (t.w1) __builtin_nontemporal_store(v, t.w1 + i);
-        if (t.w2) __builtin_nontemporal_store(v, t.w2 + i);
+        if (t.w2) {
+            if (T.wide) { __builtin_nontemporal_store(v, t.w2 + i); __builtin_nontemporal_store(v, t.w2 + m + i); }   // the headline's mix: Xo is twice W (two coalesced rows)
+            else __builtin_nontemporal_store(v, t.w2 + i);
+        }
     }
 }
 static float run_ms(const Trips &T, size_t m)
@@ -99,6 +102,15 @@ int main()
     printf("halves crossed over two pieces                %7.0f GB/s\n", gbs(T2(Trip{D(A, 0), D(A, 0), D(B, 0)}, Trip{D(B, H), D(B, H), D(A, H)}), 3));
     if (C) printf("thirds rotated over three pieces              %7.0f GB/s\n", gbs(T3(Trip{D(A, 0), D(A, 0), D(B, 0)}, Trip{D(B, H), D(B, H), D(C, 0)}, Trip{D(C, H), D(C, H), D(A, H)}), 3));
     if (C) printf("W, W', Xo each in its own piece (W out of place) %4.0f GB/s\n", gbs(T1(Trip{D(A, 0), D(C, 0), D(B, 0)}), 3));
+    {   // the headline's own mix: per element read 16 B of W, write 16 B of W, write 32 B of Xo (1 GiB of W, 2 GiB of Xo per run; bytes counted: 4 x 1 GiB)
+        const size_t WB = (size_t)1 << 30;
+        auto g4 = [&](Trips T) { T.wide = 1; const size_t m = WB / 16 / T.n; const float ms = run_ms(T, m); return 4.0 * (double)(m * 16) * T.n / (ms * 1e6); };
+        printf("\n== the FitzHugh-Nagumo chain step's mix 8 : 8 : 16 (read W, write W, write Xo)\n");
+        printf("W and Xo in one piece                         %7.0f GB/s\n", g4(T1(Trip{D(A, 0), D(A, 0), D(A, H)})));
+        printf("W in one piece, Xo in another (today)         %7.0f GB/s\n", g4(T1(Trip{D(A, 0), D(A, 0), D(B, 0)})));
+        if (C) printf("W in one piece, Xo's halves in the two others %7.0f GB/s\n", g4(T2(Trip{D(A, 0), D(A, 0), D(B, 0)}, Trip{D(A, H), D(A, H), D(C, 0)})));
+        if (C) printf("thirds rotated over three pieces              %7.0f GB/s\n", g4(T3(Trip{D(A, 0), D(A, 0), D(B, 0)}, Trip{D(B, H), D(B, H), D(C, 0)}, Trip{D(C, H), D(C, H), D(A, H)})));
+    }
     printf("\n== copy (read one, write another), bytes counted 2 x\n");
     printf("inside one piece                              %7.0f GB/s\n", gbs(T1(Trip{D(A, 0), D(A, H), nullptr}), 2));
     printf("across two pieces                             %7.0f GB/s\n", gbs(T1(Trip{D(A, 0), D(B, 0), nullptr}), 2));
