@@ -648,6 +648,15 @@ int bhip_proposal_set_aux(bhip_proposal *po, int kind, const double *apar, int n
     return BHIP_OK;
 }
 
+// a component-wise user drift (bhip_model_define_components) of a dimension whose proposals AND pCN chains run one path per lane
+static bool lanes_only_candidate(const ModelHost &mh)
+{
+    if (mh.id < USER_MODEL_BASE || mh.d < 4 || mh.d > BHIP_MID_MAX_CHAINS) return false;
+    std::lock_guard<std::mutex> lk(user_models_mutex());
+    const UserModel *um = find_user_model(mh.id);
+    return um && um->components;
+}
+
 int bhip_proposal_set_aux_linearappr(bhip_proposal *po, const double *xx, const double *B, const double *b, const double *Sigma)
 {
     if (!po) return BHIP_EINVAL;
@@ -657,7 +666,10 @@ int bhip_proposal_set_aux_linearappr(bhip_proposal *po, const double *xx, const 
     const size_t N = po->tt.size();
     // (d > 3 since round 5: LinPro targets -- one path per lane or the tile kernel, whose per-step coefficients take B~_i, beta~_i by
     // grid index like every time-dependent auxiliary; the per-chain device-built guides of bhip_segchains_adapt_device stay at d <= 3)
-    if (d > 3 && po->mh.id != BHIP_MODEL_LINPRO) return fail(ctx, BHIP_EUNSUPPORTED, "LinearAppr auxiliary at d > 3: LinPro targets");
+    // (a component-wise user drift of dimension 4..BHIP_MID_MAX_CHAINS takes them too: its one-path-per-lane rows carry B~_i, beta~_i per step;
+    // the tile kernel keeps -B~ as a constant matrix beside a user drift, so such a proposal runs one path per lane only -- finish_guide)
+    if (d > 3 && po->mh.id != BHIP_MODEL_LINPRO && !lanes_only_candidate(po->mh))
+        return fail(ctx, BHIP_EUNSUPPORTED, "LinearAppr auxiliary at d > 3: LinPro targets, or component-wise user drifts of dimension 4..8");
     if (!po->mh.constdiff) return fail(ctx, BHIP_EUNSUPPORTED, "LinearAppr auxiliary: the target must have a constant sigma");
     // constant-diffusivity log-likelihood: the linearisation's Sigma_i must be the target's sigma (a~ = a)
     const double *sg = po->mh.id == BHIP_MODEL_LINPRO ? po->mh.par.data() + d * d + d : nullptr;
@@ -912,7 +924,7 @@ static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const d
     bhip_ctx *ctx = po->ctx;
     NEED_DEVICE(ctx);
     const int d = po->mh.d;
-    if (!po->d_steps) return fail(ctx, BHIP_ESTATE, "proposal has no large-d guide data (compute a guide first)");
+    if (!po->d_steps) return fail(ctx, BHIP_ESTATE, "proposal has no large-d guide data (compute a guide first; a component-wise user drift with a time-dependent auxiliary runs one path per lane only: dimension 4..8, BHIP_OPT_MID_VALU on, default noise specification)");
     if (!x0 && !x0_dev) return fail(ctx, BHIP_EINVAL, "need a starting point");
     if (npaths < 1 || skip < 0) return fail(ctx, BHIP_EINVAL, "bad npaths/skip");
     TArgs a;
@@ -979,14 +991,26 @@ static int finish_guide(bhip_proposal *po)
     if (ctx->host_only) return BHIP_OK;   // coefficients stay on the host (bhip_proposal_guide_get)
     po->mid = false;
     if (d > 3) {
-        const int rct = build_tile_data(po);
         bool comp = false;
         if (po->mh.id >= USER_MODEL_BASE) {
             std::lock_guard<std::mutex> lk(user_models_mutex());
             const UserModel *um = find_user_model(po->mh.id);
             comp = um && um->components;
         }
-        if (rct || d > BHIP_MAXD_LANE || !(po->mh.id == BHIP_MODEL_LINPRO || comp)) return rct;
+        // a component-wise user drift with a TIME-DEPENDENT auxiliary (callback, LinearAppr by grid index): the tile kernel keeps -B~ as one
+        // constant matrix beside a user drift (build_tile_data), the one-path-per-lane rows carry B~_i, beta~_i per step.  At the dimensions
+        // where everything -- proposals, llikelihood, innovations!, pCN chains -- runs one path per lane such a proposal is built for the
+        // lanes alone; whatever would need the tile kernel (BHIP_OPT_MID_VALU = 0, another noise specification's chains) fails with BHIP_ESTATE.
+        const bool aux_const = po->has_aux && (po->aux.kind == BHIP_AUX_AFFINE || po->aux.kind == BHIP_AUX_LINPRO);
+        const bool lanes_only = comp && d <= BHIP_MID_MAX_CHAINS && po->g.kind != BHIP_GUIDE_NONE && po->has_aux && !aux_const &&
+                                po->aux.kind != BHIP_AUX_FHN_STARTEND;
+        if (lanes_only) {
+            for (double **q : {&po->d_steps, &po->d_hdr, &po->d_cst})
+                if (*q) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(*q)); *q = nullptr; }
+        } else {
+            const int rct = build_tile_data(po);
+            if (rct || d > BHIP_MAXD_LANE || !(po->mh.id == BHIP_MODEL_LINPRO || comp)) return rct;
+        }
         po->mid = true;   // ... and the rows below, for one path per lane (LinPro targets and component-wise user drifts)
     }
     std::vector<double> rows;

@@ -203,7 +203,10 @@ int bhip_proposal_set_aux_callback(bhip_proposal *po, bhip_aux_fn fn, void *user
  * src/ode.jl:98-113 (restated with the loop index it evidently means, see DESIGN.md: the reference constructor reads an
  * undefined variable).  The log-likelihood uses the constant-diffusivity form, i.e. Sigma_i must equal the target's sigma
  * (checked): the reference's own !constdiff branch for GuidedBridge is not defined.  d <= 3: every target; 4 <= d <= 32:
- * LinPro targets (the coefficients of grid index i enter step i's coefficient row / the tile kernel's per-step matrices). */
+ * LinPro targets (the coefficients of grid index i enter step i's coefficient row / the tile kernel's per-step matrices), and
+ * component-wise user drifts (bhip_model_define_components) of dimension 4..8: a user drift with ANY time-dependent auxiliary (this one,
+ * a callback) is built for the one-path-per-lane kernels alone -- proposals, llikelihood, innovations!, pCN chains under the default noise
+ * specification; with BHIP_OPT_MID_VALU = 0 its launches return BHIP_ESTATE (the tile kernel keeps -B~ constant beside a user drift). */
 int bhip_proposal_set_aux_linearappr(bhip_proposal *po, const double *xx, const double *B, const double *b, const double *Sigma);
 /* linearappr(Y, P) / linearappr!(Pt, Y, P)  src/linpro.jl:196-204 (host): fills B, b, Sigma (layouts as above) for the
  * target of `po` along Y [N][d]; for the processes the reference defines bderiv for: Lorenz, Pendulum, LinPro, Wiener. */
