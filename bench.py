@@ -15,6 +15,8 @@ fused kernel = chains x 1000 path-steps, each path-step being: Philox normal -> 
 pCN mix -> guided Euler step -> log-likelihood increment (+ the accept at the end of the path).
 All inputs are resident in HBM when the timed region starts.  The timed region ends with the
 device-side reduction of the acceptance / log-weight statistics and (N > 1) ONE RCCL all-gather.
+It holds exactly its K steps, back to back between two HIP events (roofline.kernel_avg_ms = their distance / K);
+the per-launch durations (kernel_min_ms / kernel_max_ms) come from an untimed pass of K more steps after it.
 
 Other modes (`--mode`), each a named BASELINE / SURVEY 8(d) configuration:
   proposals   C3 as independent fresh proposals (sample!+solve!+llikelihood, X stored), 262 144 paths
@@ -397,14 +399,20 @@ class Workload:
         self.step = step
 
     def roofline(self, kern_ms):
-        """achieved = algorithmic bytes (or flops) per launch / mean launch duration (HIP events)"""
-        avg_s = float(np.mean(kern_ms)) * 1e-3
+        """achieved = algorithmic bytes (or flops) per launch / mean launch duration (HIP events: LaunchTimes.avg, the launches back to back
+        between two events, where the caller measured it; else the mean of the per-launch durations)"""
+        back_to_back = getattr(kern_ms, "avg", None)
+        avg_s = float(back_to_back if back_to_back else np.mean(kern_ms)) * 1e-3
         per_launch = float(self.P) * (N_GRID - 1)
         gbs = per_launch * self.bytes_per_pathstep / avg_s / 1e9
         r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
              "kernel": self.kernel, "kernel_avg_ms": avg_s * 1e3, "kernel_min_ms": float(np.min(kern_ms)),
              "kernel_max_ms": float(np.max(kern_ms)), "algorithmic_bytes_per_path_step": self.bytes_per_pathstep,
              "path_steps_per_launch": self.P * (N_GRID - 1)}
+        if back_to_back:   # (min / max above are of this second, untimed pass)
+            r["per_launch_pass"] = {"launches": len(kern_ms), "avg_ms": float(np.mean(kern_ms)),
+                                    "note": "as many launches again with a HIP event between consecutive ones (each record costs the stream 6-10 us); kernel_avg_ms is "
+                                            "the average over the launches issued back to back between two events"}
         if self.flops_per_pathstep:   # compute-bound kernel: report against the fp64 matrix-core peak
             tf = per_launch * self.flops_per_pathstep / avg_s / 1e12
             # achieved / frac: the ALGORITHMIC flops (the reference's five d x d mat-vecs per path-step, SURVEY 8(d): 10 240 at d = 32).  Since
@@ -434,8 +442,18 @@ class Workload:
         return r
 
 
+class LaunchTimes(list):
+    """Per-launch HIP-event durations (an event recorded BETWEEN consecutive launches: min / max / spread) plus `.avg`, the average launch
+    duration of as many launches issued BACK TO BACK between two events.  An event record between two kernels costs the stream 6-10 us --
+    0.5 % of the headline's launch, 6 % of C2's 150-us one -- that neither rocprofv3's kernel durations nor a caller's loop contain (same
+    call, C2: 150.8 us per kernel in the trace, 160 between per-launch events): since the end of round 5 the timed region holds its K
+    steps and TWO events, and the roofline's kernel_avg_ms is that region's average; the per-launch pass follows it, untimed."""
+    avg = None
+
+
 def kernel_times(w, steps, warmup, min_ms=0.0):
-    """HIP-event duration of every launch (events on the stream the kernels go to: torch's current stream).
+    """HIP-event durations of `steps` launches (events on the stream the kernels go to: torch's current stream): first the launches back
+    to back between two events (-> .avg), then as many with an event between consecutive launches (the list: min / max).
     min_ms: sample at least that long (short launches measured for a few ms right after another workload see the clock
     state that workload left behind, not their own)"""
     for _ in range(warmup):
@@ -444,15 +462,31 @@ def kernel_times(w, steps, warmup, min_ms=0.0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); w.step(); e1.record(); torch.cuda.synchronize()
         steps = max(steps, min(4000, int(min_ms / max(e0.elapsed_time(e1), 1e-3))))
-        for _ in range(steps // 4):      # settle the clocks on THIS kernel before sampling
+        # settle the clocks on THIS kernel before sampling -- with a burst as long as the sampled one: the first long burst of launches in a
+        # process costs the host up to the kernel's own duration per launch (HIP's command / kernel-argument pools growing; C2, same process:
+        # 135 us per launch to issue the first 300, 4.5 us the next -- scripts/gpu_issue_probe2.py), and a 150-us kernel then waits for its host
+        for _ in range(steps):
             w.step()
+        torch.cuda.synchronize()
+    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b0.record()
+    for k in range(steps):
+        w.step()
+    b1.record()
+    out = per_launch_pass(w, steps)
+    out.avg = b0.elapsed_time(b1) / steps
+    return out
+
+
+def per_launch_pass(w, steps):
+    """`steps` launches with a HIP event between consecutive ones: the duration of every launch (min / max of the record)"""
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     for k in range(steps):
         evs[k].record()
         w.step()
     evs[steps].record()
     torch.cuda.synchronize()
-    return [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
+    return LaunchTimes(evs[k].elapsed_time(evs[k + 1]) for k in range(steps))
 
 
 # what the implementation moves per path-step: padded W lines read + written 64, the proposal path into the other parity half 24, mcnext!
@@ -596,12 +630,12 @@ def timed_region(w, steps, world, ctx, stats, comm=None):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e0.record()
     for k in range(steps):
-        evs[k].record()
         w.step()
-    evs[steps].record()
+    e1.record()
     if w.chains is not None:
         w.chains.stats(stats)
     else:
@@ -616,7 +650,9 @@ def timed_region(w, steps, world, ctx, stats, comm=None):
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    return elapsed, [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)], gathered
+    kern = per_launch_pass(w, steps)          # untimed: the same number of launches again, an event between consecutive ones
+    kern.avg = e0.elapsed_time(e1) / steps
+    return elapsed, kern, gathered
 
 
 PREWARM_S = 0.5   # see prewarm(): what the step counts below amount to at the bench sizes
@@ -656,9 +692,11 @@ def timed_region_local(ws, steps, stats, group):
     for d in devs:
         torch.cuda.synchronize(d)
     t0 = time.perf_counter()
+    b0 = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+    b1 = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+    for r in range(n):
+        b0[r].record(streams[r])
     for k in range(steps):
-        for r in range(n):
-            evs[r][k].record(streams[r])
         if grp is not None:
             ti = time.perf_counter()
             grp.step(ws[0].rho, 1)
@@ -667,7 +705,7 @@ def timed_region_local(ws, steps, stats, group):
             for r in range(n):
                 ws[r].step()
     for r in range(n):
-        evs[r][steps].record(streams[r])
+        b1[r].record(streams[r])
     if grp is not None:
         grp.stats(stats)
     else:
@@ -680,8 +718,24 @@ def timed_region_local(ws, steps, stats, group):
     for d in devs:
         torch.cuda.synchronize(d)
     elapsed = time.perf_counter() - t0
-    kern = [[evs[r][k].elapsed_time(evs[r][k + 1]) for k in range(steps)] for r in range(n)]
-    return (elapsed, kern, gathered[0], [evs[r][0].elapsed_time(evs[r][steps]) for r in range(n)], g0.elapsed_time(g1),
+    # untimed: the same number of iterations again with an event between consecutive launches on every device (min / max per launch)
+    for k in range(steps):
+        for r in range(n):
+            evs[r][k].record(streams[r])
+        if grp is not None:
+            grp.step(ws[0].rho, 1)
+        else:
+            for r in range(n):
+                ws[r].step()
+    for r in range(n):
+        evs[r][steps].record(streams[r])
+    for d in devs:
+        torch.cuda.synchronize(d)
+    kern = [LaunchTimes(evs[r][k].elapsed_time(evs[r][k + 1]) for k in range(steps)) for r in range(n)]
+    per_dev = [b0[r].elapsed_time(b1[r]) for r in range(n)]
+    for r in range(n):
+        kern[r].avg = per_dev[r] / steps
+    return (elapsed, kern, gathered[0], per_dev, g0.elapsed_time(g1),
             host_issue / steps * 1e6 if grp is not None else None)
 
 
@@ -823,7 +877,7 @@ def main_per_rank(args, world):
     bdist.allgather_stats(stats, world, comm)
     elapsed, kern_ms, gathered = timed_region(w, args.steps, world, ctx, stats, comm)
     # every rank's own device time over the timed steps (HIP events), so that a straggler shows in the record
-    mine = torch.tensor([float(sum(kern_ms))], dtype=torch.float64, device=ctx.device)
+    mine = torch.tensor([float(kern_ms.avg * args.steps)], dtype=torch.float64, device=ctx.device)
     allms = torch.empty(world, dtype=torch.float64, device=ctx.device)
     if world > 1:
         dist.all_gather_into_tensor(allms, mine)
@@ -918,7 +972,10 @@ def main_local(args):
                 stats[k].zero_()
         group.allgather(stats)
     elapsed, kern, gathered, per_gpu_ms, gather_ms, issue_us = timed_region_local(ws, args.steps, stats, group)
-    kern_ms = kern[0] if n == 1 else [float(np.mean([kern[r][k] for r in range(n)])) for k in range(args.steps)]
+    kern_ms = kern[0]
+    if n > 1:
+        kern_ms = LaunchTimes(float(np.mean([kern[r][k] for r in range(n)])) for k in range(args.steps))
+        kern_ms.avg = float(np.mean([kern[r].avg for r in range(n)]))
     out = base_record(args, n, w, elapsed, kern_ms,
                       "one process, one context per device; bhip_comm_init_all + bhip_comm_allgather_group" + (f" [{comm_note}]" if comm_note else ""))
     out["per_gpu_ms_per_step"] = [t / args.steps for t in per_gpu_ms]
@@ -938,7 +995,7 @@ def main_local(args):
     default_run = args.mode == "mcmc" and args.chains == 0
     if n == 1 and default_run and not args.no_other_modes:
         # >= 1 s of back-to-back launches of the headline kernel (the timed region above is K = 20 launches = 30-40 ms)
-        n_sus = max(50, int(1.2e3 / max(float(np.mean(kern_ms)), 1e-3)))
+        n_sus = max(50, int(1.2e3 / max(float(kern_ms.avg), 1e-3)))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_sus):
@@ -957,7 +1014,7 @@ def main_local(args):
             wo = Workload(mode, ctx, 0, 0)
             ms = kernel_times(wo, args.steps, args.warmup, min_ms=100.0)
             others.append({"mode": mode, "workload": wo.workload, "paths": wo.P,
-                           "path_steps_per_s": wo.P * steps_per_unit / (float(np.mean(ms)) * 1e-3), "roofline": wo.roofline(ms)})
+                           "path_steps_per_s": wo.P * steps_per_unit / (float(ms.avg) * 1e-3), "roofline": wo.roofline(ms)})
             if wo.parts:
                 others[-1]["parts"] = {"n": wo.parts, "pairwise_apart": wo.parts_apart}
                 wo.X.free()
