@@ -1678,7 +1678,12 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     if (nchains < 1) return fail(ctx, BHIP_EINVAL, "nchains must be positive");
     PATH_RANGE(ctx, path0, nchains);
     if (po->g.kind == BHIP_GUIDE_NONE) return fail(ctx, BHIP_EINVAL, "chains need a guided proposal");
-    if (po->mh.d > 3 && !po->d_steps) return fail(ctx, BHIP_ESTATE, "chains: the proposal has no large-d guide data");
+    // d > 3: one path per lane (slots) up to the chains' cut -- lower than the proposals' (the slots' traffic and registers: 8.5 vs 5.6 ms at
+    // d = 9) --, and never under the full-resolution noise specification (the slot kernel draws the default stream only)
+    const bool on_tile = po->mh.d > 3 && !(po->mid && po->mh.d <= std::min(ctx->mid_max, (int)BHIP_MID_MAX_CHAINS) && ctx->noise_spec == 4);
+    if (on_tile && !po->d_steps)
+        return fail(ctx, BHIP_ESTATE, "chains: the proposal has no large-d guide data (a component-wise user drift with a time-dependent auxiliary runs one path per lane "
+                                      "only: dimension 4..8, BHIP_OPT_MID_VALU on, default noise specification)");
     bhip_chains *ch = new (std::nothrow) bhip_chains();
     if (!ch) return fail(ctx, BHIP_EHIP, "out of host memory");
     ch->ctx = ctx; ch->po = po; ch->n = nchains; ch->ld = (nchains + 63) / 64 * 64;
@@ -1688,9 +1693,7 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     ctx_retain(ctx);
     ch->path0 = path0; ch->seed = seed; ch->flags = flags; ch->noise_spec = ctx->noise_spec;
     const size_t N = po->tt.size();
-    // d > 3: one path per lane (slots) up to the chains' cut -- lower than the proposals' (the slots' traffic and registers: 8.5 vs 5.6 ms at
-    // d = 9) --, and never under the full-resolution noise specification (the slot kernel draws the default stream only)
-    ch->tile = po->mh.d > 3 && !(po->mid && po->mh.d <= std::min(ctx->mid_max, (int)BHIP_MID_MAX_CHAINS) && ctx->noise_spec == 4);
+    ch->tile = on_tile;
     ch->lines = po->mh.d <= 3 && po->mh.mp <= 3;
     const size_t spc = LINE_DOUBLES / (ch->lines ? line_mpp(po->mh.mp) : 1);   // grid points per line (m' = 3: padded to 4 components)
     ch->nch = (int)((N + spc - 1) / spc);

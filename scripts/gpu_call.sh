@@ -14,6 +14,7 @@
 #     env:<K>=<V>      export an environment variable for the following steps (e.g. env:BHIP_PC_LARGE_NPAIR=1)
 #     py:<script>      python <script> (a probe under scripts/), stdout to <basename>.txt
 #     profile:<m>      scripts/gpu_profile.sh <tag>_<m> with the warm protocol (see that script)
+set -o pipefail   # a step's rc is its command's, not that of the `tail` behind it (a failing suite read "tests rc=0" until the end of round 5)
 TAG=${1:?tag}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
