@@ -119,6 +119,7 @@ def cpu_baseline(seconds_budget=20.0):
     return {"value": ratec, "unit": "path-steps/s", "cores": best_t, "kind": "port",
             "value_1thread": rate1, "host_cpus": os.cpu_count(), "affinity_cpus": ncpu, "cgroup_cpu_quota": quota,
             "probed_threads": {str(k): v for k, v in probed.items()},
+            "sample_short": f"{nchc} chains x {iters + 1} pCN iterations x {N_GRID - 1} steps of the bench workload, {best_t} OpenMP threads; C port, not Bridge.jl",
             "sample": f"{nchc} chains x {iters + 1} pCN iterations x {N_GRID - 1} steps of the bench workload, OpenMP over chains, "
                       f"{best_t} threads (fastest probed; {usable} usable); 1-thread figure on {nch1} chains; C restatement of "
                       "Bridge.jl's four-pass loop, not Bridge.jl (no Julia here)"}
@@ -771,7 +772,10 @@ def base_record(args, world, w, elapsed, kern_ms, launch):
         "data": "synthetic",
         "config": {"workload": w.workload, "mode": args.mode, "paths_per_gpu": w.P, "grid_points": N_GRID,
                    "path_steps_per_step": w.P * steps_per_unit * world,
-                   "noise_spec": NOISE_SPEC,
+                   "noise_spec": NOISE_SPEC, "noise_spec_short": SHORT_NOISE[4],
+                   "workload_short": f"FitzHugh-Nagumo PartialBridge d=2 m'=1 (v=1.1, Sigma=1e-10), 1001-pt tau-grid T=2, {'pCN-MCMC rho=0.9' if w.chains is not None else 'fresh proposals'}"
+                                     if w.mode in ("mcmc", "c4shard", "proposals") else w.workload,
+                   "parallelism_short": f"chains sharded over {world} GPU(s) by contiguous global id; one RCCL all-gather of a 64-B statistics block",
                    "prewarm_steps": PREWARM_STEPS.get(args.mode, 300),   # untimed, queued right before the timed region opens: the same step (clocks of an idle box)
                    "parallelism": f"chains sharded over {world} GPU(s) by contiguous global id, no data-path collective, one RCCL all-gather "
                                   "of the 64-byte statistics block inside libbridgehip.so",
@@ -1067,11 +1071,18 @@ def main_local(args):
         # the whole record once more, compact and LAST on the line (a 2 000-character tail of it still holds every mode):
         # mode -> [ms per launch, fraction of its roofline (8 TB/s; fp64 matrix peak for linpro32*), what binds it]
         r = out["roofline"]
-        modes = {"mcmc": [round(r["kernel_avg_ms"], 4), round(r["frac"], 3), r["bound"]],
+        def entry(ro):
+            e = [round(ro["kernel_avg_ms"], 4), round(ro["frac"], 3), ro["bound"]]
+            if "mfma_pipe_frac" in ro:   # d = 32: frac is on the reference's flop count; the share of the matrix pipe the executed flops occupy beside it
+                e.append(round(ro["mfma_pipe_frac"], 3))
+            return e
+        modes = {"mcmc": entry(r),
                  "mcmc_sustained": [round(out["sustained"]["ms_per_step"], 4), round(out["sustained"]["hbm_frac"], 3), "hbm"]}
         for o in out["other_modes"]:
-            ro = o["roofline"]
-            modes[o["mode"]] = [round(ro["kernel_avg_ms"], 4), round(ro["frac"], 3), ro["bound"]]
+            modes[o["mode"]] = entry(o["roofline"])
+            if o["mode"] == "mcmc_v2noise":   # the headline workload on the full-resolution stream (53 + 53-bit Box-Muller), in the head of the line
+                out["headline_v2noise"] = {"ms_per_step": o["roofline"]["kernel_avg_ms"], "frac": o["roofline"]["frac"],
+                                           "path_steps_per_s": o["path_steps_per_s"], "noise_spec": SHORT_NOISE[2]}
         sm = out.get("smoothing") or {}
         for key, short in (("iteration_shared_guides", "smooth_shared"), ("iteration_shared_guides_stats_every_iteration", "smooth_shared_k1"),
                            ("iteration_shared_guides_means_only", "smooth_means"),
@@ -1085,6 +1096,12 @@ def main_local(args):
 
 
 _JSON_FD = None
+CONTRACT_MAX_BYTES = 6144      # the ONE line on stdout; everything else goes to bench_full.json and stderr (a 25-30 KB line was not parsed)
+CONTRACT_STR_MAX = 118         # the driver's record cuts strings at ~120 characters: say it shorter, not truncated
+FULL_RECORD = "bench_full.json"
+SHORT_NOISE = {4: "bhip-philox-v4: Philox4x32-10, one normal per 32-bit word (piecewise deg-4 inverse CDF, |z|<=6.34)",
+               3: "bhip-philox-v3: Philox4x32-10, two Box-Muller pairs of 40+24 bits per call",
+               2: "bhip-philox-v2: Philox4x32-10, one Box-Muller pair of 53+53 bits per call"}
 
 
 def claim_stdout():
@@ -1097,12 +1114,114 @@ def claim_stdout():
     os.dup2(2, 1)
 
 
+def _short(s, n=CONTRACT_STR_MAX):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def _num(x, sig=6):
+    """numbers of the contract line to `sig` significant digits (a 17-digit double says nothing a 6-digit one does not, at 3x the bytes)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}") if math.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _num(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_num(v, sig) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def contract_record(out):
+    """The record the driver parses, cut from the full one: the contract's keys, `config`, `roofline` and `cpu_baseline` with what a
+    consistency check needs, `comm`, `sustained`, the headline under the full-resolution noise stream, and the compact `modes` map
+    (mode -> [ms per launch, fraction of its roofline, what binds it (, share of the matrix pipe)]).  Strings are short by
+    construction (<= CONTRACT_STR_MAX), numbers carry 6 significant digits, the whole line is <= CONTRACT_MAX_BYTES -- asserted."""
+    rec = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    cfg = out.get("config", {})
+    c = _pick(cfg, ("mode", "paths_per_gpu", "grid_points", "path_steps_per_step", "prewarm_steps", "acceptance_rate", "mean_ll", "chains_total"))
+    c["workload"] = _short(cfg.get("workload_short") or cfg.get("workload", ""))
+    c["noise_spec"] = _short(cfg.get("noise_spec_short") or cfg.get("noise_spec", ""))
+    c["parallelism"] = _short(cfg.get("parallelism_short") or cfg.get("parallelism", ""))
+    c["launch"] = _short(cfg.get("launch", ""))
+    if "placement" in cfg:
+        c["placement"] = _pick(cfg["placement"], ("tries", "gbs_same_piece", "gbs_kept", "piece_w", "piece_xo"))
+    rec["config"] = c
+    ro = out.get("roofline", {})
+    r = _pick(ro, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "kernel", "kernel_avg_ms", "kernel_min_ms",
+                   "kernel_max_ms", "algorithmic_bytes_per_path_step", "path_steps_per_launch", "algorithmic_flops_per_path_step",
+                   "executed_flops_per_path_step", "mfma_pipe_frac", "valu_frac", "hbm_frac_at_full_issue"))
+    if "traffic_box" in ro:
+        r["traffic_source"] = _short("rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, " + ("this box, this run" if ro.get("traffic_box") == "this box, this run"
+                                                                                           else "committed profiles/ (another box)" if ro.get("traffic") else "none"))
+    rec["roofline"] = r
+    if "cpu_baseline" in out:
+        cb = out["cpu_baseline"]
+        rec["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "value_1thread", "host_cpus", "cgroup_cpu_quota"))
+        rec["cpu_baseline"]["sample"] = _short(cb.get("sample_short") or cb.get("sample", ""))
+    if "comm" in out:
+        rec["comm"] = {k: (_short(v) if isinstance(v, str) else v) for k, v in out["comm"].items()}
+    for k in ("per_gpu_ms_per_step", "allgather_ms", "host_issue_us_per_step"):
+        if k in out:
+            rec[k] = out[k]
+    if "no_prewarm" in out:
+        rec["no_prewarm_ms_per_step"] = out["no_prewarm"].get("ms_per_step")
+    if "sustained" in out:
+        rec["sustained"] = _pick(out["sustained"], ("launches", "seconds", "ms_per_step", "path_steps_per_s", "hbm_frac"))
+    if "survey_c4" in out:
+        sc = out["survey_c4"]
+        rec["survey_c4"] = _pick(sc, ("chains_per_gpu", "value", "unit", "ms_per_step", "scaling", "host_issue_us_per_step"))
+        rec["survey_c4"]["roofline"] = _pick(sc.get("roofline", {}), ("bound", "frac", "kernel_avg_ms", "achieved", "unit"))
+    if "headline_v2noise" in out:
+        rec["headline_v2noise"] = out["headline_v2noise"]
+    if "modes" in out:
+        rec["modes"] = out["modes"]
+    rec["full_record"] = out.get("full_record")
+    rec = _num(rec)
+    for k in ("value", "ms_per_step"):   # the two figures the driver checks against its own clock: at full precision
+        if k in out:
+            rec[k] = out[k]
+    line = json.dumps(rec, separators=(",", ":"))
+    if len(line.encode()) > CONTRACT_MAX_BYTES and "modes" in rec:
+        # never lose the head of the line to its tail: drop the compact map first (it is in the full record), loudly
+        print(f"bench.py: contract line {len(line.encode())} B > {CONTRACT_MAX_BYTES}: `modes` left to {FULL_RECORD}", file=sys.stderr)
+        rec["modes"] = {"dropped": f"see {FULL_RECORD}"}
+        line = json.dumps(rec, separators=(",", ":"))
+    assert len(line.encode()) <= CONTRACT_MAX_BYTES, f"contract line is {len(line.encode())} bytes, the cap is {CONTRACT_MAX_BYTES}"
+    assert "\n" not in line
+    return rec, line
+
+
+def write_full_record(out):
+    """the whole record (every mode's roofline dict, the smoothing record, the box, notes): bench_full.json next to bench.py, a copy under
+    gpurun_out/ when that exists (it travels back from a GPU box), and stderr"""
+    full = json.dumps(out, indent=1)
+    where = []
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, FULL_RECORD), "w") as f:
+                    f.write(full + "\n")
+                where.append(os.path.relpath(os.path.join(d, FULL_RECORD), ROOT))
+            except OSError as e:
+                print(f"bench.py: could not write {d}/{FULL_RECORD}: {e}", file=sys.stderr)
+    print("bench.py: full record follows (also: " + ", ".join(where) + ")\n" + json.dumps(out), file=sys.stderr)
+    return where[0] if where else None
+
+
 def emit_json(out):
-    line = (json.dumps(out) + "\n").encode()
+    out["full_record"] = FULL_RECORD
+    write_full_record(out)
+    _, line = contract_record(out)
+    data = (line + "\n").encode()
     if _JSON_FD is None:
-        sys.stdout.write(line.decode()); sys.stdout.flush()
+        sys.stdout.write(data.decode()); sys.stdout.flush()
     else:
-        os.write(_JSON_FD, line)
+        os.write(_JSON_FD, data)
 
 
 def main():

@@ -132,7 +132,7 @@ def test_bench_under_the_launcher_at_one_rank_and_its_fallback():
     assert "bhip_comm_init_rank" in out[0]["config"]["launch"]
     assert out[0]["comm"]["backend"] == "rccl" and out[0]["comm"]["rccl_nranks"] == 1 and out[0]["comm"]["ranks_seen"] == [0] and out[0]["comm"]["consistent"]
     assert "fall-back" in out[1]["comm"]["backend"] and "rccl_nranks" not in out[1]["comm"] and out[1]["comm"]["gathered_blocks"] == 1
-    assert "torch.distributed" in out[1]["config"]["launch"] and "forced by BENCH_FORCE_COMM_FAILURE" in out[1]["config"]["launch"]
+    assert "torch.distributed" in out[1]["config"]["launch"] and "forced by BENCH_FORCE_COMM_FAILURE" in out[1]["comm"]["note"]
     assert out[0]["config"]["acceptance_rate"] == out[1]["config"]["acceptance_rate"] and out[0]["config"]["chains_total"] == 4096
     assert len(out[0]["per_gpu_ms_per_step"]) == 1 and 0 < out[0]["per_gpu_ms_per_step"][0] <= out[0]["ms_per_step"] * 1.0001
 
