@@ -1872,23 +1872,44 @@ static bool place_apart(const bhip_ctx *ctx, const PairRates &pr)
 }
 // the piece of [ptr, ptr + bytes) by the context's map: the id of the representative it shares a piece with; a NEW id (the smallest
 // unused one, *is_new set) when it lies apart from every piece the map knows; -1 when the tests are inconclusive (a buffer astride
-// a cut, a plain allocation mixed from several pieces) or the map is empty.  apart_piece: a piece the buffer is already known to lie
-// apart from (the W of its own pair), not tested again.  The contents of the tested ranges are overwritten.
+// a cut, a plain allocation mixed from several pieces), the map is empty, or there is no memory for the save area.  apart_piece: a piece
+// the buffer is already known to lie apart from (the W of its own pair), not tested again.
+// WHAT IS WRITTEN: the tested ranges of [ptr, ptr + bytes) -- its head and tail -- are overwritten.  The representatives are buffers of
+// LIVE ensembles (their W holds the chains' state): the head and tail ranges of a representative that the write streams go over are saved
+// to a scratch allocation first and restored afterwards, on the context's stream, in order -- an ensemble created, or a foreign buffer
+// classified, beside older ensembles leaves their W / Xo bit for bit as they were (advisor r5; tests/test_gpu_pc.py steps the FIRST of six
+// ensembles after the sixth was placed).
 static int place_classify(bhip_ctx *ctx, void *ptr, size_t bytes, bool *is_new, int apart_piece = -1)
 {
     if (is_new) *is_new = false;
     if (!(ctx->r_same > 0.f) || bytes < PLACE.min_bytes) return -1;
     bool seen[3] = {false, false, false}, all_apart = true;
-    int known = 0;
+    int known = 0, result = -2;
+    char *save = nullptr; size_t save_bytes = 0;
     for (const bhip_ctx::PieceEnt &e : ctx->pieces) {
         if (e.piece < 0 || e.piece > 2 || seen[e.piece] || e.p == ptr || e.bytes < PLACE.min_bytes) continue;
         seen[e.piece] = true; known++;
         if (e.piece == apart_piece) continue;
+        // the ranges place_pair_rates writes in the representative: sp bytes at its head and at its tail (same arithmetic)
+        const size_t sp = place_stream_bytes(e.bytes / 2, bytes / 2);
+        char *head = (char *)e.p, *tail = (char *)e.p + (e.bytes - sp) / 4096 * 4096;
+        if (save_bytes < 2 * sp) {
+            if (save) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(save); save = nullptr; }
+            if (hipMalloc((void **)&save, 2 * sp) != hipSuccess) { (void)hipGetLastError(); save = nullptr; result = -1; break; }
+            save_bytes = 2 * sp;
+        }
+        if (hipMemcpyAsync(save, head, sp, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(save + sp, tail, sp, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { (void)hipGetLastError(); result = -1; break; }
         const PairRates pr = place_pair_rates(ctx, e.p, e.bytes, ptr, bytes, 0.f, false);
-        if (!(pr.smallest > 0.f)) return -1;
-        if (pr.mean <= PLACE.same_mean_max * ctx->r_same) return e.piece;
+        const bool restored = hipMemcpyAsync(head, save, sp, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+                              hipMemcpyAsync(tail, save + sp, sp, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess;
+        if (!restored) { (void)hipGetLastError(); ctx->err = "bhip placement: restoring a live ensemble's buffer after a write-stream test failed"; result = -1; break; }
+        if (!(pr.smallest > 0.f)) { result = -1; break; }
+        if (pr.mean <= PLACE.same_mean_max * ctx->r_same) { result = e.piece; break; }
         if (!place_apart(ctx, pr)) all_apart = false;
     }
+    if (save) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(save); }
+    if (result != -2) return result;
     if (!known || !all_apart || known >= 3) return -1;
     for (int k = 0; k < 3; k++)
         if (!seen[k]) { if (is_new) *is_new = true; return k; }
@@ -2079,6 +2100,7 @@ int bhip_alloc_apart(bhip_ctx *ctx, int nparts, size_t bytes, void **out, int *a
                 out[j] = nullptr;
                 return fail(ctx, BHIP_EHIP, "bhip_alloc_apart: out of device memory");
             }
+        for (int j = 0; j < nparts; j++) { { std::lock_guard<std::mutex> g(ctx->buf_mu); ctx->bufs.insert(out[j]); } ctx_retain(ctx); }
         return BHIP_OK;
     }
     void *p = nullptr;
@@ -2123,18 +2145,30 @@ int bhip_alloc_apart(bhip_ctx *ctx, int nparts, size_t bytes, void **out, int *a
     }
     (void)hipStreamSynchronize(ctx->stream);
     release(held);
-    for (int j = 0; j < nparts; j++) out[j] = kept[j];
+    for (int j = 0; j < nparts; j++) { out[j] = kept[j]; { std::lock_guard<std::mutex> g(ctx->buf_mu); ctx->bufs.insert(out[j]); } ctx_retain(ctx); }
     if (apart) *apart = judge ? n_apart : 0;
     return BHIP_OK;
 }
 
+// the parts are children of the context like bhip_malloc buffers (each holds a reference: a finalizer may give them back after the
+// context was destroyed -- Julia runs finalizers in no particular order at exit; advisor r5)
 int bhip_free_apart(bhip_ctx *ctx, int nparts, void *const *ptrs)
 {
     if (!ctx || !ptrs || nparts < 0) return BHIP_EINVAL;
-    NEED_DEVICE(ctx);
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int j = 0; j < nparts; j++) if (ptrs[j]) (void)hipFree(ptrs[j]);
-    return BHIP_OK;
+    if (ctx->host_only) return fail(ctx, BHIP_EHIP, "host-only context (device -1): no device memory");
+    int rc = BHIP_OK;
+    bool quiesced = false;
+    for (int j = 0; j < nparts; j++) {
+        if (!ptrs[j]) continue;
+        {
+            std::lock_guard<std::mutex> g(ctx->buf_mu);
+            if (ctx->bufs.erase(ptrs[j]) == 0) { rc = fail(ctx, BHIP_EINVAL, "bhip_free_apart: not a live bhip_alloc_apart buffer of this context (foreign pointer or double free)"); continue; }
+        }
+        if (!quiesced) { ctx_quiesce(ctx); quiesced = true; }
+        if (hipFree(ptrs[j]) != hipSuccess) { (void)hipGetLastError(); rc = BHIP_EHIP; }
+        ctx_release(ctx);
+    }
+    return rc;
 }
 
 // ONE pCN proposal of every chain of a segment with the decision deferred (multi-segment ensembles): Wo = w_old*W + w_new*W2,

@@ -275,7 +275,8 @@ int bhip_sample_solve_parts(bhip_ctx *ctx, const bhip_proposal *po, const double
 /* nparts (1..3) physically contiguous device buffers of `bytes` each, pairwise in different pieces of the device memory (tested with
  * write streams like the placement of chain ensembles; candidates that fail stay held until the set is complete).  *apart (optional):
  * how many of them ended up pairwise apart -- nparts when all did, 0 when the buffers are too small to be tested (< 64 MiB).
- * bhip_free_apart gives them back. */
+ * bhip_free_apart gives them back; like bhip_malloc buffers the parts hold a reference to their context (they may be freed after
+ * bhip_ctx_destroy, in any order). */
 int bhip_alloc_apart(bhip_ctx *ctx, int nparts, size_t bytes, void **out, int *apart);
 int bhip_free_apart(bhip_ctx *ctx, int nparts, void *const *ptrs);
 
@@ -333,7 +334,11 @@ int bhip_chains_placement_info(const bhip_chains *ch, int *tries, float *gbs_sam
 int bhip_chains_placement_pieces(const bhip_chains *ch, int *piece_w, int *piece_xo);
 /* the piece of the device memory a buffer of >= 64 MiB lies in, by the context's map (built by the first placed ensemble, alive with
  * the ensembles): a buffer the map holds is looked up; any other is classified with write streams -- ITS CONTENTS ARE OVERWRITTEN --
- * against one representative per known piece: that piece's id, a new id when it lies apart from all of them, -1 when inconclusive */
+ * against one representative per known piece: that piece's id, a new id when it lies apart from all of them, -1 when inconclusive.
+ * The representatives are buffers of LIVE ensembles: the ranges of a representative the write streams go over (head and tail, up to
+ * 512 MiB each) are copied to a scratch allocation before the test and copied back after it, on the context's stream -- the
+ * ensembles' states are bit for bit what they were (up to 1 GiB of transient device memory; without it the answer is -1 and nothing
+ * is written).  The same holds for the classification bhip_chains_init / bhip_segchains_init run for a new ensemble's own buffers. */
 int bhip_ctx_piece_of(bhip_ctx *ctx, void *dev_ptr, size_t bytes, int *piece);
 /* `iters` pCN iterations: sample!(W2); Wo = rho*W + sqrt(1-rho^2)*W2; solve!; llo; accept iff
  * log(U) <= llo - ll.  skip applies to llo like partialbridge_nclar.jl:121; pass BHIP_SKIP_OF_INIT to use the skip the

@@ -194,12 +194,24 @@ def test_piece_map_of_the_context_places_six_ensembles_alive_at_once():
     scratch = torch.empty(1 << 27, dtype=torch.float64, device=c2.device)            # 1 GiB
     c2.check(c2.lib.bhip_ctx_piece_of(c2.h, C.c_void_p(scratch.data_ptr()), C.c_size_t(scratch.numel() * 8), C.byref(pc)))
     assert pc.value in (-1, 0, 1, 2)
-    # the ensembles still run, and give what an unplaced ensemble gives
+    # the ensembles still run, and give what an unplaced ensemble gives -- the LAST one, and the FIRST one too: its W and Xo were the
+    # map's representatives while five later ensembles and a foreign buffer were classified with write streams against them
+    # (advisor r5: the tested ranges of a representative are saved and restored; before that the first ensemble's chain state was overwritten)
     ens[5].step(0.9, 2)
+    ens[0].step(0.9, 2)
+    X0, W0 = ens[0].paths(0, 4)
+    XL, WL = ens[0].paths(n - 4, 4)                      # head and tail of the buffers: where the streams went
     c2.set_option(bh.OPT_TUNE_PLACEMENT, 0)
     ref = bh.Chains(Po, case.x0, n, seed=14)
     ref.step(0.9, 2)
     assert np.array_equal(ens[5].ll(), ref.ll()) and np.array_equal(ens[5].acc(), ref.acc())
+    del ref
+    ref0 = bh.Chains(Po, case.x0, n, seed=9)
+    ref0.step(0.9, 2)
+    assert np.array_equal(ens[0].ll(), ref0.ll()) and np.array_equal(ens[0].acc(), ref0.acc())
+    for got, want in ((X0, ref0.paths(0, 4)[0]), (W0, ref0.paths(0, 4)[1]), (XL, ref0.paths(n - 4, 4)[0]), (WL, ref0.paths(n - 4, 4)[1])):
+        assert np.array_equal(got, want)
+    ref = ref0
     # every set-up after the first: W sample + solve of 65 536 chains plus the tests -- tens of milliseconds at most, not round 4's 23-60 on top
     assert sorted(setup_ms[1:])[2] < 150.0, (setup_ms, infos)      # (the median; an ensemble that went through all its candidates takes longer)
     del ens, ref
