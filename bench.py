@@ -363,6 +363,8 @@ class Workload:
             (" [X kept in two buffers of half the paths each, in different 96-GiB pieces of the device memory: bhip_alloc_apart + bhip_sample_solve_parts, "
              "one launch, the same values]" if self.parts else "")
         self.kernel = kname(self.P).replace("bhip::", "bhip_fused::") if self.fused else kname(self.P)
+        if self.fused:   # LinPro targets at d <= 3 run the regrouped step (GUIDE_QF = 5) under the option (bhip_path_kernel.h)
+            self.kernel = self.kernel.replace("double const*>, 1, 1,", "double const*>, 5, 1,")
         if self.v2noise:   # large ensembles under v3 / v2: one pair per workgroup (bhip_pc_kernel.h launch_pc)
             self.kernel = self.kernel.replace("4, false, false>", "1, false, false>")
         self.flops_per_pathstep = 5 * 2 * d * d if d > 8 else None   # d = 32: five d x d mat-vecs per path-step on the matrix cores

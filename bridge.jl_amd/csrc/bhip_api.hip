@@ -187,6 +187,8 @@ struct bhip_proposal {
     double *d_rows = nullptr;
     double *d_rows_innov = nullptr;   // LinPro target at 4 <= d <= 12: the (nu, H) rows innovations! reads (d_rows holds the regrouped ones)
     int rs_innov = 0;
+    double *d_rows_qf = nullptr;      // LinPro target at d <= 3 with a guide: the REGROUPED rows (GUIDE_QF, dt folded in) the fused build runs on
+    int rs_qf = 0;                    // under BHIP_OPT_FUSED_ARITHMETIC (do_launch); d_rows keeps the reference's form for everything else
     int rs = 0;
     double *d_rdtp = nullptr;   // rdtp[j] = sqrt(tt[j] - tt[j-1]), rdtp[0] = 0, zero padded to a multiple of 16 (bhip_pc_kernel.h)
     bool use_vend = false;
@@ -248,6 +250,18 @@ static int fail(bhip_ctx *ctx, int code, const std::string &msg)
         hipError_t e_ = (call);                                                                   \
         if (e_ != hipSuccess) return fail(ctx, BHIP_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+// end of a call that launched work reading / writing a temporary device buffer: wait for the context's stream, release the buffer, and
+// report what the wait says -- an asynchronous fault of the work just launched surfaces HERE (or never: the next call would see it,
+// without knowing whose it was) and must not be returned as BHIP_OK
+static int sync_free_rc(bhip_ctx *ctx, void *tmp, int rc)
+{
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (tmp) (void)hipFree(tmp);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(ctx, BHIP_EHIP, std::string("hipStreamSynchronize after the call's kernels: ") + hipGetErrorString(e));
+    return BHIP_OK;
+}
 
 // every entry point that touches the device: refuse host-only contexts and make the context's device
 // current for the calling thread (a process may drive several devices through several contexts)
@@ -620,6 +634,7 @@ void bhip_proposal_destroy(bhip_proposal *po)
         ctx_quiesce(ctx);
         if (po->d_rows) (void)hipFree(po->d_rows);
         if (po->d_rows_innov) (void)hipFree(po->d_rows_innov);
+        if (po->d_rows_qf) (void)hipFree(po->d_rows_qf);
         if (po->d_tt) (void)hipFree(po->d_tt);
         if (po->d_rdtp) (void)hipFree(po->d_rdtp);
         if (po->d_steps) (void)hipFree(po->d_steps);
@@ -1015,63 +1030,95 @@ static int finish_guide(bhip_proposal *po)
     }
     std::vector<double> rows;
     int rs = 0;
-    if (po->mid) {
-        // the guide in the form r = H_i (nu_i - x), as build_tile_data brings it for the tile kernel:
-        //   GuidedBridge: H = inv(Hdiamond_i) (LU, path-independent), nu = V_i;  (L,M,mu): H = L'ML, nu = L'(LL')^-1 (v - mu);  (nu,H) as is
-        Guide g2;
+    // the guide in the form r = H_i (nu_i - x), as build_tile_data brings it for the tile kernel:
+    //   GuidedBridge: H = inv(Hdiamond_i) (LU, path-independent), nu = V_i;  (L,M,mu): H = L'ML, nu = L'(LL')^-1 (v - mu);  (nu,H) as is
+    auto nuh_form = [&](Guide &g2) {
         g2.kind = po->g.kind == BHIP_GUIDE_NONE ? BHIP_GUIDE_NONE : BHIP_GUIDE_NUH;
         g2.m = po->g.m;
-        if (g2.kind != BHIP_GUIDE_NONE) {
-            g2.H.resize(N); g2.nu.resize(N);
-            for (int i = 0; i < N; i++) {
-                if (po->g.kind == BHIP_GUIDE_HV) { g2.H[i] = i < N - 1 ? inv(po->g.Hd[i]) : Mat(d, d); g2.nu[i] = po->g.V[i]; }
-                else if (po->g.kind == BHIP_GUIDE_LMMU) {
-                    const Mat &L = po->g.L[i];
-                    g2.H[i] = (tr(L) * po->g.M[i]) * L;
-                    g2.nu[i] = tr(L) * solve(L * tr(L), po->g.v - po->g.mu[i]);
-                } else { g2.H[i] = po->g.H[i]; g2.nu[i] = po->g.nu[i]; }
-            }
+        if (g2.kind == BHIP_GUIDE_NONE) return;
+        g2.H.resize(N); g2.nu.resize(N);
+        for (int i = 0; i < N; i++) {
+            if (po->g.kind == BHIP_GUIDE_HV) { g2.H[i] = i < N - 1 ? inv(po->g.Hd[i]) : Mat(d, d); g2.nu[i] = po->g.V[i]; }
+            else if (po->g.kind == BHIP_GUIDE_LMMU) {
+                const Mat &L = po->g.L[i];
+                g2.H[i] = (tr(L) * po->g.M[i]) * L;
+                g2.nu[i] = tr(L) * solve(L * tr(L), po->g.v - po->g.mu[i]);
+            } else { g2.H[i] = po->g.H[i]; g2.nu[i] = po->g.nu[i]; }
         }
+    };
+    // LinPro target: the REGROUPED step (bhip_path_kernel.h GUIDE_QF; the algebra of build_tile_data): per step A_i, bv_i, P_i, q_i, c0_i in
+    // place of B~_i, beta~_i, H_i, nu_i, from the (nu, H) form g2.  times[i*ts .. +2] = t, dt, sqrt(dt) of step i.  fold_dt (the d <= 3
+    // form): A_i, bv_i, c0_i multiplied by dt here, so that the step adds c0' + x.(bv' + A'x) to the log-likelihood as it is.
+    auto regroup_rows = [&](const Guide &g2, const double *times, int ts, bool fold_dt, std::vector<double> &rowsq, int &rq) {
+        rq = row_stride(BHIP_GUIDE_QF, d, 1, true);
+        rowsq.assign((size_t)(N - 1) * rq, 0.0);
+        const double *par = po->mh.par.data();
+        const Mat Bm(d, d, par), mu(d, 1, par + (size_t)d * d);
+        const Mat Bmu = Bm * mu;
+        Mat Id(d, d);
+        for (int k = 0; k < d; k++) Id(k, k) = 1.0;
+        for (int i = 0; i < N - 1; i++) {
+            Mat Bt = po->aux.B(po->tt[i]), mua(d, 1), beta(d, 1);
+            if (po->aux.linpro_form()) std::memcpy(mua.a.data(), po->aux.mu(), sizeof(double) * d);
+            else beta = po->aux.beta(po->tt[i]);
+            const Mat Dm = Bm - Bt, DmT = tr(Dm), c = Bt * mua - Bmu - beta;
+            const Mat &Hm = g2.H[i], &nu = g2.nu[i];
+            const double dt = po->tt[i + 1] - po->tt[i], f = fold_dt ? dt : 1.0;
+            const Mat hnu = Hm * nu;
+            const Mat A = (-f) * (DmT * Hm), bv = f * (DmT * hnu - tr(Hm) * c);
+            const Mat P = Id + dt * (Bm - po->mh.a * Hm), q = dt * (po->mh.a * hnu - Bmu);
+            double *r = &rowsq[(size_t)i * rq];
+            std::memcpy(r, times + (size_t)i * ts, 3 * sizeof(double));                       // t, dt, sqrt(dt)
+            std::memcpy(r + 3, A.a.data(), sizeof(double) * d * d);
+            std::memcpy(r + 3 + d * d, bv.a.data(), sizeof(double) * d);
+            std::memcpy(r + 3 + d * d + d, P.a.data(), sizeof(double) * d * d);
+            std::memcpy(r + 3 + 2 * d * d + d, q.a.data(), sizeof(double) * d);
+            r[3 + 2 * d * d + 2 * d] = f * dot(c, hnu);
+        }
+    };
+    if (po->d_rows_qf) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(po->d_rows_qf)); po->d_rows_qf = nullptr; po->rs_qf = 0; }
+    if (po->mid) {
+        Guide g2;
+        nuh_form(g2);
         pack_rows(po->tt, po->mh, po->has_aux ? &po->aux : nullptr, g2, rows, rs);
         if (po->d_rows_innov) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(po->d_rows_innov)); po->d_rows_innov = nullptr; }
         if (po->mh.id == BHIP_MODEL_LINPRO && g2.kind != BHIP_GUIDE_NONE) {
-            // LinPro target: the REGROUPED step (bhip_path_kernel.h GUIDE_QF; the algebra of build_tile_data): per step A_i, bv_i, P_i, q_i,
-            // c0_i in place of B~_i, beta~_i, H_i, nu_i.  innovations! keeps the (nu, H) rows packed above (a second, small array).
+            // innovations! keeps the (nu, H) rows packed above (a second, small array)
             HIPCHK(ctx, hipMalloc((void **)&po->d_rows_innov, sizeof(double) * rows.size()));
             HIPCHK(ctx, hipMemcpy(po->d_rows_innov, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice));
             po->rs_innov = rs;
-            const int rq = row_stride(BHIP_GUIDE_QF, d, 1, true);
-            std::vector<double> rowsq((size_t)(N - 1) * rq, 0.0);
-            const double *par = po->mh.par.data();
-            const Mat Bm(d, d, par), mu(d, 1, par + (size_t)d * d);
-            const Mat Bmu = Bm * mu;
-            Mat Id(d, d);
-            for (int k = 0; k < d; k++) Id(k, k) = 1.0;
-            for (int i = 0; i < N - 1; i++) {
-                Mat Bt = po->aux.B(po->tt[i]), mua(d, 1), beta(d, 1);
-                if (po->aux.linpro_form()) std::memcpy(mua.a.data(), po->aux.mu(), sizeof(double) * d);
-                else beta = po->aux.beta(po->tt[i]);
-                const Mat Dm = Bm - Bt, DmT = tr(Dm), c = Bt * mua - Bmu - beta;
-                const Mat &Hm = g2.H[i], &nu = g2.nu[i];
-                const double dt = po->tt[i + 1] - po->tt[i];
-                const Mat hnu = Hm * nu;
-                const Mat A = -(DmT * Hm), bv = DmT * hnu - tr(Hm) * c;
-                const Mat P = Id + dt * (Bm - po->mh.a * Hm), q = dt * (po->mh.a * hnu - Bmu);
-                double *r = &rowsq[(size_t)i * rq];
-                std::memcpy(r, &rows[(size_t)i * rs], 3 * sizeof(double));                       // t, dt, sqrt(dt)
-                std::memcpy(r + 3, A.a.data(), sizeof(double) * d * d);
-                std::memcpy(r + 3 + d * d, bv.a.data(), sizeof(double) * d);
-                std::memcpy(r + 3 + d * d + d, P.a.data(), sizeof(double) * d * d);
-                std::memcpy(r + 3 + 2 * d * d + d, q.a.data(), sizeof(double) * d);
-                r[3 + 2 * d * d + 2 * d] = dot(c, hnu);
-            }
+            std::vector<double> rowsq;
+            int rq = 0;
+            regroup_rows(g2, rows.data(), rs, false, rowsq, rq);
             rows.swap(rowsq);
             rs = rq;
         }
         if (!po->d_mpar) HIPCHK(ctx, hipMalloc((void **)&po->d_mpar, sizeof(double) * po->mh.dpar.size()));
         HIPCHK(ctx, hipMemcpy(po->d_mpar, po->mh.dpar.data(), sizeof(double) * po->mh.dpar.size(), hipMemcpyHostToDevice));
-    } else
-    pack_rows(po->tt, po->mh, po->has_aux ? &po->aux : nullptr, po->g, rows, rs);
+    } else {
+        pack_rows(po->tt, po->mh, po->has_aux ? &po->aux : nullptr, po->g, rows, rs);
+        // d <= 3, LinPro target, any guide, any auxiliary: the regrouped rows beside the reference-form ones -- what the fused build's
+        // GUIDE_QF kernels read when the context runs under BHIP_OPT_FUSED_ARITHMETIC (do_launch).  Needs the (nu, H) form: a GuidedBridge
+        // whose Hdiamond_i cannot be inverted keeps the reference form alone.
+        if (po->mh.id == BHIP_MODEL_LINPRO && po->mh.constdiff && po->g.kind != BHIP_GUIDE_NONE && po->has_aux) {
+            bool ok = true;
+            if (po->g.kind == BHIP_GUIDE_HV)
+                for (int i = 0; i < N - 1 && ok; i++) { const double c = std::fabs(det(po->g.Hd[i])); ok = c > 0x1.0p-200 && c < 0x1.0p200; }
+            if (ok) {
+                Guide g2;
+                nuh_form(g2);
+                std::vector<double> rowsq;
+                int rq = 0;
+                regroup_rows(g2, rows.data(), rs, true, rowsq, rq);
+                for (double x : rowsq) ok = ok && std::isfinite(x);
+                if (ok) {
+                    HIPCHK(ctx, hipMalloc((void **)&po->d_rows_qf, sizeof(double) * rowsq.size()));
+                    HIPCHK(ctx, hipMemcpy(po->d_rows_qf, rowsq.data(), sizeof(double) * rowsq.size(), hipMemcpyHostToDevice));
+                    po->rs_qf = rq;
+                }
+            }
+        }
+    }
     if (po->g.kind == BHIP_GUIDE_HV && po->mid) {
         // 4 <= d <= 8: the rows above hold inv(Hdiamond_i) (the (nu, H) form); what has to hold is that the inverse exists
         for (int i = 0; i < N - 1; i++) {
@@ -1339,6 +1386,20 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         if (!fm) return fail(ctx, BHIP_EUNSUPPORTED, "no path-per-lane kernel for this mode at 4 <= d <= 12");
         HIPCHK(ctx, fm(am, ctx->stream));
         return BHIP_OK;
+    }
+    if (ctx->fused && po->d_rows_qf && a.rows == po->d_rows && noise != NOISE_INNOV && po->mh.id == BHIP_MODEL_LINPRO) {
+        // BHIP_OPT_FUSED_ARITHMETIC, LinPro target at d <= 3: the regrouped step (bhip_path_kernel.h GUIDE_QF) on the rows finish_guide
+        // keeps beside the reference-form ones -- one dependent fused multiply-add per component and step instead of the reference's chain
+        // (tolerance parity, tests/test_gpu_fused.py); innovations! needs _b itself and stays on the reference form
+        KArgs aq = a;
+        aq.rows = po->d_rows_qf; aq.rs = po->rs_qf;
+        launch_fn f = nullptr;
+        if (wave_spec && a.rdtp && a.wstride == 1) {
+            if (noise == NOISE_FRESH && a.P <= pc_fresh_max_paths()) f = find_launch(po->mh, BHIP_GUIDE_QF, 1, NOISE_FRESH_PC, fl, true);
+            else if (noise == NOISE_PCN_LINES) f = find_launch(po->mh, BHIP_GUIDE_QF, 1, NOISE_PCN_LINES_PC, fl, true);
+        }
+        if (!f) f = find_launch(po->mh, BHIP_GUIDE_QF, 1, noise, fl, true);
+        if (f) { HIPCHK(ctx, f(aq, ctx->stream)); return BHIP_OK; }
     }
     if (a.rs != row_stride(gk, po->mh.d, po->g.m, po->mh.constdiff)) return fail(ctx, BHIP_ESTATE, "row stride mismatch");
     if (!po->mh.constdiff) {
@@ -1756,8 +1817,7 @@ static int chains_init_impl(bhip_chains *ch, const double *x0, const double *x0_
             hipLaunchKernelGGL(k_soa_to_tlines, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, tmpW, ch->Wc, N, d, T, ch->ld, ch->n);
             if (hipGetLastError() != hipSuccess) rct = fail(ctx, BHIP_EHIP, "k_soa_to_tlines launch failed");
         }
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(tmpW);
+        rct = sync_free_rc(ctx, tmpW, rct);
         if (rct) return rct;
         ch->skip0 = skip; ch->iter = 0; ch->inited = true;
         return BHIP_OK;
@@ -1782,7 +1842,7 @@ static int chains_init_impl(bhip_chains *ch, const double *x0, const double *x0_
                            ch->Wc, ch->ld, ch->n);
         if (hipGetLastError() != hipSuccess) rc = fail(ctx, BHIP_EHIP, "k_soa_to_lines launch failed");
     }
-    if (tmpW) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(tmpW); }
+    if (tmpW) rc = sync_free_rc(ctx, tmpW, rc);
     if (rc) return rc;
     ch->iter = 0; ch->inited = true;
     return BHIP_OK;
@@ -2395,9 +2455,7 @@ int bhip_chains_get_paths(bhip_chains *ch, long p0, long np, double *X_aos, doub
     int rc = X_aos ? current_X(ch, p0, np, tmp, tmp + nW) : gather_current_W(ch, p0, np, tmp);
     if (!rc && W_aos) rc = bhip_download_aos(ctx, tmp, (int)N, (int)mp, np, 0, np, W_aos);
     if (!rc && X_aos) rc = bhip_download_aos(ctx, tmp + nW, (int)N, (int)d, np, 0, np, X_aos);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(tmp);
-    return rc;
+    return sync_free_rc(ctx, tmp, rc);
 }
 
 int bhip_chains_current_X(bhip_chains *ch, double *X_dev, long ldX)
@@ -2417,9 +2475,7 @@ int bhip_chains_current_X(bhip_chains *ch, double *X_dev, long ldX)
         rc = fill_common(ch->po, a, ch->x0.data(), nullptr, ch->n, 0);
         if (!rc) { a.Win = tmp; a.ldWin = ch->n; a.X = X_dev; a.ldX = ldX; rc = do_launch(ch->po, NOISE_EXT, a); }
     }
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(tmp);
-    return rc;
+    return sync_free_rc(ctx, tmp, rc);
 }
 
 /* ---- checkpoint / resume */
@@ -2543,9 +2599,7 @@ int bhip_chains_pathstats(bhip_chains *ch, double *mean, double *m2)
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = fail(ctx, BHIP_EHIP, hipGetErrorString(e));
     }
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(tmp);
-    return rc;
+    return sync_free_rc(ctx, tmp, rc);
 }
 
 int bhip_welford_merge(long entries, int d, double *na, double *mean_a, double *m2_a, double nb, const double *mean_b, const double *m2_b)

@@ -44,13 +44,17 @@ template <class M> struct has_sinv<M, bhip_void_t<decltype(&M::sinv_mul)>> { sta
 template <class M, class = void> struct is_constdiff { static constexpr bool value = true; };
 template <class M> struct is_constdiff<M, bhip_void_t<decltype(M::STATE_SIGMA)>> { static constexpr bool value = !M::STATE_SIGMA; };
 
-// GUIDE_QF (internal, not part of the ABI; round 5): the REGROUPED step of the LinPro family at 4 <= d <= 12.  Target and auxiliary are
+// GUIDE_QF (internal, not part of the ABI; round 5; d <= 3 under BHIP_OPT_FUSED_ARITHMETIC since round 6): the REGROUPED step of the LinPro family at 4 <= d <= 12.  Target and auxiliary are
 // affine and everything but x and dW is path-independent, so the host (finish_guide, regroup_step) turns the five d x d products of a
 // step into three whose accumulators start from path-independent vectors, exactly as for the tile kernel (bhip_tile_kernel.h):
 //     dot(b - b~, r) = c0_i + x . (bv_i + A_i x)        x_{i+1} = q_i + P_i x + sigma dW
 // row: t, dt, sqrt(dt), A_i (d*d), bv_i (d), P_i (d*d), q_i (d), c0_i.  Tolerance parity, like every path at d > 3.
 #define BHIP_GUIDE_QF 5
 constexpr int BHIP_MAXD_LANE = 12;   // one path per lane up to here (4..8 since round 3, 9..12 since round 4); beyond: the MFMA tile kernel
+
+// targets with an affine drift and a constant sigma, for which the regrouped rows exist at d <= 3 (MLinPro<1..3>: `AFFINE_TARGET`)
+template <class M, class = void> struct is_affine_target { static constexpr bool value = false; };
+template <class M> struct is_affine_target<M, bhip_void_t<decltype(M::AFFINE_TARGET)>> { static constexpr bool value = M::AFFINE_TARGET; };
 
 // processes whose parameter block is re-opened from device memory at every step (MLinPro<4..8, bhip_cptr_t>)
 template <class M, class = void> struct is_streamed { static constexpr bool value = false; };
@@ -435,9 +439,42 @@ BHIP_DEV void path_step(const M &model, const KArgs &a, RowPtr row, int i, int n
     }
     PSTAMP(1);   // phase 1: dw + the issue of the X stores (back-pressure shows here)
 
-    if constexpr (GK == BHIP_GUIDE_QF) {
+    if constexpr (GK == BHIP_GUIDE_QF && !STR) {
+        // the regrouped step at d <= 3 (round 6; BHIP_OPT_FUSED_ARITHMETIC only -- tolerance parity like every regrouped step): the whole
+        // row is in registers, A_i, bv_i and c0_i carry dt already (finish_guide), every product is a fused multiply-add:
+        //     ll += c0'_i + x . (bv'_i + A'_i x)          x_{i+1} = (q_i + sigma dW) + P_i x
+        // What the bit-exact step makes the NEXT step wait for -- b, the guide solve, a r, b~, the dot product, the update: a chain of
+        // ~15 dependent fp64 operations at d = 1 -- is here ONE dependent fused multiply-add per component (q_i + sigma dW does not
+        // depend on the state, the log-likelihood hangs off the chain): a consumer wave that is alone on its SIMD stops being bound
+        // by the latency of its own recurrence (C2: ~310 cycles per step for ~50 instructions, profiles/r5_c2_sq.txt).
+        double part = rw[RL::G + D * D + D];                                             // c0'_i
+#pragma unroll
+        for (int q = 0; q < D; q++) {
+            double s = rw[RL::BETA + q];                                                 // bv'_i
+#pragma unroll
+            for (int j = 0; j < D; j++) s = __builtin_fma(rw[RL::B + q + D * j], st.y[j], s);
+            part = __builtin_fma(st.y[q], s, part);
+        }
+        const double lln = st.ll + part;
+        st.ll = (i < nll) ? lln : st.ll;
+        if constexpr (NOISE != NOISE_LLONLY) {
+            double sw[D], xn[D];
+            model.sdw(t, st.y, dw, sw);                                                  // sigma dW (constant sigma: off the state's chain)
+#pragma unroll
+            for (int q = 0; q < D; q++) {
+                double s = rw[RL::G + D * D + q] + sw[q];                                // q_i + sigma dW
+#pragma unroll
+                for (int j = 0; j < D; j++) s = __builtin_fma(rw[RL::G + q + D * j], st.y[j], s);
+                xn[q] = s;
+            }
+#pragma unroll
+            for (int q = 0; q < D; q++) st.y[q] = xn[q];
+        }
+        PSTAMP(2); PSTAMP(3); PSTAMP(4);
+        return;
+    } else if constexpr (GK == BHIP_GUIDE_QF) {
         // the regrouped step (see BHIP_GUIDE_QF above): three products, accumulators started from the row's vectors
-        static_assert(STR, "the regrouped rows exist for the streamed LinPro family (4 <= d <= 12)");
+        static_assert(STR, "the streamed form of the regrouped rows (4 <= d <= 12)");
         double yv[D], xn[D];
         RowPtr ra = row;
         bhip_after(ra, st.y[D - 1]);
@@ -862,7 +899,7 @@ launch_fn get_launch_gk(int noise, int fl)
         if constexpr (GK != BHIP_GUIDE_NONE) return launch_paths<M, GK, MO, NOISE_LLONLY, 0 | T>;
         return nullptr;
     case NOISE_INNOV:
-        if constexpr (has_sinv<M>::value && !TWO) return launch_paths<M, GK, MO, NOISE_INNOV, 2>;
+        if constexpr (has_sinv<M>::value && !TWO && GK != BHIP_GUIDE_QF) return launch_paths<M, GK, MO, NOISE_INNOV, 2>;   // (innovations! needs _b itself: never on regrouped rows)
         return nullptr;
     }
     return nullptr;
@@ -915,6 +952,11 @@ launch_fn get_launch(int gk, int mo, int noise, int fl)
     case BHIP_GUIDE_HV: return get_launch_gk<M, BHIP_GUIDE_HV, 1, 0>(noise, fl);
     case BHIP_GUIDE_NUH: return get_launch_gk<M, BHIP_GUIDE_NUH, 1, 0>(noise, fl);
     case BHIP_GUIDE_NUH_INPLACE: return get_launch_gk<M, BHIP_GUIDE_NUH, 1, 1>(noise, fl);
+#ifdef BHIP_FUSED
+    case BHIP_GUIDE_QF:   // the regrouped step of an affine target at d <= 3 (host: finish_guide; do_launch selects it under BHIP_OPT_FUSED_ARITHMETIC)
+        if constexpr (is_affine_target<M>::value) return get_launch_gk<M, BHIP_GUIDE_QF, 1, 0>(noise, fl);
+        return nullptr;
+#endif
     case BHIP_GUIDE_LMMU:
         if (mo == 1) return get_launch_gk<M, BHIP_GUIDE_LMMU, 1, 0>(noise, fl);
         if constexpr (D >= 2) { if (mo == 2) return get_launch_gk<M, BHIP_GUIDE_LMMU, 2, 0>(noise, fl); }
