@@ -337,14 +337,16 @@ class Workload:
     1e-9 / 1e-8 instead of bit for bit, tests/test_gpu_fused.py) on a context of its own."""
 
     def __init__(self, mode, ctx, chains, rank):
+        self.parts = None   # fresh proposals: the container decides (EnsemblePath: two buffers in different pieces of the device memory from 1 GiB on)
+        if mode.endswith("_parts"):   # ... X kept in two buffers whatever its size
+            mode, self.parts = mode[:-len("_parts")], 2
+        if mode.endswith("_1buf"):    # ... X in ONE buffer whatever its size (the default of rounds 1-5)
+            mode, self.parts = mode[:-len("_1buf")], 1
         self.fused = mode.endswith("_fused")
         if self.fused:
             mode = mode[:-len("_fused")]
             ctx = bh.Context(ctx.device.index)
             ctx.set_option(bh.OPT_FUSED_ARITHMETIC, 1)
-        self.parts = 0
-        if mode.endswith("_parts"):   # fresh proposals with X kept in two buffers lying in different pieces of the device memory (bhip_sample_solve_parts)
-            mode, self.parts = mode[:-len("_parts")], 2
         self.v2noise = 0
         for spec in (2, 3):   # the same workload under an earlier noise specification, bhip-philox-v2 / -v3 (BHIP_OPT_NOISE_SPEC = 2 / 3)
             if mode.endswith(f"_v{spec}noise"):
@@ -361,7 +363,7 @@ class Workload:
             (" [BHIP_OPT_NOISE_SPEC = 2: bhip-philox-v2, one Box-Muller pair of 53 + 53 bits per Philox call]" if self.v2noise == 2 else
              " [BHIP_OPT_NOISE_SPEC = 3: bhip-philox-v3, two Box-Muller pairs of 40 + 24 bits per Philox call]" if self.v2noise == 3 else "") + \
             (" [X kept in two buffers of half the paths each, in different 96-GiB pieces of the device memory: bhip_alloc_apart + bhip_sample_solve_parts, "
-             "one launch, the same values]" if self.parts else "")
+             "one launch, the same values]" if self.parts == 2 else " [X in ONE buffer]" if self.parts == 1 else "")
         self.kernel = kname(self.P).replace("bhip::", "bhip_fused::") if self.fused else kname(self.P)
         if self.fused:   # LinPro targets at d <= 3 run the regrouped step (GUIDE_QF = 5) under the option (bhip_path_kernel.h)
             self.kernel = self.kernel.replace("double const*>, 1, 1,", "double const*>, 5, 1,")
@@ -383,22 +385,21 @@ class Workload:
         self.ll = ctx.empty(P)
         self.it = 0
         self.x0 = np.ascontiguousarray(x0, dtype=np.float64)
-        if self.parts:
-            self.X = X = bh.EnsembleParts(self.Po.tt, d, P, self.parts, ctx)
-            self.parts_apart = X.apart
-
-            def step_parts():
+        # ONE container type: EnsemblePath keeps an ensemble of 1 GiB and more in two buffers lying in different pieces of the device memory
+        # (parts=None), and the fused proposal writes both in one launch
+        self.X = X = bh.EnsemblePath(self.Po.tt, d, P, ctx, parts=self.parts)
+        self.nparts, self.parts_apart = X.nparts, X.apart
+        x0p, llp, lib, h, poh = bh.api._dptr(self.x0), bh.api.vp(self.ll.data_ptr()), ctx.lib, ctx.h, self.Po.h
+        if X.nparts > 1:
+            def step():
                 self.it += 1
-                ctx.check(ctx.lib.bhip_sample_solve_parts(ctx.h, self.Po.h, bh.api._dptr(self.x0), X.nparts, X._ptrs, X.part_paths, X.part_paths,
-                                                          bh.api.vp(self.ll.data_ptr()), 0, P, seed, self.it, self.path0))
-            self.step = step_parts
-            return
-        self.X = bh.EnsemblePath(self.Po.tt, d, P, ctx)
+                ctx.check(lib.bhip_sample_solve_parts(h, poh, x0p, X.nparts, X._ptrs, X.part_paths, X.part_paths, llp, 0, P, seed, self.it, self.path0))
+        else:
+            xp = X.ptr()
 
-        def step():
-            self.it += 1
-            ctx.check(ctx.lib.bhip_sample_solve(ctx.h, self.Po.h, bh.api._dptr(self.x0), None, None, P, self.X.ptr(), P,
-                                                bh.api.vp(self.ll.data_ptr()), 0, P, seed, self.it, self.path0))
+            def step():
+                self.it += 1
+                ctx.check(lib.bhip_sample_solve(h, poh, x0p, None, None, P, xp, P, llp, 0, P, seed, self.it, self.path0))
         self.step = step
 
     def roofline(self, kern_ms):
@@ -1015,14 +1016,14 @@ def main_local(args):
         others = []
         del w, ws
         torch.cuda.empty_cache()
-        for mode in ("c4shard", "c2", "proposals", "nclar", "nclar_mcmc", "linpro4", "linpro32", "linpro32_mcmc", "c2_fused", "proposals_fused", "nclar_fused", "proposals_parts",
+        for mode in ("c4shard", "c2", "proposals", "nclar", "nclar_mcmc", "linpro4", "linpro32", "linpro32_mcmc", "c2_fused", "proposals_fused", "nclar_fused", "proposals_1buf", "c2_parts", "c2_fused_parts",
                      "mcmc_v3noise", "proposals_v3noise", "c2_v3noise", "mcmc_v2noise", "proposals_v2noise", "c2_v2noise"):
             wo = Workload(mode, ctx, 0, 0)
             ms = kernel_times(wo, args.steps, args.warmup, min_ms=100.0)
             others.append({"mode": mode, "workload": wo.workload, "paths": wo.P,
                            "path_steps_per_s": wo.P * steps_per_unit / (float(ms.avg) * 1e-3), "roofline": wo.roofline(ms)})
-            if wo.parts:
-                others[-1]["parts"] = {"n": wo.parts, "pairwise_apart": wo.parts_apart}
+            if getattr(wo, "nparts", 1) > 1:
+                others[-1]["parts"] = {"n": wo.nparts, "pairwise_apart": wo.parts_apart}
                 wo.X.free()
             del wo
             torch.cuda.empty_cache()
@@ -1232,7 +1233,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chains", type=int, default=0, help="chains (paths) per GPU; 0 = the mode's named size")
-    ap.add_argument("--mode", choices=sorted(MODES) + sorted(m + "_fused" for m in MODES if MODES[m][1] <= 3) + sorted(m + "_v2noise" for m in MODES) + sorted(m + "_v3noise" for m in MODES) + sorted(m + "_parts" for m in MODES if not MODES[m][5] and MODES[m][1] <= 12),
+    ap.add_argument("--mode", choices=sorted(MODES) + sorted(m + "_fused" for m in MODES if MODES[m][1] <= 3) + sorted(m + "_v2noise" for m in MODES) + sorted(m + "_v3noise" for m in MODES) + sorted(m + sfx for m in MODES if not MODES[m][5] and MODES[m][1] <= 12 for sfx in ("_parts", "_1buf", "_fused_parts", "_fused_1buf") if not (sfx.startswith("_fused") and MODES[m][1] > 3)),
                     default="mcmc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true")

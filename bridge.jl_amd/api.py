@@ -436,54 +436,185 @@ class SamplePath:
         return SamplePath(self.tt.copy(), self.yy.copy())
 
 
+PARTS_MIN_BYTES = 1 << 30   # ensembles of this size and more are kept in two parts by default (EnsemblePath(parts=None))
+
+
+class _DevView:
+    """library-owned device memory as something torch.as_tensor accepts (__cuda_array_interface__, version 2)"""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": "<f8", "data": (int(ptr), False), "version": 2, "strides": None}
+
+
 class EnsemblePath:
     """An ensemble of sample paths on one GPU, struct-of-arrays fp64:
-    data[i, k, p] = component k of path p at grid index i (contiguous in p)."""
+    data[i, k, p] = component k of path p at grid index i (contiguous in p).
 
-    def __init__(self, tt, dim, npaths, ctx=None, data=None):
+    ONE container, kept in `nparts` device buffers (src/types.jl:71-81 has one SamplePath type; an ensemble is a loop there):
+      nparts = 1   a torch tensor [N, dim, npaths] (`data`, `ptr()`), leading dimension npaths;
+      nparts = 2/3 paths [j*part_paths, (j+1)*part_paths) live in buffer j, [N, dim, part_paths] each, the buffers pairwise in DIFFERENT
+                   96-GiB pieces of the device memory (bhip_alloc_apart): an ensemble written by one kernel is ONE write stream, and a
+                   write stream inside one piece moves 4.3-4.4 TB/s where two streams in two pieces move 5.8-6.0 (profiles/r5_three_pieces.txt).
+    parts = None (default): 2 from PARTS_MIN_BYTES (1 GiB) on, else 1.  Every function of this module takes either form: it walks the
+    column ranges that lie inside one buffer of every ensemble involved (`segments`) and hands the library (pointer, leading dimension,
+    paths) per range -- the fused proposal kernel writes all parts in one launch (bhip_sample_solve_parts)."""
+
+    def __init__(self, tt, dim, npaths, ctx=None, data=None, parts=None):
         self.ctx = ctx or default_context()
         self.tt = np.array(tt, dtype=np.float64)
         self.dim, self.npaths = int(dim), int(npaths)
         N = len(self.tt)
-        if data is None:
-            data = torch.zeros((N, self.dim, self.npaths), dtype=torch.float64, device=self.ctx.device)
-        if tuple(data.shape) != (N, self.dim, self.npaths) or data.dtype != torch.float64 or not data.is_contiguous():
-            raise BridgeError("EnsemblePath: data must be a contiguous float64 tensor [N, dim, npaths]")
-        self.data = data
+        if data is not None:
+            parts = 1
+        if parts is None:
+            # (one path per lane writes all parts in one launch; above d = 12 the MFMA tile kernel writes ONE buffer and is not bound by its store stream)
+            parts = 2 if (8 * N * self.dim * self.npaths >= PARTS_MIN_BYTES and self.dim <= 12 and getattr(self.ctx, "device", None) is not None
+                          and getattr(self.ctx.device, "type", "cpu") != "cpu") else 1
+        self.nparts = int(parts)
+        if not 1 <= self.nparts <= 3:
+            raise BridgeError("EnsemblePath: 1, 2 or 3 parts")
+        self._ptrs, self.parts, self.apart = None, [self], 0
+        if self.nparts == 1:
+            self.part_paths = self.npaths
+            if data is None:
+                data = torch.zeros((N, self.dim, self.npaths), dtype=torch.float64, device=self.ctx.device)
+            if tuple(data.shape) != (N, self.dim, self.npaths) or data.dtype != torch.float64 or not data.is_contiguous():
+                raise BridgeError("EnsemblePath: data must be a contiguous float64 tensor [N, dim, npaths]")
+            self._data = data
+            return
+        self._data = None
+        self.part_paths = ((self.npaths + self.nparts - 1) // self.nparts + 63) // 64 * 64
+        self._ptrs = (vp * self.nparts)()
+        apart = C.c_int()
+        self.ctx.check(self.ctx.lib.bhip_alloc_apart(self.ctx.h, self.nparts, N * self.dim * self.part_paths * 8, self._ptrs, C.byref(apart)))
+        self.apart = apart.value
+        self.parts = [_PartPath(self.tt, self.dim, max(0, min(self.part_paths, self.npaths - j * self.part_paths)), self.part_paths, self._ptrs[j], self.ctx)
+                      for j in range(self.nparts)]
 
     def __len__(self):
         return len(self.tt)
 
     @property
     def ld(self):
-        return self.npaths
+        """leading dimension of a buffer (of THE buffer when there is one)"""
+        return self.part_paths
+
+    @property
+    def data(self):
+        """the ensemble as one tensor [N, dim, npaths]: the tensor itself (one buffer) or a gathered COPY (parts)"""
+        if self.nparts == 1:
+            return self._data
+        return torch.cat([q.data[:, :, :q.npaths] for q in self.parts if q.npaths > 0], dim=2)
 
     def ptr(self):
-        return vp(self.data.data_ptr())
+        if self.nparts != 1:
+            raise BridgeError("this ensemble is kept in parts: address it by colptr(p) / segments()")
+        return vp(self._data.data_ptr())
+
+    def colptr(self, p):
+        """device address of column p (its buffer's leading dimension is `ld`)"""
+        if self.nparts == 1:
+            return vp(self._data.data_ptr() + 8 * int(p))
+        j, q = divmod(int(p), self.part_paths)
+        return vp(int(self._ptrs[j]) + 8 * q)
+
+    def segments(self, *others):
+        """column ranges (start, n) that lie inside ONE buffer of this ensemble and of every ensemble in `others` (None entries skipped)"""
+        cuts = {0, self.npaths}
+        for E in (self,) + tuple(o for o in others if o is not None):
+            if E.npaths != self.npaths:
+                raise BridgeError("ensembles differ in the number of paths")
+            cuts.update(range(E.part_paths, E.npaths, E.part_paths))
+        cuts = sorted(cuts)
+        return [(a, b - a) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
 
     def copy(self):
-        return EnsemblePath(self.tt.copy(), self.dim, self.npaths, self.ctx, self.data.clone())
+        if self.nparts == 1:
+            return EnsemblePath(self.tt.copy(), self.dim, self.npaths, self.ctx, self._data.clone())
+        E = EnsemblePath(self.tt.copy(), self.dim, self.npaths, self.ctx, parts=self.nparts)
+        for a, b in zip(E.parts, self.parts):
+            a.data.copy_(b.data)
+        return E
 
     @classmethod
-    def from_paths(cls, tt, yy, ctx=None):
+    def from_paths(cls, tt, yy, ctx=None, parts=None):
         """upload host paths yy [npaths, N, dim] (Vector{SVector} per path) -> SoA ensemble"""
         yy = np.ascontiguousarray(yy, dtype=np.float64)
         if yy.ndim == 2:
             yy = yy[:, :, None]
         npaths, N, dim = yy.shape
-        E = cls(tt, dim, npaths, ctx)
-        E.ctx.check(E.ctx.lib.bhip_upload_aos(E.ctx.h, E.ptr(), N, dim, E.ld, 0, npaths, _dptr(yy)))
+        E = cls(tt, dim, npaths, ctx, parts=parts)
+        for a, n in E.segments():
+            E.ctx.check(E.ctx.lib.bhip_upload_aos(E.ctx.h, E.colptr(a), N, dim, E.ld, 0, n, _dptr(yy[a:a + n])))
         return E
 
     def paths(self, p0=0, n=None):
         """download paths p0..p0+n as host array [n, N, dim]"""
         n = self.npaths - p0 if n is None else n
         out = np.empty((n, len(self.tt), self.dim))
-        self.ctx.check(self.ctx.lib.bhip_download_aos(self.ctx.h, self.ptr(), len(self.tt), self.dim, self.ld, p0, n, _dptr(out)))
+        for a, m in self.segments():
+            lo, hi = max(a, p0), min(a + m, p0 + n)
+            if hi > lo:
+                seg = np.empty((hi - lo, len(self.tt), self.dim))
+                self.ctx.check(self.ctx.lib.bhip_download_aos(self.ctx.h, self.colptr(a), len(self.tt), self.dim, self.ld, lo - a, hi - lo, _dptr(seg)))
+                out[lo - p0:hi - p0] = seg
         return out
 
     def path(self, p):
         return SamplePath(self.tt, self.paths(p, 1)[0])
+
+    def endpoints(self):
+        """yy[N] of every path: tensor [dim, npaths]"""
+        if self.nparts == 1:
+            return self._data[-1]
+        return torch.cat([q.data[-1][:, :q.npaths] for q in self.parts if q.npaths > 0], dim=1)
+
+    def free(self):
+        """give the buffers of an ensemble in parts back now (otherwise: when the object goes)"""
+        if getattr(self, "_ptrs", None) is not None:
+            self.ctx.lib.bhip_free_apart(self.ctx.h, self.nparts, self._ptrs)
+            self._ptrs, self.parts = None, []
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class _PartPath(EnsemblePath):
+    """one buffer of an ensemble in parts: an ensemble [N, dim, ld] in a library allocation, seen as a tensor through
+    __cuda_array_interface__"""
+
+    def __init__(self, tt, dim, npaths, ld, ptr, ctx):
+        self.ctx, self.tt, self.dim, self.npaths = ctx, tt, int(dim), int(npaths)
+        self.nparts, self.part_paths, self._ptr, self._ptrs, self.parts, self.apart = 1, int(ld), ptr, None, [self], 0
+        self._view = None
+
+    @property
+    def data(self):
+        """[N, dim, ld] -- columns npaths..ld-1 are padding"""
+        if self._view is None:
+            with torch.cuda.device(self.ctx.device):
+                self._view = torch.as_tensor(_DevView(self._ptr, (len(self.tt), self.dim, self.part_paths)), device=self.ctx.device)
+        return self._view
+
+    def ptr(self):
+        return vp(self._ptr)
+
+    def colptr(self, p):
+        return vp(int(self._ptr) + 8 * int(p))
+
+    def copy(self):
+        raise BridgeError("a part of an ensemble is a view of the library's allocation")
+
+    def free(self):
+        pass
+
+
+def EnsembleParts(tt, dim, npaths, nparts=3, ctx=None):
+    """an EnsemblePath kept in `nparts` buffers (the name of round 5's second container; there is one container now)"""
+    return EnsemblePath(tt, dim, npaths, ctx, parts=nparts)
 
 
 class SDESolver:
@@ -642,7 +773,8 @@ def sample_(W, P, seed=0, iter=0, path0=0):
     if not isinstance(P, Wiener) or P.mp != W.dim:
         raise BridgeError("sample!: dimension of W and of the Wiener process differ")
     ctx = W.ctx
-    ctx.check(ctx.lib.bhip_wiener_sample(ctx.h, _dptr(W.tt), len(W.tt), W.dim, W.ptr(), W.ld, W.npaths, seed, iter, path0))
+    for a, n in W.segments():
+        ctx.check(ctx.lib.bhip_wiener_sample(ctx.h, _dptr(W.tt), len(W.tt), W.dim, W.colptr(a), W.ld, n, seed, iter, path0 + a))
     return W
 
 
@@ -676,14 +808,21 @@ def solve_(method, Y, u, W, P, ll=None, skip=0):
     x0d = vp(u.data_ptr()) if per_path else None
     if per_path and (tuple(u.shape) != (P.d, Y.npaths) or not u.is_contiguous()):
         raise BridgeError("per-path starting points must be a contiguous tensor [d, npaths]")
-    llp = None if ll is None else vp(ll.data_ptr())
-    ctx.check(ctx.lib.bhip_solve(ctx.h, P.h, x0, x0d, W.ptr(), W.ld, Y.ptr(), Y.ld, llp, skip, Y.npaths))
-    return Y.data[-1]
+    for a, n in Y.segments(W):
+        llp = None if ll is None else vp(ll.data_ptr() + 8 * a)
+        xs = None
+        if per_path:   # x0_dev is [d][ldX]: this range's starts in a block of the buffer's leading dimension
+            xs = u[:, a:a + n] if (Y.nparts == 1 and a == 0) else torch.zeros((P.d, Y.ld), dtype=torch.float64, device=u.device)
+            if xs.shape[1] == Y.ld and xs is not u:
+                xs[:, :n] = u[:, a:a + n]
+            x0d = vp(xs.data_ptr())
+        ctx.check(ctx.lib.bhip_solve(ctx.h, P.h, x0, x0d, W.colptr(a), W.ld, Y.colptr(a), Y.ld, llp, skip, n))
+    return Y.endpoints()
 
 
 def solve(method, u, W, P, ll=None, skip=0):
     """solve(::SDESolver, u, W, P) -> X   src/euler.jl:117-118,246"""
-    X = EnsemblePath(W.tt, P.d, W.npaths, W.ctx)
+    X = EnsemblePath(W.tt, P.d, W.npaths, W.ctx, parts=W.nparts if W.nparts > 1 else None)
     solve_(method, X, u, W, P, ll=ll, skip=skip)
     return X
 
@@ -702,7 +841,8 @@ def llikelihood(rule, X, Po, skip=0):
         raise BridgeError("llikelihood: only LeftRule is implemented on the device")
     ctx = X.ctx
     out = ctx.empty(X.npaths)
-    ctx.check(ctx.lib.bhip_llikelihood(ctx.h, Po.h, X.ptr(), X.ld, vp(out.data_ptr()), skip, X.npaths))
+    for a, n in X.segments():
+        ctx.check(ctx.lib.bhip_llikelihood(ctx.h, Po.h, X.colptr(a), X.ld, vp(out.data_ptr() + 8 * a), skip, n))
     return out
 
 
@@ -717,13 +857,14 @@ def innovations_(method, W, Y, P):
         raise BridgeError("innovations!: needs square sigma and matching ensembles")
     W.tt[:] = Y.tt                                                       # :366
     ctx = Y.ctx
-    ctx.check(ctx.lib.bhip_innovations(ctx.h, P.h, Y.ptr(), Y.ld, W.ptr(), W.ld, Y.npaths))
+    for a, n in Y.segments(W):
+        ctx.check(ctx.lib.bhip_innovations(ctx.h, P.h, Y.colptr(a), Y.ld, W.colptr(a), W.ld, n))
     return W
 
 
 def innovations(method, Y, P):
     """innovations(method, Y, P) = innovations!(method, copy(Y), Y, P)   src/euler.jl:357"""
-    return innovations_(method, EnsemblePath(Y.tt, P.mp, Y.npaths, Y.ctx), Y, P)
+    return innovations_(method, EnsemblePath(Y.tt, P.mp, Y.npaths, Y.ctx, parts=Y.nparts if Y.nparts > 1 else None), Y, P)
 
 
 def girsanov(X, P, Pt):
@@ -753,7 +894,8 @@ def girsanov(X, P, Pt):
     else:
         raise BridgeError("girsanov: Pt must be of the same process type as P, or Wiener")
     out = ctx.empty(X.npaths)
-    ctx.check(ctx.lib.bhip_girsanov(ctx.h, Po.h, par_t, npar_t, X.ptr(), X.ld, vp(out.data_ptr()), X.npaths))
+    for a, n in X.segments():
+        ctx.check(ctx.lib.bhip_girsanov(ctx.h, Po.h, par_t, npar_t, X.colptr(a), X.ld, vp(out.data_ptr() + 8 * a), n))
     return out
 
 
@@ -809,90 +951,55 @@ def write_info(fn, aux_choice, endpoint, iterations, skip_it, x0, T, v, Sigma, L
     return ave_acc_perc
 
 
-def sample_solve(u, Po, npaths, seed=0, iter=0, path0=0, store_W=False, store_X=True, skip=0, ctx=None):
+def sample_solve(u, Po, npaths, seed=0, iter=0, path0=0, store_W=False, store_X=True, skip=0, ctx=None, parts=None):
     """fused  W = sample(tt, Wiener()); X = solve(Euler(), u, W, Po); ll = llikelihood(LeftRule(), X, Po)
-    with in-kernel Philox noise.  Returns (X or None, W or None, ll or None)."""
+    with in-kernel Philox noise.  Returns (X or None, W or None, ll or None).  A large X (1 GiB and more; `parts`) is kept in two
+    buffers lying in different pieces of the device memory and written by ONE launch (bhip_sample_solve_parts)."""
     ctx = ctx or Po.ctx
-    X = EnsemblePath(Po.tt, Po.d, npaths, ctx) if store_X else None
-    W = EnsemblePath(Po.tt, Po.mp, npaths, ctx) if store_W else None
+    X = EnsemblePath(Po.tt, Po.d, npaths, ctx, parts=parts) if store_X else None
+    W = EnsemblePath(Po.tt, Po.mp, npaths, ctx, parts=(X.nparts if X is not None and X.nparts > 1 else parts)) if store_W else None
     ll = ctx.empty(npaths) if Po.kind != GUIDE_NONE else None
-    per_path = isinstance(u, torch.Tensor)
-    x0 = None if per_path else _dptr(_x0(u, Po.d))
-    x0d = vp(u.data_ptr()) if per_path else None
-    ctx.check(ctx.lib.bhip_sample_solve(ctx.h, Po.h, x0, x0d,
-                                        None if W is None else W.ptr(), npaths,
-                                        None if X is None else X.ptr(), npaths,
-                                        None if ll is None else vp(ll.data_ptr()), skip, npaths, seed, iter, path0))
+    sample_solve_(X, W, ll, u, Po, npaths, seed=seed, iter=iter, path0=path0, skip=skip)
     return X, W, ll
 
 
-class _PartPath(EnsemblePath):
-    """one part of an EnsembleParts: an ensemble [N, dim, ld] in a library allocation (no tensor behind it)"""
-
-    def __init__(self, tt, dim, npaths, ld, ptr, ctx):
-        self.ctx, self.tt, self.dim, self.npaths = ctx, tt, int(dim), int(npaths)
-        self._ld, self._ptr, self.data = int(ld), ptr, None
-
-    @property
-    def ld(self):
-        return self._ld
-
-    def ptr(self):
-        return vp(self._ptr)
-
-    def copy(self):
-        raise BridgeError("a part of an EnsembleParts is a view of the library's allocation")
-
-
-class EnsembleParts:
-    """An ensemble kept in nparts (1..3) buffers that lie in DIFFERENT pieces of the device memory (bhip_alloc_apart): paths
-    [j*part_paths, (j+1)*part_paths) are part j, an EnsemblePath [N, dim, part_paths] like any other.  Written by sample_solve_parts in one
-    launch -- three write streams in three pieces move 6.8-6.9 TB/s where the one stream of a single buffer moves 4.3-4.4
-    (profiles/r5_three_pieces.txt)."""
-
-    def __init__(self, tt, dim, npaths, nparts=3, ctx=None):
-        self.ctx = ctx or default_context()
-        self.tt = np.array(tt, dtype=np.float64)
-        self.dim, self.npaths, self.nparts = int(dim), int(npaths), int(nparts)
-        self.part_paths = ((self.npaths + self.nparts - 1) // self.nparts + 63) // 64 * 64
-        self._ptrs = (vp * self.nparts)()
-        apart = C.c_int()
-        self.ctx.check(self.ctx.lib.bhip_alloc_apart(self.ctx.h, self.nparts, len(self.tt) * self.dim * self.part_paths * 8, self._ptrs, C.byref(apart)))
-        self.apart = apart.value
-        self.parts = [_PartPath(self.tt, self.dim, max(0, min(self.part_paths, self.npaths - j * self.part_paths)), self.part_paths, self._ptrs[j], self.ctx)
-                      for j in range(self.nparts)]
-
-    def paths(self, p0=0, n=None):
-        """download paths p0..p0+n as host array [n, N, dim]"""
-        n = self.npaths - p0 if n is None else n
-        out = np.empty((n, len(self.tt), self.dim))
-        p = p0
-        while p < p0 + n:
-            j, q = divmod(p, self.part_paths)
-            k = min(p0 + n - p, self.part_paths - q)
-            out[p - p0:p - p0 + k] = self.parts[j].paths(q, k)
-            p += k
-        return out
-
-    def free(self):
-        if getattr(self, "_ptrs", None) is not None:
-            self.ctx.lib.bhip_free_apart(self.ctx.h, self.nparts, self._ptrs)
-            self._ptrs, self.parts = None, []
-
-    def __del__(self):
-        try:
-            self.free()
-        except Exception:
-            pass
+def sample_solve_(X, W, ll, u, Po, npaths=None, seed=0, iter=0, path0=0, skip=0):
+    """the fused proposal into existing containers (any of X, W, ll may be None): what sample_solve runs, and what a loop over
+    iterations calls (bench.py's `proposals` mode)"""
+    E = X if X is not None else W
+    ctx = Po.ctx if E is None else E.ctx
+    npaths = E.npaths if npaths is None else npaths
+    per_path = isinstance(u, torch.Tensor)
+    x0 = None if per_path else _dptr(_x0(u, Po.d))
+    llp = lambda a: None if ll is None else vp(ll.data_ptr() + 8 * a)
+    if X is not None and X.nparts > 1 and W is None and not per_path:   # X in parts alone: all parts by one launch
+        rc = ctx.lib.bhip_sample_solve_parts(ctx.h, Po.h, x0, X.nparts, X._ptrs, X.part_paths, X.part_paths, llp(0), skip, npaths, seed, iter, path0)
+        if rc != -3:   # (BHIP_EUNSUPPORTED: the tile kernel writes one buffer per launch -- range by range below)
+            ctx.check(rc)
+            return X, W, ll
+    segs = E.segments(X, W) if E is not None else [(0, npaths)]
+    for a, n in segs:
+        x0d = None
+        if per_path:   # x0_dev is [d][ldX]
+            ldx = X.ld if X is not None else npaths
+            xs = u if (len(segs) == 1 and ldx == u.shape[1]) else torch.zeros((Po.d, ldx), dtype=torch.float64, device=u.device)
+            if xs is not u:
+                xs[:, :n] = u[:, a:a + n]
+            x0d = vp(xs.data_ptr())
+        ctx.check(ctx.lib.bhip_sample_solve(ctx.h, Po.h, x0, x0d,
+                                            None if W is None else W.colptr(a), n if W is None else W.ld,
+                                            None if X is None else X.colptr(a), X.ld if X is not None else (ldx if per_path else n),
+                                            llp(a), skip, n, seed, iter, path0 + a))
+    return X, W, ll
 
 
 def sample_solve_parts(u, Po, npaths, nparts=3, seed=0, iter=0, path0=0, skip=0, ctx=None, X=None):
-    """sample_solve with X kept in parts (bhip_sample_solve_parts): the same values, column p of the ensemble = column p - j*part_paths
-    of part j.  Returns (EnsembleParts, ll)."""
+    """sample_solve with X kept in `nparts` buffers (bhip_sample_solve_parts): the same values, column p of the ensemble = column
+    p - j*part_paths of part j.  Returns (X, ll).  (= sample_solve(..., parts=nparts) without W.)"""
     ctx = ctx or Po.ctx
-    X = X if X is not None else EnsembleParts(Po.tt, Po.d, npaths, nparts, ctx)
+    X = X if X is not None else EnsemblePath(Po.tt, Po.d, npaths, ctx, parts=nparts)
     ll = ctx.empty(npaths) if Po.kind != GUIDE_NONE else None
-    ctx.check(ctx.lib.bhip_sample_solve_parts(ctx.h, Po.h, _dptr(_x0(u, Po.d)), X.nparts, X._ptrs, X.part_paths, X.part_paths,
+    ctx.check(ctx.lib.bhip_sample_solve_parts(ctx.h, Po.h, _dptr(_x0(u, Po.d)), X.nparts, X._ptrs if X.nparts > 1 else (vp * 1)(X.ptr()), X.part_paths, X.part_paths,
                                               None if ll is None else vp(ll.data_ptr()), skip, npaths, seed, iter, path0))
     return X, ll
 
@@ -953,7 +1060,7 @@ class Chains:
 
     def current_X(self):
         """EnsemblePath of the chains' CURRENT paths X (re-materialised from the current W)"""
-        X = EnsemblePath(self.Po.tt, self.Po.d, self.n, self.ctx)
+        X = EnsemblePath(self.Po.tt, self.Po.d, self.n, self.ctx, parts=1)   # (the library writes all chains into one array)
         self.ctx.check(self.ctx.lib.bhip_chains_current_X(self.h, X.ptr(), X.ld))
         return X
 

@@ -1444,7 +1444,7 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         if (npair != 0) {
             const int spc = LINE_DOUBLES / line_mpp(po->mh.mp), np = npair < 0 ? -npair : npair;
             const unsigned lds = (unsigned)(pc_lds_bytes(a.noise_spec, np, npair > 1 ? spc * a.rs : 0) + (a.Xtb ? pc_xs_bytes(po->mh.d, np) : 0));
-            HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)((groups + np - 1) / np), 1, 1, 128 * np, 1, 1, lds, ctx->stream, params, nullptr));
+            HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)((groups + np - 1) / np), 1, 1, (unsigned)pc_threads(knoise, npair > 1, np), 1, 1, lds, ctx->stream, params, nullptr));
             return BHIP_OK;
         }
         const long grid = (a.P + 255) / 256;

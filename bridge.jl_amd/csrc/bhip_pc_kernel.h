@@ -52,6 +52,20 @@ enum { NOISE_FRESH_PC = 6, NOISE_PCN_LINES_PC = 7 };
 #else
 #define PC_CONS_UNROLL (RLDS ? PC_CONS_UNROLL_SMALL : 2)
 #endif
+// DRAWER waves per pair (round 6).  Fresh proposals of a small ensemble (RLDS workgroups: one wave per role and SIMD) are bound by the
+// PRODUCER wave -- its stream of ~20 vector instructions per normal is mostly serial inside one wave, and one wave per SIMD cannot fill
+// the issue port (profiles/r4_c2_budget.txt: producer 383 cycles of work per step, consumer 217, the launch 397).  The draws of a chunk
+// are independent of each other once the Wiener cumulation leaves the producer: the tile carries the INCREMENTS rdt*z, the consumer
+// adds them up (W[j] = W[j-1] + rdt*z: the very operation, the very bits, src/wiener.jl:55) and stores W where it is kept.  So the
+// Philox calls of a chunk are dealt to PC_NDRAW producer waves of the pair (calls [dr*NQ/NDRAW, (dr+1)*NQ/NDRAW) to drawer dr; the
+// drawer of the last call carries its last m' normals into the next chunk), every one on its own SIMD slot.  pCN chains keep one
+// producer (its cumulation of W2 and the line moves are sequential in the chunk).
+#ifndef PC_NDRAW
+#define PC_NDRAW 2
+#endif
+constexpr int pc_ndraw(int mode, bool rlds) { return (mode == NOISE_FRESH_PC && rlds) ? PC_NDRAW : 1; }
+constexpr int pc_threads(int mode, bool rlds, int npair) { return 64 * npair * (pc_ndraw(mode, rlds) + 1); }
+template <int V> struct PcInt { static constexpr int value = V; };
 constexpr int PC_TILE = 64 * LINE_ROW;                          // doubles per hand-over tile
 // LDS of a workgroup: the generator's table of the launch's noise specification (v4: 10 240 bytes, v3 / v2: 2 576), then per pair the two
 // hand-over tiles (17 408 bytes) and, with RLDS, two chunks of coefficient rows.  Large ensembles want 8 pairs per CU: one pair per
@@ -104,9 +118,10 @@ struct PcStamp {
 
 template <class M, int GK, int MO, int MODE, int FL, int NPAIR, bool PPR = false /* per-chain guide rows (bhip_guide_kernel.h) */,
           bool RLDS = (NPAIR > 1) /* coefficient rows through LDS (small ensembles); false at NPAIR = 4: the large-ensemble workgroup of v4 */>
-__global__ __launch_bounds__(128 * NPAIR, (RLDS || PPR) ? 2 : PC_WPE) void k_pc(const KArgs a)
+__global__ __launch_bounds__(pc_threads(MODE, RLDS, NPAIR), (RLDS || PPR) ? (pc_ndraw(MODE, RLDS) + 1) : PC_WPE) void k_pc(const KArgs a)
 {
     constexpr int D = M::D, MP = M::MP;
+    constexpr int NDRAW = pc_ndraw(MODE, RLDS), NTHR = pc_threads(MODE, RLDS, NPAIR);
     static_assert(MP >= 1 && MP <= 3, "a chunk holds 16/m' grid points (m' = 3: lines padded to 4 components)");
     static_assert(MODE == NOISE_FRESH_PC || MODE == NOISE_PCN_LINES_PC, "producer/consumer kernel: fresh proposals or pCN on the line layout");
     constexpr bool PCN = MODE == NOISE_PCN_LINES_PC;
@@ -125,13 +140,13 @@ __global__ __launch_bounds__(128 * NPAIR, (RLDS || PPR) ? 2 : PC_WPE) void k_pc(
     double *tab = pc_lds_all;                                           // [pc_tab_doubles(noise_spec)], shared by the pairs
     const int tabd = pc_tab_doubles(a.noise_spec);
     constexpr int CROW = SPC * RL::RS;                                  // doubles of coefficient rows per chunk
-    const int wave = threadIdx.x >> 6, pair = wave % NPAIR, role = wave / NPAIR;   // waves 0..NPAIR-1 produce, the others consume
+    const int wave = threadIdx.x >> 6, pair = wave % NPAIR, role = wave / NPAIR;   // waves 0..NDRAW*NPAIR-1 produce (role = drawer index), the last NPAIR consume
     double *pc_lds = pc_lds_all + tabd + pair * (2 * PC_TILE + (RLDS ? 2 * CROW : 0));   // [2][PC_TILE] then (RLDS) [2][CROW]
     double *crow = pc_lds + 2 * PC_TILE;
     // (time-blocked path stores: the consumers' staging rows lie behind the pairs' tiles -- allocated by the launch only when a.Xtb is set)
     double *xs_all = pc_lds_all + tabd + NPAIR * (2 * PC_TILE + (RLDS ? 2 * CROW : 0));
-    if (a.noise_spec == 2 || a.noise_spec == 3) TabLDS::load(tab, threadIdx.x, 128 * NPAIR);
-    else IcdfLDS::load(tab, threadIdx.x, 128 * NPAIR);
+    if (a.noise_spec == 2 || a.noise_spec == 3) TabLDS::load(tab, threadIdx.x, NTHR);
+    else IcdfLDS::load(tab, threadIdx.x, NTHR);
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -149,13 +164,16 @@ __global__ __launch_bounds__(128 * NPAIR, (RLDS || PPR) ? 2 : PC_WPE) void k_pc(
     const int nch = (N + SPC - 1) / SPC;
     const uint32_t path = a.path0 + (uint32_t)p;
 
-    if (role == 0) {
-        // ------------------------------------------------------------------ producer
+    auto producer = [&](auto drc) {
+        // ------------------------------------------------------------------ producer (drawer DR of NDRAW)
+        constexpr int DR = decltype(drc)::value;
+        constexpr int CLO = DR * NQ / NDRAW, CHI = (DR + 1) * NQ / NDRAW;   // this drawer's Philox calls of a chunk
+        constexpr bool LASTDR = CHI == NQ;                                   // ... the last call's tail is carried into the next chunk
         const TabLDS rtab(tab);
         const cptr_t rdtp = (cptr_t)(uintptr_t)a.rdtp;
-        double wprev[MP], w2prev[MP];
+        double w2prev[MP];
 #pragma unroll
-        for (int c = 0; c < MP; c++) { wprev[c] = 0.0; w2prev[c] = 0.0; }
+        for (int c = 0; c < MP; c++) w2prev[c] = 0.0;
         // grid point j, component c takes normal (j-1)*m' + c: a chunk's first m' values are the LAST m' normals of the Philox
         // call drawn at the end of the previous chunk (chunk 0: grid point 0, multiplied by rdtp[0] = 0)
         double carry[MP];
@@ -184,9 +202,6 @@ __global__ __launch_bounds__(128 * NPAIR, (RLDS || PPR) ? 2 : PC_WPE) void k_pc(
                 hbits |= (uint32_t)(a.cur[c0 + 8 * q + sub] & 1) << q;
             fetch(0);
         }
-        double *wout = nullptr;
-        long ldwo = 0;
-        if constexpr (!PCN && (FL & 2) != 0) { wout = a.Wout + (size_t)p * a.wstride; ldwo = a.ldWout * a.wstride; }
         // RLDS: chunk k needs the rows of steps i = SPC*k - 1 .. SPC*k + SPC - 2, contiguous in memory; every lane moves
         // 16-byte pieces (RS is even and the rows are 256-byte aligned), clamped into the array at both ends
         constexpr int NRV = (CROW + 127) / 128;
@@ -200,14 +215,14 @@ __global__ __launch_bounds__(128 * NPAIR, (RLDS || PPR) ? 2 : PC_WPE) void k_pc(
                 rstage[q] = *(const d2v *)(a.rows + e);
             }
         };
-        if constexpr (RLDS) fetch_rows(0);
+        if constexpr (RLDS && DR == 0) fetch_rows(0);   // (the coefficient rows travel with drawer 0)
         PC_ST(PcStamp ps; ps.begin();)
 
         for (int k = 0; k <= nch; k++) {
             if (k < nch) {
                 double *tile = pc_lds + (k & 1) * PC_TILE;
                 double *mine = tile + row * LINE_ROW;
-                if constexpr (RLDS) {
+                if constexpr (RLDS && DR == 0) {
 #pragma unroll
                     for (int q = 0; q < NRV; q++) {
                         const int e = (q * 64 + lane) * 2;
@@ -241,12 +256,8 @@ __global__ __launch_bounds__(128 * NPAIR, (RLDS || PPR) ? 2 : PC_WPE) void k_pc(
                     if constexpr (RLDS) rdt = rd[s];
                     else rdt = rdtp[j];                                           // wave-uniform: scalar load
                     if constexpr (!PCN) {
-                        const double wn = wprev[c] + rdt * zz;                 // yy[i] = yy[i-1] + rootdt*randn   src/wiener.jl:55
-                        wprev[c] = wn;
-                        mine[pos] = wn;
-                        if constexpr ((FL & 2) != 0) {
-                            if (j < N) st_stream(&wout[((size_t)j * MP + c) * ldwo], wn);
-                        }
+                        (void)j;
+                        mine[pos] = rdt * zz;                                   // the INCREMENT rootdt*randn; the consumer adds it up   src/wiener.jl:55
                     } else {
                         const double wc = mine[pos];
                         const double w2 = w2prev[c] + rdt * zz;
@@ -265,19 +276,22 @@ __global__ __launch_bounds__(128 * NPAIR, (RLDS || PPR) ? 2 : PC_WPE) void k_pc(
                         normal_quad(tb, a.k0, a.k1, path, a.iter, q0 + (uint32_t)i, z[0], z[1], z[2], z[3]);
 #endif
                     };
+                    if constexpr (LASTDR) {
 #pragma unroll
-                    for (int c = 0; c < MP; c++) value(c, carry[c]);
-                    // every call but the last: all four normals are values of this chunk (component index static for m' = 1, 2 at any
-                    // unrolling; m' = 3 -- three calls -- is unrolled fully)
+                        for (int c = 0; c < MP; c++) value(c, carry[c]);
+                    }
+                    // every call but the chunk's last: all four normals are values of this chunk (component index static for m' = 1, 2 at
+                    // any unrolling; m' = 3 -- three calls -- is unrolled fully)
+                    constexpr int CEND = LASTDR ? NQ - 1 : CHI;
                     constexpr int QU = (RLDS || MP == 3) ? NQ : PC_QUAD_UNROLL;
 #pragma unroll QU
-                    for (int i = 0; i < NQ - 1; i++) {
+                    for (int i = CLO; i < CEND; i++) {
                         double z[4];
                         draw(i, z);
 #pragma unroll
                         for (int u = 0; u < 4; u++) value(4 * i + u + MP, z[u]);
                     }
-                    {
+                    if constexpr (LASTDR) {
                         double z[4];
                         draw(NQ - 1, z);
 #pragma unroll
@@ -304,7 +318,15 @@ __global__ __launch_bounds__(128 * NPAIR, (RLDS || PPR) ? 2 : PC_WPE) void k_pc(
             pc_barrier();   // chunk k is complete; the consumer has finished chunk k-1 (the tile written next)
             PC_ST(ps.after_barrier();)
         }
-        PC_ST(ps.write(a.stamp, blockIdx.x * (2 * NPAIR) + wave, 0, nullptr);)
+        PC_ST(ps.write(a.stamp, blockIdx.x * ((NDRAW + 1) * NPAIR) + wave, 0, nullptr);)
+    };
+    if (role < NDRAW) {   // (wave-uniform)
+        if constexpr (NDRAW == 1) producer(PcInt<0>());
+        else if constexpr (NDRAW == 2) { if (role == 0) producer(PcInt<0>()); else producer(PcInt<1>()); }
+        else {
+            static_assert(NDRAW == 4, "PC_NDRAW: 1, 2 or 4 drawer waves per pair");
+            if (role == 0) producer(PcInt<0>()); else if (role == 1) producer(PcInt<1>()); else if (role == 2) producer(PcInt<2>()); else producer(PcInt<3>());
+        }
         return;
     }
 
@@ -388,7 +410,22 @@ __global__ __launch_bounds__(128 * NPAIR, (RLDS || PPR) ? 2 : PC_WPE) void k_pc(
             xout = (j == 0 ? a.X : j == 1 ? a.Xp1 : a.Xp2) - (long)j * a.xpart; ldx = a.ldX;
         }
     }
-    constexpr int CFL = FL & ~2;   // the W store belongs to the producer
+    constexpr int CFL = FL & ~2;   // (path_step stores no W under NOISE_EXT: the consumer's loop below does)
+    // fresh proposals: the tile holds the increments; W[j] = W[j-1] + rdt*z is added up here and, where W is kept, stored from here
+    double *wout = nullptr;
+    long ldwo = 0;
+    if constexpr (!PCN && (FL & 2) != 0) { wout = a.Wout + (size_t)p * a.wstride; ldwo = a.ldWout * a.wstride; }
+    auto tile_w = [&](const double *mine, int s, int j, double (&wn)[MP]) {
+#pragma unroll
+        for (int c = 0; c < MP; c++) {
+            const double v = mine[s * MPP + c];
+            if constexpr (PCN) wn[c] = v;
+            else {
+                wn[c] = st.wprev[c] + v;                                    // yy[i] = yy[i-1] + rootdt*randn   src/wiener.jl:55
+                if constexpr ((FL & 2) != 0) st_stream(&wout[((size_t)j * MP + c) * ldwo], wn[c]);
+            }
+        }
+    };
     // per-chain guides: the chain's compact row (Hd, V, linearisation datum) of step i+1 is fetched while step i is computed
     // and expanded into the row entries right before its step (expand_pp_row); the three time entries stay shared
     constexpr int NPP = PPR ? pp_row_len<D>() : 1, NE = PPR ? RL::LEN - 3 : 1;
@@ -427,8 +464,7 @@ __global__ __launch_bounds__(128 * NPAIR, (RLDS || PPR) ? 2 : PC_WPE) void k_pc(
 #pragma unroll UNR
                 for (int s = 0; s < SPC; s++) {
                     double wn[MP];
-#pragma unroll
-                    for (int c = 0; c < MP; c++) wn[c] = mine[s * MPP + c];
+                    tile_w(mine, s, j0 + s, wn);
                     const int i = j0 + s - 1;
                     stage_x(tbx_on, i, s == 0);
 #ifdef PC_KNOCKOUT_STEP   /* measurement only: what the producer alone costs */
@@ -444,11 +480,11 @@ __global__ __launch_bounds__(128 * NPAIR, (RLDS || PPR) ? 2 : PC_WPE) void k_pc(
 #pragma unroll 1
                 for (int s = 0; s < SPC; s++) {
                     const int i = j0 + s - 1;
-                    if (i < 0 || i >= nsteps) continue;
-                    stage_x(tbx_on, i, true);
+                    if (i >= nsteps) continue;
                     double wn[MP];
-#pragma unroll
-                    for (int c = 0; c < MP; c++) wn[c] = mine[s * MPP + c];
+                    tile_w(mine, s, j0 + s, wn);                            // (grid point 0: W[0] = 0 + 0*z, stored where W is kept; no step)
+                    if (i < 0) continue;
+                    stage_x(tbx_on, i, true);
                     if constexpr (PPR) ppr_step(i, wn);
                     else if constexpr (RLDS) path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, lrows + s * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p * 8u);
                     else path_step<M, GK, MO, NOISE_EXT, CFL>(model, a, rows + (size_t)i * RL::RS, i, nll, path, wn, nullptr, 0, xout, ldx, st, TabConst(), (uint32_t)p * 8u);
@@ -464,7 +500,7 @@ __global__ __launch_bounds__(128 * NPAIR, (RLDS || PPR) ? 2 : PC_WPE) void k_pc(
         if (xtb) chunk_loop(TabTrue());
         else chunk_loop(TabFalse());
     } else chunk_loop(TabFalse());
-    PC_ST(ps.write(a.stamp, blockIdx.x * (2 * NPAIR) + wave, 1, st.tacc);)
+    PC_ST(ps.write(a.stamp, blockIdx.x * ((NDRAW + 1) * NPAIR) + wave, 1, st.tacc);)
 
     if constexpr (PPR) {
         if (a.uv_pc[p]) {
@@ -540,7 +576,7 @@ hipError_t launch_pc_n(const KArgs &a, hipStream_t st, long groups)
         const hipError_t e = hipFuncSetAttribute((const void *)k_pc<M, GK, MO, MODE, FL, NPAIR, PPR, RLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_pc<M, GK, MO, MODE, FL, NPAIR, PPR, RLDS>), dim3((unsigned)((groups + NPAIR - 1) / NPAIR)), dim3(128 * NPAIR), lds, st, a);
+    hipLaunchKernelGGL((k_pc<M, GK, MO, MODE, FL, NPAIR, PPR, RLDS>), dim3((unsigned)((groups + NPAIR - 1) / NPAIR)), dim3(pc_threads(MODE, RLDS, NPAIR)), lds, st, a);
     return hipGetLastError();
 }
 // pairs per workgroup of a launch (also what the hipRTC route of do_launch follows): 2 / 4 (RLDS) for small ensembles -- fewer when

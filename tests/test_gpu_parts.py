@@ -121,3 +121,77 @@ def test_buffers_apart_and_argument_checks(ctx):
                            0.1 * np.ones(d), ctx=ctx)
     with pytest.raises(bh.BridgeError, match="tile kernel"):
         bh.sample_solve_parts(np.zeros(d), Po16, 256, nparts=2)
+
+
+# ------------------------------------------------------------------ round 6: ONE container (EnsemblePath keeps large ensembles in parts by itself)
+@pytest.mark.parametrize("name,n,parts", [("fhn_partialbridge_extreme", 1000, 2), ("linpro2_guidedbridge", 4099, 3), ("linpro3_guidedbridge", 130, 2),
+                                           ("ou_guidedbridge", 640, 2)])
+def test_every_reader_and_writer_takes_an_ensemble_in_parts(ctx, name, n, parts):
+    """sample!, solve!, llikelihood, innovations!, girsanov, upload / download, copy, data: an EnsemblePath in parts gives, column by column,
+    what the same calls give on one buffer -- including where the two ensembles of a call are cut differently (W in 3 parts, X in 2)"""
+    case = [c for c in problems.cases(65) if c.name == name][0]
+    Po = case.bh_proposal(bh, ctx)
+    d, mp = Po.d, Po.mp
+    # the fused proposal with W kept too: X and W in parts, per range of columns
+    X1, W1, ll1 = bh.sample_solve(case.x0, Po, n, seed=5, iter=2, path0=3, store_W=True, parts=1)
+    XP, WP, llp = bh.sample_solve(case.x0, Po, n, seed=5, iter=2, path0=3, store_W=True, parts=parts)
+    assert XP.nparts == WP.nparts == parts and X1.nparts == 1
+    assert torch.equal(ll1, llp) and np.array_equal(X1.paths(), XP.paths()) and np.array_equal(W1.paths(), WP.paths())
+    assert torch.equal(X1.data, XP.data) and XP.data.shape == (len(case.tt), d, n)
+    with pytest.raises(bh.BridgeError):
+        XP.ptr()
+    # sample! into parts == sample! into one buffer (the noise is keyed by the global path id)
+    Wa = bh.sample(case.tt, bh.Wiener(mp), npaths=n, seed=8, iter=1, path0=11, ctx=ctx)
+    Wb = bh.sample_(bh.EnsemblePath(case.tt, mp, n, ctx, parts=3), bh.Wiener(mp), seed=8, iter=1, path0=11)
+    assert np.array_equal(Wa.paths(), Wb.paths())
+    # solve! with an external W: Y in `parts` buffers, W in 3 (differently cut), ll fused; per-path starts
+    lla, llb = ctx.empty(n), ctx.empty(n)
+    Ya = bh.solve(bh.Euler(), case.x0, Wa, Po, ll=lla)
+    Yb = bh.EnsemblePath(case.tt, d, n, ctx, parts=parts)
+    endb = bh.solve_(bh.Euler(), Yb, case.x0, Wb, Po, ll=llb)
+    assert np.array_equal(Ya.paths(), Yb.paths()) and torch.equal(lla, llb) and torch.equal(endb, Ya.data[-1])
+    u = torch.as_tensor(np.ascontiguousarray(np.array(case.x0)[:, None] + 0.01 * np.arange(n)[None, :] / n), device=ctx.device)
+    Yc = bh.solve(bh.Euler(), u, Wa, Po)
+    Yd = bh.EnsemblePath(case.tt, d, n, ctx, parts=parts)
+    bh.solve_(bh.Euler(), Yd, u, Wb, Po)
+    assert np.array_equal(Yc.paths(), Yd.paths())
+    Xe, _, lle = bh.sample_solve(u, Po, n, seed=6, parts=1)
+    Xf, _, llf = bh.sample_solve(u, Po, n, seed=6, parts=parts)
+    assert np.array_equal(Xe.paths(), Xf.paths()) and torch.equal(lle, llf)
+    # the stand-alone readers
+    assert torch.equal(bh.llikelihood(bh.LeftRule(), Ya, Po), bh.llikelihood(bh.LeftRule(), Yb, Po))
+    if d == mp:
+        Ia, Ib = bh.innovations(bh.EulerMaruyama(), Ya, Po), bh.innovations(bh.EulerMaruyama(), Yb, Po)
+        assert Ib.nparts == parts and np.array_equal(Ia.paths(), Ib.paths())
+    if name.startswith("linpro") or name.startswith("ou"):
+        assert torch.equal(bh.girsanov(Ya, Po, bh.Wiener(d)), bh.girsanov(Yb, Po, bh.Wiener(d)))
+    # upload / download / copy
+    host = Ya.paths()
+    Up = bh.EnsemblePath.from_paths(case.tt, host, ctx, parts=parts)
+    assert Up.nparts == parts and np.array_equal(Up.paths(), host) and np.array_equal(Up.paths(n - 7, 5), host[n - 7:n - 2])
+    assert np.array_equal(Up.copy().paths(), host) and np.array_equal(Up.path(n // 2).yy, host[n // 2])
+    for E in (XP, WP, Wb, Yb, Yd, Xf, Up):
+        E.free()
+
+
+def test_large_ensembles_are_kept_in_parts_by_default(ctx, monkeypatch):
+    """EnsemblePath(parts=None): two buffers from PARTS_MIN_BYTES on (1 GiB; lowered here), one below it and above d = 12; bh.sample_solve and
+    bh.solve hand such containers out without the caller asking"""
+    case = [c for c in problems.cases(65) if c.name == "fhn_partialbridge_extreme"][0]
+    Po = case.bh_proposal(bh, ctx)
+    assert bh.api.PARTS_MIN_BYTES == 1 << 30
+    small = bh.EnsemblePath(case.tt, 2, 4096, ctx)
+    assert small.nparts == 1 and small.ld == 4096
+    monkeypatch.setattr(bh.api, "PARTS_MIN_BYTES", 1 << 20)
+    n = 8192                                                          # 65 x 2 x 8192 x 8 = 8.5 MB
+    X, _, ll = bh.sample_solve(case.x0, Po, n, seed=2)
+    assert X.nparts == 2 and X.part_paths == 4096 and X.ld == 4096
+    X1, _, ll1 = bh.sample_solve(case.x0, Po, n, seed=2, parts=1)
+    assert torch.equal(ll, ll1) and np.array_equal(X.paths(), X1.paths())
+    W = bh.sample(case.tt, bh.Wiener(1), npaths=4 * n, seed=1, ctx=ctx)   # 65 x 1 x 32768 x 8 = 17 MB
+    assert W.nparts == 2
+    Y = bh.solve(bh.Euler(), case.x0, W, Po)
+    assert Y.nparts == 2
+    assert bh.EnsemblePath(case.tt, 16, 2048, ctx).nparts == 1       # the tile kernel's dimensions: one buffer
+    for E in (X, W, Y):
+        E.free()
