@@ -124,27 +124,56 @@ struct HIPEnsemble
 end
 HIPEnsemble(n; seed = 0, iter = 0, path0 = 0) = HIPEnsemble(n, seed, iter, path0)
 
-"An ensemble of sample paths in HBM: element (i, k, p) at `(i*dim + k)*ld + p` (0-based), Float64."
+"""
+An ensemble of sample paths in HBM, Float64, struct of arrays: element (i, k, p) (0-based) of buffer j at `(i*dim + k)*ld + (p - j*ld)`.
+ONE container (src/types.jl:71-81 has one `SamplePath` type; an ensemble is a loop there), kept in `length(ptrs)` device buffers:
+paths `j*ld : (j+1)*ld - 1` live in buffer j.  Ensembles of 1 GiB and more get TWO buffers lying in different 96-GiB pieces of the
+device memory (`bhip_alloc_apart`): an ensemble written by one kernel is one write stream, and a write stream inside one piece moves
+4.3-4.4 TB/s where two streams in two pieces move 5.8-6.0.  Every method below walks the column ranges that lie inside one buffer of
+every ensemble involved (`segments`); the fused proposal `sample_solve!` writes all buffers in one launch.
+"""
 mutable struct EnsemblePath{T} <: Bridge.AbstractPath{T}
     tt::Vector{Float64}
-    dev::Ptr{Cdouble}
+    ptrs::Vector{Ptr{Cvoid}}     # the buffers (bhip_alloc_apart)
     dim::Int
     npaths::Int
+    ld::Int                      # leading dimension of every buffer = paths per buffer (a multiple of 64 when there are several)
+    apart::Int                   # how many of the buffers were found pairwise in different pieces
     ctx::Context
 end
 Base.length(X::EnsemblePath) = length(X.tt)
-function EnsemblePath{T}(tt, dim, npaths, c::Context = default_context()) where {T}
-    r = Ref{Ptr{Cvoid}}(C_NULL)
-    check(c, ccall((:bhip_malloc, lib), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), c.h, 8 * length(tt) * dim * npaths, r))
-    X = EnsemblePath{T}(collect(Float64, tt), Ptr{Cdouble}(r[]), dim, npaths, c)
-    finalizer(x -> ccall((:bhip_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), x.ctx.h, x.dev), X)
+const PARTS_MIN_BYTES = 1 << 30
+function EnsemblePath{T}(tt, dim, npaths, c::Context = default_context(); parts::Union{Nothing,Integer} = nothing) where {T}
+    nparts = parts === nothing ? (8 * length(tt) * dim * npaths >= PARTS_MIN_BYTES && dim <= 12 ? 2 : 1) : Int(parts)
+    ld = nparts == 1 ? npaths : cld(cld(npaths, nparts), 64) * 64
+    ptrs = fill(Ptr{Cvoid}(C_NULL), nparts)
+    apart = Ref{Cint}(0)
+    check(c, ccall((:bhip_alloc_apart, lib), Cint, (Ptr{Cvoid}, Cint, Csize_t, Ptr{Ptr{Cvoid}}, Ref{Cint}),
+        c.h, nparts, 8 * length(tt) * dim * ld, ptrs, apart))
+    X = EnsemblePath{T}(collect(Float64, tt), ptrs, dim, npaths, ld, Int(apart[]), c)
+    # (the buffers hold a reference to their context: finalizers may run in any order)
+    finalizer(x -> ccall((:bhip_free_apart, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}), x.ctx.h, length(x.ptrs), x.ptrs), X)
+end
+"device address of column p (0-based); its buffer's leading dimension is `X.ld`"
+colptr(X::EnsemblePath, p::Integer) = Ptr{Cdouble}(X.ptrs[p ÷ X.ld + 1]) + 8 * (p % X.ld)
+"column ranges (start (0-based), n) lying inside ONE buffer of every ensemble given"
+function segments(X::EnsemblePath, others::EnsemblePath...)
+    cuts = Set{Int}((0, X.npaths))
+    for E in (X, others...)
+        E.npaths == X.npaths || error("ensembles differ in the number of paths")
+        for c in E.ld:E.ld:(E.npaths - 1)
+            push!(cuts, c)
+        end
+    end
+    cs = sort!(collect(cuts))
+    [(cs[k], cs[k + 1] - cs[k]) for k in 1:length(cs) - 1]
 end
 "download path p (1-based) as an ordinary Bridge.SamplePath"
 function Bridge.SamplePath(X::EnsemblePath{T}, p::Integer) where {T}
     yy = Vector{T}(undef, length(X))
     check(X.ctx, ccall((:bhip_download_aos, lib), Cint,
         (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Clong, Clong, Clong, Ptr{Cdouble}),
-        X.ctx.h, X.dev, length(X), X.dim, X.npaths, p - 1, 1, pointer(reinterpret(Float64, yy))))
+        X.ctx.h, colptr(X, p - 1), length(X), X.dim, X.ld, 0, 1, pointer(reinterpret(Float64, yy))))
     Bridge.SamplePath(copy(X.tt), yy)
 end
 
@@ -222,69 +251,58 @@ function sample(tt, P::Wiener{T}, E::HIPEnsemble; ctx = default_context()) where
     W = EnsemblePath{T}(tt, length(zero(T)), E.npaths, ctx)
     sample!(W, P; seed = E.seed, iter = E.iter, path0 = E.path0)
 end
-"sample!(W, Wiener())  src/wiener.jl:24-58"
+"sample!(W, Wiener())  src/wiener.jl:24-58 (the noise is keyed by the global path id: path0 + column)"
 function sample!(W::EnsemblePath{T}, ::Wiener{T}; seed = 0, iter = 0, path0 = 0) where {T}
-    check(W.ctx, ccall((:bhip_wiener_sample, lib), Cint,
-        (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Clong, Clong, UInt64, UInt32, UInt32),
-        W.ctx.h, W.tt, length(W.tt), W.dim, W.dev, W.npaths, W.npaths, seed, iter, path0))
+    for (a, n) in segments(W)
+        check(W.ctx, ccall((:bhip_wiener_sample, lib), Cint,
+            (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Clong, Clong, UInt64, UInt32, UInt32),
+            W.ctx.h, W.tt, length(W.tt), W.dim, colptr(W, a), W.ld, n, seed, iter, path0 + a))
+    end
     W
 end
 
-"solve!(HIPEuler(), Y, u, W, Po): src/euler.jl:247-268 for every path; returns Y (endpoints are Y[end])"
+"solve!(HIPEuler(), Y, u, W, Po): src/euler.jl:247-268 for every path; returns Y (endpoints are Y[end]); `ll`: device pointer to npaths values or C_NULL"
 function solve!(::HIPEuler, Y::EnsemblePath, u, W::EnsemblePath, Po::HIPProposal; ll::Ptr{Cdouble} = Ptr{Cdouble}(C_NULL), skip = 0)
     length(W) != length(Y) && error("Y and W differ in length.")        # src/euler.jl:251
     Y.tt[:] = Po.tt                                                       # src/euler.jl:256
-    check(Y.ctx, ccall((:bhip_solve, lib), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Cint, Clong),
-        Y.ctx.h, Po.h, collect(Float64, u), C_NULL, W.dev, W.npaths, Y.dev, Y.npaths, ll, skip, Y.npaths))
+    for (a, n) in segments(Y, W)
+        check(Y.ctx, ccall((:bhip_solve, lib), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Cint, Clong),
+            Y.ctx.h, Po.h, collect(Float64, u), C_NULL, colptr(W, a), W.ld, colptr(Y, a), Y.ld, ll == C_NULL ? ll : ll + 8 * a, skip, n))
+    end
     Y
 end
 solve(m::HIPEuler, u, W::EnsemblePath, Po::HIPProposal{T}; kw...) where {T} =
-    solve!(m, EnsemblePath{T}(W.tt, Po.d, W.npaths, W.ctx), u, W, Po; kw...)
+    solve!(m, EnsemblePath{T}(W.tt, Po.d, W.npaths, W.ctx; parts = length(W.ptrs) > 1 ? length(W.ptrs) : nothing), u, W, Po; kw...)
 "deprecated alias  src/deprecated.jl:16-17"
 bridge!(Y::EnsemblePath, u, W::EnsemblePath, Po::HIPProposal) = solve!(HIPEuler(), Y, u, W, Po)
 
 """
-An ensemble kept in `nparts` (1..3) buffers that lie in different 96-GiB pieces of the device memory (`bhip_alloc_apart`): paths
-`(j-1)*part_paths+1 : j*part_paths` are `parts[j]`, an `EnsemblePath` like any other (leading dimension `part_paths`).  Written by
-`sample_solve_parts!` in one launch: a write stream per piece moves 5.8-6.9 TB/s where the one stream of a single buffer moves 4.3-4.4.
-"""
-mutable struct EnsembleParts{T}
-    parts::Vector{EnsemblePath{T}}
-    ptrs::Vector{Ptr{Cvoid}}
-    part_paths::Int
-    npaths::Int
-    apart::Int
-    ctx::Context
-end
-function EnsembleParts{T}(tt, dim, npaths, nparts = 2, c::Context = default_context()) where {T}
-    part = cld(cld(npaths, nparts), 64) * 64
-    ptrs = fill(Ptr{Cvoid}(C_NULL), nparts)
-    apart = Ref{Cint}(0)
-    check(c, ccall((:bhip_alloc_apart, lib), Cint, (Ptr{Cvoid}, Cint, Csize_t, Ptr{Ptr{Cvoid}}, Ref{Cint}),
-        c.h, nparts, 8 * length(tt) * dim * part, ptrs, apart))
-    parts = [EnsemblePath{T}(collect(Float64, tt), Ptr{Cdouble}(ptrs[j]), dim, part, c) for j in 1:nparts]   # (inner constructor: no finalizer of their own)
-    E = EnsembleParts{T}(parts, ptrs, part, npaths, Int(apart[]), c)
-    finalizer(e -> ccall((:bhip_free_apart, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}), e.ctx.h, length(e.ptrs), e.ptrs), E)
-end
-"path p (1-based) of the whole ensemble"
-Bridge.SamplePath(E::EnsembleParts, p::Integer) = Bridge.SamplePath(E.parts[cld(p, E.part_paths)], (p - 1) % E.part_paths + 1)
+    sample_solve!(X, u, Po; ll, skip, seed, iter, path0)
 
-"fused sample! + solve! + llikelihood into an ensemble kept in parts (`bhip_sample_solve_parts`); `ll`: device pointer to npaths values or C_NULL"
-function sample_solve_parts!(E::EnsembleParts, u, Po::HIPProposal; ll::Ptr{Cdouble} = Ptr{Cdouble}(C_NULL), skip = 0, seed = 0, iter = 0, path0 = 0)
-    check(E.ctx, ccall((:bhip_sample_solve_parts, lib), Cint,
+The fused proposal -- `sample!(W, Wiener())`, `solve!(Euler(), X, u, W, Po)`, `llikelihood(LeftRule(), X, Po; skip)` in one kernel with
+in-kernel Philox noise, W never stored -- into `X`, ALL its buffers by one launch (`bhip_sample_solve_parts`; one buffer: the values and
+the kernel of `bhip_sample_solve`).  `ll`: device pointer to npaths values or C_NULL.
+"""
+function sample_solve!(X::EnsemblePath, u, Po::HIPProposal; ll::Ptr{Cdouble} = Ptr{Cdouble}(C_NULL), skip = 0, seed = 0, iter = 0, path0 = 0)
+    X.tt[:] = Po.tt
+    check(X.ctx, ccall((:bhip_sample_solve_parts, lib), Cint,
         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Ptr{Cvoid}}, Clong, Clong, Ptr{Cdouble}, Cint, Clong, UInt64, UInt32, UInt32),
-        E.ctx.h, Po.h, collect(Float64, u), length(E.ptrs), E.ptrs, E.part_paths, E.part_paths, ll, skip, E.npaths, seed, iter, path0))
-    E
+        X.ctx.h, Po.h, collect(Float64, u), length(X.ptrs), X.ptrs, X.ld, X.ld, ll, skip, X.npaths, seed, iter, path0))
+    X
 end
+sample_solve(u, Po::HIPProposal{T}, E::HIPEnsemble; kw...) where {T} =
+    sample_solve!(EnsemblePath{T}(Po.tt, Po.d, E.npaths, Po.ctx), u, Po; seed = E.seed, iter = E.iter, path0 = E.path0, kw...)
 
 "llikelihood(LeftRule(), X, Po; skip): one value per path  src/partialbridge.jl:67-77 etc."
 function llikelihood(::LeftRule, X::EnsemblePath, Po::HIPProposal; skip = 0)
     out = Vector{Float64}(undef, X.npaths)
     r = Ref{Ptr{Cvoid}}(C_NULL)
     check(X.ctx, ccall((:bhip_malloc, lib), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), X.ctx.h, 8 * X.npaths, r))
-    check(X.ctx, ccall((:bhip_llikelihood, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Cint, Clong),
-        X.ctx.h, Po.h, X.dev, X.npaths, r[], skip, X.npaths))
+    for (a, n) in segments(X)
+        check(X.ctx, ccall((:bhip_llikelihood, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Cint, Clong),
+            X.ctx.h, Po.h, colptr(X, a), X.ld, Ptr{Cdouble}(r[]) + 8 * a, skip, n))
+    end
     check(X.ctx, ccall((:bhip_memcpy_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), X.ctx.h, out, r[], 8 * X.npaths))
     ccall((:bhip_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), X.ctx.h, r[])
     out
@@ -300,8 +318,10 @@ function Bridge.girsanov(X::EnsemblePath, Po::HIPProposal, Pt)
     out = Vector{Float64}(undef, X.npaths)
     r = Ref{Ptr{Cvoid}}(C_NULL)
     check(X.ctx, ccall((:bhip_malloc, lib), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), X.ctx.h, 8 * X.npaths, r))
-    check(X.ctx, ccall((:bhip_girsanov, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Clong),
-        X.ctx.h, Po.h, Pt isa Wiener ? C_NULL : par, length(par), X.dev, X.npaths, r[], X.npaths))
+    for (a, n) in segments(X)
+        check(X.ctx, ccall((:bhip_girsanov, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Clong),
+            X.ctx.h, Po.h, Pt isa Wiener ? C_NULL : par, length(par), colptr(X, a), X.ld, Ptr{Cdouble}(r[]) + 8 * a, n))
+    end
     check(X.ctx, ccall((:bhip_memcpy_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), X.ctx.h, out, r[], 8 * X.npaths))
     ccall((:bhip_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), X.ctx.h, r[])
     out

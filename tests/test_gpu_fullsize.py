@@ -83,8 +83,33 @@ def test_C3_fhn_partial_bridge_262144_paths(ctx):
     X3, _, ll3 = bh.sample_solve(c3.x0, Po3, P, seed=3)
     assert bool(torch.isfinite(ll3).all()) and float((X3.data[-1, 0] - c3.v[0]).abs().max()) < 5e-3
     ref3 = c3.oracle_proposal()
-    Xr = o.solve_guided(ref3, c3.x0, o.wiener_sample(c3.tt, 1, 3, 4242, 0))
-    assert np.abs(X3.paths(4242, 1)[0] - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max())
+    for p in (4242, P - 1):   # `==`: MNCLAR::b and the oracle share one sin (bhip_trig.h det_sin); both parts of the container
+        Xr = o.solve_guided(ref3, c3.x0, o.wiener_sample(c3.tt, 1, 3, p, 0))
+        assert np.array_equal(X3.paths(p, 1)[0], Xr) and float(ll3[p]) == o.llikelihood(ref3, Xr)
+    # the containers of this size are kept in two buffers (EnsemblePath: 1 GiB and more), written by one launch
+    assert X.nparts == 2 and X3.nparts == 2 and X.part_paths == P // 2
+
+
+def test_linpro4_262144_paths_on_the_lanes(ctx):
+    """the `linpro4` bench mode at its full size: LinPro d = 4 GuidedBridge (dense sigma), 1001 steps, 262 144 paths, one path per lane on
+    the regrouped rows (three products per step: tolerance parity like every d > 3 path) -- finite, endpoint rule, stand-alone
+    llikelihood == fused to tolerance, sharding invariance `==`, spot checks against the oracle in both parts of the container"""
+    d, P = 4, 262144
+    c = problems.linpro_big_case(d, N)
+    Po = c.bh_proposal(bh, ctx)
+    X, _, ll = bh.sample_solve(c.x0, Po, P, seed=6)
+    assert X.nparts == 2 and bool(torch.isfinite(ll).all())
+    assert bool((X.endpoints() == torch.as_tensor(c.v, device=ll.device)[:, None]).all())      # endpoint rule src/euler.jl:241-242
+    ll2 = bh.llikelihood(bh.LeftRule(), X, Po)
+    assert float((ll2 - ll).abs().max()) <= 1e-8 * (1 + float(ll.abs().max()))
+    Xq, _, llq = bh.sample_solve(c.x0, Po, P // 4, seed=6, path0=3 * P // 4)
+    assert torch.equal(llq, ll[3 * P // 4:]) and np.array_equal(Xq.paths(0, 64), X.paths(3 * P // 4, 64)) and np.array_equal(Xq.paths(P // 4 - 3, 3), X.paths(P - 3, 3))
+    ref = c.oracle_proposal()
+    for p in (0, P // 2 - 1, P // 2, P - 1):
+        Xr = o.solve_guided(ref, c.x0, o.wiener_sample(c.tt, d, 6, p, 0))
+        assert np.abs(X.paths(p, 1)[0] - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max())
+        llr = o.llikelihood(ref, Xr)
+        assert abs(float(ll[p]) - llr) <= 1e-8 * (1 + abs(llr))
 
 
 def _linpro_logdensity(B, mu, sig, u, T, v):
