@@ -127,7 +127,7 @@ def cpu_baseline(seconds_budget=20.0):
 
 NOISE_SPEC = ("bhip-philox-v4: Philox4x32-10, four normals per call = one per 32-bit word through a piecewise polynomial inverse distribution "
               "function (256 segments of degree 4, within 3.7e-9 of the quantile, |z| <= 6.34; DESIGN 4); the reference's randn is a 52-bit ziggurat")
-PROFILE_TAG = "r5"   # profiles/<PROFILE_TAG>_<mode>_{trace,fetch,write}.txt, written by scripts/gpu_profile_all.sh this round
+PROFILE_TAG = "r6"   # profiles/<PROFILE_TAG>_<mode>_{trace,fetch,write}.txt, written by scripts/gpu_profile_all.sh this round
 
 
 def profiled_traffic(mode, kernel_name):

@@ -21,6 +21,7 @@ SIGNATURES = {
     "bhip_ctx_destroy": (None, [vp]),
     "bhip_ctx_sync": (C.c_int, [vp]),
     "bhip_ctx_set_option": (C.c_int, [vp, C.c_int, C.c_int]),
+    "bhip_ctx_get_option": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
     "bhip_last_error": (C.c_char_p, [vp]),
     "bhip_malloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
     "bhip_free": (C.c_int, [vp, vp]),

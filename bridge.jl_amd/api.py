@@ -109,6 +109,12 @@ class Context:
         """bhip_ctx_set_option: OPT_WAVE_SPECIALISED 1 (default) / 0"""
         self.check(self.lib.bhip_ctx_set_option(self.h, int(option), int(value)))
 
+    def get_option(self, option):
+        """bhip_ctx_get_option, e.g. get_option(OPT_NOISE_SPEC) -> 4 | 3 | 2 (which stream of normals this context draws)"""
+        v = C.c_int()
+        self.check(self.lib.bhip_ctx_get_option(self.h, int(option), C.byref(v)))
+        return v.value
+
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float64, device=self.device)
 

@@ -199,6 +199,7 @@ struct bhip_proposal {
     double *d_mpar = nullptr;
     // large-d (tile kernel) data: per-step fragment matrices, step header, constants
     double *d_steps = nullptr, *d_hdr = nullptr, *d_cst = nullptr, *d_tt = nullptr;
+    bool tile_tda = false;   // the step rows carry -B~_i, c_i per step (component-wise user drift with a time-dependent auxiliary: k_tile<.., TDA = true>)
 };
 
 struct bhip_chains {
@@ -417,6 +418,18 @@ int bhip_ctx_set_option(bhip_ctx *ctx, int option, int value)
         return BHIP_OK;
     }
     return fail(ctx, BHIP_EINVAL, "bhip_ctx_set_option: unknown option");
+}
+int bhip_ctx_get_option(const bhip_ctx *ctx, int option, int *value)
+{
+    if (!ctx || !value) return BHIP_EINVAL;
+    switch (option) {
+    case BHIP_OPT_WAVE_SPECIALISED: *value = ctx->wave_specialised ? 1 : 0; return BHIP_OK;
+    case BHIP_OPT_TUNE_PLACEMENT: *value = ctx->tune_placement ? 1 : 0; return BHIP_OK;
+    case BHIP_OPT_MID_VALU: *value = ctx->mid_max; return BHIP_OK;                 // the largest dimension that runs one path per lane (0: none)
+    case BHIP_OPT_FUSED_ARITHMETIC: *value = ctx->fused ? 1 : 0; return BHIP_OK;
+    case BHIP_OPT_NOISE_SPEC: *value = ctx->noise_spec; return BHIP_OK;
+    }
+    return BHIP_EINVAL;
 }
 
 int bhip_malloc(bhip_ctx *ctx, size_t bytes, void **dev)
@@ -663,10 +676,10 @@ int bhip_proposal_set_aux(bhip_proposal *po, int kind, const double *apar, int n
     return BHIP_OK;
 }
 
-// a component-wise user drift (bhip_model_define_components) of a dimension whose proposals AND pCN chains run one path per lane
-static bool lanes_only_candidate(const ModelHost &mh)
+// a component-wise user drift (bhip_model_define_components)
+static bool components_model(const ModelHost &mh)
 {
-    if (mh.id < USER_MODEL_BASE || mh.d < 4 || mh.d > BHIP_MID_MAX_CHAINS) return false;
+    if (mh.id < USER_MODEL_BASE || mh.d < 4) return false;
     std::lock_guard<std::mutex> lk(user_models_mutex());
     const UserModel *um = find_user_model(mh.id);
     return um && um->components;
@@ -683,8 +696,8 @@ int bhip_proposal_set_aux_linearappr(bhip_proposal *po, const double *xx, const 
     // grid index like every time-dependent auxiliary; the per-chain device-built guides of bhip_segchains_adapt_device stay at d <= 3)
     // (a component-wise user drift of dimension 4..BHIP_MID_MAX_CHAINS takes them too: its one-path-per-lane rows carry B~_i, beta~_i per step;
     // the tile kernel keeps -B~ as a constant matrix beside a user drift, so such a proposal runs one path per lane only -- finish_guide)
-    if (d > 3 && po->mh.id != BHIP_MODEL_LINPRO && !lanes_only_candidate(po->mh))
-        return fail(ctx, BHIP_EUNSUPPORTED, "LinearAppr auxiliary at d > 3: LinPro targets, or component-wise user drifts of dimension 4..8");
+    if (d > 3 && po->mh.id != BHIP_MODEL_LINPRO && !components_model(po->mh))
+        return fail(ctx, BHIP_EUNSUPPORTED, "LinearAppr auxiliary at d > 3: LinPro targets, or component-wise user drifts (bhip_model_define_components)");
     if (!po->mh.constdiff) return fail(ctx, BHIP_EUNSUPPORTED, "LinearAppr auxiliary: the target must have a constant sigma");
     // constant-diffusivity log-likelihood: the linearisation's Sigma_i must be the target's sigma (a~ = a)
     const double *sg = po->mh.id == BHIP_MODEL_LINPRO ? po->mh.par.data() + d * d + d : nullptr;
@@ -839,8 +852,11 @@ static int build_tile_data(bhip_proposal *po)
     // LinPro / affine forms, a caller's callback, LinearAppr / LinearNoiseAppr coefficients by grid index.  A component-wise user drift
     // keeps -B~ as a CONSTANT matrix in the kernel (bhip_tile_kernel.h, UD::ON): time-constant auxiliaries only.
     const bool aux_const = po->has_aux && (po->aux.kind == BHIP_AUX_AFFINE || po->aux.kind == BHIP_AUX_LINPRO);
-    if (!plain && (!po->has_aux || (user && !aux_const) || po->aux.kind == BHIP_AUX_FHN_STARTEND))
-        return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: no auxiliary process, or a time-dependent one with a component-wise user drift");
+    if (!plain && (!po->has_aux || po->aux.kind == BHIP_AUX_FHN_STARTEND))
+        return fail(ctx, BHIP_EUNSUPPORTED, "large-d device path: no auxiliary process for a guided proposal");
+    // (round 6) a component-wise user drift beside a TIME-DEPENDENT auxiliary: -B~_i and c_i travel with the step row (k_tile<.., TDA = true>)
+    const bool tda = user && !plain && !aux_const;
+    po->tile_tda = tda;
     const int Dp = tile_dim(d);
     // The step regrouped into products with path-independent accumulator starts (bhip_tile_kernel.h, head of the file):
     //   built-in (LinPro) target, three products:
@@ -850,7 +866,7 @@ static int build_tile_data(bhip_proposal *po)
     //   component-wise user drift (it takes the place of B (x - mu) as a vector term in the kernel: B = 0, mu = 0 here), four products:
     //     per step   -Hm_i, P_i (fragment order), hnu_i, q_i, dt_i, sqrt(dt_i)
     //     constant   sigma, B - B~ = -B~ (fragment order), vend, c
-    const size_t DD = (size_t)Dp * Dp, STEP = 2 * DD + 2 * Dp + 4, dd = (size_t)d * d;
+    const size_t DD = (size_t)Dp * Dp, STEP = (size_t)tile_step_doubles(Dp, tda), dd = (size_t)d * d;
     const double *par = po->mh.par.data();
     const double *sig = user ? par + (po->mh.par.size() - (size_t)dd) : par + dd + d;   // user: [drift parameters, sigma]; LinPro: [B, mu, sigma]
     const Mat Bm = user ? Mat(d, d) : Mat(d, d, par);
@@ -895,6 +911,10 @@ static int build_tile_data(bhip_proposal *po)
         if (user) {
             to_fragments(pad_mat(-Hm, Dp), st);
             std::memcpy(st + 2 * DD, hnu.a.data(), sizeof(double) * d);
+            if (tda) {   // B = 0, mu = 0 beside a user drift: Dm = -B~_i, c = B~_i mu~ - beta~_i of grid point i (set just above)
+                to_fragments(pad_mat(Dm, Dp), st + 2 * DD + 2 * Dp + 4);
+                std::memcpy(st + 3 * DD + 2 * Dp + 4, c.a.data(), sizeof(double) * d);
+            }
         } else {
             const Mat A = -(DmT * Hm), b = DmT * hnu - tr(Hm) * c;
             to_fragments(pad_mat(A, Dp), st);
@@ -939,7 +959,7 @@ static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const d
     bhip_ctx *ctx = po->ctx;
     NEED_DEVICE(ctx);
     const int d = po->mh.d;
-    if (!po->d_steps) return fail(ctx, BHIP_ESTATE, "proposal has no large-d guide data (compute a guide first; a component-wise user drift with a time-dependent auxiliary runs one path per lane only: dimension 4..8, BHIP_OPT_MID_VALU on, default noise specification)");
+    if (!po->d_steps) return fail(ctx, BHIP_ESTATE, "proposal has no large-d guide data (compute a guide first)");
     if (!x0 && !x0_dev) return fail(ctx, BHIP_EINVAL, "need a starting point");
     if (npaths < 1 || skip < 0) return fail(ctx, BHIP_EINVAL, "bad npaths/skip");
     TArgs a;
@@ -968,17 +988,17 @@ static int launch_tile_path(const bhip_proposal *po_c, const double *x0, const d
             std::lock_guard<std::mutex> lk(user_models_mutex());
             UserModel *um = find_user_model(po->mh.id);
             if (!um || !um->components) return fail(ctx, BHIP_EINVAL, "unknown component-wise user model id");
-            const std::vector<int> key = {ctx->device, -1, D, noise, pad ? 1 : 0};
+            const std::vector<int> key = {ctx->device, -1, D, noise, pad ? 1 : 0, po->tile_tda ? 1 : 0};
             auto it = um->fns.find(key);
             if (it == um->fns.end()) {
-                const std::string log = rtc_tile_build(*um, D, noise, pad, &fn);
+                const std::string log = rtc_tile_build(*um, D, noise, pad, &fn, po->tile_tda);
                 if (!log.empty()) return fail(ctx, BHIP_EHIP, log);
                 um->fns[key] = fn;
             } else fn = it->second;
         }
         TArgs args = a;
         void *params[] = {&args};
-        HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)((npaths + 63) / 64), 1, 1, 256, 1, 1, (unsigned)tile_lds_bytes(D, true), ctx->stream, params, nullptr));
+        HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)((npaths + 63) / 64), 1, 1, 256, 1, 1, (unsigned)tile_lds_bytes(D, true, true, po->tile_tda), ctx->stream, params, nullptr));
         return BHIP_OK;
     }
     hipError_t le = hipSuccess;
@@ -1012,20 +1032,10 @@ static int finish_guide(bhip_proposal *po)
             const UserModel *um = find_user_model(po->mh.id);
             comp = um && um->components;
         }
-        // a component-wise user drift with a TIME-DEPENDENT auxiliary (callback, LinearAppr by grid index): the tile kernel keeps -B~ as one
-        // constant matrix beside a user drift (build_tile_data), the one-path-per-lane rows carry B~_i, beta~_i per step.  At the dimensions
-        // where everything -- proposals, llikelihood, innovations!, pCN chains -- runs one path per lane such a proposal is built for the
-        // lanes alone; whatever would need the tile kernel (BHIP_OPT_MID_VALU = 0, another noise specification's chains) fails with BHIP_ESTATE.
-        const bool aux_const = po->has_aux && (po->aux.kind == BHIP_AUX_AFFINE || po->aux.kind == BHIP_AUX_LINPRO);
-        const bool lanes_only = comp && d <= BHIP_MID_MAX_CHAINS && po->g.kind != BHIP_GUIDE_NONE && po->has_aux && !aux_const &&
-                                po->aux.kind != BHIP_AUX_FHN_STARTEND;
-        if (lanes_only) {
-            for (double **q : {&po->d_steps, &po->d_hdr, &po->d_cst})
-                if (*q) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(*q)); *q = nullptr; }
-        } else {
-            const int rct = build_tile_data(po);
-            if (rct || d > BHIP_MAXD_LANE || !(po->mh.id == BHIP_MODEL_LINPRO || comp)) return rct;
-        }
+        // (until round 5 a component-wise user drift with a TIME-DEPENDENT auxiliary was built for the lanes alone, dimension 4..8; the tile
+        // kernel now streams -B~_i, c_i with the step row -- build_tile_data, k_tile<.., TDA> -- and takes every dimension 4..32)
+        const int rct = build_tile_data(po);
+        if (rct || d > BHIP_MAXD_LANE || !(po->mh.id == BHIP_MODEL_LINPRO || comp)) return rct;
         po->mid = true;   // ... and the rows below, for one path per lane (LinPro targets and component-wise user drifts)
     }
     std::vector<double> rows;
@@ -1743,8 +1753,7 @@ int bhip_chains_create(bhip_ctx *ctx, const bhip_proposal *po, long nchains, uin
     // d = 9) --, and never under the full-resolution noise specification (the slot kernel draws the default stream only)
     const bool on_tile = po->mh.d > 3 && !(po->mid && po->mh.d <= std::min(ctx->mid_max, (int)BHIP_MID_MAX_CHAINS) && ctx->noise_spec == 4);
     if (on_tile && !po->d_steps)
-        return fail(ctx, BHIP_ESTATE, "chains: the proposal has no large-d guide data (a component-wise user drift with a time-dependent auxiliary runs one path per lane "
-                                      "only: dimension 4..8, BHIP_OPT_MID_VALU on, default noise specification)");
+        return fail(ctx, BHIP_ESTATE, "chains: the proposal has no large-d guide data (compute a guide first)");
     bhip_chains *ch = new (std::nothrow) bhip_chains();
     if (!ch) return fail(ctx, BHIP_EHIP, "out of host memory");
     ch->ctx = ctx; ch->po = po; ch->n = nchains; ch->ld = (nchains + 63) / 64 * 64;

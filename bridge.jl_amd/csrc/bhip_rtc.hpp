@@ -245,15 +245,16 @@ inline std::string rtc_compile(const UserModel &um, int gk, int mo, int noise, i
 }
 
 // ---- d > 3: k_tile<D, NOISE, PAD, MUserBig>, the target drift evaluated component-wise by the user's text
-inline std::string rtc_tile_compile(const UserModel &um, int D, int noise, bool pad, std::vector<char> &code, std::string &low)
+inline std::string rtc_tile_compile(const UserModel &um, int D, int noise, bool pad, std::vector<char> &code, std::string &low, bool tda = false)
 {
     std::string s = RTC_PREFIX_TILE;
     s += "\nnamespace bhip {\nstruct MUserBig {\n    static constexpr bool ON = true;\n";
     s += "    static __device__ __forceinline__ double bk(int k, double t, const double *x, const double *par)\n    {\n";
     s += "        const int d = " + std::to_string(um.d) + "; (void)d; (void)t; (void)par; (void)k;\n        double o = 0.0;\n        " + um.drift + "\n        return o;\n    }\n};\n";
-    const std::string inst = "k_tile<" + std::to_string(D) + ", " + std::to_string(noise) + ", " + (pad ? "true" : "false") + ", MUserBig>";
+    const std::string tail = tda ? ", true>" : ", false>";   // TDA: a per-step auxiliary matrix beside the user drift (bhip_tile_kernel.h)
+    const std::string inst = "k_tile<" + std::to_string(D) + ", " + std::to_string(noise) + ", " + (pad ? "true" : "false") + ", MUserBig" + tail;
     s += "template __global__ void " + inst + "(const TArgs);\n}\n";
-    const std::string name = "bhip::k_tile<" + std::to_string(D) + ", " + std::to_string(noise) + ", " + (pad ? "true" : "false") + ", bhip::MUserBig>";
+    const std::string name = "bhip::k_tile<" + std::to_string(D) + ", " + std::to_string(noise) + ", " + (pad ? "true" : "false") + ", bhip::MUserBig" + tail;
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, s.c_str(), "bhip_user_model_tile.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return "hiprtcCreateProgram failed";
     hiprtcAddNameExpression(prog, name.c_str());
@@ -277,11 +278,11 @@ inline std::string rtc_tile_compile(const UserModel &um, int D, int noise, bool 
     hiprtcDestroyProgram(&prog);
     return "";
 }
-inline std::string rtc_tile_build(UserModel &um, int D, int noise, bool pad, hipFunction_t *out)
+inline std::string rtc_tile_build(UserModel &um, int D, int noise, bool pad, hipFunction_t *out, bool tda = false)
 {
     std::vector<char> code;
     std::string low;
-    const std::string log = rtc_tile_compile(um, D, noise, pad, code, low);
+    const std::string log = rtc_tile_compile(um, D, noise, pad, code, low, tda);
     if (!log.empty()) return log;
     hipModule_t mod;
     if (hipModuleLoadData(&mod, code.data()) != hipSuccess) return "hipModuleLoadData failed for the compiled user model";

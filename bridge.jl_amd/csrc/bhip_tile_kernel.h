@@ -151,12 +151,18 @@ __device__ __forceinline__ void tile_mv_acc(const double *__restrict__ Mf, const
     }
 }
 
-template <int D, int NOISE, bool PAD = false, class UD = NoUserDrift>
+// TDA (round 6; user drift only): a TIME-DEPENDENT auxiliary beside a component-wise user drift -- B~(t), beta~(t) are functions of t for
+// any dimension (src/partialbridge.jl:13-15, src/linpro.jl:181-204) -- : the step row carries a THIRD matrix, -B~_i in fragment order, and
+// the vector c_i = B~_i mu~ - beta~_i behind its scalars, streamed to LDS with the row like A_i and P_i, in place of the two constants
+// of the kernel (cst's second matrix and last vector).  Same four products, 8 KiB more per step and block at d = 32.
+constexpr int tile_step_doubles(int D, bool tda) { return (tda ? 3 : 2) * D * D + (tda ? 3 : 2) * D + 4; }
+template <int D, int NOISE, bool PAD = false, class UD = NoUserDrift, bool TDA = false>
 __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per SIMD: <= 256 VGPR+AGPR
 {
+    static_assert(!TDA || UD::ON, "the per-step auxiliary matrix exists beside a user drift only (a LinPro target folds B~_i into A_i, b_i, c0_i)");
     constexpr int T = D / 16;
     constexpr int DD = D * D;
-    constexpr int STEP = 2 * DD + 2 * D + 4;   // A_i | -Hm_i, P_i (fragment order), b_i | hnu_i, q_i, dt_i, sqrt(dt_i), c0_i, 0
+    constexpr int STEP = tile_step_doubles(D, TDA);   // A_i | -Hm_i, P_i (fragment order), b_i | hnu_i, q_i, dt_i, sqrt(dt_i), c0_i, 0 [, -B~_i (fragment order), c_i]
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *cm = lds;                  // 2*DD fragment matrices + 2*D vectors
     double *hb = lds + 2 * DD + 2 * D; // 2 * STEP
@@ -188,8 +194,8 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
     __syncthreads();
     const TabLDS rtab(rtab_lds);
     bool cold = false;
-    const double *Sf = cm, *Dmf = cm + DD;                       // sigma; B - B~ (user drift only)
-    const double *vend = cm + 2 * DD, *cvec = vend + D;          // V[N-1]; B~ mu~ - B mu - beta~ (user drift only)
+    const double *Sf = cm, *Dmf_c = cm + DD;                     // sigma; B - B~ (user drift with a time-constant auxiliary only)
+    const double *vend = cm + 2 * DD, *cvec_c = vend + D;        // V[N-1]; B~ mu~ - B mu - beta~ (the same)
 
     // Addressing: the lane's element (t, r) of grid row i lives at  base + i*D*ld + (4t + r)*(4*ld), base = array +
     // kq*ld + p.  One running pointer per array is advanced once per step and the 4T elements are reached by a
@@ -553,6 +559,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
             spread(0);
             tile_mv_acc<T, decltype(hook_at(0)), PAD>(hm, x, rr, lane, hook_at(0), nks);        // r = hnu_i - Hm_i x
             spread(1);
+            const double *Dmf = TDA ? hm + 2 * DD + 2 * D + 4 : Dmf_c, *cvec = TDA ? hm + 3 * DD + 2 * D + 4 : cvec_c;   // -B~_i, c_i of THIS step's row
             init(db, cvec);
             tile_mv_acc<T, TileNoHook, PAD>(Dmf, x, db, lane, TileNoHook(), nks);                 // bT - bA = c + (0 - B~) x  (+ b below)
             // gather the path's state (its components sit in 4 lanes x 8 registers) and evaluate b_k for this lane's rows
@@ -650,9 +657,9 @@ __global__ __launch_bounds__(256, 2) void k_tile(const TArgs a)   // 2 waves per
 // ---- BHIP_RTC_END  (above: device code, also embedded for hipRTC user drifts at large d; below: host launch)
 
 // dynamic LDS of k_tile<D, ., ., UD>: constants, two step buffers, generator tables (+ the gathered states for a user drift)
-constexpr size_t tile_lds_bytes(int D, bool user, bool chains = true)
+constexpr size_t tile_lds_bytes(int D, bool user, bool chains = true, bool tda = false)
 {
-    return sizeof(double) * (2 * D * D + 2 * D + 2 * (2 * D * D + 2 * D + 4) + TILE_RNG_DOUBLES + (user ? 64 * D : 0) + 4 * TILE_ZB + (chains ? 4 * 2 * (D / 16) * 128 : 0));
+    return sizeof(double) * (2 * D * D + 2 * D + 2 * tile_step_doubles(D, tda) + TILE_RNG_DOUBLES + (user ? 64 * D : 0) + 4 * TILE_ZB + (chains ? 4 * 2 * (D / 16) * 128 : 0));
 }
 
 template <int D, int NOISE, bool PAD = false>

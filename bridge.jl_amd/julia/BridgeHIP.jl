@@ -48,6 +48,12 @@ default bhip-philox-v4 (one normal per 32-bit Philox word through the inverse di
 """
 set_option!(c::Context, option::Integer, value::Integer) =
     check(c, ccall((:bhip_ctx_set_option, lib), Cint, (Ptr{Cvoid}, Cint, Cint), c.h, option, value))
+"`get_option(c, OPT_NOISE_SPEC)` -> 4 | 3 | 2: the stream of normals this context draws (store it with a run's results)"
+function get_option(c::Context, option::Integer)
+    v = Ref{Cint}(0)
+    check(c, ccall((:bhip_ctx_get_option, lib), Cint, (Ptr{Cvoid}, Cint, Ref{Cint}), c.h, option, v))
+    Int(v[])
+end
 
 const default_ctx = Ref{Union{Nothing,Context}}(nothing)
 function default_context()          # (not named `ctx`: a keyword default `ctx = ctx()` would refer to the keyword itself)

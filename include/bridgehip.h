@@ -145,6 +145,11 @@ int bhip_ctx_sync(bhip_ctx *ctx);
  * (BHIP_EUNSUPPORTED): the register-tight kernels hold the default stream only. */
 #define BHIP_OPT_NOISE_SPEC 5
 int bhip_ctx_set_option(bhip_ctx *ctx, int option, int value);
+/* what an option stands at -- e.g. BHIP_OPT_NOISE_SPEC -> 4 | 3 | 2: a stored run can record (and a reader assert) which stream of normals
+ * its paths were drawn under (the DEFAULT moved from 3 to 4 in round 5: the same (seed, path, iter) gives other normals under another
+ * specification; a saved chain ensemble carries its own and refuses to resume under another).  BHIP_OPT_MID_VALU reads back as the largest
+ * dimension that runs one path per lane (0: none). */
+int bhip_ctx_get_option(const bhip_ctx *ctx, int option, int *value);
 const char *bhip_last_error(const bhip_ctx *ctx);
 /* device memory helpers for callers without their own allocator */
 int bhip_malloc(bhip_ctx *ctx, size_t bytes, void **dev);
@@ -182,8 +187,8 @@ int bhip_model_define_sigma(bhip_ctx *ctx, int d, int mp, int npar, const char *
  *     Lorenz-96:  "o = (x[(k+1)%d] - x[(k+d-2)%d])*x[(k+d-1)%d] - x[k] + par[0];"
  * Proposals on the returned model id take par = [npar drift parameters, sigma (d x d, column-major)].  Runs everything the
  * built-in LinPro target runs at large d: plain Euler-Maruyama, GuidedBridge / (nu,H) / PartialBridge guides, fused and
- * stand-alone llikelihood, pCN chains (and innovations! at d <= 12) -- with a time-constant auxiliary (a LinPro target also takes
- * B~(t), beta~(t) per grid point: a callback or LinearAppr coefficients). */
+ * stand-alone llikelihood, pCN chains (and innovations! at d <= 12) -- with a time-constant or a time-dependent auxiliary (B~(t), beta~(t)
+ * per grid point: a callback or LinearAppr coefficients; src/partialbridge.jl:13-15). */
 int bhip_model_define_components(bhip_ctx *ctx, int d, int npar, const char *component_src, int *model_id);
 
 /* ------------------------------------------------------------------ proposal  ("Po")
@@ -203,10 +208,10 @@ int bhip_proposal_set_aux_callback(bhip_proposal *po, bhip_aux_fn fn, void *user
  * src/ode.jl:98-113 (restated with the loop index it evidently means, see DESIGN.md: the reference constructor reads an
  * undefined variable).  The log-likelihood uses the constant-diffusivity form, i.e. Sigma_i must equal the target's sigma
  * (checked): the reference's own !constdiff branch for GuidedBridge is not defined.  d <= 3: every target; 4 <= d <= 32:
- * LinPro targets (the coefficients of grid index i enter step i's coefficient row / the tile kernel's per-step matrices), and
- * component-wise user drifts (bhip_model_define_components) of dimension 4..8: a user drift with ANY time-dependent auxiliary (this one,
- * a callback) is built for the one-path-per-lane kernels alone -- proposals, llikelihood, innovations!, pCN chains under the default noise
- * specification; with BHIP_OPT_MID_VALU = 0 its launches return BHIP_ESTATE (the tile kernel keeps -B~ constant beside a user drift). */
+ * LinPro targets (the coefficients of grid index i enter step i's coefficient row / the tile kernel's per-step matrices) and
+ * component-wise user drifts (bhip_model_define_components): beside a user drift ANY time-dependent auxiliary (this one, a callback) enters
+ * the one-path-per-lane rows as B~_i, beta~_i per step and the tile kernel's step row as a third per-step matrix -B~_i with the vector
+ * c_i = B~_i mu~ - beta~_i (since round 6; until then such a proposal ran one path per lane only, dimension 4..8). */
 int bhip_proposal_set_aux_linearappr(bhip_proposal *po, const double *xx, const double *B, const double *b, const double *Sigma);
 /* linearappr(Y, P) / linearappr!(Pt, Y, P)  src/linpro.jl:196-204 (host): fills B, b, Sigma (layouts as above) for the
  * target of `po` along Y [N][d]; for the processes the reference defines bderiv for: Lorenz, Pendulum, LinPro, Wiener. */

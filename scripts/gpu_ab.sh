@@ -1,4 +1,5 @@
 # A/B: every library under bridge.jl_amd/variants + the default build, both bench modes
+set -o pipefail   # a step's exit code is its command's, not that of the `tail` / `tee` behind it
 for so in default $(ls bridge.jl_amd/variants/*.so); do
   for m in mcmc proposals; do
     if [ $so = default ]; then unset BRIDGEHIP_SO; else export BRIDGEHIP_SO=$PWD/$so; fi

@@ -1,6 +1,7 @@
 #!/bin/bash
 # same-box A/B of bench modes: the current build vs an older library build (default ab/r2.so = the round-2 library built from
 # its commit), alternating, two rounds.  usage: [AB_OLD=ab/x.so] gpu_ab3.sh mode...
+set -o pipefail   # a step's exit code is its command's, not that of the `tail` / `tee` behind it
 OLD=${AB_OLD:-ab/r2.so}
 for rep in 1 2; do
   for v in old cur; do

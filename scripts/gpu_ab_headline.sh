@@ -2,6 +2,7 @@
 # same-box A/B of the headline / shard / proposals kernels: the current build against an older library build
 # (bridge.jl_amd/variants/<name>.so, default a50f5cd = the commit profiles/r2_bench_default.json was taken at), alternating.
 # The old library lacks newer entry points: the Python mirror only binds what it finds?  -> run the raw modes only.
+set -o pipefail   # a step's exit code is its command's, not that of the `tail` / `tee` behind it
 OLD=${1:-a50f5cd}
 for rep in 1 2; do
   for v in old cur; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # same-box A/B of arbitrary bench modes: current build vs bridge.jl_amd/variants/$OLD.so, alternating.  usage: gpu_ab_modes.sh <old> mode...
+set -o pipefail   # a step's exit code is its command's, not that of the `tail` / `tee` behind it
 OLD=$1; shift
 for rep in 1 2; do
   for v in old cur; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # same-box A/B of the d = 32 kernels: the current build against bridge.jl_amd/variants/head.so (the last commit), alternating
+set -o pipefail   # a step's exit code is its command's, not that of the `tail` / `tee` behind it
 for rep in 1 2; do
   for v in head cur; do
     so=""; [ $v = head ] && so=$PWD/bridge.jl_amd/variants/head.so

@@ -12,7 +12,7 @@
 #     mode:<m>[:P]     bench.py --mode <m> [--chains P] --no-other-modes --no-cpu-baseline --steps 200   -> mode_<m>[_P].json
 #     rdf              tests/rng_device_forms.hip (exhaustive device checks of the generator)
 #     env:<K>=<V>      export an environment variable for the following steps (e.g. env:BHIP_PC_LARGE_NPAIR=1)
-#     py:<script>      python <script> (a probe under scripts/), stdout to <basename>.txt
+#     py:<script> [args]  python <script> [args] (a probe under scripts/), stdout to <basename>.txt
 #     profile:<m>      scripts/gpu_profile.sh <tag>_<m> with the warm protocol (see that script)
 set -o pipefail   # a step's rc is its command's, not that of the `tail` behind it (a failing suite read "tests rc=0" until the end of round 5)
 TAG=${1:?tag}; shift
@@ -35,7 +35,7 @@ for step in "$@"; do
     rdf) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -I bridge.jl_amd/csrc tests/rng_device_forms.hip -o /tmp/rdf 2> /dev/null \
            && timeout 300 /tmp/rdf > $OUT/rdf.txt 2>&1 ;;
     env:*) kv=${step#env:}; export "$kv"; SUFFIX="_${kv//[^A-Za-z0-9]/}" ;;
-    py:*) s=${step#py:}; timeout 900 python $s > $OUT/$(basename ${s%.py}).txt 2>&1 ;;
+    py:*) s=${step#py:}; n=$(basename ${s%% *}); timeout 900 python $s > $OUT/${n%.py}.txt 2>&1 ;;   # ("py:script.py arg ...": arguments allowed)
     profile:*) bash scripts/gpu_profile.sh ${TAG}_${step#profile:} --mode ${step#profile:} ;;
     *) echo "unknown step $step" >> $OUT/errors.txt ;;
   esac

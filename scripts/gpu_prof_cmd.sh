@@ -2,6 +2,7 @@
 # Profile an arbitrary command (run on the GPU box through gpurun):  bash scripts/gpu_prof_cmd.sh <tag> <passes> -- <cmd...>
 #   passes: comma list of  trace,fetch,write,sq,sq2   (each its own run; PMC passes never combined with other trace domains)
 # Text summaries land in gpurun_out/<tag>_<pass>.txt (copy the ones to be judged into profiles/).
+set -o pipefail   # a step's exit code is its command's, not that of the `tail` / `tee` behind it
 TAG=$1; PASSES=$2; shift 3
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG

@@ -7,6 +7,7 @@
 #   2. separate --pmc passes (never combined with other trace domains; 20 steps: counters do not depend on the clocks): FETCH_SIZE,
 #      WRITE_SIZE, two SQ sets.
 # Text summaries land in gpurun_out/<tag>_*.txt (copy the ones to be judged into profiles/).  rc = 1 when the check of step 1 fails.
+set -o pipefail   # a step's exit code is its command's, not that of the `tail` / `tee` behind it
 TAG=${1:-prof}; shift
 ARGS=${@:---mode mcmc}
 R=${GRAFT_REPO_ROOT:-$(pwd)}

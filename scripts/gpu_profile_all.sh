@@ -3,6 +3,7 @@
 # protocol (300 queued steps, 300 traced + HIP-event-timed launches, scripts/profile_check.py) + separate FETCH / WRITE / SQ passes --, then
 # the default bench line ON THE SAME BOX.  Summaries land in gpurun_out/${T}_<mode>_{trace,fetch,write,sq,sq2,check}.txt; copy them into
 # profiles/.  rc = 1 when any mode's trace and HIP events differ by more than 5 %.
+set -o pipefail   # a step's exit code is its command's, not that of the `tail` / `tee` behind it
 T=${T:-r5}
 rc=0
 for m in ${MODES:-mcmc c4shard c2 proposals nclar nclar_mcmc linpro4 linpro32 linpro32_mcmc}; do

@@ -3,6 +3,7 @@
 # path; chains keyed by global id, so the values are those of the one ensemble): does dealing the chain state over more pieces of the
 # device memory -- every shard places its own W and Xo apart -- and running the shards' launches concurrently move the headline?
 #     gpurun -- 'bash scripts/gpu_shards_same_device.sh <tag>'
+set -o pipefail   # a step's exit code is its command's, not that of the `tail` / `tee` behind it
 TAG=${1:-shards}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG

@@ -1,5 +1,6 @@
 #!/bin/bash
 # the smoothing loop (bench.py's `smoothing` record) under rocprofv3: kernel trace, then FETCH_SIZE and WRITE_SIZE in their own passes
+set -o pipefail   # a step's exit code is its command's, not that of the `tail` / `tee` behind it
 R=$GRAFT_REPO_ROOT; T=${T:-r4}; OUT=$R/gpurun_out/${T}_smooth; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $R/scripts/gpu_smooth_probe.py > $OUT/trace.log 2>&1

@@ -35,7 +35,7 @@ def stamps():
     return s[s[:, 0] > 0]
 
 
-for mode in os.environ.get("STAMP_MODES", "c2 c4shard mcmc proposals64k").split():
+for mode in os.environ.get("STAMP_MODES", "c2 c2_fused proposals64k c4shard").split():
     chains = 0
     m = mode
     if mode == "proposals64k":

@@ -163,15 +163,17 @@ def l96_drift(x, F):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("d", [4, 5, 8])
+@pytest.mark.parametrize("d", [4, 5, 8, 9, 12, 16, 23, 32])
 def test_component_drift_with_a_time_dependent_auxiliary(d):
     """B~(t), beta~(t) are functions of t throughout the reference (src/partialbridge.jl:13-15, src/linpro.jl:188-189); a user's process
-    of dimension > 3 (README.md:69-77) with such an auxiliary was refused until round 5 (the tile kernel keeps -B~ constant beside a user
-    drift).  At 4 <= d <= 8 the proposal is now built for the one-path-per-lane kernels alone, whose rows carry B~_i, beta~_i per step:
-    a Lorenz-96 target with its LinearAppr linearisation along a reference curve (src/linpro.jl:196-204 with the caller's own bderiv),
-    GuidedBridge by the index-based Heun guide -- fresh proposals with the fused log-likelihood, the stand-alone llikelihood, innovations!
-    of the plain process, pCN chains -- against the oracle at the large-d tolerance; what needs the tile kernel fails with BHIP_ESTATE."""
-    ctx = bh.default_context(0)
+    of dimension > 3 (README.md:69-77) with such an auxiliary was refused until round 5 at every d > 3 and until round 6 at 9 <= d <= 32 (the
+    tile kernel kept -B~ constant beside a user drift).  A Lorenz-96 target with its LinearAppr linearisation along a reference curve
+    (src/linpro.jl:196-204 with the caller's own bderiv), GuidedBridge by the index-based Heun guide -- fresh proposals with the fused
+    log-likelihood, the stand-alone llikelihood, pCN chains -- against the oracle at the large-d tolerance:
+      * one path per lane where the dimension runs there (rows carry B~_i, beta~_i per step),
+      * on the MFMA tile kernel at EVERY dimension (BHIP_OPT_MID_VALU = 0 below 13): -B~_i and c_i = B~_i mu~ - beta~_i travel with the
+        step row as a third per-step matrix (k_tile<.., TDA = true>)."""
+    ctx = bh.Context(0)
     tt, x0, v, sig, _, F = problem(d, N=101)
     N = len(tt)
     s = (tt - tt[0]) / (tt[-1] - tt[0])
@@ -186,50 +188,53 @@ def test_component_drift_with_a_time_dependent_auxiliary(d):
     assert np.abs(Po.Hd - Hd).max() <= 1e-12 * (1 + np.abs(Hd).max()) and np.abs(Po.V - V).max() <= 1e-12 * (1 + np.abs(V).max())
     ref = o.proposal_hv(tt, d, d, o.MODEL_LORENZ96, par, o.AUX_LINEARAPPR, o.linearappr_par(tt, Y, Bi, bi, Si), Po.Hd, Po.V)
     n = 130
-    X, W, ll = bh.sample_solve(x0, Po, n, seed=21, iter=2, path0=7, store_W=True)
-    Xh, Wh, llh = X.paths(), W.paths(), ll.cpu().numpy()
-    ll2 = bh.llikelihood(bh.LeftRule(), X, Po).cpu().numpy()
-    for p in (0, 63, 64, n - 1):
-        assert np.array_equal(Wh[p], o.wiener_sample(tt, d, 21, 7 + p, 2))
-        Xr = o.solve_guided(ref, x0, Wh[p])
-        llr = o.llikelihood(ref, Xr)
-        assert np.abs(Xh[p] - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max()), (d, p, np.abs(Xh[p] - Xr).max())
-        assert abs(llh[p] - llr) <= 1e-8 * (1 + abs(llr)) and abs(ll2[p] - llr) <= 1e-8 * (1 + abs(llr)), (d, p, llh[p], ll2[p], llr)
-    assert abs(llr) > 1e-3                                   # (a genuinely time-dependent auxiliary: the weights are not trivial)
-    assert np.array_equal(Xh[:, -1, :], np.tile(v, (n, 1)))
-    # the same paths under a time-CONSTANT auxiliary differ: the per-step coefficients are what the kernel read
     Poc = bh.GuidedBridge(tt, P, bh.LinPro(-np.eye(d), F * np.ones(d), sig), v, ctx=ctx)
-    Xc = bh.solve(bh.Euler(), x0, W, Poc).paths()
-    assert np.abs(Xc - Xh).max() > 1e-3
-    # pCN chains (16-byte slots, one path per lane) against the oracle's decisions
-    ch = bh.Chains(Po, x0, 64, seed=5)
-    ch.step(0.9, 4)
-    acc, llc = ch.acc(), ch.ll()
-    Xk, Wk = ch.paths(0, 64)
-    same = 0
-    for p in (0, 17, 63):
-        r = o.mcmc(ref, x0, 0.9, 4, 5, p)
-        if acc[p] == r["acc"]:
-            same += 1
-            assert np.array_equal(Wk[p], r["W"]), (d, p)
-            assert np.abs(Xk[p] - r["X"]).max() <= 1e-9 * (1 + np.abs(r["X"]).max()) and abs(llc[p] - r["ll"]) <= 1e-8 * (1 + abs(r["ll"]))
-    assert same >= 2
-    # the tile kernel cannot take it: a clean refusal, not a wrong answer
-    ctx.set_option(bh.OPT_MID_VALU, 0)
-    try:
-        with pytest.raises(bh.BridgeError, match="one path per lane only"):
-            bh.sample_solve(x0, Po, n, seed=21)
-    finally:
-        ctx.set_option(bh.OPT_MID_VALU, 1)
+    for mid in ((1, 0) if d <= 12 else (1,)):       # the lanes where they run, then the tile kernel; above 12 the tile kernel anyway
+        ctx.set_option(bh.OPT_MID_VALU, mid)
+        X, W, ll = bh.sample_solve(x0, Po, n, seed=21, iter=2, path0=7, store_W=True)
+        Xh, Wh, llh = X.paths(), W.paths(), ll.cpu().numpy()
+        ll2 = bh.llikelihood(bh.LeftRule(), X, Po).cpu().numpy()
+        for p in (0, 63, 64, n - 1):
+            assert np.array_equal(Wh[p], o.wiener_sample(tt, d, 21, 7 + p, 2))
+            Xr = o.solve_guided(ref, x0, Wh[p])
+            llr = o.llikelihood(ref, Xr)
+            assert np.abs(Xh[p] - Xr).max() <= 1e-9 * (1 + np.abs(Xr).max()), (d, mid, p, np.abs(Xh[p] - Xr).max())
+            assert abs(llh[p] - llr) <= 1e-8 * (1 + abs(llr)) and abs(ll2[p] - llr) <= 1e-8 * (1 + abs(llr)), (d, mid, p, llh[p], ll2[p], llr)
+        assert abs(llr) > 1e-3                                   # (a genuinely time-dependent auxiliary: the weights are not trivial)
+        assert np.array_equal(Xh[:, -1, :], np.tile(v, (n, 1)))
+        # the same paths under a time-CONSTANT auxiliary differ: the per-step coefficients are what the kernel read
+        Xc = bh.solve(bh.Euler(), x0, W, Poc).paths()
+        assert np.abs(Xc - Xh).max() > 1e-3
+        # an external W through solve! with the fused log-likelihood == the fused proposal's
+        lle = ctx.empty(n)
+        Xe = bh.solve(bh.Euler(), x0, W, Po, ll=lle).paths()
+        assert np.abs(Xe - Xh).max() <= 1e-9 * (1 + np.abs(Xh).max()) and np.abs(lle.cpu().numpy() - llh).max() <= 1e-8 * (1 + np.abs(llh).max())
+        # pCN chains (16-byte slots on the lanes up to d = 8, the tile lines otherwise) against the oracle's decisions
+        ch = bh.Chains(Po, x0, 64, seed=5)
+        ch.step(0.9, 4)
+        acc, llc = ch.acc(), ch.ll()
+        Xk, Wk = ch.paths(0, 64)
+        same = 0
+        for p in (0, 17, 63):
+            r = o.mcmc(ref, x0, 0.9, 4, 5, p)
+            if acc[p] == r["acc"]:
+                same += 1
+                assert np.array_equal(Wk[p], r["W"]), (d, mid, p)
+                assert np.abs(Xk[p] - r["X"]).max() <= 1e-9 * (1 + np.abs(r["X"]).max()) and abs(llc[p] - r["ll"]) <= 1e-8 * (1 + abs(r["ll"]))
+        assert same >= 2
+        del ch
 
 
-def test_linearappr_auxiliary_for_a_user_drift_above_eight_dimensions_is_refused():
-    ctx = bh.Context(-1)       # host context: the check is the library's, no device needed
-    d = 9
-    tt, x0, v, sig, _, F = problem(d, N=41)
-    N = len(tt)
-    P = bh.UserProcessComponents(d, L96, [F], sig, ctx=ctx)
-    Y = np.tile(x0, (N, 1))
-    with pytest.raises(bh.BridgeError, match="dimension 4..8"):
-        bh.GuidedBridge(tt, P, bh.LinearAppr(Y, np.stack([l96_jacobian(y) for y in Y]), np.stack([l96_drift(y, F) for y in Y]),
-                                             np.broadcast_to(sig, (N, d, d)).copy()), v, ctx=ctx)
+def test_linearappr_auxiliary_for_a_user_drift_is_taken_at_every_dimension_of_the_tile_kernel():
+    """(until round 6: refused above d = 8)  host context: the guide of a component-wise user drift with a LinearAppr auxiliary at d = 9
+    and 32 is computed and equals the oracle's index-based Heun guide"""
+    ctx = bh.Context(-1)
+    for d in (9, 32):
+        tt, x0, v, sig, _, F = problem(d, N=41)
+        N = len(tt)
+        P = bh.UserProcessComponents(d, L96, [F], sig, ctx=ctx)
+        Y = np.tile(x0, (N, 1))
+        Bi, bi, Si = np.stack([l96_jacobian(y) for y in Y]), np.stack([l96_drift(y, F) for y in Y]), np.broadcast_to(sig, (N, d, d)).copy()
+        Po = bh.GuidedBridge(tt, P, bh.LinearAppr(Y, Bi, bi, Si), v, ctx=ctx)
+        Hd, V = o.gp_hv_heuni(tt, d, d, Y, Bi, bi, Si, v)
+        assert np.abs(Po.Hd - Hd).max() <= 1e-12 * (1 + np.abs(Hd).max()) and np.abs(Po.V - V).max() <= 1e-12 * (1 + np.abs(V).max())

@@ -280,6 +280,16 @@ def test_context_options_are_validated():
         assert lib.bhip_ctx_set_option(c.h, opt, 0) == 0 and lib.bhip_ctx_set_option(c.h, opt, 1) == 0
     assert lib.bhip_ctx_set_option(c.h, 99, 1) == -1 and b"unknown option" in lib.bhip_last_error(c.h)
     assert lib.bhip_ctx_set_option(None, bh.OPT_NOISE_SPEC, 2) == -1
+    # bhip_ctx_get_option (round 6): what an option stands at -- the noise specification a stored run was drawn under
+    fresh = bh.Context(-1)
+    assert fresh.get_option(bh.OPT_NOISE_SPEC) == 4 and fresh.get_option(bh.OPT_FUSED_ARITHMETIC) == 0 and fresh.get_option(bh.OPT_WAVE_SPECIALISED) == 1
+    fresh.set_option(bh.OPT_NOISE_SPEC, 2)
+    fresh.set_option(bh.OPT_MID_VALU, 0)
+    assert fresh.get_option(bh.OPT_NOISE_SPEC) == 2 and fresh.get_option(bh.OPT_MID_VALU) == 0
+    fresh.set_option(bh.OPT_MID_VALU, 7)
+    assert fresh.get_option(bh.OPT_MID_VALU) == 7
+    import ctypes as C
+    assert lib.bhip_ctx_get_option(fresh.h, 99, C.byref(C.c_int())) == -1 and lib.bhip_ctx_get_option(fresh.h, bh.OPT_NOISE_SPEC, None) == -1
 
 
 def test_group_entry_points_reject_bad_arguments_without_a_device():
