@@ -324,10 +324,10 @@ MODES = {
                 lambda P: "k_paths<bhip::MLinPro<4, double const AS4*>, 5, 1, 1, 1, false>"),
     "linpro32": (_linpro32, 32, 32, tuple([0.0] * 32), 65536, False, None,
                  "LinPro d=32 GuidedBridge (dense sigma, pre-inverted Hdiamond), 1001-point grid T=1, independent fused proposals",
-                 lambda P: "k_tile<32, 1, false, bhip::NoUserDrift>"),
+                 lambda P: "k_tile<32, 1, false, bhip::NoUserDrift, false>"),
     "linpro32_mcmc": (_linpro32, 32, 32, tuple([0.0] * 32), 65536, True, 0.95,
                       "LinPro d=32 GuidedBridge (dense sigma, pre-inverted Hdiamond), 1001-point grid T=1, pCN-MCMC rho=0.95",
-                      lambda P: "k_tile<32, 2, false, bhip::NoUserDrift>"),
+                      lambda P: "k_tile<32, 2, false, bhip::NoUserDrift, false>"),
 }
 
 

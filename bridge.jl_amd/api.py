@@ -524,6 +524,12 @@ class EnsemblePath:
         j, q = divmod(int(p), self.part_paths)
         return vp(int(self._ptrs[j]) + 8 * q)
 
+    def _parts_args(self):
+        """(nparts, pointer array, leading dimension, paths per part) as the *_parts entry points take an ensemble"""
+        if self.nparts == 1:
+            return 1, (vp * 1)(self.ptr()), self.ld, self.ld
+        return self.nparts, self._ptrs, self.part_paths, self.part_paths
+
     def segments(self, *others):
         """column ranges (start, n) that lie inside ONE buffer of this ensemble and of every ensemble in `others` (None entries skipped)"""
         cuts = {0, self.npaths}
@@ -814,6 +820,13 @@ def solve_(method, Y, u, W, P, ll=None, skip=0):
     x0d = vp(u.data_ptr()) if per_path else None
     if per_path and (tuple(u.shape) != (P.d, Y.npaths) or not u.is_contiguous()):
         raise BridgeError("per-path starting points must be a contiguous tensor [d, npaths]")
+    if (Y.nparts > 1 or W.nparts > 1) and not per_path:   # ensembles in parts: ONE launch reads and writes all buffers
+        nw, wp, ldw, wpart = W._parts_args()
+        nx, xp, ldx, xpart = Y._parts_args()
+        rc = ctx.lib.bhip_solve_parts(ctx.h, P.h, x0, nw, wp, ldw, wpart, nx, xp, ldx, xpart, None if ll is None else vp(ll.data_ptr()), skip, Y.npaths)
+        if rc != -3:   # (BHIP_EUNSUPPORTED: the tile kernel takes one buffer per launch -- range by range below)
+            ctx.check(rc)
+            return Y.endpoints()
     for a, n in Y.segments(W):
         llp = None if ll is None else vp(ll.data_ptr() + 8 * a)
         xs = None
@@ -847,6 +860,12 @@ def llikelihood(rule, X, Po, skip=0):
         raise BridgeError("llikelihood: only LeftRule is implemented on the device")
     ctx = X.ctx
     out = ctx.empty(X.npaths)
+    if X.nparts > 1:   # ONE launch over all buffers
+        nx, xp, ldx, xpart = X._parts_args()
+        rc = ctx.lib.bhip_llikelihood_parts(ctx.h, Po.h, nx, xp, ldx, xpart, vp(out.data_ptr()), skip, X.npaths)
+        if rc != -3:   # (BHIP_EUNSUPPORTED: the tile kernel -- range by range below)
+            ctx.check(rc)
+            return out
     for a, n in X.segments():
         ctx.check(ctx.lib.bhip_llikelihood(ctx.h, Po.h, X.colptr(a), X.ld, vp(out.data_ptr() + 8 * a), skip, n))
     return out

@@ -1522,6 +1522,70 @@ int bhip_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, const d
     return do_launch(po, NOISE_EXT, a);
 }
 
+// the geometry of an ensemble in parts as the kernels address it: 1..3 buffers, paths [j*part, (j+1)*part) in buffer j (part a multiple of 64)
+static int check_parts(bhip_ctx *ctx, const char *who, int nparts, const void *const *ptrs, long ld, long part_paths, long npaths)
+{
+    if (!ptrs || nparts < 1 || nparts > 3) return fail(ctx, BHIP_EINVAL, std::string(who) + ": 1..3 parts");
+    for (int j = 0; j < nparts; j++) if (!ptrs[j]) return fail(ctx, BHIP_EINVAL, std::string(who) + ": null part");
+    if (nparts == 1) return ld < npaths ? fail(ctx, BHIP_ELENGTH, "leading dimension smaller than npaths") : BHIP_OK;
+    if (part_paths < 64 || part_paths % 64 != 0) return fail(ctx, BHIP_EINVAL, std::string(who) + ": part_paths must be a positive multiple of 64");
+    if (ld < part_paths) return fail(ctx, BHIP_ELENGTH, "leading dimension smaller than part_paths");
+    if ((long)nparts * part_paths < npaths) return fail(ctx, BHIP_ELENGTH, std::string(who) + ": nparts * part_paths must cover npaths");
+    return BHIP_OK;
+}
+
+// bhip_solve with the driving W and / or the paths X kept in parts (the containers of large ensembles): ONE launch reads and writes all
+// of them -- two launches of half the paths each leave half of the waves per SIMD to hide the recurrence's latency
+int bhip_solve_parts(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, int nwparts, const double *const *W_parts, long ldW, long wpart_paths,
+                     int nxparts, double *const *X_parts, long ldX, long xpart_paths, double *ll_dev, int skip, long npaths)
+{
+    if (!ctx || !po || !x0) return BHIP_EINVAL;
+    SAME_CTX(ctx, po);
+    int rc = check_parts(ctx, "bhip_solve_parts (W)", nwparts, (const void *const *)W_parts, ldW, wpart_paths, npaths);
+    if (!rc && X_parts) rc = check_parts(ctx, "bhip_solve_parts (X)", nxparts, (const void *const *)X_parts, ldX, xpart_paths, npaths);
+    if (rc) return rc;
+    if (nwparts == 1 && (!X_parts || nxparts == 1))
+        return bhip_solve(ctx, po, x0, nullptr, W_parts[0], ldW, X_parts ? X_parts[0] : nullptr, ldX, ll_dev, skip, npaths);
+    if (po->g.kind == BHIP_GUIDE_NONE) {
+        if (ll_dev) return fail(ctx, BHIP_EINVAL, "bhip_solve: llikelihood needs a guided proposal");
+        rc = ensure_plain_rows(const_cast<bhip_proposal *>(po));
+        if (rc) return rc;
+    }
+    if (po->mh.d > 3 && !(po->mid && po->mh.d <= ctx->mid_max))
+        return fail(ctx, BHIP_EUNSUPPORTED, "bhip_solve_parts: one path per lane (d <= 3, LinPro / component-wise user drifts up to BHIP_OPT_MID_VALU); the tile kernel takes one buffer per launch");
+    KArgs a;
+    rc = fill_common(po, a, x0, nullptr, npaths, skip);
+    if (rc) return rc;
+    a.Win = W_parts[0]; a.ldWin = ldW;
+    if (nwparts > 1) { a.Winp1 = W_parts[1]; a.Winp2 = nwparts > 2 ? W_parts[2] : nullptr; a.wpart = wpart_paths; }
+    if (X_parts) {
+        a.X = X_parts[0]; a.ldX = ldX;
+        if (nxparts > 1) { a.Xp1 = X_parts[1]; a.Xp2 = nxparts > 2 ? X_parts[2] : nullptr; a.xpart = xpart_paths; }
+    }
+    a.ll = ll_dev;
+    return do_launch(po, NOISE_EXT, a);
+}
+
+// bhip_llikelihood of an ensemble kept in parts, by ONE launch
+int bhip_llikelihood_parts(bhip_ctx *ctx, const bhip_proposal *po, int nparts, const double *const *X_parts, long ldX, long part_paths,
+                           double *ll_dev, int skip, long npaths)
+{
+    if (!ctx || !po || !ll_dev) return BHIP_EINVAL;
+    SAME_CTX(ctx, po);
+    int rc = check_parts(ctx, "bhip_llikelihood_parts", nparts, (const void *const *)X_parts, ldX, part_paths, npaths);
+    if (rc) return rc;
+    if (nparts == 1) return bhip_llikelihood(ctx, po, X_parts[0], ldX, ll_dev, skip, npaths);
+    if (po->g.kind == BHIP_GUIDE_NONE) return fail(ctx, BHIP_EINVAL, "bhip_llikelihood: needs a guided proposal");
+    if (po->mh.d > 3 && !(po->mid && po->mh.d <= ctx->mid_max))
+        return fail(ctx, BHIP_EUNSUPPORTED, "bhip_llikelihood_parts: one path per lane (d <= 3, LinPro / component-wise user drifts up to BHIP_OPT_MID_VALU); the tile kernel takes one buffer per launch");
+    KArgs a;
+    const double zero[BHIP_MAXD_LANE] = {0};
+    rc = fill_common(po, a, zero, nullptr, npaths, skip);
+    if (rc) return rc;
+    a.Win = X_parts[0]; a.ldWin = ldX; a.Winp1 = X_parts[1]; a.Winp2 = nparts > 2 ? X_parts[2] : nullptr; a.wpart = part_paths; a.ll = ll_dev;
+    return do_launch(po, NOISE_LLONLY, a);
+}
+
 int bhip_sample_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, const double *x0_dev, double *W_dev, long ldW,
                       double *X_dev, long ldX, double *ll_dev, int skip, long npaths, uint64_t seed, uint32_t iter, uint32_t path0)
 {

@@ -78,6 +78,10 @@ struct KArgs {
     // its own (different pieces of the device memory: one write stream per piece instead of one in all); xpart = 0: one buffer
     double *Xp1, *Xp2;
     long xpart;           // paths per part, a multiple of 64
+    // the INPUT ensemble (Win: the driving W of NOISE_EXT, the stored X of NOISE_LLONLY / NOISE_INNOV) in parts, likewise (bhip_solve_parts,
+    // bhip_llikelihood_parts): paths [j*wpart, (j+1)*wpart) are read from part j -- Win, Winp1, Winp2, each [N][.][ldWin]; 0: one buffer
+    const double *Winp1, *Winp2;
+    long wpart;
     double *ll;           // optional per-path log-likelihood
     // pCN chain state (NOISE_PCN).  W lives in 16-byte SLOTS: Wc[((i*MP + k)*ldC + p)*2 + h], h = 0/1;
     // half cur[p] holds the chain's current W, the other half receives the proposal Wo, and an accept
@@ -131,6 +135,14 @@ __device__ __forceinline__ double *x_store_base(const KArgs &a, long p)
     if (!a.xpart) return a.X;
     const int j = (int)(p / a.xpart);
     return (j == 0 ? a.X : j == 1 ? a.Xp1 : a.Xp2) - (long)j * a.xpart;
+}
+
+// ... and the input ensemble's base for path p (KArgs::wpart)
+__device__ __forceinline__ const double *in_base(const KArgs &a, long p)
+{
+    if (!a.wpart) return a.Win;
+    const int j = (int)(p / a.wpart);
+    return (j == 0 ? a.Win : j == 1 ? a.Winp1 : a.Winp2) - (long)j * a.wpart;
 }
 
 typedef const __attribute__((address_space(4))) double *cptr_t;
@@ -667,7 +679,7 @@ __global__ __launch_bounds__(256, (PPR || M::D > 4 || (M::D > 3 && NOISE == NOIS
         wslot = reinterpret_cast<d2v *>(a.Wc) + p;
         if constexpr ((FL & 1) != 0) { xout = a.Xo + p; ldx = a.ldC; }
     } else {
-        if constexpr (NOISE != NOISE_FRESH) { win = a.Win + p; ldwi = a.ldWin; }
+        if constexpr (NOISE != NOISE_FRESH) { win = in_base(a, p) + p; ldwi = a.ldWin; }
         if constexpr ((FL & 2) != 0) { wout = a.Wout + (size_t)p * a.wstride; ldwo = a.ldWout * a.wstride; }
         if constexpr ((FL & 1) != 0) { xout = x_store_base(a, p) + p; ldx = a.ldX; }
     }

@@ -444,6 +444,9 @@ BHIP_HD void normal_pair(const Tab &tab, uint32_t k0, uint32_t k1, uint32_t path
                          uint32_t stream = 0u)
 {
     if constexpr (noise_spec_of<Tab>::value == 4) {
+        // (advisor r5) the hot-rows table answers only through normal_quad, which checks `cold` and redraws from the full table; here a
+        // far-octave word would silently take a value from the wrong row
+        static_assert(!is_hot_only<Tab>::value, "IcdfLDSHot holds the near octaves only: draw with normal_quad (it handles the cold words)");
         const u32x4 r = philox4x32_10(path, stream, iter, h >> 1, k0, k1);
         const bool second = (h & 1u) != 0u;
         z0 = icdf_normal(tab, second ? r.z : r.x);

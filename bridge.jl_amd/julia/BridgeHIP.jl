@@ -271,6 +271,11 @@ end
 function solve!(::HIPEuler, Y::EnsemblePath, u, W::EnsemblePath, Po::HIPProposal; ll::Ptr{Cdouble} = Ptr{Cdouble}(C_NULL), skip = 0)
     length(W) != length(Y) && error("Y and W differ in length.")        # src/euler.jl:251
     Y.tt[:] = Po.tt                                                       # src/euler.jl:256
+    # all buffers of W and Y by ONE launch (one path per lane); the tile kernel (BHIP_EUNSUPPORTED = -3) takes a buffer per launch: range by range
+    rc = ccall((:bhip_solve_parts, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Ptr{Cvoid}}, Clong, Clong, Cint, Ptr{Ptr{Cvoid}}, Clong, Clong, Ptr{Cdouble}, Cint, Clong),
+        Y.ctx.h, Po.h, collect(Float64, u), length(W.ptrs), W.ptrs, W.ld, W.ld, length(Y.ptrs), Y.ptrs, Y.ld, Y.ld, ll, skip, Y.npaths)
+    rc == -3 || (check(Y.ctx, rc); return Y)
     for (a, n) in segments(Y, W)
         check(Y.ctx, ccall((:bhip_solve, lib), Cint,
             (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Cint, Clong),
@@ -305,9 +310,14 @@ function llikelihood(::LeftRule, X::EnsemblePath, Po::HIPProposal; skip = 0)
     out = Vector{Float64}(undef, X.npaths)
     r = Ref{Ptr{Cvoid}}(C_NULL)
     check(X.ctx, ccall((:bhip_malloc, lib), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), X.ctx.h, 8 * X.npaths, r))
-    for (a, n) in segments(X)
-        check(X.ctx, ccall((:bhip_llikelihood, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Cint, Clong),
-            X.ctx.h, Po.h, colptr(X, a), X.ld, Ptr{Cdouble}(r[]) + 8 * a, skip, n))
+    rc = ccall((:bhip_llikelihood_parts, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}, Clong, Clong, Ptr{Cdouble}, Cint, Clong),
+        X.ctx.h, Po.h, length(X.ptrs), X.ptrs, X.ld, X.ld, Ptr{Cdouble}(r[]), skip, X.npaths)      # ONE launch over all buffers ...
+    rc == -3 || check(X.ctx, rc)
+    if rc == -3                                                                                      # ... the tile kernel: range by range
+        for (a, n) in segments(X)
+            check(X.ctx, ccall((:bhip_llikelihood, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Cint, Clong),
+                X.ctx.h, Po.h, colptr(X, a), X.ld, Ptr{Cdouble}(r[]) + 8 * a, skip, n))
+        end
     end
     check(X.ctx, ccall((:bhip_memcpy_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), X.ctx.h, out, r[], 8 * X.npaths))
     ccall((:bhip_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), X.ctx.h, r[])

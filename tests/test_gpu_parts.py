@@ -195,3 +195,48 @@ def test_large_ensembles_are_kept_in_parts_by_default(ctx, monkeypatch):
     assert bh.EnsemblePath(case.tt, 16, 2048, ctx).nparts == 1       # the tile kernel's dimensions: one buffer
     for E in (X, W, Y):
         E.free()
+
+
+def test_one_launch_forms_for_ensembles_in_parts_check_their_arguments(ctx):
+    """bhip_solve_parts / bhip_llikelihood_parts (round 6): the geometry checks of bhip_sample_solve_parts, one buffer delegates to the plain
+    entry point, the tile kernel's dimensions are refused with BHIP_EUNSUPPORTED (the mirror then walks the ranges)"""
+    case = [c for c in problems.cases(33) if c.name == "fhn_partialbridge_extreme"][0]
+    Po = case.bh_proposal(bh, ctx)
+    n = 300
+    W = bh.sample_(bh.EnsemblePath(case.tt, 1, n, ctx, parts=2), bh.Wiener(1), seed=3)
+    X = bh.EnsemblePath(case.tt, 2, n, ctx, parts=2)
+    ll = ctx.empty(n)
+    x0 = bh.api._dptr(bh.api._x0(case.x0, 2))
+    L, vp = ctx.lib, bh.api.vp
+    nw, wp, ldw, wpart = W._parts_args()
+    nx, xp, ldx, xpart = X._parts_args()
+    llp = vp(ll.data_ptr())
+    assert L.bhip_solve_parts(ctx.h, Po.h, x0, nw, wp, ldw, wpart, nx, xp, ldx, xpart, llp, 0, n) == 0
+    assert L.bhip_solve_parts(ctx.h, Po.h, x0, nw, wp, ldw, 100, nx, xp, ldx, xpart, llp, 0, n) == -1       # part_paths not a multiple of 64
+    assert L.bhip_solve_parts(ctx.h, Po.h, x0, nw, wp, 64, wpart, nx, xp, ldx, xpart, llp, 0, n) == -5        # leading dimension below part_paths
+    assert L.bhip_solve_parts(ctx.h, Po.h, x0, nw, wp, ldw, 128, nx, xp, ldx, xpart, llp, 0, n) == -5         # the parts do not cover the paths
+    assert L.bhip_solve_parts(ctx.h, Po.h, x0, 4, wp, ldw, wpart, nx, xp, ldx, xpart, llp, 0, n) == -1
+    assert L.bhip_solve_parts(ctx.h, Po.h, None, nw, wp, ldw, wpart, nx, xp, ldx, xpart, llp, 0, n) == -1    # shared start only
+    ll2 = ctx.empty(n)
+    assert L.bhip_llikelihood_parts(ctx.h, Po.h, nx, xp, ldx, xpart, vp(ll2.data_ptr()), 0, n) == 0 and torch.equal(ll, ll2)
+    assert L.bhip_llikelihood_parts(ctx.h, Po.h, nx, xp, ldx, 96, vp(ll2.data_ptr()), 0, n) == -1
+    assert L.bhip_llikelihood_parts(ctx.h, Po.h, nx, xp, ldx, xpart, None, 0, n) == -1
+    # X not stored: ll alone, the same values
+    ll3 = ctx.empty(n)
+    assert L.bhip_solve_parts(ctx.h, Po.h, x0, nw, wp, ldw, wpart, 0, None, 0, 0, vp(ll3.data_ptr()), 0, n) == 0 and torch.equal(ll, ll3)
+    # d = 16: the tile kernel -> BHIP_EUNSUPPORTED from the one-launch forms, and the mirror's fall-back gives the values of one buffer
+    c16 = problems.linpro_big_case(16, 41)
+    Po16 = c16.bh_proposal(bh, ctx)
+    W16 = bh.sample_(bh.EnsemblePath(c16.tt, 16, 200, ctx, parts=2), bh.Wiener(16), seed=2)
+    Y16 = bh.EnsemblePath(c16.tt, 16, 200, ctx, parts=2)
+    a, b, c, d_ = W16._parts_args()
+    e, f, g, h = Y16._parts_args()
+    assert L.bhip_solve_parts(ctx.h, Po16.h, bh.api._dptr(bh.api._x0(c16.x0, 16)), a, b, c, d_, e, f, g, h, None, 0, 200) == -3
+    lla, llb = ctx.empty(200), ctx.empty(200)
+    bh.solve_(bh.Euler(), Y16, c16.x0, W16, Po16, ll=lla)
+    W1 = bh.sample(c16.tt, bh.Wiener(16), npaths=200, seed=2, ctx=ctx)
+    Y1 = bh.solve(bh.Euler(), c16.x0, W1, Po16, ll=llb)
+    assert np.array_equal(Y16.paths(), Y1.paths()) and torch.equal(lla, llb)
+    assert torch.equal(bh.llikelihood(bh.LeftRule(), Y16, Po16), bh.llikelihood(bh.LeftRule(), Y1, Po16))
+    for E in (W, X, W16, Y16):
+        E.free()
