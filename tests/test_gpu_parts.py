@@ -218,12 +218,14 @@ def test_one_launch_forms_for_ensembles_in_parts_check_their_arguments(ctx):
     assert L.bhip_solve_parts(ctx.h, Po.h, x0, 4, wp, ldw, wpart, nx, xp, ldx, xpart, llp, 0, n) == -1
     assert L.bhip_solve_parts(ctx.h, Po.h, None, nw, wp, ldw, wpart, nx, xp, ldx, xpart, llp, 0, n) == -1    # shared start only
     ll2 = ctx.empty(n)
-    assert L.bhip_llikelihood_parts(ctx.h, Po.h, nx, xp, ldx, xpart, vp(ll2.data_ptr()), 0, n) == 0 and torch.equal(ll, ll2)
+    same = lambda a, b: np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True)   # (on this coarse grid a few FitzHugh-Nagumo paths leave the Euler scheme's stability region: NaN in both)
+    assert L.bhip_llikelihood_parts(ctx.h, Po.h, nx, xp, ldx, xpart, vp(ll2.data_ptr()), 0, n) == 0 and same(ll, ll2)
+    assert int(torch.isfinite(ll).sum()) > n // 2
     assert L.bhip_llikelihood_parts(ctx.h, Po.h, nx, xp, ldx, 96, vp(ll2.data_ptr()), 0, n) == -1
     assert L.bhip_llikelihood_parts(ctx.h, Po.h, nx, xp, ldx, xpart, None, 0, n) == -1
     # X not stored: ll alone, the same values
     ll3 = ctx.empty(n)
-    assert L.bhip_solve_parts(ctx.h, Po.h, x0, nw, wp, ldw, wpart, 0, None, 0, 0, vp(ll3.data_ptr()), 0, n) == 0 and torch.equal(ll, ll3)
+    assert L.bhip_solve_parts(ctx.h, Po.h, x0, nw, wp, ldw, wpart, 0, None, 0, 0, vp(ll3.data_ptr()), 0, n) == 0 and same(ll, ll3)
     # d = 16: the tile kernel -> BHIP_EUNSUPPORTED from the one-launch forms, and the mirror's fall-back gives the values of one buffer
     c16 = problems.linpro_big_case(16, 41)
     Po16 = c16.bh_proposal(bh, ctx)
