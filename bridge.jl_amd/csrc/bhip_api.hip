@@ -96,9 +96,7 @@ bhip::launch_fn get_launch_intdiff(int, int, int, int);
 bhip::launch_fn get_launch_lorenz(int, int, int, int);
 bhip::launch_fn get_launch_fhn2(int, int, int, int);
 bhip::launch_fn get_launch_pendulum(int, int, int, int);
-bhip::launch_fn get_launch_wiener1(int, int, int, int);
-bhip::launch_fn get_launch_wiener2(int, int, int, int);
-bhip::launch_fn get_launch_wiener3(int, int, int, int);
+// (no fused Wiener: its drift is zero, there is no a*b + c to contract -- the exact build's kernels serve the option; 12 MB less library)
 }  // namespace bhip_fused
 
 #ifndef BHIP_MID_MAX_DEFAULT
@@ -332,9 +330,9 @@ static launch_fn find_launch_fused(const ModelHost &mh, int gk, int mo, int nois
     case BHIP_MODEL_FHN2: return bhip_fused::get_launch_fhn2(gk, mo, noise, fl);
     case BHIP_MODEL_PENDULUM: return bhip_fused::get_launch_pendulum(gk, mo, noise, fl);
     case BHIP_MODEL_WIENER:
-        if (mh.d == 1) return bhip_fused::get_launch_wiener1(gk, mo, noise, fl);
-        if (mh.d == 2) return bhip_fused::get_launch_wiener2(gk, mo, noise, fl);
-        if (mh.d == 3) return bhip_fused::get_launch_wiener3(gk, mo, noise, fl);
+        if (mh.d == 1) return get_launch_wiener1(gk, mo, noise, fl);
+        if (mh.d == 2) return get_launch_wiener2(gk, mo, noise, fl);
+        if (mh.d == 3) return get_launch_wiener3(gk, mo, noise, fl);
         return nullptr;
     }
     return nullptr;
@@ -516,7 +514,20 @@ int bhip_download_aos(bhip_ctx *ctx, const double *dev, int N, int dim, long ld,
 static int model_define(bhip_ctx *ctx, int d, int mp, int npar, const char *drift_src, const char *sigma_src, int *model_id)
 {
     if (!ctx || !drift_src || !model_id) return BHIP_EINVAL;
-    if (d < 1 || d > 3 || mp < 1 || mp > 3) return fail(ctx, BHIP_EUNSUPPORTED, "bhip_model_define: user processes run on the path-per-lane kernel, d and m' in 1..3");
+    if (d > 3 && d <= 32 && mp == d && !sigma_src) {
+        // (round 6) the FULL-FORM method body -- "o[0] = ...; o[1] = ...;" from (t, x, par), README.md:69-77 -- above d = 3: carried as a
+        // component-wise model (bhip_model_define_components) whose component function evaluates the body into a local vector and returns
+        // entry k.  One path per lane (d <= 12) the d calls of a step are inlined beside each other with k constant and the common
+        // sub-expressions merge: the cost of the body once; on the tile kernel a lane holds 8 of a path's 32 rows and evaluates the whole
+        // body for them (the component-wise text stays the fast form there).  Same parameter layout: [npar drift parameters, sigma (d x d)].
+        std::string body = "double bhip_full_o[" + std::to_string(d) + "];\n        for (int bhip_q = 0; bhip_q < " + std::to_string(d) +
+                           "; bhip_q++) bhip_full_o[bhip_q] = 0.0;\n        { double *o = bhip_full_o; (void)o;\n        " + std::string(drift_src) +
+                           "\n        }\n        o = bhip_full_o[k];";
+        return bhip_model_define_components(ctx, d, npar, body.c_str(), model_id);
+    }
+    if (d < 1 || d > 3 || mp < 1 || mp > 3)
+        return fail(ctx, BHIP_EUNSUPPORTED, "bhip_model_define: d and m' in 1..3 on the path-per-lane kernel; 4 <= d <= 32 with m' = d and a constant dense sigma "
+                                            "(full-form or component-wise text: bhip_model_define_components); a state-dependent sigma at d <= 3 only");
     const int derived = sigma_src ? 0 : d * mp + 2 * d * d;
     if (npar < 0 || npar + derived > 40) return fail(ctx, BHIP_EINVAL, "bhip_model_define: too many parameters (npar + d*mp + 2*d*d <= 40)");
     std::unique_ptr<UserModel> um(new UserModel());

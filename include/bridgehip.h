@@ -167,8 +167,10 @@ int bhip_download_aos(bhip_ctx *ctx, const double *dev, int N, int dim, long ld,
  *     inputs  double t, const double* x (d), const double* par (npar);  output double* o (d), e.g.
  *     "o[0] = (x[0]-x[1]-x[0]*x[0]*x[0]+par[1])/par[0]; o[1] = par[2]*x[0]-x[1]+par[3];"
  * The (constant) diffusion coefficient is data: proposals on the returned model id take
- * par = [npar drift parameters, sigma (d x mp, column-major)].  d, mp <= 3.  A syntax error returns
- * BHIP_EINVAL with the compiler log in bhip_last_error().  Kernels are compiled on first use. */
+ * par = [npar drift parameters, sigma (d x mp, column-major)].  d, mp <= 3 -- or 4 <= d <= 32 with mp = d (constant dense sigma, npar <= 16;
+ * since round 6): the same full-form body is then carried as a component-wise model (bhip_model_define_components below: it runs everything
+ * that form runs; component-wise text is the faster form on the tile kernel, where a lane holds only part of a path's state).  A syntax
+ * error returns BHIP_EINVAL with the compiler log in bhip_last_error().  Kernels are compiled on first use. */
 int bhip_model_define(bhip_ctx *ctx, int d, int mp, int npar, const char *drift_src, int *model_id);
 /* The same with a STATE-DEPENDENT diffusion coefficient sigma(t,x,P) (the other half of the reference's
  * extension point, README.md:69-77; a = sigma*sigma' by src/types.jl:32; constdiff(P) = false):

@@ -9,6 +9,7 @@ Tolerance as for the built-in large-d path (tests/test_gpu_tile.py): 1e-9 relati
 """
 import numpy as np
 import pytest
+import torch
 
 import bridgehip as bh
 import oracle as o
@@ -238,3 +239,40 @@ def test_linearappr_auxiliary_for_a_user_drift_is_taken_at_every_dimension_of_th
         Po = bh.GuidedBridge(tt, P, bh.LinearAppr(Y, Bi, bi, Si), v, ctx=ctx)
         Hd, V = o.gp_hv_heuni(tt, d, d, Y, Bi, bi, Si, v)
         assert np.abs(Po.Hd - Hd).max() <= 1e-12 * (1 + np.abs(Hd).max()) and np.abs(Po.V - V).max() <= 1e-12 * (1 + np.abs(V).max())
+
+
+L96_FULL = "for (int j = 0; j < d; j++) o[j] = (x[(j+1)%d] - x[(j+d-2)%d])*x[(j+d-1)%d] - x[j] + par[0];"
+
+
+def test_full_form_drift_text_above_three_dimensions_is_validated_without_a_gpu():
+    """bhip_model_define at 4 <= d <= 32 (round 6): the full-form body `o[0] = ...; o[1] = ...;` of README.md:69-77 is carried as a
+    component-wise model; m' must equal d (constant dense sigma), a state-dependent sigma stays at d <= 3"""
+    hctx = bh.Context(-1)
+    P = bh.UserProcess(12, L96_FULL, [2.0], sigma=0.5 * np.eye(12), ctx=hctx)
+    assert P.model_id >= 1000 and P.d == 12 and P.mp == 12
+    with pytest.raises(bh.BridgeError, match="error"):
+        bh.UserProcess(6, "o[0] = undefined_name;", [1.0], sigma=np.eye(6), ctx=hctx)
+    with pytest.raises(bh.BridgeError, match="m' = d"):
+        bh.UserProcess(6, L96_FULL, [1.0], sigma=np.ones((6, 2)), ctx=hctx)
+    with pytest.raises(bh.BridgeError):
+        bh.UserProcess(6, L96_FULL, [1.0], sigma_src="s[0] = 1.0;", mp=6, ctx=hctx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [5, 16, 23])
+def test_full_form_drift_equals_the_component_wise_model(d):
+    """the same Lorenz-96 drift given as a full-form body and component-wise: identical paths and log-likelihoods on the lanes (d = 5) and
+    on the MFMA tile kernel (d = 16, zero padded d = 23), fresh proposals and pCN chains"""
+    ctx = bh.Context(0)
+    tt, x0, v, sig, Baux, F = problem(d, N=81)
+    Pc = bh.UserProcessComponents(d, L96, [F], sig, ctx=ctx)
+    Pf = bh.UserProcess(d, L96_FULL, [F], sigma=sig, ctx=ctx)
+    Pt = bh.LinPro(Baux, F * np.ones(d), sig)
+    Poc, Pof = bh.GuidedBridge(tt, Pc, Pt, v, ctx=ctx), bh.GuidedBridge(tt, Pf, Pt, v, ctx=ctx)
+    n = 200
+    Xc, _, llc = bh.sample_solve(x0, Poc, n, seed=3, iter=1)
+    Xf, _, llf = bh.sample_solve(x0, Pof, n, seed=3, iter=1)
+    assert np.array_equal(Xc.paths(), Xf.paths()) and torch.equal(llc, llf) and bool(torch.isfinite(llc).all())
+    chc, chf = bh.Chains(Poc, x0, 128, seed=2), bh.Chains(Pof, x0, 128, seed=2)
+    chc.step(0.9, 3); chf.step(0.9, 3)
+    assert np.array_equal(chc.ll(), chf.ll()) and np.array_equal(chc.acc(), chf.acc())

@@ -23,8 +23,10 @@ def test_define_validate_and_errors():
     assert P.model_id >= 1000 and P.mp == 1
     with pytest.raises(bh.BridgeError, match="undeclared identifier"):
         bh.UserProcess(1, "o[0] = nope * x[0];", [1.0], [[1.0]], ctx=h)
+    # (round 6: the full-form body runs above d = 3 as a component-wise model when m' = d; what stays refused is m' != d there)
+    assert bh.UserProcess(4, "o[0] = 0;", [1.0], np.eye(4), ctx=h).model_id >= 1000
     with pytest.raises(bh.BridgeError, match="1..3"):
-        bh.UserProcess(4, "o[0] = 0;", [1.0], np.eye(4), ctx=h)
+        bh.UserProcess(4, "o[0] = 0;", [1.0], np.ones((4, 2)), ctx=h)
     # the host side (guide ODEs) treats a user model like any other: a = sigma*sigma'
     c = [k for k in problems.cases(51) if k.name == "fhn_partialbridge_first"][0]
     Po = bh.PartialBridge(c.tt, P, c.bh_aux(bh), c.L, c.v, c.Sigma, ctx=h)
