@@ -11,7 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ODIR = os.path.join(os.path.dirname(_HERE), "oracle")
-_SO = os.path.join(_ODIR, "libbridge_oracle.so")
+# BRIDGE_ORACLE_SO: another build of the same source (the sanitizer leg, tests/test_oracle_sanitizers.py: `make -C oracle san`)
+_SO = os.environ.get("BRIDGE_ORACLE_SO") or os.path.join(_ODIR, "libbridge_oracle.so")
 
 MODEL_WIENER, MODEL_OU, MODEL_LINPRO, MODEL_FHN, MODEL_NCLAR, MODEL_INTDIFF, MODEL_LORENZ, MODEL_FHN2, MODEL_PENDULUM = range(9)
 MODEL_SDIFF1, MODEL_SDIFF2 = 9, 10        # state-dependent sigma (oracle-side stand-ins for hipRTC user processes)
@@ -25,7 +26,7 @@ dp = C.POINTER(C.c_double)
 def _build():
     src = os.path.join(_ODIR, "bridge_oracle.c")
     if (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _ODIR, "-s"])
+        subprocess.check_call(["make", "-C", _ODIR, "-s"] + (["san"] if _SO.endswith("_san.so") else []))
 
 
 def load():
