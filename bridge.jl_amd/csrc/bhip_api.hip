@@ -1443,7 +1443,7 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
             else if (noise == NOISE_PCN_LINES) knoise = NOISE_PCN_LINES_PC;
             if (knoise != noise) {   // the workgroup shape launch_pc would choose
                 bool rlds = true;
-                npair = pc_choose_npair_rt(a, groups, po->mh.d, a.rs, po->mh.mp, &rlds);
+                npair = pc_choose_npair_rt(a, groups, po->mh.d, a.rs, po->mh.mp, &rlds, knoise);
                 if (!rlds && npair > 1) npair = -npair;
             }
         }
@@ -1465,7 +1465,7 @@ static int do_launch(const bhip_proposal *po, int noise, const KArgs &a)
         if (npair != 0) {
             const int spc = LINE_DOUBLES / line_mpp(po->mh.mp), np = npair < 0 ? -npair : npair;
             const unsigned lds = (unsigned)(pc_lds_bytes(a.noise_spec, np, npair > 1 ? spc * a.rs : 0) + (a.Xtb ? pc_xs_bytes(po->mh.d, np) : 0));
-            HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)((groups + np - 1) / np), 1, 1, (unsigned)pc_threads(knoise, npair > 1, np), 1, 1, lds, ctx->stream, params, nullptr));
+            HIPCHK(ctx, hipModuleLaunchKernel(fn, (unsigned)((groups + np - 1) / np), 1, 1, (unsigned)pc_threads(knoise, npair > 1, np, po->mh.d), 1, 1, lds, ctx->stream, params, nullptr));
             return BHIP_OK;
         }
         const long grid = (a.P + 255) / 256;

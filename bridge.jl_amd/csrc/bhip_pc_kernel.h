@@ -63,8 +63,11 @@ enum { NOISE_FRESH_PC = 6, NOISE_PCN_LINES_PC = 7 };
 #ifndef PC_NDRAW
 #define PC_NDRAW 2
 #endif
-constexpr int pc_ndraw(int mode, bool rlds) { return (mode == NOISE_FRESH_PC && rlds) ? PC_NDRAW : 1; }
-constexpr int pc_threads(int mode, bool rlds, int npair) { return 64 * npair * (pc_ndraw(mode, rlds) + 1); }
+#ifndef PC_NDRAW_D1
+#define PC_NDRAW_D1 PC_NDRAW   // drawers per pair for state dimension 1 (measurement hook: 4 = one Philox call per drawer and chunk, five waves per SIMD at <= 96 registers)
+#endif
+constexpr int pc_ndraw(int mode, bool rlds, int d) { return (mode == NOISE_FRESH_PC && rlds) ? (d == 1 ? PC_NDRAW_D1 : PC_NDRAW) : 1; }
+constexpr int pc_threads(int mode, bool rlds, int npair, int d) { return 64 * npair * (pc_ndraw(mode, rlds, d) + 1); }
 template <int V> struct PcInt { static constexpr int value = V; };
 constexpr int PC_TILE = 64 * LINE_ROW;                          // doubles per hand-over tile
 // LDS of a workgroup: the generator's table of the launch's noise specification (v4: 10 240 bytes, v3 / v2: 2 576), then per pair the two
@@ -118,10 +121,10 @@ struct PcStamp {
 
 template <class M, int GK, int MO, int MODE, int FL, int NPAIR, bool PPR = false /* per-chain guide rows (bhip_guide_kernel.h) */,
           bool RLDS = (NPAIR > 1) /* coefficient rows through LDS (small ensembles); false at NPAIR = 4: the large-ensemble workgroup of v4 */>
-__global__ __launch_bounds__(pc_threads(MODE, RLDS, NPAIR), (RLDS || PPR) ? (pc_ndraw(MODE, RLDS) + 1) : PC_WPE) void k_pc(const KArgs a)
+__global__ __launch_bounds__(pc_threads(MODE, RLDS, NPAIR, M::D) <= 1024 ? pc_threads(MODE, RLDS, NPAIR, M::D) : 1024, (RLDS || PPR) ? (pc_ndraw(MODE, RLDS, M::D) + 1) : PC_WPE) void k_pc(const KArgs a)
 {
     constexpr int D = M::D, MP = M::MP;
-    constexpr int NDRAW = pc_ndraw(MODE, RLDS), NTHR = pc_threads(MODE, RLDS, NPAIR);
+    constexpr int NDRAW = pc_ndraw(MODE, RLDS, M::D), NTHR = pc_threads(MODE, RLDS, NPAIR, M::D);
     static_assert(MP >= 1 && MP <= 3, "a chunk holds 16/m' grid points (m' = 3: lines padded to 4 components)");
     static_assert(MODE == NOISE_FRESH_PC || MODE == NOISE_PCN_LINES_PC, "producer/consumer kernel: fresh proposals or pCN on the line layout");
     constexpr bool PCN = MODE == NOISE_PCN_LINES_PC;
@@ -576,15 +579,16 @@ hipError_t launch_pc_n(const KArgs &a, hipStream_t st, long groups)
         const hipError_t e = hipFuncSetAttribute((const void *)k_pc<M, GK, MO, MODE, FL, NPAIR, PPR, RLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_pc<M, GK, MO, MODE, FL, NPAIR, PPR, RLDS>), dim3((unsigned)((groups + NPAIR - 1) / NPAIR)), dim3(pc_threads(MODE, RLDS, NPAIR)), lds, st, a);
+    hipLaunchKernelGGL((k_pc<M, GK, MO, MODE, FL, NPAIR, PPR, RLDS>), dim3((unsigned)((groups + NPAIR - 1) / NPAIR)), dim3(pc_threads(MODE, RLDS, NPAIR, M::D)), lds, st, a);
     return hipGetLastError();
 }
 // pairs per workgroup of a launch (also what the hipRTC route of do_launch follows): 2 / 4 (RLDS) for small ensembles -- fewer when
 // the time-blocked staging rows of a d = 3 guide would not fit next to four pairs' tiles --, then 1 or 4 without RLDS
-inline int pc_choose_npair_rt(const KArgs &a, long groups, int d, int rs, int mp, bool *rlds)
+inline int pc_choose_npair_rt(const KArgs &a, long groups, int d, int rs, int mp, bool *rlds, int mode)
 {
     const int crow = (LINE_DOUBLES / line_mpp(mp)) * rs;
-    auto fits = [&](int np, bool rl) { return pc_lds_bytes(a.noise_spec, np, rl ? crow : 0) + (a.Xtb ? pc_xs_bytes(d, np) : 0) <= PC_LDS_MAX; };
+    // (a workgroup holds 1024 threads at most: with four drawers per pair two pairs are the largest RLDS workgroup)
+    auto fits = [&](int np, bool rl) { return pc_lds_bytes(a.noise_spec, np, rl ? crow : 0) + (a.Xtb ? pc_xs_bytes(d, np) : 0) <= PC_LDS_MAX && pc_threads(mode, rl, np, d) <= 1024; };
     *rlds = true;
     if (groups <= PC_MAX_GROUPS_2PAIR && fits(2, true)) return 2;
     if (groups <= PC_MAX_GROUPS_4PAIR && fits(4, true)) return 4;
@@ -600,7 +604,7 @@ hipError_t launch_pc(const KArgs &a, hipStream_t st)
     using RL = RowLayout<GK, M::D, MO, is_constdiff<M>::value>;
     const long groups = (a.P + 63) / 64;
     bool rlds;
-    const int np = pc_choose_npair_rt(a, groups, M::D, RL::RS, M::MP, &rlds);
+    const int np = pc_choose_npair_rt(a, groups, M::D, RL::RS, M::MP, &rlds, MODE);
     if (np == 2) return launch_pc_n<M, GK, MO, MODE, FL, 2, PPR>(a, st, groups);
     if (np == 4 && rlds) return launch_pc_n<M, GK, MO, MODE, FL, 4, PPR>(a, st, groups);
     if (np == 4) return launch_pc_n<M, GK, MO, MODE, FL, 4, PPR, false>(a, st, groups);
