@@ -1016,7 +1016,7 @@ def main_local(args):
         others = []
         del w, ws
         torch.cuda.empty_cache()
-        for mode in ("c4shard", "c2", "proposals", "nclar", "nclar_mcmc", "linpro4", "linpro32", "linpro32_mcmc", "c2_fused", "proposals_fused", "nclar_fused", "proposals_1buf", "c2_parts", "c2_fused_parts",
+        for mode in ("c4shard", "c2", "proposals", "nclar", "nclar_mcmc", "linpro4", "linpro32", "linpro32_mcmc", "c2_fused", "proposals_fused", "nclar_fused", "c4shard_fused", "proposals_1buf", "c2_parts", "c2_fused_parts",
                      "mcmc_v3noise", "proposals_v3noise", "c2_v3noise", "mcmc_v2noise", "proposals_v2noise", "c2_v2noise"):
             wo = Workload(mode, ctx, 0, 0)
             ms = kernel_times(wo, args.steps, args.warmup, min_ms=100.0)
