@@ -2229,7 +2229,7 @@ int bhip_alloc_apart(bhip_ctx *ctx, int nparts, size_t bytes, void **out, int *a
     for (int j = 0; j < nparts; j++) out[j] = nullptr;
     if (apart) *apart = 0;
     auto release = [&](std::vector<void *> &v) { for (void *q : v) (void)hipFree(q); v.clear(); };
-    std::vector<void *> kept, held;
+    std::vector<void *> kept, held, spacers;
     const size_t sb = place_stream_bytes(bytes / 2, bytes / 2);
     const bool testable = bytes >= PLACE.min_bytes && sb >= PLACE.min_bytes / 2;
     if (!testable) {
@@ -2271,24 +2271,38 @@ int bhip_alloc_apart(bhip_ctx *ctx, int nparts, size_t bytes, void **out, int *a
             if (ok) { best = q; good = true; break; }
             if (sc > best_score) { best_score = sc; best = q; }
         }
-        while (!good && (int)held.size() < max_cands) {
+        // candidates; when every one of them shares a piece with a kept part the allocator is still walking through that piece (up to 96 GiB,
+        // block by block -- runs of 2-GB blocks are longer than the 4-GB ones the candidate count was chosen for): a spacer -- a plain allocation,
+        // never written, freed below -- takes the next stretch of the walk in one step, twice at most, with a few more candidates beyond it
+        // (the same device as chains_place; round 6: one default `proposals` container in four came out with both buffers in one piece)
+        int extra = 0;
+        for (int round = 0;; round++) {
+            while (!good && (int)held.size() < max_cands + extra) {
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 2 * bytes) break;
+                void *q = nullptr;
+                if (alloc_run(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+                held.push_back(q);
+                if (!judge) { best = q; good = false; break; }
+                bool ok = false; const float sc = score_of(q, &ok);
+                if (ok) { best = q; good = true; break; }
+                if (sc > best_score) { best_score = sc; best = q; }
+            }
+            if (good || !judge || round == 2) break;
             size_t fr = 0, tot = 0;
-            if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 2 * bytes) break;
-            void *q = nullptr;
-            if (alloc_run(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-            held.push_back(q);
-            if (!judge) { best = q; good = false; break; }
-            bool ok = false; const float sc = score_of(q, &ok);
-            if (ok) { best = q; good = true; break; }
-            if (sc > best_score) { best_score = sc; best = q; }
+            void *sp = nullptr;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < PLACE.spacer_bytes + 4 * bytes || hipMalloc(&sp, PLACE.spacer_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            spacers.push_back(sp);
+            extra += 6;
         }
-        if (!best) { (void)hipStreamSynchronize(ctx->stream); release(held); release(kept); return fail(ctx, BHIP_EHIP, "bhip_alloc_apart: out of device memory"); }
+        if (!best) { (void)hipStreamSynchronize(ctx->stream); release(held); release(kept); release(spacers); return fail(ctx, BHIP_EHIP, "bhip_alloc_apart: out of device memory"); }
         held.erase(std::find(held.begin(), held.end(), best));
         kept.push_back(best);
         if (good) n_apart++;
     }
     (void)hipStreamSynchronize(ctx->stream);
     release(held);
+    release(spacers);
     for (int j = 0; j < nparts; j++) { out[j] = kept[j]; { std::lock_guard<std::mutex> g(ctx->buf_mu); ctx->bufs.insert(out[j]); } ctx_retain(ctx); }
     if (apart) *apart = judge ? n_apart : 0;
     return BHIP_OK;
