@@ -419,7 +419,7 @@ int bhip_welford_merge(long entries, int d, double *na, double *mean_a, double *
 typedef struct bhip_segchains bhip_segchains;
 #define BHIP_SEGCHAINS_MCNEXT 1   /* keep the per-chain mcnext! state (mean, m2 per grid point) of every segment on the device */
 #define BHIP_SEGCHAINS_MCNEXT_MEAN 4 /* an economy for ensembles: keep the per-chain MEANS only (what the adaptation reads, smoothing.jl:133); mcnext! itself also keeps the second moments -- 3x the traffic of the commit pass */
-#define BHIP_SEGCHAINS_STATS_EVERY_ITERATION 8 /* with BHIP_SEGCHAINS_MCNEXT[_MEAN] at d <= 3: one statistics pass per iteration and two path buffers per segment (the least memory) instead of one pass per eight iterations on a ring of sixteen (bhip_segchains_statistics_info); same results */
+#define BHIP_SEGCHAINS_STATS_EVERY_ITERATION 8 /* with BHIP_SEGCHAINS_MCNEXT[_MEAN] at d <= 3: one statistics pass per iteration and two path buffers per segment (the least memory) instead of one pass per twelve iterations on a ring of sixteen (bhip_segchains_statistics_info); same results */
 #define BHIP_SEGCHAINS_POOLED 2   /* keep ONE state per segment pooled over chains x iterations (one extra read of the current paths per iteration) */
 int bhip_segchains_create(bhip_ctx *ctx, int m, const bhip_proposal *const *pos, long nchains, uint32_t path0, uint64_t seed,
                           int flags, bhip_segchains **out);
@@ -440,7 +440,7 @@ int bhip_segchains_placement_info(const bhip_segchains *sc, int segment, int *tr
  * the number of iterations one statistics pass covers (1: a pass per iteration) -- with d <= 3 and BHIP_SEGCHAINS_MCNEXT[_MEAN] the
  * segments' paths live in a ring of *buffers = K + L path buffers, the K current paths of a batch stay where they are until ONE pass has
  * applied the K updates of src/mclog.jl:48-56 in order (same bits; the state travels once per K iterations), running beside the first
- * L iterations of the next batch; every bhip_segchains_step call ends with a pass over what is pending.  K = 8, L = 8 (K = L = 4 until the end of round 5) unless the device
+ * L iterations of the next batch; every bhip_segchains_step call ends with a pass over what is pending.  K = 12, L = 4 (8 + 8 at the end of round 5, 4 + 4 before) unless the device
  * lacks the memory for the buffers.  Any pointer may be NULL. */
 int bhip_segchains_statistics_info(const bhip_segchains *sc, int *every, int *buffers);
 /* host outputs (any may be NULL): ll [m][nchains] (current, per segment), acc [nchains], y0 [nchains][d] */

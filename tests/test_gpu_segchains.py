@@ -219,7 +219,7 @@ def test_time_blocked_paths_with_user_process_noise_spec_2_and_fused_build(ctx):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("defer", ["1 1", "2 1", "3 2", "4 4", "8 4", "5 5", "8 8"])
+@pytest.mark.parametrize("defer", ["1 1", "2 1", "3 2", "4 4", "8 4", "5 5", "8 8", "12 4", "15 1"])
 def test_deferred_statistics_equal_a_pass_per_iteration(ctx, defer, monkeypatch):
     """mcnext! of the time-blocked paths is applied every K iterations to the K current paths a ring of K + L buffers has kept, the
     pass running beside the first L iterations of the next batch (bhip_segchains.inc): whatever K and L (BHIP_SEG_DEFER at creation),
@@ -279,7 +279,7 @@ def test_joint_mh_over_partial_bridge_segments(ctx, name):
         assert np.array_equal(ll[:, p], r["ll"])
 
 
-@pytest.mark.parametrize("defer", [None, "3 1", "7 3", "4 4"])
+@pytest.mark.parametrize("defer", [None, "3 1", "7 3", "4 4", "8 8"])
 def test_deferred_statistics_over_many_iterations(ctx, defer, monkeypatch):
     """600 iterations in calls of irregular length: the ring of path buffers is walked hundreds of times in every pattern of accepts
     and rejects; chains, statistics and acceptance counts equal the oracle's."""
@@ -295,7 +295,7 @@ def test_deferred_statistics_over_many_iterations(ctx, defer, monkeypatch):
         monkeypatch.delenv("BHIP_SEG_DEFER")
         assert sc.statistics_info() == (int(defer.split()[0]), sum(int(x) for x in defer.split()))
     else:
-        assert sc.statistics_info() == (8, 16)     # the default ring since the end of round 5 (4 + 4 before)
+        assert sc.statistics_info() == (12, 16)    # the default ring since round 6 (8 + 8 at the end of round 5, 4 + 4 before)
         every = bh.SegChains(segs, mu, chol, n, seed=5, path0=0, mcnext=True, stats_every_iteration=True)   # BHIP_SEGCHAINS_STATS_EVERY_ITERATION
         assert every.statistics_info() == (1, 2)
         every.step(w_old[:50], w_new[:50])
