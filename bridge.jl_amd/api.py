@@ -995,6 +995,8 @@ def sample_solve_(X, W, ll, u, Po, npaths=None, seed=0, iter=0, path0=0, skip=0)
     ctx = Po.ctx if E is None else E.ctx
     npaths = E.npaths if npaths is None else npaths
     per_path = isinstance(u, torch.Tensor)
+    if per_path and (tuple(u.shape) != (Po.d, npaths) or not u.is_contiguous() or u.dtype != torch.float64):
+        raise BridgeError("per-path starting points must be a contiguous float64 tensor [d, npaths]")
     x0 = None if per_path else _dptr(_x0(u, Po.d))
     llp = lambda a: None if ll is None else vp(ll.data_ptr() + 8 * a)
     if X is not None and X.nparts > 1 and W is None and not per_path:   # X in parts alone: all parts by one launch

@@ -2316,6 +2316,7 @@ int bhip_free_apart(bhip_ctx *ctx, int nparts, void *const *ptrs)
     if (ctx->host_only) return fail(ctx, BHIP_EHIP, "host-only context (device -1): no device memory");
     int rc = BHIP_OK;
     bool quiesced = false;
+    ctx_retain(ctx);   // (the last part's release may be the context's last reference: it must outlive the loop and its messages)
     for (int j = 0; j < nparts; j++) {
         if (!ptrs[j]) continue;
         {
@@ -2326,6 +2327,7 @@ int bhip_free_apart(bhip_ctx *ctx, int nparts, void *const *ptrs)
         if (hipFree(ptrs[j]) != hipSuccess) { (void)hipGetLastError(); rc = BHIP_EHIP; }
         ctx_release(ctx);
     }
+    ctx_release(ctx);
     return rc;
 }
 
