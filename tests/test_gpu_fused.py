@@ -61,3 +61,25 @@ def test_fused_kernels_differ_from_the_exact_ones_only_in_rounding_and_chains_ag
     assert np.abs(lle[same] - llf[same]).max() <= 1e-8 * (1 + np.abs(lle[same]).max())
     assert np.abs(Xe[same[:64]] - Xf[same[:64]]).max() <= 1e-9 * (1 + np.abs(Xe).max())
     assert abs(acce.mean() - accf.mean()) < 0.02 * iters
+
+
+def test_K9_of_the_regrouped_step_at_a_million_paths(fctx):
+    """C2 under BHIP_OPT_FUSED_ARITHMETIC runs the REGROUPED step at d = 1 (GUIDE_QF rows, one dependent FMA per step; round 6).  K9
+    (test/guip.jl:245-274) at 2^20 paths on the 1001-point grid: the importance weights have mean 1 within 5 standard errors + the Euler
+    scheme's O(dt) allowance, and -- the noise being the same stream -- every path's log-likelihood agrees with the exact build's to the
+    stated 1e-8, on the one-path-per-lane kernel (2^20 paths) and on the wave-specialised one (65 536 paths)."""
+    import math
+    c = [k for k in problems.cases(1001) if k.name == "ou_guidedbridge"][0]
+    ectx = bh.Context(0)
+    beta, a, T, u, v = 0.8, 0.7, 2.0, float(c.x0[0]), float(c.v[0])
+    K = a / (2 * beta) * (1 - math.exp(-2 * beta * T))
+    lp = -0.5 * ((v - u * math.exp(-beta * T)) ** 2 / K + math.log(K) + math.log(2 * math.pi))
+    Pof, Poe = c.bh_proposal(bh, fctx), c.bh_proposal(bh, ectx)
+    for P in (1 << 20, 65536):
+        _, _, llf = bh.sample_solve(c.x0, Pof, P, seed=2025, store_X=False)
+        _, _, lle = bh.sample_solve(c.x0, Poe, P, seed=2025, store_X=False)
+        assert bool(torch.isfinite(llf).all())
+        assert float(((llf - lle).abs() / (1 + lle.abs())).max()) <= 1e-8
+        assert not torch.equal(llf, lle)                                  # (it IS another arithmetic)
+        w = torch.exp(llf + (bh.lptilde(Pof, c.x0) - lp))
+        assert abs(float(w.mean()) - 1.0) < 5 * math.sqrt(float(w.var()) / P) + 5e-3, (P, float(w.mean()))
