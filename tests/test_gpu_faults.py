@@ -43,7 +43,10 @@ def test_a_faulting_kernel_is_never_reported_as_ok():
 def test_sync_errors_are_propagated_in_source():
     """static guard: no `(void)hipStreamSynchronize(ctx->stream); (void)hipFree(tmp); return rc;` tail is left in the library"""
     import re
-    for fn in ("bhip_api.hip", "bhip_segchains.inc"):
-        src = open(os.path.join(ROOT, "bridge.jl_amd", "csrc", fn)).read()
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "bridge.jl_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "bridge.jl_amd", "csrc", "*.inc")))
+    assert len(files) >= 7          # bhip_api.hip, its five sections (bhip_api_*.inc, bhip_segchains.inc), bhip_inst.hip
+    for fn in files:
+        src = open(fn).read()
         assert not re.search(r"\(void\)hipStreamSynchronize\(ctx->stream\);\s*\(void\)hipFree\(tmp\w*\);\s*(if \(rc\w*\) )?return rc", src), fn
     assert "sync_free_rc" in open(os.path.join(ROOT, "bridge.jl_amd", "csrc", "bhip_api.hip")).read()
