@@ -81,15 +81,23 @@ __global__ void k_soa_to_tlines(const double *__restrict__ soa, double *__restri
 // component-minor normals, src/wiener.jl:24-35; test/with_srand.jl)
 template <int MP>
 __global__ __launch_bounds__(256) void k_wiener(const double *__restrict__ rootdt, int N, double *__restrict__ W, long ld, long P,
-                                                uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0, int noise_spec)
+                                                uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0, int noise_spec,
+                                                double *__restrict__ W1 = nullptr, double *__restrict__ W2 = nullptr, long wpart = 0 /* W in parts: paths [j*wpart, (j+1)*wpart) in buffer j */)
 {
+    // the generator's table in LDS like in the path kernels (round 6: the stand-alone sample! read it from constant memory with a different
+    // index per lane -- 0.72 ms for 262 144 x 1000 normals where the fused proposal kernel, which draws the same normals AND solves, takes 0.75)
+    __shared__ __attribute__((aligned(16))) double rng_tab[RNG_LDS_DOUBLES];
+    if (noise_spec == 2 || noise_spec == 3) TabLDS::load(rng_tab, threadIdx.x, blockDim.x);
+    else IcdfLDS::load(rng_tab, threadIdx.x, blockDim.x);
+    __syncthreads();
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const uint32_t path = path0 + (uint32_t)p;
     // the noise specification (bhip_rng.h) travels in the table accessor's type; one wave-uniform branch per launch picks the body
     auto run = [&](const auto &tab) {
         double w[MP];
-        double *out = W + p;
+        const int part = wpart ? (int)(p / wpart) : 0;
+        double *out = (part == 0 ? W : part == 1 ? W1 : W2) + (p - (long)part * wpart);
 #pragma unroll
         for (int k = 0; k < MP; k++) { w[k] = 0.0; out[(size_t)k * ld] = 0.0; }
         out += (size_t)MP * ld;
@@ -122,9 +130,9 @@ __global__ __launch_bounds__(256) void k_wiener(const double *__restrict__ rootd
             out += (size_t)MP * ld;
         }
     };
-    if (noise_spec == 2) run(FullRes<TabConst>(TabConst()));
-    else if (noise_spec == 3) run(TabConst());
-    else run(IcdfConst());
+    if (noise_spec == 2) run(FullRes<TabLDS>(TabLDS(rng_tab)));
+    else if (noise_spec == 3) run(TabLDS(rng_tab));
+    else run(IcdfLDS(rng_tab));
 }
 // mp > 4 (large-d Wiener): state kept in memory instead of registers
 __global__ __launch_bounds__(256) void k_wiener_big(const double *__restrict__ rootdt, int N, int mp, double *__restrict__ W, long ld, long P,

@@ -279,12 +279,14 @@ int bhip_sample_solve(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, 
  * (d <= 3; LinPro and component-wise user drifts up to BHIP_OPT_MID_VALU); the reference has no counterpart (an ensemble is a loop). */
 int bhip_sample_solve_parts(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, int nparts, double *const *X_parts, long ldX,
                             long part_paths, double *ll_dev, int skip, long npaths, uint64_t seed, uint32_t iter, uint32_t path0);
-/* bhip_solve / bhip_llikelihood of ensembles kept in parts, by ONE launch each (two launches of half the paths leave every SIMD half of
+/* bhip_wiener_sample / bhip_solve / bhip_llikelihood of ensembles kept in parts, by ONE launch each (two launches of half the paths leave every SIMD half of
  * the waves that hide the recurrence's latency: the stand-alone llikelihood of 262 144 stored paths 0.82 ms range by range, 0.69 in one
  * launch).  W_parts / X_parts: nparts pointers to buffers [N][.][ld], paths [j*part_paths, (j+1)*part_paths) in buffer j; the two
  * ensembles of bhip_solve_parts may be cut differently; X_parts NULL: no path store.  Shared start x0 only (per-path starts: range by range
  * through bhip_solve).  One path per lane like bhip_sample_solve_parts; the tile kernel (d > 12, or BHIP_OPT_MID_VALU = 0) returns
  * BHIP_EUNSUPPORTED and the caller walks the ranges.  The reference has no counterpart (an ensemble is a loop there). */
+int bhip_wiener_sample_parts(bhip_ctx *ctx, const double *tt, int N, int mp, int nparts, double *const *W_parts, long ld, long part_paths, long npaths,
+                             uint64_t seed, uint32_t iter, uint32_t path0);   /* sample!(W, Wiener()) into all buffers by one launch (mp <= 4) */
 int bhip_solve_parts(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, int nwparts, const double *const *W_parts, long ldW, long wpart_paths,
                      int nxparts, double *const *X_parts, long ldX, long xpart_paths, double *ll_dev, int skip, long npaths);
 int bhip_llikelihood_parts(bhip_ctx *ctx, const bhip_proposal *po, int nparts, const double *const *X_parts, long ldX, long part_paths,

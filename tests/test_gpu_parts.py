@@ -223,6 +223,19 @@ def test_one_launch_forms_for_ensembles_in_parts_check_their_arguments(ctx):
     assert int(torch.isfinite(ll).sum()) > n // 2
     assert L.bhip_llikelihood_parts(ctx.h, Po.h, nx, xp, ldx, 96, vp(ll2.data_ptr()), 0, n) == -1
     assert L.bhip_llikelihood_parts(ctx.h, Po.h, nx, xp, ldx, xpart, None, 0, n) == -1
+    # sample!(W) into the buffers by one launch: the geometry checks, and the values of the range-by-range calls
+    W2 = bh.EnsemblePath(case.tt, 1, n, ctx, parts=2)
+    a2, b2, c2, d2 = W2._parts_args()
+    ttp = bh.api._dptr(W2.tt)
+    assert L.bhip_wiener_sample_parts(ctx.h, ttp, len(W2.tt), 1, a2, b2, c2, d2, n, 3, 0, 0) == 0 and np.array_equal(W2.paths(), W.paths())
+    assert L.bhip_wiener_sample_parts(ctx.h, ttp, len(W2.tt), 1, a2, b2, c2, 100, n, 3, 0, 0) == -1
+    assert L.bhip_wiener_sample_parts(ctx.h, ttp, len(W2.tt), 1, a2, b2, 64, d2, n, 3, 0, 0) == -5
+    assert L.bhip_wiener_sample_parts(ctx.h, ttp, len(W2.tt), 1, 4, b2, c2, d2, n, 3, 0, 0) == -1
+    Wr = bh.EnsemblePath(case.tt, 1, n, ctx, parts=1)
+    for a, m in ((0, d2), (d2, n - d2)):                       # the same columns by plain calls with the global path offset
+        assert L.bhip_wiener_sample(ctx.h, ttp, len(W2.tt), 1, Wr.colptr(a), Wr.ld, m, 3, 0, a) == 0
+    assert np.array_equal(Wr.paths(), W2.paths())
+    W2.free()
     # X not stored: ll alone, the same values
     ll3 = ctx.empty(n)
     assert L.bhip_solve_parts(ctx.h, Po.h, x0, nw, wp, ldw, wpart, 0, None, 0, 0, vp(ll3.data_ptr()), 0, n) == 0 and same(ll, ll3)
