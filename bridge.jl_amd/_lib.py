@@ -54,6 +54,7 @@ SIGNATURES = {
                                     C.c_uint64, C.c_uint32, C.c_uint32]),
     "bhip_wiener_sample_parts": (C.c_int, [vp, dp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.c_long, C.c_long, C.c_long, C.c_uint64, C.c_uint32, C.c_uint32]),
     "bhip_solve_parts": (C.c_int, [vp, vp, dp, C.c_int, C.POINTER(vp), C.c_long, C.c_long, C.c_int, C.POINTER(vp), C.c_long, C.c_long, vp, C.c_int, C.c_long]),
+    "bhip_girsanov_parts": (C.c_int, [vp, vp, dp, C.c_int, C.c_int, C.POINTER(vp), C.c_long, C.c_long, vp, C.c_long]),
     "bhip_llikelihood_parts": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp), C.c_long, C.c_long, vp, C.c_int, C.c_long]),
     "bhip_sample_solve_parts": (C.c_int, [vp, vp, dp, C.c_int, C.POINTER(vp), C.c_long, C.c_long, vp, C.c_int, C.c_long,
                                           C.c_uint64, C.c_uint32, C.c_uint32]),

@@ -923,6 +923,10 @@ def girsanov(X, P, Pt):
     else:
         raise BridgeError("girsanov: Pt must be of the same process type as P, or Wiener")
     out = ctx.empty(X.npaths)
+    if X.nparts > 1:   # ONE launch over all buffers
+        nx, xp, ldx, xpart = X._parts_args()
+        ctx.check(ctx.lib.bhip_girsanov_parts(ctx.h, Po.h, par_t, npar_t, nx, xp, ldx, xpart, vp(out.data_ptr()), X.npaths))
+        return out
     for a, n in X.segments():
         ctx.check(ctx.lib.bhip_girsanov(ctx.h, Po.h, par_t, npar_t, X.colptr(a), X.ld, vp(out.data_ptr() + 8 * a), n))
     return out

@@ -18,6 +18,8 @@ struct GirsArgs {
     int rs, N;
     long P;
     const double *X;      // [N][D][ldX]
+    const double *X1, *X2;   // the ensemble in parts (bhip_girsanov_parts): paths [j*xpart, (j+1)*xpart) in buffer j; xpart = 0: one buffer
+    long xpart;
     long ldX;
     double *out;          // [P]
     int zero_t;           // Pt = Wiener: Bt = 0
@@ -33,7 +35,8 @@ __global__ __launch_bounds__(256) void k_girsanov(const GirsArgs a)
     const long p = (long)blockIdx.x * 256 + threadIdx.x;
     if (p >= a.P) return;
     const M mp(a.mpar), mt(a.mpar_t);
-    const double *x = a.X + p;
+    const int part = a.xpart ? (int)(p / a.xpart) : 0;
+    const double *x = (part == 0 ? a.X : part == 1 ? a.X1 : a.X2) + (p - (long)part * a.xpart);
     double xc[D], xn[D], xnn[D];
 #pragma unroll
     for (int k = 0; k < D; k++) xc[k] = ld_stream(x + (size_t)k * a.ldX);

@@ -340,10 +340,9 @@ function Bridge.girsanov(X::EnsemblePath, Po::HIPProposal, Pt)
     out = Vector{Float64}(undef, X.npaths)
     r = Ref{Ptr{Cvoid}}(C_NULL)
     check(X.ctx, ccall((:bhip_malloc, lib), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), X.ctx.h, 8 * X.npaths, r))
-    for (a, n) in segments(X)
-        check(X.ctx, ccall((:bhip_girsanov, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Clong, Ptr{Cdouble}, Clong),
-            X.ctx.h, Po.h, Pt isa Wiener ? C_NULL : par, length(par), colptr(X, a), X.ld, Ptr{Cdouble}(r[]) + 8 * a, n))
-    end
+    check(X.ctx, ccall((:bhip_girsanov_parts, lib), Cint,      # all buffers by ONE launch
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Ptr{Ptr{Cvoid}}, Clong, Clong, Ptr{Cdouble}, Clong),
+        X.ctx.h, Po.h, Pt isa Wiener ? C_NULL : par, length(par), length(X.ptrs), X.ptrs, X.ld, X.ld, Ptr{Cdouble}(r[]), X.npaths))
     check(X.ctx, ccall((:bhip_memcpy_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), X.ctx.h, out, r[], 8 * X.npaths))
     ccall((:bhip_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), X.ctx.h, r[])
     out

@@ -291,6 +291,8 @@ int bhip_solve_parts(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, i
                      int nxparts, double *const *X_parts, long ldX, long xpart_paths, double *ll_dev, int skip, long npaths);
 int bhip_llikelihood_parts(bhip_ctx *ctx, const bhip_proposal *po, int nparts, const double *const *X_parts, long ldX, long part_paths,
                            double *ll_dev, int skip, long npaths);
+int bhip_girsanov_parts(bhip_ctx *ctx, const bhip_proposal *po, const double *par_t, int npar_t, int nparts, const double *const *X_parts, long ldX,
+                        long part_paths, double *out_dev, long npaths);   /* bhip_girsanov (below) of an ensemble in parts, one launch */
 /* nparts (1..3) physically contiguous device buffers of `bytes` each, pairwise in different pieces of the device memory (tested with
  * write streams like the placement of chain ensembles; candidates that fail stay held until the set is complete).  *apart (optional):
  * how many of them ended up pairwise apart -- nparts when all did, 0 when the buffers are too small to be tested (< 64 MiB).

@@ -35,6 +35,8 @@ NOT_BOUND = {
     "bhip_gpupdate", "bhip_welford_merge",
     # hot path variants the Julia methods do not expose: the fused form goes through sample_solve_parts!, innovations stays Bridge.jl's
     "bhip_sample_solve", "bhip_innovations",
+    # reached through its one-launch form over the container's buffers (bhip_girsanov_parts; one buffer delegates to it)
+    "bhip_girsanov",
     # chains: read-backs beyond ll / acc / stats, checkpointing
     "bhip_chains_get_paths", "bhip_chains_current_X", "bhip_chains_proposal_X", "bhip_chains_pathstats", "bhip_chains_state_bytes",
     "bhip_chains_save", "bhip_chains_load", "bhip_ctx_piece_of",
