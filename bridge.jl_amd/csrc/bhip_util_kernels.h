@@ -134,7 +134,41 @@ __global__ __launch_bounds__(256) void k_wiener(const double *__restrict__ rootd
     else if (noise_spec == 3) run(TabLDS(rng_tab));
     else run(IcdfLDS(rng_tab));
 }
-// mp > 4 (large-d Wiener): state kept in memory instead of registers
+// mp > 4 with mp % 4 == 0 (round 6): the components in blocks of four -- a block's normals (i*mp + 4kb .. + 3) are ONE Philox quad, number i*(mp/4) + kb --,
+// the whole time loop per block with the block's four running sums in registers: every normal drawn once, W written once, nothing read back
+// (the generic kernel below re-reads W[i] for every W[i+1] and draws by pairs from the constant-memory tables)
+__global__ __launch_bounds__(256) void k_wiener_blocks(const double *__restrict__ rootdt, int N, int mp, double *__restrict__ W, long ld, long P,
+                                                       uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0, int noise_spec)
+{
+    __shared__ __attribute__((aligned(16))) double rng_tab[RNG_LDS_DOUBLES];
+    if (noise_spec == 2 || noise_spec == 3) TabLDS::load(rng_tab, threadIdx.x, blockDim.x);
+    else IcdfLDS::load(rng_tab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const uint32_t path = path0 + (uint32_t)p;
+    const int nq = mp >> 2;
+    auto run = [&](const auto &tab) {
+        for (int kb = 0; kb < nq; kb++) {
+            double w[4] = {0.0, 0.0, 0.0, 0.0};
+            double *out = W + (size_t)(4 * kb) * ld + p;
+#pragma unroll
+            for (int k = 0; k < 4; k++) out[(size_t)k * ld] = 0.0;
+            for (int i = 0; i < N - 1; i++) {
+                double z[4];
+                normal_quad(tab, k0, k1, path, iter, (uint32_t)i * (uint32_t)nq + (uint32_t)kb, z[0], z[1], z[2], z[3]);
+                const double rdt = rootdt[i];
+                out += (size_t)mp * ld;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { w[k] = w[k] + rdt * z[k]; __builtin_nontemporal_store(w[k], out + (size_t)k * ld); }
+            }
+        }
+    };
+    if (noise_spec == 2) run(FullRes<TabLDS>(TabLDS(rng_tab)));
+    else if (noise_spec == 3) run(TabLDS(rng_tab));
+    else run(IcdfLDS(rng_tab));
+}
+// mp > 4 (large-d Wiener), any mp: state kept in memory instead of registers
 __global__ __launch_bounds__(256) void k_wiener_big(const double *__restrict__ rootdt, int N, int mp, double *__restrict__ W, long ld, long P,
                                                     uint32_t k0, uint32_t k1, uint32_t iter, uint32_t path0, int noise_spec)
 {

@@ -50,7 +50,7 @@ def check_ll(case, ll_gpu, ll_ref, libm_trig=False):
 
 
 # --------------------------------------------------------------------------- LOOP A
-@pytest.mark.parametrize("mp", [1, 2, 3, 5])
+@pytest.mark.parametrize("mp", [1, 2, 3, 5, 6, 8, 12, 32])     # (<= 4: registers; multiples of 4 above: blocks of four components; else the generic kernel)
 def test_wiener_sample_bit_exact(ctx, mp):
     tt = problems.tau_grid(2.0, 257)
     P = 70                      # not a multiple of the wave size: exercises the tail
