@@ -785,7 +785,7 @@ def sample_(W, P, seed=0, iter=0, path0=0):
     if not isinstance(P, Wiener) or P.mp != W.dim:
         raise BridgeError("sample!: dimension of W and of the Wiener process differ")
     ctx = W.ctx
-    if W.nparts > 1 and W.dim <= 4:   # ONE launch over all buffers
+    if W.nparts > 1 and W.dim <= 12:   # ONE launch over all buffers
         nw, wp, ldw, wpart = W._parts_args()
         ctx.check(ctx.lib.bhip_wiener_sample_parts(ctx.h, _dptr(W.tt), len(W.tt), W.dim, nw, wp, ldw, wpart, W.npaths, seed, iter, path0))
         return W

@@ -259,7 +259,7 @@ function sample(tt, P::Wiener{T}, E::HIPEnsemble; ctx = default_context()) where
 end
 "sample!(W, Wiener())  src/wiener.jl:24-58 (the noise is keyed by the global path id: path0 + column)"
 function sample!(W::EnsemblePath{T}, ::Wiener{T}; seed = 0, iter = 0, path0 = 0) where {T}
-    if W.dim <= 4        # all buffers by ONE launch
+    if W.dim <= 12       # all buffers by ONE launch
         check(W.ctx, ccall((:bhip_wiener_sample_parts, lib), Cint,
             (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint, Ptr{Ptr{Cvoid}}, Clong, Clong, Clong, UInt64, UInt32, UInt32),
             W.ctx.h, W.tt, length(W.tt), W.dim, length(W.ptrs), W.ptrs, W.ld, W.ld, W.npaths, seed, iter, path0))

@@ -286,7 +286,7 @@ int bhip_sample_solve_parts(bhip_ctx *ctx, const bhip_proposal *po, const double
  * through bhip_solve).  One path per lane like bhip_sample_solve_parts; the tile kernel (d > 12, or BHIP_OPT_MID_VALU = 0) returns
  * BHIP_EUNSUPPORTED and the caller walks the ranges.  The reference has no counterpart (an ensemble is a loop there). */
 int bhip_wiener_sample_parts(bhip_ctx *ctx, const double *tt, int N, int mp, int nparts, double *const *W_parts, long ld, long part_paths, long npaths,
-                             uint64_t seed, uint32_t iter, uint32_t path0);   /* sample!(W, Wiener()) into all buffers by one launch (mp <= 4) */
+                             uint64_t seed, uint32_t iter, uint32_t path0);   /* sample!(W, Wiener()) into all buffers by one launch (mp <= 12) */
 int bhip_solve_parts(bhip_ctx *ctx, const bhip_proposal *po, const double *x0, int nwparts, const double *const *W_parts, long ldW, long wpart_paths,
                      int nxparts, double *const *X_parts, long ldX, long xpart_paths, double *ll_dev, int skip, long npaths);
 int bhip_llikelihood_parts(bhip_ctx *ctx, const bhip_proposal *po, int nparts, const double *const *X_parts, long ldX, long part_paths,

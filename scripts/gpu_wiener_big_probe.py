@@ -3,7 +3,7 @@ sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
 import numpy as np, torch, bridgehip as bh
 ctx = bh.Context(0)
 tt = np.linspace(0, 1, 1001)
-for mp, n in ((32, 65536), (30, 65536), (8, 262144)):
+for mp, n in ((32, 65536), (30, 65536), (8, 262144), (5, 262144), (12, 131072), (16, 131072)):
     W = bh.EnsemblePath(tt, mp, n, ctx, parts=1)
     bh.sample_(W, bh.Wiener(mp), seed=1); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
